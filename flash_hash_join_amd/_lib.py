@@ -1,0 +1,107 @@
+"""ctypes binding of libflashjoin_hip.so (C ABI: include/flashjoin.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded, importing the join
+API raises, and every call on a box without a HIP device fails with the library's error string.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libflashjoin_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+# every symbol include/flashjoin.h declares
+SYMBOLS = [
+    "fj_initialize", "fj_last_error", "fj_device_count", "fj_version",
+    "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes",
+    "fj_join_host", "fj_free_host", "fj_last_timings",
+    "fj_join_device", "fj_emit_pairs", "fj_owner_split",
+    "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
+    "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h",
+]
+
+
+class FjTimings(ctypes.Structure):
+    _fields_ = [
+        ("total_ms", ctypes.c_double), ("build_phase_ms", ctypes.c_double), ("probe_phase_ms", ctypes.c_double),
+        ("join_ms", ctypes.c_double), ("emit_ms", ctypes.c_double), ("probe_part_kernel_ms", ctypes.c_double * 4),
+        ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
+        ("path", ctypes.c_int), ("passes", ctypes.c_int), ("radix_bits", ctypes.c_int), ("fell_back", ctypes.c_int),
+        ("partitions", ctypes.c_uint64),
+    ]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "probe_part_kernel_ms"}
+        d["probe_part_kernel_ms"] = list(self.probe_part_kernel_ms)
+        return d
+
+
+def build_native(force: bool = False) -> str:
+    """Compile the HIP library in-tree with hipcc for gfx950 (csrc/Makefile)."""
+    cmd = ["make", "-C", CSRC, "-j4", "-s"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"hipcc build did not produce {LIB_PATH}")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"flash_hash_join_amd: HIP library {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C flash_hash_join_amd/csrc`. "
+            "There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    u64, sz, vp, i32 = ctypes.c_uint64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
+    pu64 = ctypes.POINTER(u64)
+    L.fj_initialize.restype = i32
+    L.fj_last_error.restype = ctypes.c_char_p
+    L.fj_device_count.restype = i32
+    L.fj_version.restype = ctypes.c_char_p
+    L.fj_ctx_create.restype = vp; L.fj_ctx_create.argtypes = [i32]
+    L.fj_ctx_destroy.restype = None; L.fj_ctx_destroy.argtypes = [vp]
+    L.fj_ctx_workspace_bytes.restype = sz; L.fj_ctx_workspace_bytes.argtypes = [vp]
+    L.fj_join_host.restype = i32
+    L.fj_join_host.argtypes = [i32, i32, i32, vp, vp, sz, vp, sz, pu64, ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.fj_free_host.restype = None; L.fj_free_host.argtypes = [vp]
+    L.fj_last_timings.restype = i32; L.fj_last_timings.argtypes = [ctypes.POINTER(FjTimings)]
+    L.fj_join_device.restype = i32
+    L.fj_join_device.argtypes = [vp, i32, i32, i32, vp, vp, sz, vp, sz, vp, i32, pu64, vp, vp, sz,
+                                 ctypes.POINTER(FjTimings)]
+    L.fj_emit_pairs.restype = i32
+    L.fj_emit_pairs.argtypes = [vp, vp, vp, sz, vp, ctypes.POINTER(FjTimings)]
+    L.fj_owner_split.restype = i32
+    L.fj_owner_split.argtypes = [vp, vp, vp, sz, i32, vp, vp, pu64, vp]
+    L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]
+    L.fj_generate_probe.restype = i32
+    L.fj_generate_probe.argtypes = [vp, vp, u64, sz, u64, u64, ctypes.c_uint32, pu64, vp]
+    L.fj_debug_partition.restype = i32
+    L.fj_debug_partition.argtypes = [vp, vp, vp, sz, i32, i32, vp, vp, vp, vp, pu64]
+    L.fj_device_malloc.restype = i32; L.fj_device_malloc.argtypes = [ctypes.POINTER(vp), sz]
+    L.fj_device_free.restype = i32; L.fj_device_free.argtypes = [vp]
+    L.fj_memcpy_h2d.restype = i32; L.fj_memcpy_h2d.argtypes = [vp, vp, sz]
+    L.fj_memcpy_d2h.restype = i32; L.fj_memcpy_d2h.argtypes = [vp, vp, sz]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().fj_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = last_error()
+        if "out of" in msg and "memory" in msg:
+            raise MemoryError(msg)
+        raise RuntimeError(msg)

@@ -1,0 +1,528 @@
+// fj_api.hip -- host orchestration + C ABI (include/flashjoin.h) for the MI355X hash join.
+//
+// Plays the role of the reference's join drivers (_hash_join_{radix,scalar}_{count,materialize}
+// and adaptive_hash_join_*, hash_join.cpp:315-594): plan the radix passes, run partition ->
+// group -> join on one HIP stream, read back the count, and fall back to the global-table path
+// when a partition does not fit its LDS table.  No CPU join path exists here: without a HIP
+// device every entry point fails with an error string.
+#include "fj_internal.h"
+#include "../../include/flashjoin.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+thread_local fj_timings g_last;
+
+int set_err(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIPCHK(x)                                                                                          \
+    do {                                                                                                   \
+        hipError_t e_ = (x);                                                                               \
+        if (e_ != hipSuccess) return set_err("%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Scalars {                       // device scratch words, mirrored in pinned host memory
+    unsigned long long total;
+    unsigned long long expected;
+    u64 empty_val;
+    u32 err;
+    u32 flags;
+    u32 alloc[8];                      // [side*4 + pass] chunk allocators
+    unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
+};
+
+enum Slot {
+    // [side][pingpong][kind]
+    W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_BKEYS, W_BOFF, W_KINDS,
+    W_SIDE_STRIDE = 2 * W_KINDS,
+    W_PART_COUNT = 2 * W_SIDE_STRIDE, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
+    W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_NSLOTS
+};
+
+struct Buf { void* p = nullptr; size_t bytes = 0; };
+
+enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_PK0, E_NEV = E_PK0 + 8 };
+
+struct Pending {
+    bool valid = false;
+    int path = 0;
+    FjLdsJoinArgs lds{};
+    FjGtArgs gt{};
+    u32 nitems = 0, gt_grid = 0;
+    u64 count = 0;
+};
+
+}  // namespace
+
+struct fj_ctx {
+    int device = 0;
+    Buf bufs[W_NSLOTS];
+    hipEvent_t ev[E_NEV];
+    Scalars* d_sc = nullptr;
+    Scalars* h_sc = nullptr;
+    Pending pend;
+    size_t ws_bytes = 0;
+    size_t radix_threshold = 0;
+};
+
+namespace {
+
+int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
+    Buf& b = c->bufs[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.bytes < bytes) {
+        if (b.p) { HIPCHK(hipFree(b.p)); c->ws_bytes -= b.bytes; b.p = nullptr; b.bytes = 0; }
+        size_t want = (bytes + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) return set_err("hipMalloc(%zu bytes) for workspace slot %d failed: %s", want, slot, hipGetErrorString(e));
+        b.bytes = want; c->ws_bytes += want;
+    }
+    *out = b.p;
+    return 0;
+}
+
+struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; };
+
+Plan make_plan(size_t nb) {
+    Plan p;
+    if (nb > FJ_PART_TARGET_KEYS) {
+        u64 parts = (nb + FJ_PART_TARGET_KEYS - 1) / FJ_PART_TARGET_KEYS;
+        while ((1ull << p.bits) < parts) ++p.bits;
+    }
+    p.npass = (p.bits + 7) / 8;
+    for (int i = 0; i < p.npass; ++i) p.fan_log[i] = p.bits / p.npass + (i < p.bits % p.npass ? 1 : 0);
+    return p;
+}
+
+// run the plan's partition passes over one relation; `out` describes the final level
+int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, const Plan& plan, int top_bits,
+               hipStream_t s, FjChunkSet* out, int* ev_cursor) {
+    FjChunkSet prev{};
+    bool have_prev = false;
+    u32 parents = 1;
+    int used = top_bits;
+    u64 lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
+    const u32 tile_chunks = vals ? 8 : 16;
+    for (int i = 0; i < plan.npass; ++i) {
+        const u32 F = 1u << plan.fan_log[i];
+        used -= plan.fan_log[i];
+        u64 g64 = lbound / tile_chunks;
+        const u32 G = (u32)std::min<u64>(512, std::max<u64>(1, g64));
+        const u64 nb_out = (u64)parents * F;
+        const u64 cap64 = n / FJ_CHUNK + 1 + 2ull * (G + parents) * F + (u64)(G + 1) * FJ_SLAB;
+        if (cap64 >= (1ull << 24) || nb_out >= (1u << 22))
+            return set_err("relation of %zu rows is too large for one GPU's chunk directory", n);
+        FjChunkSet cs{};
+        cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0;
+        const int base = side * W_SIDE_STRIDE + (i & 1) * W_KINDS;
+        void* p;
+        if (get_buf(c, base + W_POOL_K, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.keys = (u64*)p;
+        cs.vals = nullptr;
+        if (vals) { if (get_buf(c, base + W_POOL_V, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.vals = (u64*)p; }
+        if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
+        if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
+        if (get_buf(c, base + W_BCHUNKS, nb_out * 4, &p)) return 1; cs.bchunks = (u32*)p;
+        if (get_buf(c, base + W_BKEYS, nb_out * 8, &p)) return 1; cs.bkeys = (u64*)p;
+        if (get_buf(c, base + W_BOFF, (nb_out + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
+        cs.alloc = &c->d_sc->alloc[side * 4 + i];
+        HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
+        HIPCHK(hipMemsetAsync(cs.alloc, 0, 4, s));
+
+        FjPartArgs a{};
+        if (have_prev) {
+            a.in_keys = prev.keys; a.in_vals = prev.vals; a.in_list = prev.list; a.in_dir = prev.dir;
+            a.in_nlist = prev.boff + prev.nb; a.n_flat = 0;
+        } else {
+            a.in_keys = keys; a.in_vals = vals; a.in_list = nullptr; a.in_dir = nullptr; a.in_nlist = nullptr; a.n_flat = n;
+        }
+        a.parent0 = 0;
+        a.out_keys = cs.keys; a.out_vals = cs.vals; a.out_dir = cs.dir; a.alloc = cs.alloc; a.cap_chunks = cs.cap;
+        a.err = &c->d_sc->err;
+        a.shift = (u32)used; a.fan_log = (u32)plan.fan_log[i];
+        const int line_log = F <= 128 ? 4 : 3;
+        if (ev_cursor) HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor)], s));
+        HIPCHK(fj_launch_partition(a, vals != nullptr, line_log, G, s));
+        if (ev_cursor) { HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor) + 1], s)); ++*ev_cursor; }
+        HIPCHK(fj_launch_group(cs, s));
+        prev = cs; have_prev = true;
+        lbound = n / FJ_CHUNK + 1 + (u64)(G + parents) * F;
+        parents = (u32)nb_out;
+    }
+    if (!have_prev) {       // no pass needed: the join kernel reads the flat arrays as virtual chunks
+        prev.keys = const_cast<u64*>(keys); prev.vals = const_cast<u64*>(vals); prev.n_flat = n; prev.list = nullptr; prev.nb = 1;
+    }
+    *out = prev;
+    return 0;
+}
+
+int read_scalars(fj_ctx* c, hipStream_t s) {
+    HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+float ev_ms(fj_ctx* c, int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; }
+
+int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_timings* t) {
+    Pending& pd = c->pend;
+    if (!pd.valid) return set_err("fj_emit_pairs: no counted materialising join is pending on this context");
+    if (pd.count > cap) return set_err("fj_emit_pairs: output capacity %zu < %llu pairs", cap, (unsigned long long)pd.count);
+    HIPCHK(hipEventRecord(c->ev[E_EMIT0], s));
+    if (pd.count > 0) {
+        if (((uintptr_t)d_ok | (uintptr_t)d_ov) & 7) return set_err("output buffers must be 8-byte aligned");
+        void* p;
+        if (pd.path == 0) {
+            if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
+            HIPCHK(fj_launch_scan_u32_to_u64(pd.lds.part_count, (u64*)p, pd.nitems, s));
+            pd.lds.out_off = (const u64*)p; pd.lds.out_keys = d_ok; pd.lds.out_vals = d_ov;
+            HIPCHK(fj_launch_lds_join(pd.lds, true, s));
+        } else {
+            if (get_buf(c, W_OUT_OFF, ((size_t)pd.gt_grid + 1) * 8, &p)) return 1;
+            HIPCHK(fj_launch_scan_u32_to_u64(pd.gt.wg_count, (u64*)p, pd.gt_grid, s));
+            pd.gt.out_off = (const u64*)p; pd.gt.out_keys = d_ok; pd.gt.out_vals = d_ov;
+            HIPCHK(fj_launch_gt_probe(pd.gt, true, pd.gt_grid, s));
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev[E_EMIT1], s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (t) { t->emit_ms = ev_ms(c, E_EMIT0, E_EMIT1); t->total_ms += t->emit_ms; t->probe_phase_ms += t->emit_ms; }
+    pd.valid = false;
+    return 0;
+}
+
+// non-partitioned path: one table in HBM (Infinity-Cache / L2 resident when small)
+int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np,
+                hipStream_t s, fj_timings* t, u64* out_count) {
+    u64 cap = 64;
+    while (cap < 2 * (u64)nb) cap <<= 1;
+    FjGtArgs a{};
+    void* p;
+    if (get_buf(c, W_GT_KEYS, cap * 8, &p)) return 1; a.tkeys = (u64*)p;
+    if (get_buf(c, W_GT_VALS, cap * 8, &p)) return 1; a.tvals = (u64*)p;
+    a.bloom = nullptr;
+    if (bloom) { if (get_buf(c, W_GT_BLOOM, cap / 8 * 4, &p)) return 1; a.bloom = (u32*)p; }
+    const u64 npairs = (np + 1) / 2;
+    const u32 grid = (u32)std::min<u64>(2048, std::max<u64>(1, npairs / 256));
+    if (get_buf(c, W_WG_COUNT, (size_t)grid * 4, &p)) return 1; a.wg_count = (u32*)p;
+    a.cap_mask = cap - 1; a.flags = &c->d_sc->flags; a.empty_val = &c->d_sc->empty_val;
+    a.bk = bk; a.bv = bv; a.nb = nb; a.pk = pk; a.np = np; a.total = &c->d_sc->total;
+
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    HIPCHK(hipMemsetAsync(a.tkeys, 0xFF, cap * 8, s));
+    if (a.bloom) HIPCHK(hipMemsetAsync(a.bloom, 0, cap / 8 * 4, s));
+    HIPCHK(fj_launch_gt_build(a, s));
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+    if (np > 0) HIPCHK(fj_launch_gt_probe(a, false, grid, s));
+    else HIPCHK(hipMemsetAsync(a.wg_count, 0, (size_t)grid * 4, s));
+    HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+    if (read_scalars(c, s)) return 1;
+    *out_count = c->h_sc->total;
+    t->path = 1; t->passes = 0; t->radix_bits = 0; t->partitions = 1;
+    t->build_phase_ms = ev_ms(c, E_START, E_BUILD);
+    t->join_ms = ev_ms(c, E_PPART, E_JOIN);
+    t->probe_phase_ms = t->join_ms;
+    t->total_ms = ev_ms(c, E_START, E_JOIN);
+    c->pend.valid = false;
+    if (materialize) {
+        c->pend.valid = true; c->pend.path = 1; c->pend.gt = a; c->pend.gt_grid = grid; c->pend.count = *out_count;
+    }
+    return 0;
+}
+
+// radix path: partition both relations, then one LDS-table join per final partition
+int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
+               hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
+    const Plan plan = make_plan(nb);
+    *lds_full = false;
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    FjLdsJoinArgs ja{};
+    if (run_passes(c, 0, bk, bv, nb, plan, top_bits, s, &ja.build, nullptr)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    int evc = 0;
+    if (run_passes(c, 1, pk, nullptr, np, plan, top_bits, s, &ja.probe, &evc)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+
+    ja.nparts = 1u << plan.bits;
+    const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
+    u64 nsplit = 1;
+    if (ja.nparts < 2048) {
+        nsplit = (2048 + ja.nparts - 1) / ja.nparts;
+        const u64 per_part = pchunks / ja.nparts;
+        nsplit = std::min<u64>(nsplit, std::max<u64>(1, per_part / 32));
+    }
+    ja.nsplit = (u32)nsplit;
+    const u32 nitems = ja.nparts * ja.nsplit;
+    void* p;
+    if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
+    ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
+    HIPCHK(fj_launch_lds_join(ja, false, s));
+    HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+    if (read_scalars(c, s)) return 1;
+    if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
+    t->path = 0; t->passes = plan.npass; t->radix_bits = plan.bits; t->partitions = ja.nparts;
+    t->build_phase_ms = ev_ms(c, E_START, E_BUILD);
+    t->join_ms = ev_ms(c, E_PPART, E_JOIN);
+    t->probe_phase_ms = ev_ms(c, E_BUILD, E_JOIN);
+    t->total_ms = ev_ms(c, E_START, E_JOIN);
+    for (int i = 0; i < evc && i < 4; ++i) t->probe_part_kernel_ms[i] = ev_ms(c, E_PK0 + 2 * i, E_PK0 + 2 * i + 1);
+    if (c->h_sc->err & FJ_ERR_LDS_FULL) { *lds_full = true; return 0; }
+    *out_count = c->h_sc->total;
+    c->pend.valid = false;
+    if (materialize) {
+        c->pend.valid = true; c->pend.path = 0; c->pend.lds = ja; c->pend.nitems = nitems; c->pend.count = *out_count;
+    }
+    return 0;
+}
+
+fj_ctx* g_host_ctx = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+const char* fj_last_error(void) { return g_err.c_str(); }
+const char* fj_version(void) { return "flash_hash_join_amd 0.1 (gfx950)"; }
+
+int fj_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fj_initialize(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return set_err("fj_initialize: no usable HIP device (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return 0;
+}
+
+fj_ctx* fj_ctx_create(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device < 0 || device >= n) { set_err("fj_ctx_create: HIP device %d not available (%d devices)", device, n); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_err("fj_ctx_create: hipSetDevice(%d) failed", device); return nullptr; }
+    fj_ctx* c = new fj_ctx();
+    c->device = device;
+    bool ok = hipMalloc((void**)&c->d_sc, sizeof(Scalars)) == hipSuccess &&
+              hipHostMalloc((void**)&c->h_sc, sizeof(Scalars), hipHostMallocDefault) == hipSuccess &&
+              hipMemset(c->d_sc, 0, sizeof(Scalars)) == hipSuccess;
+    for (int i = 0; ok && i < E_NEV; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    if (!ok) { set_err("fj_ctx_create: allocating context scratch failed: %s", hipGetErrorString(hipGetLastError())); delete c; return nullptr; }
+    const char* th = getenv("FJ_RADIX_THRESHOLD");
+    c->radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)262144;
+    return c;
+}
+
+void fj_ctx_destroy(fj_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto& b : c->bufs) if (b.p) (void)hipFree(b.p);
+    for (int i = 0; i < E_NEV; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->d_sc) (void)hipFree(c->d_sc);
+    if (c->h_sc) (void)hipHostFree(c->h_sc);
+    delete c;
+}
+
+size_t fj_ctx_workspace_bytes(const fj_ctx* c) { return c ? c->ws_bytes : 0; }
+
+int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
+                   const uint64_t* d_bk, const uint64_t* d_bv, size_t nb, const uint64_t* d_pk, size_t np,
+                   void* stream, int hash_top_bits, uint64_t* out_count,
+                   uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, fj_timings* timings) {
+    if (!c) return set_err("fj_join_device: null context");
+    if (algo < 0 || algo > 2) return set_err("fj_join_device: unknown algo %d", algo);
+    if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_join_device: hash_top_bits must be 64 or 48");
+    if ((nb && (!d_bk || !d_bv)) || (np && !d_pk)) return set_err("fj_join_device: null input pointer");
+    if (((uintptr_t)d_bk | (uintptr_t)d_bv | (uintptr_t)d_pk) & 15) return set_err("fj_join_device: input pointers must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    fj_timings t; memset(&t, 0, sizeof t);
+    u64 count = 0;
+    c->pend.valid = false;
+    bool use_radix = algo == FJ_ALGO_RADIX || (algo == FJ_ALGO_ADAPTIVE && nb >= c->radix_threshold);
+    if (nb == 0 || np == 0) {                   // empty side: (0, t), hash_join.cpp behaviour for empty inputs
+        count = 0;
+    } else if (use_radix) {
+        bool lds_full = false;
+        if (join_radix(c, materialize, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count, &lds_full)) return 1;
+        if (lds_full) {
+            fj_timings t2; memset(&t2, 0, sizeof t2);
+            if (join_global(c, bloom, materialize, d_bk, d_bv, nb, d_pk, np, s, &t2, &count)) return 1;
+            t2.total_ms += t.total_ms; t2.fell_back = 1; t = t2;
+        }
+    } else {
+        if (join_global(c, bloom, materialize, d_bk, d_bv, nb, d_pk, np, s, &t, &count)) return 1;
+    }
+    if (out_count) *out_count = count;
+    if (materialize && d_out_keys && d_out_vals && c->pend.valid) {
+        if (emit_pending(c, d_out_keys, d_out_vals, out_capacity, s, &t)) return 1;
+    }
+    if (timings) *timings = t;
+    g_last = t;
+    return 0;
+}
+
+int fj_emit_pairs(fj_ctx* c, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, void* stream, fj_timings* timings) {
+    if (!c) return set_err("fj_emit_pairs: null context");
+    HIPCHK(hipSetDevice(c->device));
+    fj_timings t = g_last;
+    if (emit_pending(c, d_out_keys, d_out_vals, out_capacity, (hipStream_t)stream, &t)) return 1;
+    if (timings) *timings = t;
+    g_last = t;
+    return 0;
+}
+
+int fj_owner_split(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, int nranks,
+                   uint64_t* d_out_keys, uint64_t* d_out_vals, uint64_t* h_counts, void* stream) {
+    if (!c) return set_err("fj_owner_split: null context");
+    if (nranks < 1 || nranks > 64) return set_err("fj_owner_split: nranks must be 1..64");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(c->d_sc->owner_counts, 0, sizeof(unsigned long long) * 128, s));   // counts + cursors
+    HIPCHK(fj_launch_owner_hist(d_keys, n, (u32)nranks, c->d_sc->owner_counts, s));
+    HIPCHK(hipMemcpyAsync(c->h_sc->owner_counts, c->d_sc->owner_counts, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    unsigned long long run = 0;
+    for (int r = 0; r < nranks; ++r) { c->h_sc->owner_offsets[r] = run; run += c->h_sc->owner_counts[r]; h_counts[r] = c->h_sc->owner_counts[r]; }
+    if (run != n) return set_err("fj_owner_split: histogram covers %llu of %zu rows", run, n);
+    HIPCHK(hipMemcpyAsync(c->d_sc->owner_offsets, c->h_sc->owner_offsets, sizeof(unsigned long long) * 64, hipMemcpyHostToDevice, s));
+    HIPCHK(fj_launch_owner_scatter(d_keys, d_vals, n, (u32)nranks, c->d_sc->owner_offsets, c->d_sc->owner_cursors, d_out_keys, d_out_vals, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int fj_generate_build(fj_ctx* c, uint64_t* d_keys, uint64_t* d_vals, uint64_t first, size_t n, void* stream) {
+    if (!c) return set_err("fj_generate_build: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(fj_launch_gen_build(d_keys, d_vals, first, n, (hipStream_t)stream));
+    return 0;
+}
+
+int fj_generate_probe(fj_ctx* c, uint64_t* d_keys, uint64_t first, size_t n, uint64_t build_total, uint64_t seed,
+                      uint32_t hit_bp, uint64_t* h_expected_hits, void* stream) {
+    if (!c) return set_err("fj_generate_probe: null context");
+    if (build_total == 0) return set_err("fj_generate_probe: build_total must be > 0");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(&c->d_sc->expected, 0, sizeof(unsigned long long), s));
+    HIPCHK(fj_launch_gen_probe(d_keys, first, n, build_total, seed, hit_bp, &c->d_sc->expected, s));
+    HIPCHK(hipMemcpyAsync(&c->h_sc->expected, &c->d_sc->expected, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h_expected_hits) *h_expected_hits = c->h_sc->expected;
+    return 0;
+}
+
+// Diagnostic: run `total_bits` of radix partitioning over a flat relation and linearise the final
+// chunk lists on the host (bucket by bucket).  Used by the tests to check the partition pass in
+// isolation: output must be a permutation of the input with every row in the bucket its hash names.
+int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, int total_bits,
+                       int hash_top_bits, void* stream, uint64_t* h_out_keys, uint64_t* h_out_vals,
+                       uint32_t* h_bucket_of, uint64_t* h_nvalid) {
+    if (!c) return set_err("fj_debug_partition: null context");
+    if (total_bits < 1 || total_bits > 24) return set_err("fj_debug_partition: total_bits must be 1..24");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    Plan plan; plan.bits = total_bits; plan.npass = (total_bits + 7) / 8;
+    for (int i = 0; i < plan.npass; ++i) plan.fan_log[i] = plan.bits / plan.npass + (i < plan.bits % plan.npass ? 1 : 0);
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    FjChunkSet cs{};
+    if (run_passes(c, d_vals ? 0 : 1, d_keys, d_vals, n, plan, hash_top_bits, s, &cs, nullptr)) return 1;
+    if (read_scalars(c, s)) return 1;
+    if (c->h_sc->err) return set_err("fj_debug_partition: device error word 0x%x", c->h_sc->err);
+    std::vector<u32> dir(cs.cap), list(cs.cap), boff(cs.nb + 1);
+    HIPCHK(hipMemcpy(dir.data(), cs.dir, (size_t)cs.cap * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(list.data(), cs.list, (size_t)cs.cap * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(boff.data(), cs.boff, (size_t)(cs.nb + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<u64> ck(FJ_CHUNK), cv(FJ_CHUNK);
+    u64 w = 0;
+    for (u32 b = 0; b < cs.nb; ++b) {
+        for (u32 i = boff[b]; i < boff[b + 1]; ++i) {
+            const u32 id = list[i];
+            if (id >= cs.cap) return set_err("fj_debug_partition: list entry %u out of range", id);
+            const u32 e = dir[id], cnt = e & FJ_DIR_CNT_MASK;
+            if ((e >> FJ_DIR_CNT_BITS) != b) return set_err("fj_debug_partition: chunk %u listed under bucket %u but tagged %u", id, b, e >> FJ_DIR_CNT_BITS);
+            if (cnt == 0 || cnt > FJ_CHUNK) return set_err("fj_debug_partition: chunk %u has count %u", id, cnt);
+            if (w + cnt > n) return set_err("fj_debug_partition: more than %zu rows in the chunk lists", n);
+            HIPCHK(hipMemcpy(ck.data(), cs.keys + (size_t)id * FJ_CHUNK, cnt * 8, hipMemcpyDeviceToHost));
+            memcpy(h_out_keys + w, ck.data(), cnt * 8);
+            if (d_vals && h_out_vals) {
+                HIPCHK(hipMemcpy(cv.data(), cs.vals + (size_t)id * FJ_CHUNK, cnt * 8, hipMemcpyDeviceToHost));
+                memcpy(h_out_vals + w, cv.data(), cnt * 8);
+            }
+            for (u32 j = 0; j < cnt; ++j) h_bucket_of[w + j] = b;
+            w += cnt;
+        }
+    }
+    *h_nvalid = w;
+    return 0;
+}
+
+int fj_device_malloc(void** p, size_t bytes) { HIPCHK(hipMalloc(p, bytes ? bytes : 16)); return 0; }
+int fj_device_free(void* p) { if (p) HIPCHK(hipFree(p)); return 0; }
+int fj_memcpy_h2d(void* d, const void* h, size_t bytes) { if (bytes) HIPCHK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return 0; }
+int fj_memcpy_d2h(void* h, const void* d, size_t bytes) { if (bytes) HIPCHK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return 0; }
+
+void fj_free_host(void* p) { free(p); }
+int fj_last_timings(fj_timings* out) { if (!out) return set_err("fj_last_timings: null"); *out = g_last; return 0; }
+
+int fj_join_host(int algo, int bloom, int materialize,
+                 const uint64_t* bk, const uint64_t* bv, size_t nb, const uint64_t* pk, size_t np,
+                 uint64_t* out_count, double* out_seconds, uint64_t** out_keys, uint64_t** out_vals) {
+    if (out_keys) *out_keys = nullptr;
+    if (out_vals) *out_vals = nullptr;
+    if (!g_host_ctx) {
+        int dev = 0;
+        if (const char* d = getenv("FJ_DEVICE")) dev = atoi(d);
+        g_host_ctx = fj_ctx_create(dev);
+        if (!g_host_ctx) return 1;
+    }
+    fj_ctx* c = g_host_ctx;
+    void *dbk, *dbv, *dpk;
+    if (get_buf(c, W_H_BK, nb * 8, &dbk) || get_buf(c, W_H_BV, nb * 8, &dbv) || get_buf(c, W_H_PK, np * 8, &dpk)) return 1;
+    auto t0 = std::chrono::steady_clock::now();
+    if (nb) { HIPCHK(hipMemcpy(dbk, bk, nb * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dbv, bv, nb * 8, hipMemcpyHostToDevice)); }
+    if (np) HIPCHK(hipMemcpy(dpk, pk, np * 8, hipMemcpyHostToDevice));
+    const double h2d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fj_timings t;
+    u64 count = 0;
+    if (fj_join_device(c, algo, bloom, materialize, (const u64*)dbk, (const u64*)dbv, nb, (const u64*)dpk, np, nullptr, 64,
+                       &count, nullptr, nullptr, 0, &t)) return 1;
+    double d2h = 0;
+    if (materialize && c->pend.valid) {
+        void *dok, *dov;
+        if (get_buf(c, W_H_OK, count * 8, &dok) || get_buf(c, W_H_OV, count * 8, &dov)) return 1;
+        if (emit_pending(c, (u64*)dok, (u64*)dov, count, nullptr, &t)) return 1;
+        if (out_keys && out_vals) {
+            u64* hk = (u64*)malloc(std::max<size_t>(count, 1) * 8);
+            u64* hv = (u64*)malloc(std::max<size_t>(count, 1) * 8);
+            if (!hk || !hv) { free(hk); free(hv); return set_err("fj_join_host: out of host memory for %llu pairs", (unsigned long long)count); }
+            auto t1 = std::chrono::steady_clock::now();
+            if (count) { HIPCHK(hipMemcpy(hk, dok, count * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hv, dov, count * 8, hipMemcpyDeviceToHost)); }
+            d2h = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            *out_keys = hk; *out_vals = hv;
+        }
+    }
+    t.h2d_ms = h2d; t.d2h_ms = d2h;
+    g_last = t;
+    if (out_count) *out_count = count;
+    if (out_seconds) *out_seconds = t.total_ms * 1e-3;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// fj_common.h -- shared device/host definitions for the MI355X (gfx950) hash-join kernels.
+//
+// Everything here is integer / indexing work bounded by HBM bandwidth: no MFMA.
+// Wavefront = 64 lanes, LDS = 160 KiB per CU, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+
+// ---- chunked-bucket geometry -------------------------------------------------------------
+// Partition passes write block-private *chunks*: 256 keys = 2 KiB, always 2-KiB aligned, so a
+// consumer reads whole 128-B lines.  A directory word per chunk says which bucket it belongs
+// to and how many keys it holds:  dir = (bucket << 9) | count   (count 1..256).
+#define FJ_CHUNK_LOG 8
+#define FJ_CHUNK (1u << FJ_CHUNK_LOG)          // keys per chunk
+#define FJ_DIR_INVALID 0xFFFFFFFFu
+#define FJ_DIR_CNT_BITS 9
+#define FJ_DIR_CNT_MASK 0x1FFu
+#define FJ_SLAB 512u                            // chunks handed to a workgroup per allocator hit
+#define FJ_MAX_FANOUT 256u                      // buckets per partition pass (8 bits, as RADIX_BITS)
+
+// LDS-resident join table (per final partition): 8192 slots, 8-B keys (+ 8-B values when
+// materialising).  Linear probing, home slot aligned to a 4-slot group so that the probe
+// compares 4 keys per LDS access (two ds_read_b128).
+#define FJ_LDS_SLOTS_LOG 13
+#define FJ_LDS_SLOTS (1u << FJ_LDS_SLOTS_LOG)
+#define FJ_LDS_GROUP 4u
+#define FJ_PART_TARGET_KEYS 4096u               // average build keys per final partition (load <= 0.5)
+
+// Global (HBM / Infinity-Cache resident) table for the non-partitioned path: groups of 8 keys
+// = one 64-B sector.
+#define FJ_GT_GROUP 8u
+
+// All 2^64 key values are legal, so the empty marker is handled out of band: a build key equal
+// to FJ_EMPTY_KEY is never stored in a table; a per-table flag + value records it instead.
+#define FJ_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+// Device hash: murmur3's 64-bit finaliser.  The reference hashes with CRC32C*const
+// (hash_join.cpp:40-44) which only has 32 bits of entropy; join results are hash-independent,
+// so the device uses a full-width mixer that costs a handful of VALU ops.
+__host__ __device__ __forceinline__ u64 fj_hash64(u64 k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// splitmix64-style counter hash used by the synthetic generators; identical in
+// NumPy (flash_hash_join_amd/datagen.py), C and HIP.
+__host__ __device__ __forceinline__ u64 fj_mix(u64 seed, u64 j) {
+    u64 z = seed * 0xD6E8FEB86659FD93ull + j + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+#define FJ_GOLDEN 0x9E3779B97F4A7C15ull
+
+struct __attribute__((aligned(16))) u64x2 { u64 x, y; };
+
+__device__ __forceinline__ u32 fj_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// wave64 sum of a u32
+__device__ __forceinline__ u32 fj_wave_sum(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}

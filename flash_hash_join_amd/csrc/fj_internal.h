@@ -1,0 +1,92 @@
+// fj_internal.h -- host-side declarations shared by the .hip translation units.
+#pragma once
+#include "fj_common.h"
+
+// device error word bits
+#define FJ_ERR_POOL 1u       // chunk pool exhausted (sizing bug) -> call fails
+#define FJ_ERR_LDS_FULL 2u   // a final partition does not fit its LDS table -> global-table fallback
+
+// ---- partition pass ---------------------------------------------------------------------------
+struct FjPartArgs {
+    // input: flat arrays (in_list == nullptr) or a bucket-grouped chunk list over a chunk pool
+    const u64* in_keys;
+    const u64* in_vals;
+    const u32* in_list;
+    const u32* in_dir;
+    const u32* in_nlist;     // device scalar: number of list entries
+    u64 n_flat;
+    u32 parent0;             // bucket id of every key of a flat input
+    // output chunk pool
+    u64* out_keys;
+    u64* out_vals;
+    u32* out_dir;            // pre-set to FJ_DIR_INVALID
+    u32* alloc;              // device scalar: next unallocated chunk id (zeroed before the pass)
+    u32 cap_chunks;
+    u32* err;
+    // radix digit: bucket = (hash >> shift) & (2^fan_log - 1)
+    u32 shift;
+    u32 fan_log;
+};
+
+// a chunk pool plus its per-bucket chunk lists (output of one pass, input of the next)
+struct FjChunkSet {
+    u64* keys;               // chunk pool, or (list == nullptr) a flat array of n_flat keys
+    u64* vals;               // nullptr for the probe side
+    u64 n_flat;
+    u32* dir;                // [cap]
+    u32* alloc;              // device scalar
+    u32 cap;
+    u32 nb;                  // number of buckets at this level
+    u32* bchunks;            // [nb]   scratch / cursors
+    u64* bkeys;              // [nb]   keys per bucket
+    u32* boff;               // [nb+1] chunk-list offsets; boff[nb] = list length
+    u32* list;               // [cap]  chunk ids grouped by bucket
+};
+
+u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log);
+hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s);
+hipError_t fj_launch_group(const FjChunkSet& cs, hipStream_t s);
+hipError_t fj_launch_scan_u32_to_u64(const u32* in, u64* out, u32 n, hipStream_t s);
+
+// ---- joins ------------------------------------------------------------------------------------
+struct FjLdsJoinArgs {
+    FjChunkSet build, probe;     // final-level chunk sets (same nb), or flat arrays (list == nullptr)
+    u32 nparts;                  // number of final partitions
+    u32 nsplit;                  // work items per partition (slices of the probe side)
+    u32* part_count;             // [nparts*nsplit] matches per work item
+    unsigned long long* total;   // device scalar
+    u32* err;
+    // materialise
+    const u64* out_off;          // [nparts*nsplit+1] exclusive scan of part_count
+    u64* out_keys;
+    u64* out_vals;
+};
+hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s);
+
+struct FjGtArgs {                // global (non-partitioned) table
+    u64* tkeys; u64* tvals; u32* bloom;    // bloom == nullptr: no precheck
+    u64 cap_mask;                           // capacity - 1 (capacity = power of two, multiple of 8)
+    u32* flags;                             // [0] = build saw FJ_EMPTY_KEY, value in empty_val
+    u64* empty_val;
+    const u64* bk; const u64* bv; u64 nb;
+    const u64* pk; u64 np;
+    u32* wg_count;                          // [grid] matches per workgroup
+    unsigned long long* total;
+    const u64* out_off;                     // [grid+1]
+    u64* out_keys; u64* out_vals;
+};
+hipError_t fj_launch_gt_build(const FjGtArgs& a, hipStream_t s);
+hipError_t fj_launch_gt_probe(const FjGtArgs& a, bool materialize, u32 grid, hipStream_t s);
+
+// ---- multi-GPU owner split --------------------------------------------------------------------
+hipError_t fj_launch_owner_hist(const u64* keys, u64 n, u32 nranks, unsigned long long* counts, hipStream_t s);
+hipError_t fj_launch_owner_scatter(const u64* keys, const u64* vals, u64 n, u32 nranks,
+                                   const unsigned long long* offsets, unsigned long long* cursors,
+                                   u64* out_keys, u64* out_vals, hipStream_t s);
+
+// ---- synthetic data ---------------------------------------------------------------------------
+hipError_t fj_launch_gen_build(u64* keys, u64* vals, u64 first, u64 n, hipStream_t s);
+hipError_t fj_launch_gen_probe(u64* keys, u64 first, u64 n, u64 build_total, u64 seed, u32 hit_bp,
+                               unsigned long long* expected_hits, hipStream_t s);
+
+__host__ __device__ inline u32 fj_owner_of(u64 h, u32 nranks) { return (u32)((((h >> 48) & 0xFFFFu) * nranks) >> 16); }

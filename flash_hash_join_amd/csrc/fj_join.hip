@@ -1,0 +1,475 @@
+// fj_join.hip -- build + probe kernels for MI355X (gfx950).
+//
+//  * fj_lds_join_kernel : one workgroup per final radix partition.  Linear-probing open-address
+//    build into an LDS table (ds_cmpst_rtn_b64 claims a slot), then the partition's probe keys
+//    are streamed through it.  Mirrors insert_local + probe_vectorized of the reference
+//    (hash_join.cpp:112-128, :153-182) inside _hash_join_radix_{count,materialize} (:315-381,
+//    :498-534).  The home slot is aligned to a 4-slot group and the probe compares 4 keys per
+//    step, so almost every probe resolves with one LDS access pair and wave divergence stays low.
+//  * fj_gt_*            : non-partitioned table in HBM / Infinity Cache (hash_join.cpp:130-151
+//    insert_concurrent, :383-496 / :536-567 scalar drivers), 8-key (64-B) groups, optional
+//    bloom word per group (role of the reference's bloom directory, :183-189).
+//
+// Materialisation is two-pass like the reference's small-table strategy (hash_join.cpp:394-444):
+// count per work item -> exclusive scan -> re-probe and write at exact offsets, so the output
+// arrays have exactly `count` rows and no global cursor is contended.
+#include "fj_internal.h"
+
+namespace {
+
+constexpr u32 S = FJ_LDS_SLOTS, SM = FJ_LDS_SLOTS - 1;
+
+struct JoinHdr {              // small scalars at the front of the dynamic LDS block
+    u32 cnt, has_empty, cursor, claimed, full;
+    u32 pad[3];
+    u64 empty_val;
+    u64 pad2;
+};
+
+__device__ __forceinline__ bool lds_lookup(const u64* __restrict__ tkeys, u64 key, u64 h, u32& where) {
+    u32 pos = ((u32)h & SM) & ~(FJ_LDS_GROUP - 1);
+    for (u32 step = 0; step < S / FJ_LDS_GROUP; ++step) {
+        const u64x2 a = *reinterpret_cast<const u64x2*>(tkeys + pos);
+        const u64x2 b = *reinterpret_cast<const u64x2*>(tkeys + pos + 2);
+        if (a.x == key) { where = pos; return true; }
+        if (a.y == key) { where = pos + 1; return true; }
+        if (b.x == key) { where = pos + 2; return true; }
+        if (b.y == key) { where = pos + 3; return true; }
+        if (a.x == FJ_EMPTY_KEY || a.y == FJ_EMPTY_KEY || b.x == FJ_EMPTY_KEY || b.y == FJ_EMPTY_KEY) return false;
+        pos = (pos + FJ_LDS_GROUP) & SM;
+    }
+    return false;
+}
+
+// chunk `idx` of a chunk set: pool id and key count.  A flat array is read as a virtual chunk list.
+__device__ __forceinline__ void chunk_at(const FjChunkSet& cs, u32 idx, u32& id, u32& cnt) {
+    if (cs.list) {
+        id = cs.list[idx];
+        cnt = cs.dir[id] & FJ_DIR_CNT_MASK;
+    } else {
+        id = idx;
+        const u64 rem = cs.n_flat - (u64)idx * FJ_CHUNK;
+        cnt = rem >= FJ_CHUNK ? FJ_CHUNK : (u32)rem;
+    }
+}
+
+// grid = nb * nsplit work items: item = (partition p, slice of p's probe chunks).  Every item
+// rebuilds p's table in LDS (cheap: the build side of a partition is <= a few thousand rows and
+// is L2 / Infinity-Cache resident), so small-build joins still fill the chip.
+template <bool MAT, int NT>
+__global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    JoinHdr* hdr = reinterpret_cast<JoinHdr*>(smem);
+    u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(JoinHdr));
+    u64* tvals = tkeys + S;        // only touched when MAT
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 item = blockIdx.x, p = item / a.nsplit, slice = item % a.nsplit;
+
+    u32 b0 = 0, nbc, p0 = 0, npc;
+    if (a.build.list) { b0 = a.build.boff[p]; nbc = a.build.boff[p + 1] - b0; }
+    else nbc = (u32)((a.build.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
+    if (a.probe.list) { p0 = a.probe.boff[p]; npc = a.probe.boff[p + 1] - p0; }
+    else npc = (u32)((a.probe.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
+    const u32 s_lo = (u32)(((u64)slice * npc) / a.nsplit), s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
+    if (nbc == 0 || s_lo >= s_hi) {      // an empty side is skipped (hash_join.cpp:343, :518)
+        if (!MAT && tid == 0) a.part_count[item] = 0;
+        return;
+    }
+    if (MAT && a.part_count[item] == 0) return;
+
+    for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
+    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->cursor = 0; hdr->claimed = 0; hdr->full = 0; hdr->empty_val = 0; }
+    __syncthreads();
+
+    // ---- build: first claim of a key wins, later duplicates are dropped (hash_join.cpp:125) ----
+    u32 claimed = 0;
+    for (u32 ci = 0; ci < nbc; ci += NT / FJ_CHUNK) {
+        const u32 c = ci + tid / FJ_CHUNK, off = tid % FJ_CHUNK;
+        if (c < nbc) {
+            u32 id, cnt;
+            chunk_at(a.build, b0 + c, id, cnt);
+            if (off < cnt) {
+                const u64 key = a.build.keys[(u64)id * FJ_CHUNK + off];
+                u64 val = 0;
+                if (MAT) val = a.build.vals[(u64)id * FJ_CHUNK + off];
+                if (key == FJ_EMPTY_KEY) {
+                    hdr->has_empty = 1;
+                    if (MAT) hdr->empty_val = val;
+                } else {
+                    u32 pos = ((u32)fj_hash64(key) & SM) & ~(FJ_LDS_GROUP - 1);
+                    u32 step = 0;
+                    for (; step < S; ++step) {
+                        const u64 old = atomicCAS((unsigned long long*)&tkeys[pos], (unsigned long long)FJ_EMPTY_KEY,
+                                                  (unsigned long long)key);
+                        if (old == FJ_EMPTY_KEY) { if (MAT) tvals[pos] = val; ++claimed; break; }
+                        if (old == key) break;
+                        pos = (pos + 1) & SM;
+                    }
+                    if (step == S) hdr->full = 1;
+                }
+            }
+        }
+    }
+    claimed = fj_wave_sum(claimed);
+    if (lane == 0 && claimed) atomicAdd(&hdr->claimed, claimed);
+    __syncthreads();
+    if (hdr->full || hdr->claimed > S - 64) {       // table (nearly) full: host falls back to the global-table path
+        if (tid == 0) { atomicOr(a.err, FJ_ERR_LDS_FULL); if (!MAT) a.part_count[item] = 0; }
+        return;
+    }
+    const bool has_empty = hdr->has_empty != 0;
+    const u64 obase = MAT ? a.out_off[item] : 0;
+
+    // ---- probe: 16 B (2 keys) per lane per load, two loads in flight ---------------------------
+    u32 local = 0;
+    constexpr u32 CPI = NT / (FJ_CHUNK / 2);          // chunks covered by one load round
+    for (u32 ci = s_lo; ci < s_hi; ci += 2 * CPI) {
+        u64 k[4] = {0, 0, 0, 0};
+        bool ok[4] = {false, false, false, false};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const u32 c = ci + u * CPI + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
+            if (c < s_hi) {
+                u32 id, cnt;
+                chunk_at(a.probe, p0 + c, id, cnt);
+                if (off + 1 < cnt) {
+                    const u64x2 kk = *reinterpret_cast<const u64x2*>(a.probe.keys + (u64)id * FJ_CHUNK + off);
+                    k[2 * u] = kk.x; k[2 * u + 1] = kk.y;
+                    ok[2 * u] = true; ok[2 * u + 1] = true;
+                } else if (off < cnt) {
+                    k[2 * u] = a.probe.keys[(u64)id * FJ_CHUNK + off];
+                    ok[2 * u] = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bool hit = false;
+            u64 val = 0;
+            if (ok[i]) {
+                if (k[i] == FJ_EMPTY_KEY) {
+                    hit = has_empty;
+                    if (MAT) val = hdr->empty_val;
+                } else {
+                    u32 where = 0;
+                    hit = lds_lookup(tkeys, k[i], fj_hash64(k[i]), where);
+                    if (MAT && hit) val = tvals[where];
+                }
+            }
+            if (MAT) {      // wave-uniform point: ballot-rank the hits, one LDS cursor bump per wave
+                const u64 m = __ballot(hit);
+                if (m) {
+                    u32 wb = 0;
+                    if (lane == 0) wb = atomicAdd(&hdr->cursor, (u32)__popcll(m));
+                    wb = __shfl(wb, 0, 64);
+                    if (hit) {
+                        const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                        a.out_keys[o] = k[i];
+                        a.out_vals[o] = val;
+                    }
+                }
+            } else {
+                local += hit ? 1u : 0u;
+            }
+        }
+    }
+    if (!MAT) {
+        local = fj_wave_sum(local);
+        if (lane == 0 && local) atomicAdd(&hdr->cnt, local);
+        __syncthreads();
+        if (tid == 0) {
+            a.part_count[item] = hdr->cnt;
+            if (hdr->cnt) atomicAdd(a.total, (unsigned long long)hdr->cnt);
+        }
+    }
+}
+
+// =============================== global (non-partitioned) table ===============================
+__device__ __forceinline__ u32 gt_bloom_mask(u64 h) {      // 3 bits of a 32-bit word per 8-slot group
+    return (1u << ((h >> 40) & 31)) | (1u << ((h >> 45) & 31)) | (1u << ((h >> 50) & 31));
+}
+
+__global__ __launch_bounds__(256) void fj_gt_build_kernel(FjGtArgs a) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < a.nb; i += stride) {
+        const u64 key = a.bk[i], val = a.bv[i];
+        if (key == FJ_EMPTY_KEY) { a.flags[0] = 1; *a.empty_val = val; continue; }
+        const u64 h = fj_hash64(key);
+        const u64 home = (h & a.cap_mask) & ~(u64)(FJ_GT_GROUP - 1);
+        u64 pos = home;
+        for (u64 step = 0; step <= a.cap_mask; ++step) {
+            const u64 old = atomicCAS((unsigned long long*)&a.tkeys[pos], (unsigned long long)FJ_EMPTY_KEY, (unsigned long long)key);
+            if (old == FJ_EMPTY_KEY) {
+                a.tvals[pos] = val;
+                if (a.bloom) atomicOr(&a.bloom[home >> 3], gt_bloom_mask(h));
+                break;
+            }
+            if (old == key) break;
+            pos = (pos + 1) & a.cap_mask;
+        }
+    }
+}
+
+__device__ __forceinline__ bool gt_lookup(const u64* __restrict__ tkeys, u64 cap_mask, u64 key, u64 h, u64& where) {
+    u64 pos = (h & cap_mask) & ~(u64)(FJ_GT_GROUP - 1);
+    const u64 ngroups = (cap_mask + 1) / FJ_GT_GROUP;
+    for (u64 step = 0; step < ngroups; ++step) {
+        const u64x2* g = reinterpret_cast<const u64x2*>(tkeys + pos);
+        const u64x2 q0 = g[0], q1 = g[1], q2 = g[2], q3 = g[3];
+        if (q0.x == key) { where = pos; return true; }
+        if (q0.y == key) { where = pos + 1; return true; }
+        if (q1.x == key) { where = pos + 2; return true; }
+        if (q1.y == key) { where = pos + 3; return true; }
+        if (q2.x == key) { where = pos + 4; return true; }
+        if (q2.y == key) { where = pos + 5; return true; }
+        if (q3.x == key) { where = pos + 6; return true; }
+        if (q3.y == key) { where = pos + 7; return true; }
+        const bool e = q0.x == FJ_EMPTY_KEY || q0.y == FJ_EMPTY_KEY || q1.x == FJ_EMPTY_KEY || q1.y == FJ_EMPTY_KEY ||
+                       q2.x == FJ_EMPTY_KEY || q2.y == FJ_EMPTY_KEY || q3.x == FJ_EMPTY_KEY || q3.y == FJ_EMPTY_KEY;
+        if (e) return false;
+        pos = (pos + FJ_GT_GROUP) & cap_mask;
+    }
+    return false;
+}
+
+template <bool MAT, bool BLOOM>
+__global__ __launch_bounds__(256) void fj_gt_probe_kernel(FjGtArgs a) {
+    __shared__ u32 s_cnt, s_cursor;
+    const u32 tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, G = gridDim.x;
+    if (tid == 0) { s_cnt = 0; s_cursor = 0; }
+    __syncthreads();
+    const u64 npairs = (a.np + 1) / 2;
+    const u64 per = npairs / G, rem = npairs % G;
+    const u64 lo = (u64)g * per + (g < rem ? g : rem), hi = lo + per + (g < rem ? 1 : 0);
+    const bool has_empty = a.flags[0] != 0;
+    const u64 obase = MAT ? a.out_off[g] : 0;
+    u32 local = 0;
+    for (u64 base = lo; base < hi; base += 256) {
+        const u64 pi = base + tid;
+        u64 k[2] = {0, 0};
+        bool ok[2] = {false, false};
+        if (pi < hi) {
+            if (2 * pi + 1 < a.np) {
+                const u64x2 kk = *reinterpret_cast<const u64x2*>(a.pk + 2 * pi);
+                k[0] = kk.x; k[1] = kk.y; ok[0] = ok[1] = true;
+            } else { k[0] = a.pk[2 * pi]; ok[0] = true; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bool hit = false;
+            u64 val = 0;
+            if (ok[i]) {
+                if (k[i] == FJ_EMPTY_KEY) {
+                    hit = has_empty;
+                    if (MAT) val = *a.empty_val;
+                } else {
+                    const u64 h = fj_hash64(k[i]);
+                    bool pass = true;
+                    if (BLOOM) {       // precheck on the home group's bloom word (role of hash_join.cpp:185-189)
+                        const u32 m = gt_bloom_mask(h);
+                        pass = (a.bloom[(h & a.cap_mask) >> 3] & m) == m;
+                    }
+                    if (pass) {
+                        u64 where = 0;
+                        hit = gt_lookup(a.tkeys, a.cap_mask, k[i], h, where);
+                        if (MAT && hit) val = a.tvals[where];
+                    }
+                }
+            }
+            if (MAT) {
+                const u64 m = __ballot(hit);
+                if (m) {
+                    u32 wb = 0;
+                    if (lane == 0) wb = atomicAdd(&s_cursor, (u32)__popcll(m));
+                    wb = __shfl(wb, 0, 64);
+                    if (hit) {
+                        const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                        a.out_keys[o] = k[i];
+                        a.out_vals[o] = val;
+                    }
+                }
+            } else {
+                local += hit ? 1u : 0u;
+            }
+        }
+    }
+    if (!MAT) {
+        local = fj_wave_sum(local);
+        if (lane == 0 && local) atomicAdd(&s_cnt, local);
+        __syncthreads();
+        if (tid == 0) {
+            a.wg_count[g] = s_cnt;
+            if (s_cnt) atomicAdd(a.total, (unsigned long long)s_cnt);
+        }
+    }
+}
+
+// =============================== multi-GPU owner split ========================================
+__global__ __launch_bounds__(256) void fj_owner_hist_kernel(const u64* __restrict__ keys, u64 n, u32 nranks,
+                                                            unsigned long long* __restrict__ counts) {
+    __shared__ u32 h[64];
+    const u32 tid = threadIdx.x;
+    if (tid < 64) h[tid] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + tid; i < n; i += stride)
+        atomicAdd(&h[fj_owner_of(fj_hash64(keys[i]), nranks)], 1u);
+    __syncthreads();
+    if (tid < nranks && h[tid]) atomicAdd(&counts[tid], (unsigned long long)h[tid]);
+}
+
+// tile-local counting sort by owner in LDS, then each owner's run is written contiguously at a
+// position reserved with ONE global atomic per (tile, owner).
+template <bool HAS_VALS>
+__global__ __launch_bounds__(512) void fj_owner_scatter_kernel(const u64* __restrict__ keys, const u64* __restrict__ vals,
+                                                               u64 n, u32 nranks,
+                                                               const unsigned long long* __restrict__ offsets,
+                                                               unsigned long long* __restrict__ cursors,
+                                                               u64* __restrict__ out_keys, u64* __restrict__ out_vals) {
+    constexpr u32 NT = 512, KPT = HAS_VALS ? 4 : 8, T = NT * KPT;
+    __shared__ u64 sk[T];
+    __shared__ u64 sv[HAS_VALS ? T : 1];
+    __shared__ u32 hist[64], toff[65];
+    __shared__ u64 gbase[64];
+    const u32 tid = threadIdx.x;
+    const u64 ntiles = (n + T - 1) / T;
+    for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        if (tid < 64) hist[tid] = 0;
+        __syncthreads();
+        u64 k[KPT], v[KPT];
+        u32 dr[KPT];
+#pragma unroll
+        for (u32 i = 0; i < KPT; ++i) {
+            const u64 idx = t * T + (u64)i * NT + tid;
+            dr[i] = 0xFFFFFFFFu;
+            if (idx < n) {
+                k[i] = keys[idx];
+                if (HAS_VALS) v[i] = vals[idx];
+                const u32 d = fj_owner_of(fj_hash64(k[i]), nranks);
+                dr[i] = (d << 16) | atomicAdd(&hist[d], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 run = 0;
+            for (u32 d = 0; d < nranks; ++d) { toff[d] = run; run += hist[d]; }
+            toff[nranks] = run;
+        }
+        if (tid < nranks && hist[tid])
+            gbase[tid] = offsets[tid] + atomicAdd(&cursors[tid], (unsigned long long)hist[tid]);
+        __syncthreads();
+#pragma unroll
+        for (u32 i = 0; i < KPT; ++i) {
+            if (dr[i] != 0xFFFFFFFFu) {
+                const u32 s = toff[dr[i] >> 16] + (dr[i] & 0xFFFFu);
+                sk[s] = k[i];
+                if (HAS_VALS) sv[s] = v[i];
+            }
+        }
+        __syncthreads();
+        const u32 total = toff[nranks];
+        for (u32 e = tid; e < total; e += NT) {
+            u32 d = 0;
+            while (e >= toff[d + 1]) ++d;
+            const u64 o = gbase[d] + (e - toff[d]);
+            out_keys[o] = sk[e];
+            if (HAS_VALS) out_vals[o] = sv[e];
+        }
+        __syncthreads();
+    }
+}
+
+// =============================== synthetic data ==============================
+__global__ void fj_gen_build_kernel(u64* __restrict__ keys, u64* __restrict__ vals, u64 first, u64 n) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        keys[i] = (first + i + 1) * FJ_GOLDEN;
+        vals[i] = first + i;
+    }
+}
+__global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u64 B, u64 seed, u32 hit_bp,
+                                    unsigned long long* __restrict__ expected) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 hits = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 j = first + i;
+        const u64 r = 1 + fj_mix(seed, j) % B;
+        const bool hit = (fj_mix(seed ^ 1ull, j) % 10000ull) < hit_bp;
+        keys[i] = (r + (hit ? 0ull : B)) * FJ_GOLDEN;
+        hits += hit ? 1u : 0u;
+    }
+    hits = fj_wave_sum(hits);
+    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(expected, (unsigned long long)hits);
+}
+
+}  // namespace
+
+hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s) {
+    const u32 nb = a.nparts * a.nsplit;
+    if (materialize) {
+        const u32 lds = sizeof(JoinHdr) + 2 * S * 8;
+        auto kern = fj_lds_join_kernel<true, 1024>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
+    } else {
+        const u32 lds = sizeof(JoinHdr) + S * 8;
+        auto kern = fj_lds_join_kernel<false, 512>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_gt_build(const FjGtArgs& a, hipStream_t s) {
+    if (a.nb == 0) return hipSuccess;
+    u64 blocks = (a.nb + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fj_gt_build_kernel, dim3((u32)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_gt_probe(const FjGtArgs& a, bool materialize, u32 grid, hipStream_t s) {
+    const bool bloom = a.bloom != nullptr;
+    if (materialize) {
+        if (bloom) hipLaunchKernelGGL((fj_gt_probe_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((fj_gt_probe_kernel<true, false>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (bloom) hipLaunchKernelGGL((fj_gt_probe_kernel<false, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((fj_gt_probe_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_owner_hist(const u64* keys, u64 n, u32 nranks, unsigned long long* counts, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    u64 blocks = (n + 2047) / 2048;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fj_owner_hist_kernel, dim3((u32)blocks), dim3(256), 0, s, keys, n, nranks, counts);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_owner_scatter(const u64* keys, const u64* vals, u64 n, u32 nranks,
+                                   const unsigned long long* offsets, unsigned long long* cursors,
+                                   u64* out_keys, u64* out_vals, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const u64 tile = vals ? 2048 : 4096;
+    u64 blocks = (n + tile - 1) / tile;
+    if (blocks > 1024) blocks = 1024;
+    if (vals) hipLaunchKernelGGL(fj_owner_scatter_kernel<true>, dim3((u32)blocks), dim3(512), 0, s, keys, vals, n, nranks, offsets, cursors, out_keys, out_vals);
+    else hipLaunchKernelGGL(fj_owner_scatter_kernel<false>, dim3((u32)blocks), dim3(512), 0, s, keys, vals, n, nranks, offsets, cursors, out_keys, out_vals);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_gen_build(u64* keys, u64* vals, u64 first, u64 n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fj_gen_build_kernel, dim3(2048), dim3(256), 0, s, keys, vals, first, n);
+    return hipGetLastError();
+}
+hipError_t fj_launch_gen_probe(u64* keys, u64 first, u64 n, u64 build_total, u64 seed, u32 hit_bp,
+                               unsigned long long* expected_hits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fj_gen_probe_kernel, dim3(2048), dim3(256), 0, s, keys, first, n, build_total, seed, hit_bp, expected_hits);
+    return hipGetLastError();
+}

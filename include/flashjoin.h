@@ -1,0 +1,137 @@
+/*
+ * flashjoin.h -- C ABI of libflashjoin_hip.so, the MI355X (gfx950) drop-in for the hot path of
+ * conanhujinming/flash_hash_join.
+ *
+ * The reference exposes this path only through a pybind11 module (hash_join.cpp:598-640):
+ * twelve join functions that all take (build_keys, build_values, probe_keys) as uint64 arrays
+ * and all return (total_results, core_duration_sec), plus initialize().  A C ABI for it does not
+ * exist in the reference; this header is what a binding for the path (ctypes / cgo / JNI / a
+ * pybind11 shim) binds instead of the reference's C++ templates.  Each entry point names the
+ * reference interface it replaces.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure; fj_last_error() then
+ * returns a thread-local, NUL-terminated description.  No torch / pybind types cross this ABI:
+ * plain pointers and sizes only.  Keys and values are 64-bit words; int64 inputs are
+ * reinterpreted bit-for-bit (the reference does the same through array_t<uint64_t>'s cast).
+ */
+#ifndef FLASHJOIN_H
+#define FLASHJOIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* algo: which of the reference's drivers the call stands for */
+#define FJ_ALGO_ADAPTIVE 0 /* adaptive_hash_join_{count,materialize}   hash_join.cpp:576-594 */
+#define FJ_ALGO_SCALAR 1   /* _hash_join_scalar_{count,materialize}     hash_join.cpp:383-496, :536-567 */
+#define FJ_ALGO_RADIX 2    /* _hash_join_radix_{count,materialize}      hash_join.cpp:315-381, :498-534 */
+
+typedef struct fj_ctx fj_ctx;
+
+/* Per-call device timings (milliseconds, HIP events on the caller's stream) and plan facts. */
+typedef struct fj_timings {
+    double total_ms;             /* whole device-resident join: what core_duration_sec reports */
+    double build_phase_ms;       /* everything that touches only the build relation            */
+    double probe_phase_ms;       /* probe-side partition passes + per-partition build/probe    */
+    double join_ms;              /* the join kernel(s) alone (part of probe_phase_ms)          */
+    double emit_ms;              /* second (writing) pass of a materialising join              */
+    double probe_part_kernel_ms[4]; /* each probe-side partition kernel launch                 */
+    double h2d_ms, d2h_ms;       /* host-buffer entry only                                     */
+    int path;                    /* 0 = radix + LDS tables, 1 = global table                   */
+    int passes;                  /* radix passes run on each relation (k)                      */
+    int radix_bits;              /* total partition bits                                       */
+    int fell_back;               /* 1 if the radix path overflowed an LDS table and the global path re-ran */
+    uint64_t partitions;
+} fj_timings;
+
+/* replaces: flash_join.initialize() / initialize_memory_system (hash_join.cpp:596, :639).
+ * Selects nothing, allocates nothing; verifies a HIP device is usable. */
+int fj_initialize(void);
+const char* fj_last_error(void);
+int fj_device_count(void);
+const char* fj_version(void);
+
+/* One context per (process, device): owns the grow-only workspace, events and scratch words. */
+fj_ctx* fj_ctx_create(int device);
+void fj_ctx_destroy(fj_ctx* ctx);
+size_t fj_ctx_workspace_bytes(const fj_ctx* ctx);
+
+/*
+ * replaces: all twelve pybind entry points hash_join.cpp:603-637 for HOST (NumPy) buffers.
+ *   algo x bloom x materialize selects the function, e.g.
+ *     hash_join_count_radix_bloom == (FJ_ALGO_RADIX, 1, 0); adaptive_join == (FJ_ALGO_ADAPTIVE, 0, 1).
+ * build_vals must hold nb words (the reference never checks this; here it is the caller's
+ * contract).  out_seconds receives the device-resident time (fj_timings.total_ms / 1e3); copies
+ * over PCIe are reported separately through fj_last_timings().  When materialize != 0 and
+ * out_keys/out_vals are non-NULL they receive malloc'ed host arrays of *out_count
+ * (probe_key, build_value) pairs, to be released with fj_free_host(); pass NULL to drop them as
+ * the reference does (hash_join.cpp:365-380).
+ */
+int fj_join_host(int algo, int bloom, int materialize,
+                 const uint64_t* build_keys, const uint64_t* build_vals, size_t nb,
+                 const uint64_t* probe_keys, size_t np,
+                 uint64_t* out_count, double* out_seconds,
+                 uint64_t** out_keys, uint64_t** out_vals);
+void fj_free_host(void* p);
+int fj_last_timings(fj_timings* out);
+
+/*
+ * Device-resident form of the same twelve functions (inputs already in HBM, 16-byte aligned).
+ * stream is a hipStream_t (NULL = default stream).  hash_top_bits is 64 for a single-GPU join and
+ * 48 after fj_owner_split (the top 16 hash bits chose the owner GPU).
+ * Materialising joins: with d_out_keys == NULL the call counts only and keeps its partitions
+ * resident; fj_emit_pairs() then writes exactly *out_count pairs into caller-allocated buffers.
+ * With d_out_keys != NULL and out_capacity >= count both steps happen in this call.
+ */
+int fj_join_device(fj_ctx* ctx, int algo, int bloom, int materialize,
+                   const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb,
+                   const uint64_t* d_probe_keys, size_t np,
+                   void* stream, int hash_top_bits,
+                   uint64_t* out_count,
+                   uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity,
+                   fj_timings* timings);
+int fj_emit_pairs(fj_ctx* ctx, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity,
+                  void* stream, fj_timings* timings);
+
+/*
+ * Multi-GPU building block (no reference counterpart: the reference is single-process).
+ * Splits n local rows by owner GPU = (top 16 hash bits * nranks) >> 16 into nranks contiguous
+ * segments of d_out_keys (and d_out_vals when d_vals != NULL); h_counts[r] = rows for rank r.
+ * The caller exchanges the segments (RCCL all-to-all) and joins what it receives with
+ * hash_top_bits = 48.
+ */
+int fj_owner_split(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, int nranks,
+                   uint64_t* d_out_keys, uint64_t* d_out_vals, uint64_t* h_counts, void* stream);
+
+/*
+ * Deterministic synthetic relations, generated in HBM:
+ *   build_keys[i] = (first+i+1)*M, build_vals[i] = first+i, M = 0x9E3779B97F4A7C15;
+ *   probe j = first+i: r = 1 + mix(seed,j) % B, hit = mix(seed^1,j) % 10000 < hit_bp,
+ *   key = (r + (hit ? 0 : B)) * M.   *h_expected_hits = number of hits generated (closed-form count).
+ */
+int fj_generate_build(fj_ctx* ctx, uint64_t* d_keys, uint64_t* d_vals, uint64_t first, size_t n, void* stream);
+int fj_generate_probe(fj_ctx* ctx, uint64_t* d_keys, uint64_t first, size_t n, uint64_t build_total,
+                      uint64_t seed, uint32_t hit_bp, uint64_t* h_expected_hits, void* stream);
+
+/*
+ * Diagnostic for the test-suite: runs total_bits (1..24) of radix partitioning over a flat
+ * device relation and writes the final per-bucket chunk lists, linearised bucket by bucket, into
+ * host arrays of n rows (h_out_vals may be NULL when d_vals is NULL).  *h_nvalid = rows written.
+ */
+int fj_debug_partition(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, int total_bits,
+                       int hash_top_bits, void* stream, uint64_t* h_out_keys, uint64_t* h_out_vals,
+                       uint32_t* h_bucket_of, uint64_t* h_nvalid);
+
+/* plain device memory helpers for hosts without another allocator */
+int fj_device_malloc(void** p, size_t bytes);
+int fj_device_free(void* p);
+int fj_memcpy_h2d(void* d, const void* h, size_t bytes);
+int fj_memcpy_d2h(void* h, const void* d, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASHJOIN_H */

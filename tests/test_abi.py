@@ -1,0 +1,106 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/flashjoin.h declares, the Python mirror exports the reference's names with the reference's
+keyword arguments, host-side validation works, and without a GPU the product fails LOUDLY
+(no CPU fallback)."""
+import inspect
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from flash_hash_join_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build_native()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from flash_hash_join_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "flashjoin.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # prose in comments may mention other names
+    declared = sorted(set(re.findall(r"\b(fj_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", out), f"{name} is not an exported text symbol"
+
+
+def test_library_contains_gfx950_code_object(lib):
+    from flash_hash_join_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"fj_partition_kernel" in blob and b"fj_lds_join_kernel" in blob
+
+
+def test_python_module_mirrors_reference_exports():
+    import flash_join
+    from flash_hash_join_amd import api
+    assert len(api.REFERENCE_EXPORTS) == 13
+    for name in api.REFERENCE_EXPORTS + api.ALIASES:
+        assert callable(getattr(flash_join, name)), name
+    for name in api.REFERENCE_EXPORTS:
+        if name == "initialize":
+            continue
+        params = list(inspect.signature(getattr(flash_join, name)).parameters)
+        assert params[:3] == ["build_keys", "build_values", "probe_keys"], name      # py::arg names, hash_join.cpp:605
+    assert flash_join.__doc__.startswith("A high-performance hash join library")     # hash_join.cpp:600
+
+
+def test_host_argument_normalisation():
+    from flash_hash_join_amd.api import _as_u64_host
+    a = _as_u64_host(np.array([-1, 2], dtype=np.int64), "x")
+    assert a.dtype == np.uint64 and int(a[0]) == 2**64 - 1                           # bit reinterpretation
+    b = _as_u64_host(np.arange(10, dtype=np.uint64)[::2], "x")                       # strided: made contiguous, not misread
+    assert b.tolist() == [0, 2, 4, 6, 8]
+    c = _as_u64_host(np.arange(6, dtype=np.uint64).reshape(2, 3), "x")               # N-D flattened
+    assert c.shape == (6,)
+    d = _as_u64_host(np.array([1, 2], dtype=np.int32), "x")
+    assert d.dtype == np.uint64
+    with pytest.raises(TypeError):
+        _as_u64_host(np.array(["a"]), "x")
+
+
+def test_length_mismatch_raises_before_any_device_work(lib):
+    import flash_join
+    with pytest.raises(ValueError):
+        flash_join.hash_join_count(np.arange(4, dtype=np.uint64), np.arange(3, dtype=np.uint64), np.arange(4, dtype=np.uint64))
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_a_gpu(lib):
+    import flash_join
+    assert lib.fj_device_count() == 0
+    with pytest.raises(RuntimeError, match="HIP device"):
+        flash_join.initialize()
+    k = np.arange(8, dtype=np.uint64)
+    with pytest.raises(RuntimeError):
+        flash_join.hash_join_count(k, k, k)          # no silent CPU path
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "flash_hash_join_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in src.lower().replace("test-suite with a stand-in engine", ""), os.path.join(dirpath, f)
+    assert "oracle" not in open(os.path.join(ROOT, "flash_join.py")).read().lower()
+
+
+def test_missing_library_is_an_import_error(tmp_path, monkeypatch):
+    from flash_hash_join_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()

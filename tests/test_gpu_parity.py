@@ -1,0 +1,254 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI via the
+flash_join drop-in module, against the CPU oracle and the committed golden vectors.
+Bit-exact bar: counts equal; materialised (key, value) pairs equal as multisets."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_inputs import CASES, make_case
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+COUNT_FUNCS = ["adaptive_join_count", "adaptive_join_count_bloom", "hash_join_count", "hash_join_count_bloom",
+               "hash_join_count_radix", "hash_join_count_radix_bloom"]
+MAT_FUNCS = ["adaptive_join", "adaptive_join_bloom", "hash_join", "hash_join_bloom", "hash_join_radix",
+             "hash_join_radix_bloom"]
+
+
+@pytest.fixture(scope="module")
+def fj():
+    import flash_join
+    from flash_hash_join_amd import _lib
+    assert _lib.load().fj_device_count() >= 1, "no HIP device: the product path must not silently fall back"
+    assert flash_join.initialize() is None
+    return flash_join
+
+
+def _digest(oracle, k, v):
+    k, v = oracle.canon_pairs(k, v)
+    return hashlib.sha256(k.tobytes() + v.tobytes()).hexdigest()
+
+
+def _golden():
+    with open(os.path.join(HERE, "golden", "golden_joins.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_all_twelve_functions_match_golden_vectors(fj, oracle, name):
+    g = _golden()[name]
+    bk, bv, pk = make_case(name)
+    for fn in COUNT_FUNCS + MAT_FUNCS:
+        res = getattr(fj, fn)(bk, bv, pk)
+        assert isinstance(res, tuple) and len(res) == 2, fn             # (int, float) like the reference
+        assert isinstance(res[0], int) and isinstance(res[1], float), fn
+        assert res[0] == g["count"], (fn, res[0], g["count"])
+    for fn in MAT_FUNCS:
+        n, sec, k, v = getattr(fj, fn)(bk, bv, pk, return_arrays=True)
+        assert n == g["count"] and k.size == n and v.size == n, fn
+        assert _digest(oracle, k, v) == g["pairs_sha256"], fn
+
+
+def test_against_c_oracle_on_fresh_random_inputs(fj, oracle):
+    rng = np.random.default_rng(2024)
+    for nb, npk in [(1, 1), (2, 3), (255, 1000), (4096, 50000), (4097, 50000), (30000, 1), (123457, 654321)]:
+        bk = np.unique(rng.integers(0, 2**64, size=nb, dtype=np.uint64))
+        bv = rng.integers(0, 2**64, size=bk.size, dtype=np.uint64)
+        pk = np.concatenate([rng.choice(bk, npk // 2 + 1), rng.integers(0, 2**64, size=npk // 2, dtype=np.uint64)])
+        exp, _, ek, ev = oracle.c_join(bk, bv, pk, algo="radix", materialize=True, return_arrays=True)
+        assert exp == oracle.np_join(bk, bv, pk)
+        for fn in COUNT_FUNCS:
+            assert getattr(fj, fn)(bk, bv, pk)[0] == exp, (fn, nb, npk)
+        for fn in ("hash_join", "hash_join_radix"):
+            n, _, k, v = getattr(fj, fn)(bk, bv, pk, return_arrays=True)
+            assert n == exp
+            a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (fn, nb, npk)
+
+
+def test_empty_inputs_return_zero(fj):
+    e = np.empty(0, dtype=np.uint64)
+    one = np.array([7], dtype=np.uint64)
+    for fn in COUNT_FUNCS + MAT_FUNCS:
+        f = getattr(fj, fn)
+        assert f(e, e, one)[0] == 0 and f(one, one, e)[0] == 0 and f(e, e, e)[0] == 0
+    n, _, k, v = fj.hash_join_radix(e, e, one, return_arrays=True)
+    assert n == 0 and k.size == 0 and v.size == 0
+
+
+def test_int64_inputs_and_duplicates(fj, oracle):
+    bk = np.array([-1, -2, 5, 5, 5, 0], dtype=np.int64)
+    bv = np.array([1, 2, 3, 3, 3, 9], dtype=np.int64)
+    pk = np.array([-1, 5, 5, -3, 0, 2**63 - 1, -2], dtype=np.int64)
+    exp = oracle.np_join(bk, bv, pk)
+    assert exp == 5
+    for fn in COUNT_FUNCS:
+        assert getattr(fj, fn)(bk, bv, pk)[0] == exp
+    n, _, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+    pairs = sorted(zip(k.view(np.int64).tolist(), v.tolist()))
+    assert pairs == sorted([(-1, 1), (5, 3), (5, 3), (0, 9), (-2, 2)])
+
+
+def test_adaptive_threshold_both_sides(fj, oracle):
+    """B = 999,999 and 1,000,000 (the reference's switch point, hash_join.cpp:576) both correct."""
+    from flash_hash_join_amd import datagen
+    for nb in (999_999, 1_000_000):
+        bk, bv = datagen.build_numpy(nb)
+        pk, exp = datagen.probe_numpy(300_000, nb, seed=3, hit_bp=5000)
+        assert fj.adaptive_join_count(bk, bv, pk)[0] == exp
+        assert fj.adaptive_join_count_bloom(bk, bv, pk)[0] == exp
+
+
+def test_lds_overflow_falls_back_to_global_table(fj, oracle):
+    """Every build key lands in ONE radix partition (> LDS table capacity): the radix path must detect
+    it and the global-table path must produce the exact result."""
+    def fmix(k):
+        k = k.copy()
+        with np.errstate(over="ignore"):
+            k ^= k >> np.uint64(33); k *= np.uint64(0xff51afd7ed558ccd)
+            k ^= k >> np.uint64(33); k *= np.uint64(0xc4ceb9fe1a85ec53)
+            k ^= k >> np.uint64(33)
+        return k
+    cand = np.arange(1, 200000, dtype=np.uint64)
+    bk = cand[(fmix(cand) >> np.uint64(60)) == 0][:9000]          # top 4 hash bits equal -> same partition for <= 16 partitions
+    assert bk.size == 9000
+    bv = bk + np.uint64(1)
+    pk = np.concatenate([bk, cand[:50000]])
+    exp = oracle.np_join(bk, bv, pk)
+    n, sec = fj.hash_join_count_radix(bk, bv, pk)
+    assert n == exp
+    assert fj.last_timings()["fell_back"] == 1
+    n, _, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+    assert n == exp and np.array_equal(np.sort(v), np.sort(k) + np.uint64(1))
+
+
+def test_device_tensor_inputs_and_device_generators(fj, oracle):
+    import torch
+    from flash_hash_join_amd import datagen
+    nb, npk = 300_000, 2_000_000
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=1, hit_bp=5000)
+    hbk, hbv = datagen.build_numpy(nb)
+    hpk, hexp = datagen.probe_numpy(npk, nb, seed=1, hit_bp=5000)
+    assert exp == hexp                                                              # same generator on both sides
+    assert np.array_equal(dbk.cpu().numpy().view(np.uint64), hbk)
+    assert np.array_equal(dbv.cpu().numpy().view(np.uint64), hbv)
+    assert np.array_equal(dpk.cpu().numpy().view(np.uint64), hpk)
+    for fn in COUNT_FUNCS:
+        assert getattr(fj, fn)(dbk, dbv, dpk)[0] == exp, fn
+    n, sec, k, v = fj.hash_join_radix(dbk, dbv, dpk, return_arrays=True)
+    assert n == exp and k.is_cuda and k.numel() == n
+    kk, vv = k.cpu().numpy().view(np.uint64), v.cpu().numpy().view(np.uint64)
+    assert np.array_equal(kk, (vv + np.uint64(1)) * datagen.M)                      # value i belongs to key (i+1)*M
+    _, ek, ev = oracle.np_join(hbk, hbv, hpk, return_arrays=True)
+    a, b = oracle.canon_pairs(kk, vv), oracle.canon_pairs(ek, ev)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("n,bits,with_vals", [(1000, 3, True), (100_000, 8, False), (300_000, 7, True),
+                                                (2_000_000, 13, False), (1_500_000, 10, True), (700_001, 16, False)])
+def test_partition_pass_in_isolation(fj, n, bits, with_vals):
+    """fj_debug_partition: the chunk lists are a permutation of the input and every row sits in the
+    bucket named by the top `bits` bits of its hash (1 pass for bits <= 8, 2 passes above)."""
+    import ctypes
+    import torch
+    from flash_hash_join_amd import _lib, api
+    L = _lib.load()
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    keys[: n // 10] = keys[0]                                                    # a heavy duplicate: skewed bucket
+    vals = np.arange(n, dtype=np.uint64)
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    dv = torch.from_numpy(vals.view(np.int64)).cuda() if with_vals else None
+    ok = np.zeros(n, dtype=np.uint64); ov = np.zeros(n, dtype=np.uint64); ob = np.zeros(n, dtype=np.uint32)
+    nvalid = ctypes.c_uint64(0)
+    _lib.check(L.fj_debug_partition(api.context(0), dk.data_ptr(), dv.data_ptr() if with_vals else None, n, bits, 64,
+                                    torch.cuda.current_stream(0).cuda_stream, ok.ctypes.data,
+                                    ov.ctypes.data if with_vals else None, ob.ctypes.data, ctypes.byref(nvalid)))
+    assert nvalid.value == n
+    h = keys.copy()
+    with np.errstate(over="ignore"):
+        h ^= h >> np.uint64(33); h *= np.uint64(0xff51afd7ed558ccd)
+        h ^= h >> np.uint64(33); h *= np.uint64(0xc4ceb9fe1a85ec53)
+        h ^= h >> np.uint64(33)
+    if with_vals:
+        assert np.array_equal(np.sort(ov), vals)                                 # permutation of the rows
+        assert np.array_equal(keys[ov.astype(np.int64)], ok)                     # values travelled with their keys
+        assert np.array_equal((h >> np.uint64(64 - bits)).astype(np.uint32)[ov.astype(np.int64)], ob)
+    else:
+        assert np.array_equal(np.sort(ok), np.sort(keys))
+        ho = ok.copy()
+        with np.errstate(over="ignore"):
+            ho ^= ho >> np.uint64(33); ho *= np.uint64(0xff51afd7ed558ccd)
+            ho ^= ho >> np.uint64(33); ho *= np.uint64(0xc4ceb9fe1a85ec53)
+            ho ^= ho >> np.uint64(33)
+        assert np.array_equal((ho >> np.uint64(64 - bits)).astype(np.uint32), ob)
+    assert np.all(np.diff(ob.astype(np.int64)) >= 0)
+
+
+def test_owner_split_then_local_joins_equals_global_join(fj):
+    """Multi-GPU building blocks on one GPU: split into 8 owner segments, join each with
+    hash_top_bits=48, sum == global count; segments are a permutation of the input."""
+    import ctypes
+    import torch
+    from flash_hash_join_amd import datagen, api
+    from flash_hash_join_amd.distributed import HipEngine
+    nb, npk, world = 1_000_000, 5_000_000, 8
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=5, hit_bp=2500)
+    eng = HipEngine("cuda:0")
+    bk_s, bv_s, bc = eng.owner_split(dbk, dbv, world)
+    pk_s, _, pc = eng.owner_split(dpk, None, world)
+    assert sum(bc) == nb and sum(pc) == npk
+    assert torch.equal(torch.sort(bk_s)[0], torch.sort(dbk)[0])
+    assert torch.equal(torch.sort(pk_s)[0], torch.sort(dpk)[0])
+    i = torch.argsort(bk_s)
+    j = torch.argsort(dbk)
+    assert torch.equal(bv_s[i], dbv[j])                                            # values moved with their keys
+    total, bo, po = 0, 0, 0
+    for r in range(world):
+        assert abs(bc[r] - nb / world) < 0.05 * nb / world                           # balanced for uniform keys
+        n, _ = api.join_device(api.ALGO_RADIX, 0, 0, bk_s[bo:bo + bc[r]].clone(), bv_s[bo:bo + bc[r]].clone(),
+                               pk_s[po:po + pc[r]].clone(), hash_top_bits=48)
+        total += n
+        bo += bc[r]; po += pc[r]
+    assert total == exp
+
+
+@pytest.mark.parametrize("nb,npk,hit_bp,fn", [
+    (1_000_000, 100_000_000, 5000, "hash_join_count"),            # BASELINE config 2
+    (1_000_000, 100_000_000, 5000, "hash_join_count_radix"),
+    (100_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),  # BASELINE config 3
+    (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom"),   # BASELINE config 4 (radix form)
+])
+def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn):
+    """BASELINE.json's full sizes, checked through the size-independent property of the generator:
+    the match count equals the number of generated hits."""
+    import torch
+    from flash_hash_join_amd import datagen
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=1, hit_bp=hit_bp)
+    assert abs(exp - npk * hit_bp / 10000) < 6 * (npk ** 0.5)
+    n, sec = getattr(fj, fn)(dbk, dbv, dpk)
+    assert n == exp
+    n2, _ = getattr(fj, fn)(dbk, dbv, dpk)                                         # idempotent, workspace reuse
+    assert n2 == exp
+    del dbk, dbv, dpk
+    torch.cuda.empty_cache()
+
+
+def test_full_size_materialize_pairs_property(fj):
+    """10M x 100M materialise: every emitted pair satisfies key == (value+1)*M, count is closed-form."""
+    import torch
+    from flash_hash_join_amd import datagen
+    nb, npk = 10_000_000, 100_000_000
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=9, hit_bp=5000)
+    n, sec, k, v = fj.hash_join_radix(dbk, dbv, dpk, return_arrays=True)
+    assert n == exp and k.numel() == exp
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")      # 0x9E3779B97F4A7C15 as int64
+    assert bool(torch.all((v + 1) * M == k))
