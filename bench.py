@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X hash-join hot path.
+
+  python bench.py --gpus N --steps K --warmup W            (N=1 directly; N>1 under torch.distributed.run)
+
+A "step" is one whole join (build phase + probe phase, count) of the workload over synthetic
+uniform-random int64 keys that are already resident in HBM when the timed region starts:
+
+  N = 1 : BASELINE.json configs[2], the configuration the metric's target is quoted on:
+          hash_join_count_radix, 100M build x 1B probe rows, 50 % hit rate, one MI355X.
+  N > 1 : the same 100M x 1B rows PER GPU (weak scaling), block-distributed, joined with one RCCL
+          all-to-all per relation over xGMI (flash_hash_join_amd/distributed.py).
+
+value = probes processed by all ranks / wall time of the K timed steps (max over ranks), in
+G probes/s, end to end (build side included).  The probe-phase-only rate, the build time, the
+roofline of the dominant kernel (probe-side partition pass) and the CPU baseline (the oracle's
+restatement of the reference algorithm on this box's host cores, bounded sample) ride along in the
+same JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide
+
+WORKLOADS = {
+    # name: (build rows per GPU, probe rows per GPU, hit rate in basis points, function)
+    "c2": (1_000_000, 100_000_000, 5000, "hash_join_count"),
+    "c2_radix": (1_000_000, 100_000_000, 5000, "hash_join_count_radix"),
+    "c3": (100_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
+    "c4": (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom"),
+    "c4_scalar_bloom": (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),
+    "c3_mat": (100_000_000, 1_000_000_000, 5000, "hash_join_radix"),
+    "small": (1_000_000, 10_000_000, 5000, "hash_join_count_radix"),
+}
+
+
+def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int) -> dict:
+    """Oracle restatement of the reference CPU path (hash_join.cpp:498-534 radix count), all host cores,
+    on a bounded sample of the same generator.  A reported baseline, not a target."""
+    import numpy as np
+    from flash_hash_join_amd import datagen
+    from oracle import oracle as O
+    O.build()
+    bk, bv = datagen.build_device(sample_b, device)
+    pk, exp = datagen.probe_device(sample_p, sample_b, device, seed=1, hit_bp=hit_bp)
+    hbk, hbv, hpk = (x.cpu().numpy().view(np.uint64) for x in (bk, bv, pk))
+    del bk, bv, pk
+    cores = O.lib().fjo_default_threads()
+    best = None
+    t_all = time.perf_counter()
+    for _ in range(3):
+        n, sec = O.c_join(hbk, hbv, hpk, algo="adaptive", bloom=False, materialize=False, threads=0)
+        assert n == exp, (n, exp)
+        best = sec if best is None else min(best, sec)
+        if time.perf_counter() - t_all > 25:
+            break
+    return {"value": round(sample_p / best / 1e9, 5), "unit": "Gprobes/s", "cores": int(cores), "kind": "port",
+            "sample": f"adaptive_join_count (radix path) restatement, {sample_b} build x {sample_p} probe rows, "
+                      f"{hit_bp / 100:.0f}% hits, best of <=3, core_duration_sec={best:.3f}s",
+            "hw_crc32c": bool(O.lib().fjo_uses_hw_crc())}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (debugging)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from flash_hash_join_amd import api, datagen
+    from flash_hash_join_amd.distributed import HipEngine, distributed_join
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` "
+                             f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    nb_gpu, np_gpu, hit_bp, fn_name = WORKLOADS[args.workload]
+    nb_gpu, np_gpu = max(1, int(nb_gpu * args.scale)), max(1, int(np_gpu * args.scale))
+    nb_total, np_total = nb_gpu * world, np_gpu * world
+    algo = {"hash_join_count": api.ALGO_SCALAR, "hash_join_count_bloom": api.ALGO_SCALAR}.get(fn_name, api.ALGO_RADIX)
+    bloom = int("bloom" in fn_name)
+    materialize = int(fn_name in ("hash_join_radix", "hash_join"))
+
+    api.initialize() if local_rank == 0 else api.context(local_rank)
+    bk, bv = datagen.build_device(nb_gpu, device, first=rank * nb_gpu)
+    pk, exp_local = datagen.probe_device(np_gpu, nb_total, device, seed=1, hit_bp=hit_bp, first=rank * np_gpu)
+    exp_total = exp_local
+    if world > 1:
+        e = torch.tensor([exp_local], dtype=torch.int64, device=device)
+        dist.all_reduce(e)
+        exp_total = int(e.item())
+    engine = HipEngine(device) if world > 1 else None
+
+    part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": []}
+    dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
+
+    def step(record: bool) -> int:
+        nonlocal part_launches
+        if world == 1:
+            res = api.join_device(algo, bloom, materialize, bk, bv, pk, return_arrays=False)
+        else:
+            t = {}
+            res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t)
+            if record:
+                for k in dtimes:
+                    dtimes[k].append(t.get(k, 0.0))
+        if record:
+            lt = api.last_timings()
+            for i in range(lt["passes"]):
+                part_ms.append(lt["probe_part_kernel_ms"][i]); part_launches += 1
+            phase["build_ms"].append(lt["build_phase_ms"]); phase["probe_ms"].append(lt["probe_phase_ms"])
+            phase["join_ms"].append(lt["join_ms"]); phase["total_ms"].append(lt["total_ms"]); phase["emit_ms"].append(lt["emit_ms"])
+        return int(res[0])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        got = step(False)
+        assert got == exp_total, f"warmup count {got} != expected {exp_total}"
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = step(True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    assert got == exp_total, f"count {got} != expected {exp_total}"
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e.item())
+
+    lt = api.last_timings()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = np_total * args.steps / elapsed / 1e9
+    mean = lambda xs: (sum(xs) / len(xs)) if xs else 0.0
+
+    # ---- roofline of the dominant kernel: probe-side partition pass, 8 B read + 8 B written per key
+    rows_per_launch = (lt.get("partitions") and np_gpu) if world == 1 else None
+    roof = None
+    if part_ms:
+        avg_ms = mean(part_ms)
+        rows = np_gpu if world == 1 else mean([float(x) for x in [np_gpu]])
+        alg_bytes = 16.0 * rows
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp) and world == 1 and args.workload == "c3" and args.scale == 1.0:
+            try:
+                traffic = json.load(open(tp)).get("fj_partition_kernel_keys_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches,
+                "traffic": traffic}
+    elif world == 1:
+        # non-partitioned workloads: the probe kernel is the dominant one; 8 B key + one 64-B group per probe
+        avg_ms = mean(phase["join_ms"])
+        alg_bytes = (8.0 + 16.0) * np_gpu
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+        roof = {"bound": "hbm", "kernel": "fj_gt_probe_kernel (non-partitioned probe)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": args.steps,
+                "traffic": None}
+
+    # phase-level accounting with SURVEY 8(d)'s formula for the declared k
+    k = lt["passes"]
+    probe_ms, build_ms = mean(phase["probe_ms"]), mean(phase["build_ms"])
+    phases = {
+        "k_radix_passes": k, "radix_bits": lt["radix_bits"], "partitions": lt["partitions"], "path": lt["path"],
+        "build_phase_ms": round(build_ms, 3), "probe_phase_ms": round(probe_ms, 3), "join_kernel_ms": round(mean(phase["join_ms"]), 3),
+        "device_total_ms": round(mean(phase["total_ms"]), 3),
+        "probe_phase_gprobes_per_s": round(np_gpu / (probe_ms * 1e-3) / 1e9, 2) if probe_ms else None,
+        "probe_phase_algorithmic_bytes": (24 * k + 8) * np_gpu,
+        "probe_phase_frac_of_hbm_peak": round((24 * k + 8) * np_gpu / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if probe_ms else None,
+        "build_phase_algorithmic_bytes": (40 * k + 16) * nb_gpu,
+    }
+    if world > 1:
+        phases.update({kk: round(mean(v) * 1e3, 3) for kk, v in (("split_ms", dtimes["split_s"]), ("exchange_ms", dtimes["exchange_s"]),
+                                                                 ("local_join_ms", dtimes["join_s"]))})
+
+    out = {
+        "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",
+        "value": round(value, 3), "unit": "Gprobes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int64", "data": "synthetic",
+        "config": {"workload": f"{fn_name}: {nb_gpu} build x {np_gpu} probe int64 rows per GPU, {hit_bp / 100:.0f}% hit rate"
+                               + (" (BASELINE configs[2])" if args.workload == "c3" and args.scale == 1.0 else ""),
+                   "function": fn_name, "build_rows_total": nb_total, "probe_rows_total": np_total,
+                   "matches": exp_total, "parallelism": f"radix-owner x{world}" if world > 1 else "single GPU"},
+        "build_time_ms": round(build_ms, 3),
+        "phases": phases,
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            sb, sp = (10_000_000, 100_000_000) if nb_gpu >= 10_000_000 else (nb_gpu, min(np_gpu, 100_000_000))
+            del bk, bv, pk
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
+        except Exception as ex:      # the baseline never blocks the GPU measurement
+            out["cpu_baseline"] = {"error": repr(ex)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
