@@ -41,12 +41,13 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     u32 err;
     u32 flags;
     u32 alloc[8];                      // [side*4 + pass] chunk allocators
+    u32 seg_counter[8];                // [side*4 + pass] segment ids
     unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
 };
 
 enum Slot {
     // [side][pingpong][kind]
-    W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_BKEYS, W_BOFF, W_KINDS,
+    W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_REL, W_BOFF, W_SEGOFF, W_TOFF, W_TILES, W_KINDS,
     W_SIDE_STRIDE = 2 * W_KINDS,
     W_PART_COUNT = 2 * W_SIDE_STRIDE, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
     W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_NSLOTS
@@ -116,6 +117,8 @@ int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, 
     int used = top_bits;
     u64 lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
     const u32 tile_chunks = vals ? 8 : 16;
+    const uint4* tiles = nullptr;
+    const u32* ntiles = nullptr;
     for (int i = 0; i < plan.npass; ++i) {
         const u32 F = 1u << plan.fan_log[i];
         used -= plan.fan_log[i];
@@ -126,30 +129,35 @@ int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, 
         if (cap64 >= (1ull << 24) || nb_out >= (1u << 22))
             return set_err("relation of %zu rows is too large for one GPU's chunk directory", n);
         FjChunkSet cs{};
-        cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0;
+        cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0; cs.fan_mask = F - 1; cs.max_segs = G + parents + 2;
         const int base = side * W_SIDE_STRIDE + (i & 1) * W_KINDS;
         void* p;
         if (get_buf(c, base + W_POOL_K, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.keys = (u64*)p;
         cs.vals = nullptr;
         if (vals) { if (get_buf(c, base + W_POOL_V, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.vals = (u64*)p; }
         if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
+        if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
         if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
         if (get_buf(c, base + W_BCHUNKS, nb_out * 4, &p)) return 1; cs.bchunks = (u32*)p;
-        if (get_buf(c, base + W_BKEYS, nb_out * 8, &p)) return 1; cs.bkeys = (u64*)p;
         if (get_buf(c, base + W_BOFF, (nb_out + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
+        if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * F * 4, &p)) return 1; cs.seg_off = (u32*)p;
         cs.alloc = &c->d_sc->alloc[side * 4 + i];
         HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
+        HIPCHK(hipMemsetAsync(cs.bchunks, 0, nb_out * 4, s));
         HIPCHK(hipMemsetAsync(cs.alloc, 0, 4, s));
+        HIPCHK(hipMemsetAsync(&c->d_sc->seg_counter[side * 4 + i], 0, 4, s));
 
         FjPartArgs a{};
         if (have_prev) {
             a.in_keys = prev.keys; a.in_vals = prev.vals; a.in_list = prev.list; a.in_dir = prev.dir;
-            a.in_nlist = prev.boff + prev.nb; a.n_flat = 0;
+            a.in_tiles = tiles; a.in_ntiles = ntiles; a.n_flat = 0;
         } else {
-            a.in_keys = keys; a.in_vals = vals; a.in_list = nullptr; a.in_dir = nullptr; a.in_nlist = nullptr; a.n_flat = n;
+            a.in_keys = keys; a.in_vals = vals; a.in_list = nullptr; a.in_dir = nullptr; a.in_tiles = nullptr; a.in_ntiles = nullptr; a.n_flat = n;
         }
         a.parent0 = 0;
-        a.out_keys = cs.keys; a.out_vals = cs.vals; a.out_dir = cs.dir; a.alloc = cs.alloc; a.cap_chunks = cs.cap;
+        a.out_keys = cs.keys; a.out_vals = cs.vals; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off;
+        a.bchunks = cs.bchunks; a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[side * 4 + i];
+        a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
         a.err = &c->d_sc->err;
         a.shift = (u32)used; a.fan_log = (u32)plan.fan_log[i];
         const int line_log = F <= 128 ? 4 : 3;
@@ -157,8 +165,15 @@ int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, 
         HIPCHK(fj_launch_partition(a, vals != nullptr, line_log, G, s));
         if (ev_cursor) { HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor) + 1], s)); ++*ev_cursor; }
         HIPCHK(fj_launch_group(cs, s));
-        prev = cs; have_prev = true;
         lbound = n / FJ_CHUNK + 1 + (u64)(G + parents) * F;
+        if (i + 1 < plan.npass) {           // tile table for the next pass over this level
+            const u64 max_tiles = lbound / tile_chunks + nb_out + 1;
+            if (get_buf(c, base + W_TOFF, (nb_out + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
+            if (get_buf(c, base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1;
+            HIPCHK(fj_launch_tile_table(cs, tile_chunks, toff, (uint4*)p, (u32)max_tiles, s));
+            tiles = (const uint4*)p; ntiles = toff + nb_out;
+        }
+        prev = cs; have_prev = true;
         parents = (u32)nb_out;
     }
     if (!have_prev) {       // no pass needed: the join kernel reads the flat arrays as virtual chunks

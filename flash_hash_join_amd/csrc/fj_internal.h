@@ -13,15 +13,21 @@ struct FjPartArgs {
     const u64* in_vals;
     const u32* in_list;
     const u32* in_dir;
-    const u32* in_nlist;     // device scalar: number of list entries
+    const uint4* in_tiles;   // list input: tile table {first list index, chunks, bucket, -}
+    const u32* in_ntiles;    // device scalar: number of tiles
     u64 n_flat;
     u32 parent0;             // bucket id of every key of a flat input
     // output chunk pool
     u64* out_keys;
     u64* out_vals;
     u32* out_dir;            // pre-set to FJ_DIR_INVALID
+    u64* out_rel;            // per chunk: (producing segment << 32) | rank inside (segment, bucket)
+    u32* seg_off;            // [max_segs][F] span offset of a segment inside a bucket's chunk list
+    u32* bchunks;            // [nb_out] chunks per bucket (zeroed before the pass)
     u32* alloc;              // device scalar: next unallocated chunk id (zeroed before the pass)
+    u32* seg_counter;        // device scalar: next segment id (zeroed before the pass)
     u32 cap_chunks;
+    u32 max_segs;
     u32* err;
     // radix digit: bucket = (hash >> shift) & (2^fan_log - 1)
     u32 shift;
@@ -34,11 +40,14 @@ struct FjChunkSet {
     u64* vals;               // nullptr for the probe side
     u64 n_flat;
     u32* dir;                // [cap]
+    u64* rel;                // [cap]
+    u32* seg_off;            // [max_segs][fan]
     u32* alloc;              // device scalar
     u32 cap;
     u32 nb;                  // number of buckets at this level
-    u32* bchunks;            // [nb]   scratch / cursors
-    u64* bkeys;              // [nb]   keys per bucket
+    u32 fan_mask;            // fan-out of the producing pass - 1
+    u32 max_segs;
+    u32* bchunks;            // [nb]   chunks per bucket
     u32* boff;               // [nb+1] chunk-list offsets; boff[nb] = list length
     u32* list;               // [cap]  chunk ids grouped by bucket
 };
@@ -46,6 +55,7 @@ struct FjChunkSet {
 u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log);
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s);
 hipError_t fj_launch_group(const FjChunkSet& cs, hipStream_t s);
+hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, hipStream_t s);
 hipError_t fj_launch_scan_u32_to_u64(const u32* in, u64* out, u32 n, hipStream_t s);
 
 // ---- joins ------------------------------------------------------------------------------------

@@ -53,15 +53,24 @@ __device__ __forceinline__ void chunk_at(const FjChunkSet& cs, u32 idx, u32& id,
     }
 }
 
-// grid = nb * nsplit work items: item = (partition p, slice of p's probe chunks).  Every item
+constexpr u32 JB_META = 128;    // build-side chunk metadata staged in LDS per batch
+constexpr u32 JP_META = 512;    // probe-side chunk metadata staged in LDS per batch
+
+// grid = nparts * nsplit work items: item = (partition p, slice of p's probe chunks).  Every item
 // rebuilds p's table in LDS (cheap: the build side of a partition is <= a few thousand rows and
 // is L2 / Infinity-Cache resident), so small-build joins still fill the chip.
+// Probe keys are prefetched one round (8 keys per lane, 4 x 16-B loads) ahead; the first round is
+// requested before the table is even initialised, so HBM reads overlap the build.
 template <bool MAT, int NT>
 __global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     JoinHdr* hdr = reinterpret_cast<JoinHdr*>(smem);
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(JoinHdr));
-    u64* tvals = tkeys + S;        // only touched when MAT
+    u64* tvals = tkeys + S;        // only present when MAT
+    u32* pm_id = reinterpret_cast<u32*>(tkeys + (MAT ? 2 * S : S));
+    u32* pm_cnt = pm_id + JP_META;
+    u32* bm_id = pm_cnt + JP_META;
+    u32* bm_cnt = bm_id + JB_META;
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 item = blockIdx.x, p = item / a.nsplit, slice = item % a.nsplit;
 
@@ -77,21 +86,55 @@ __global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     }
     if (MAT && a.part_count[item] == 0) return;
 
+    constexpr u32 CPL = NT / (FJ_CHUNK / 2);          // chunks covered by one 16-B load per lane
+    constexpr u32 CPR = 4 * CPL;                      // chunks per round (4 loads per lane)
+    // request one round of probe keys of the current metadata batch
+    auto load_round = [&](u32 r, u32 nbatch, u64 (&kk)[8], u32& okm) {
+        okm = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 c = r * CPR + u * CPL + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
+            kk[2 * u] = 0; kk[2 * u + 1] = 0;
+            if (c < nbatch) {
+                const u32 cnt = pm_cnt[c];
+                const u64 base = (u64)pm_id[c] * FJ_CHUNK + off;
+                if (off + 1 < cnt) {
+                    const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + base);
+                    kk[2 * u] = q.x; kk[2 * u + 1] = q.y; okm |= 3u << (2 * u);
+                } else if (off < cnt) {
+                    kk[2 * u] = a.probe.keys[base]; okm |= 1u << (2 * u);
+                }
+            }
+        }
+    };
+    auto load_probe_meta = [&](u32 first, u32 nbatch) {
+        for (u32 i = tid; i < nbatch; i += NT) { u32 id, cnt; chunk_at(a.probe, p0 + first + i, id, cnt); pm_id[i] = id; pm_cnt[i] = cnt; }
+    };
+
+    // ---- first probe batch: metadata, then the first round of keys goes in flight ---------------
+    u32 nbatch = (s_hi - s_lo) < JP_META ? (s_hi - s_lo) : JP_META;
+    load_probe_meta(s_lo, nbatch);
     for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
     if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->cursor = 0; hdr->claimed = 0; hdr->full = 0; hdr->empty_val = 0; }
     __syncthreads();
+    u64 kn[8];
+    u32 okn = 0;
+    load_round(0, nbatch, kn, okn);
 
     // ---- build: first claim of a key wins, later duplicates are dropped (hash_join.cpp:125) ----
     u32 claimed = 0;
-    for (u32 ci = 0; ci < nbc; ci += NT / FJ_CHUNK) {
-        const u32 c = ci + tid / FJ_CHUNK, off = tid % FJ_CHUNK;
-        if (c < nbc) {
-            u32 id, cnt;
-            chunk_at(a.build, b0 + c, id, cnt);
-            if (off < cnt) {
-                const u64 key = a.build.keys[(u64)id * FJ_CHUNK + off];
+    for (u32 bb = 0; bb < nbc; bb += JB_META) {
+        const u32 nbb = (nbc - bb) < JB_META ? (nbc - bb) : JB_META;
+        if (bb) __syncthreads();
+        if (tid < nbb) { u32 id, cnt; chunk_at(a.build, b0 + bb + tid, id, cnt); bm_id[tid] = id; bm_cnt[tid] = cnt; }
+        __syncthreads();
+        for (u32 ci = 0; ci < nbb; ci += NT / FJ_CHUNK) {
+            const u32 c = ci + tid / FJ_CHUNK, off = tid % FJ_CHUNK;
+            if (c < nbb && off < bm_cnt[c]) {
+                const u64 src = (u64)bm_id[c] * FJ_CHUNK + off;
+                const u64 key = a.build.keys[src];
                 u64 val = 0;
-                if (MAT) val = a.build.vals[(u64)id * FJ_CHUNK + off];
+                if (MAT) val = a.build.vals[src];
                 if (key == FJ_EMPTY_KEY) {
                     hdr->has_empty = 1;
                     if (MAT) hdr->empty_val = val;
@@ -120,56 +163,52 @@ __global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     const bool has_empty = hdr->has_empty != 0;
     const u64 obase = MAT ? a.out_off[item] : 0;
 
-    // ---- probe: 16 B (2 keys) per lane per load, two loads in flight ---------------------------
+    // ---- probe ------------------------------------------------------------------------------------
     u32 local = 0;
-    constexpr u32 CPI = NT / (FJ_CHUNK / 2);          // chunks covered by one load round
-    for (u32 ci = s_lo; ci < s_hi; ci += 2 * CPI) {
-        u64 k[4] = {0, 0, 0, 0};
-        bool ok[4] = {false, false, false, false};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const u32 c = ci + u * CPI + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
-            if (c < s_hi) {
-                u32 id, cnt;
-                chunk_at(a.probe, p0 + c, id, cnt);
-                if (off + 1 < cnt) {
-                    const u64x2 kk = *reinterpret_cast<const u64x2*>(a.probe.keys + (u64)id * FJ_CHUNK + off);
-                    k[2 * u] = kk.x; k[2 * u + 1] = kk.y;
-                    ok[2 * u] = true; ok[2 * u + 1] = true;
-                } else if (off < cnt) {
-                    k[2 * u] = a.probe.keys[(u64)id * FJ_CHUNK + off];
-                    ok[2 * u] = true;
-                }
-            }
+    for (u32 pb = s_lo; pb < s_hi; pb += JP_META) {
+        if (pb != s_lo) {                           // later batches (only very large partitions get here)
+            nbatch = (s_hi - pb) < JP_META ? (s_hi - pb) : JP_META;
+            __syncthreads();
+            load_probe_meta(pb, nbatch);
+            __syncthreads();
+            load_round(0, nbatch, kn, okn);
         }
+        const u32 nrounds = (nbatch + CPR - 1) / CPR;
+        for (u32 r = 0; r < nrounds; ++r) {
+            u64 k[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bool hit = false;
-            u64 val = 0;
-            if (ok[i]) {
-                if (k[i] == FJ_EMPTY_KEY) {
-                    hit = has_empty;
-                    if (MAT) val = hdr->empty_val;
-                } else {
-                    u32 where = 0;
-                    hit = lds_lookup(tkeys, k[i], fj_hash64(k[i]), where);
-                    if (MAT && hit) val = tvals[where];
-                }
-            }
-            if (MAT) {      // wave-uniform point: ballot-rank the hits, one LDS cursor bump per wave
-                const u64 m = __ballot(hit);
-                if (m) {
-                    u32 wb = 0;
-                    if (lane == 0) wb = atomicAdd(&hdr->cursor, (u32)__popcll(m));
-                    wb = __shfl(wb, 0, 64);
-                    if (hit) {
-                        const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                        a.out_keys[o] = k[i];
-                        a.out_vals[o] = val;
+            for (int i = 0; i < 8; ++i) k[i] = kn[i];
+            const u32 okm = okn;
+            if (r + 1 < nrounds) load_round(r + 1, nbatch, kn, okn);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bool hit = false;
+                u64 val = 0;
+                if (okm & (1u << i)) {
+                    if (k[i] == FJ_EMPTY_KEY) {
+                        hit = has_empty;
+                        if (MAT) val = hdr->empty_val;
+                    } else {
+                        u32 where = 0;
+                        hit = lds_lookup(tkeys, k[i], fj_hash64(k[i]), where);
+                        if (MAT && hit) val = tvals[where];
                     }
                 }
-            } else {
-                local += hit ? 1u : 0u;
+                if (MAT) {      // wave-uniform point: ballot-rank the hits, one LDS cursor bump per wave
+                    const u64 m = __ballot(hit);
+                    if (m) {
+                        u32 wb = 0;
+                        if (lane == 0) wb = atomicAdd(&hdr->cursor, (u32)__popcll(m));
+                        wb = __shfl(wb, 0, 64);
+                        if (hit) {
+                            const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                            a.out_keys[o] = k[i];
+                            a.out_vals[o] = val;
+                        }
+                    }
+                } else {
+                    local += hit ? 1u : 0u;
+                }
             }
         }
     }
@@ -407,13 +446,13 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s) {
     const u32 nb = a.nparts * a.nsplit;
     if (materialize) {
-        const u32 lds = sizeof(JoinHdr) + 2 * S * 8;
+        const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + (JP_META + JB_META) * 8;
         auto kern = fj_lds_join_kernel<true, 1024>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     } else {
-        const u32 lds = sizeof(JoinHdr) + S * 8;
+        const u32 lds = sizeof(JoinHdr) + S * 8 + (JP_META + JB_META) * 8;
         auto kern = fj_lds_join_kernel<false, 512>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

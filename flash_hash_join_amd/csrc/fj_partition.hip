@@ -4,15 +4,18 @@
 // its structure.  The reference does histogram -> prefix -> scatter with 8-byte random
 // stores.  Here one pass is a single kernel with NO histogram read:
 //
-//   * persistent workgroups each take a contiguous slice of the input;
+//   * persistent workgroups each take a contiguous run of input tiles; the keys of tile t+1 are
+//     prefetched into registers (and the chunk metadata of tile t+2) while tile t is processed,
+//     so HBM reads stay in flight across the barriers of the tile;
 //   * a tile of keys is bucket-sorted inside LDS (LDS atomics give the rank);
 //   * per bucket only WHOLE lines (LINE keys, 64 or 128 B, line-aligned in HBM) are written,
 //     the < LINE remainder is carried in LDS to the next tile  (software write-combining);
 //   * lines go into block-private 2-KiB *chunks* handed out by a slab allocator, so no two
 //     workgroups ever share a line and no global cursor is contended;
-//   * a directory word per chunk (bucket | count) is grouped by bucket afterwards
-//     (fj_group_* kernels) into per-bucket chunk lists, which is what the next pass / the
-//     join kernel consume.
+//   * chunk-list bookkeeping is done by the producer: per chunk a directory word (bucket|count)
+//     and its rank inside the (segment, bucket) it was produced in; per (segment, bucket) one
+//     global atomic reserves a span of the bucket's chunk list.  After the pass a scan of the
+//     per-bucket chunk counts plus an atomic-free kernel turn that into per-bucket chunk lists.
 //
 // Algorithmic HBM bytes per key and pass: 8 read + 8 written (keys only), 16 + 16 with values.
 #include "fj_internal.h"
@@ -21,7 +24,7 @@ namespace {
 
 // dynamic-LDS layout, shared by kernel and host-side size computation
 struct PartLds {
-    u32 sorted_k, sorted_v, lo_k, lo_v, hist, left, fill, cur, toff, kbase, lineoff, nfull;
+    u32 sorted_k, sorted_v, lo_k, lo_v, hist, left, fill, cur, toff, kbase, lineoff, nfull, nch;
     u32 line_src, line_dst, t_chunk, t_cnt, wsum, misc, total;
 };
 __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool vals, u32 nwaves) {
@@ -42,6 +45,7 @@ __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool 
     L.kbase = o; o += F * 4;
     L.lineoff = o; o += F * 4;
     L.nfull = o; o += F * 4;
+    L.nch = o; o += F * 4;
     L.line_src = o; o += maxl * 4;
     L.line_dst = o; o += maxl * 4;
     L.t_chunk = o; o += (T / FJ_CHUNK) * 4;
@@ -51,10 +55,10 @@ __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool 
     return L;
 }
 
-enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_TLEN, M_NLINES, M_FLUSH };
+enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG };
 
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS>
-__global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
+__global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LPL = LINE / 2;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT, "tile geometry");
     const u32 F = 1u << a.fan_log, FM = F - 1;
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
     u32* kbase = (u32*)(smem + Lo.kbase);
     u32* lineoff = (u32*)(smem + Lo.lineoff);
     u32* nfull = (u32*)(smem + Lo.nfull);
+    u32* nch = (u32*)(smem + Lo.nch);
     u32* line_src = (u32*)(smem + Lo.line_src);
     u32* line_dst = (u32*)(smem + Lo.line_dst);
     u32* t_chunk = (u32*)(smem + Lo.t_chunk);
@@ -82,28 +87,77 @@ __global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
     u32* misc = (u32*)(smem + Lo.misc);
 
     const bool flat = (a.in_list == nullptr);
-    const u32 Lc = flat ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : *a.in_nlist;
+    const u32 Lc = flat ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : 0u;
+    const u32 ntiles = flat ? (Lc + TC - 1) / TC : *a.in_ntiles;
     const u32 G = gridDim.x, g = blockIdx.x;
-    u32 pos = (u32)(((u64)g * Lc) / G);
-    const u32 hi = (u32)(((u64)(g + 1) * Lc) / G);
+    u32 t = (u32)(((u64)g * ntiles) / G);
+    const u32 thi = (u32)(((u64)(g + 1) * ntiles) / G);
     const u32 cap = a.cap_chunks;
+    if (t >= thi) return;
 
-    for (u32 b = tid; b < F; b += NT) { left[b] = 0; fill[b] = FJ_CHUNK; cur[b] = FJ_DIR_INVALID; }
-    if (tid == 0) { misc[M_SLAB_CUR] = 0; misc[M_SLAB_REM] = 0; misc[M_NEW_BASE] = 0; }
-    u32 cur_parent = 0xFFFFFFFFu;
-    __syncthreads();
+    // tile descriptor: first chunk (list index), number of chunks, parent bucket
+    auto get_desc = [&](u32 tt, u32& pos, u32& len, u32& parent) {
+        if (flat) { pos = tt * TC; len = (Lc - pos) < TC ? (Lc - pos) : TC; parent = a.parent0; }
+        else { const uint4 d = a.in_tiles[tt]; pos = d.x; len = d.y; parent = d.z; }
+    };
+    // chunk id + key count of the tile's tid-th chunk (count 0 beyond the tile)
+    auto meta_fetch = [&](u32 pos, u32 len, u32& id, u32& cnt) {
+        id = 0; cnt = 0;
+        if (tid < len) {
+            if (flat) {
+                id = pos + tid;
+                const u64 rem = a.n_flat - (u64)id * FJ_CHUNK;
+                cnt = rem >= FJ_CHUNK ? FJ_CHUNK : (u32)rem;
+            } else {
+                id = a.in_list[pos + tid];
+                cnt = a.in_dir[id] & FJ_DIR_CNT_MASK;
+            }
+        }
+    };
+    // issue the tile's loads (16 B per lane) using the chunk metadata currently in LDS
+    auto key_load = [&](u64 (&kk)[KPT], u64 (&vv)[KPT], u32& vmask) {
+        vmask = 0;
+#pragma unroll
+        for (int i = 0; i < KPT / 2; ++i) {
+            const u32 kidx = ((u32)i * NT + tid) * 2;
+            const u32 j = kidx >> FJ_CHUNK_LOG, off = kidx & (FJ_CHUNK - 1);
+            const u32 cnt = t_cnt[j];
+            kk[2 * i] = 0; kk[2 * i + 1] = 0;
+            if (HAS_VALS) { vv[2 * i] = 0; vv[2 * i + 1] = 0; }
+            if (off < cnt) {
+                const u64 base = (u64)t_chunk[j] * FJ_CHUNK + off;
+                if (off + 1 < cnt) {
+                    const u64x2 q = *reinterpret_cast<const u64x2*>(a.in_keys + base);
+                    kk[2 * i] = q.x; kk[2 * i + 1] = q.y;
+                    if (HAS_VALS) {
+                        const u64x2 w = *reinterpret_cast<const u64x2*>(a.in_vals + base);
+                        vv[2 * i] = w.x; vv[2 * i + 1] = w.y;
+                    }
+                    vmask |= 3u << (2 * i);
+                } else {
+                    kk[2 * i] = a.in_keys[base];
+                    if (HAS_VALS) vv[2 * i] = a.in_vals[base];
+                    vmask |= 1u << (2 * i);
+                }
+            }
+        }
+    };
+
+    for (u32 b = tid; b < F; b += NT) { left[b] = 0; fill[b] = FJ_CHUNK; cur[b] = FJ_DIR_INVALID; nch[b] = 0; }
+    if (tid == 0) { misc[M_SLAB_CUR] = 0; misc[M_SLAB_REM] = 0; misc[M_NEW_BASE] = 0; misc[M_SEG] = 0; }
 
     // id of the j-th chunk this workgroup allocates in the current tile
     auto alloc_id = [&](u32 j) -> u32 {
-        u32 rem = misc[M_SLAB_REM];
+        const u32 rem = misc[M_SLAB_REM];
         return j < rem ? misc[M_SLAB_CUR] + j : misc[M_NEW_BASE] + (j - rem);
     };
 
-    // write out the carried remainders of the segment that just ended and reset the state
+    // end of a segment (= this workgroup's share of one parent bucket): write the carried
+    // remainders, fix the last chunk's count, reserve the chunk-list spans, reset the state
     auto flush = [&](u32 parent) {
         if (tid == 0) {
             if (misc[M_SLAB_REM] < F) {
-                u32 nb = atomicAdd(a.alloc, FJ_SLAB);
+                const u32 nb = atomicAdd(a.alloc, FJ_SLAB);
                 if (nb + FJ_SLAB > cap) atomicOr(a.err, FJ_ERR_POOL);
                 misc[M_SLAB_CUR] = nb; misc[M_SLAB_REM] = FJ_SLAB;
             }
@@ -111,82 +165,75 @@ __global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
         }
         __syncthreads();
         if (tid < F) {
-            const u32 b = tid, l = left[b];
-            u32 f0 = fill[b], c = cur[b];
-            if (l > 0 && f0 == FJ_CHUNK) { c = misc[M_SLAB_CUR] + atomicAdd(&misc[M_FLUSH], 1u); f0 = 0; }
+            const u32 b = tid, l = left[b], seg = misc[M_SEG];
+            u32 f0 = fill[b], c = cur[b], n = nch[b];
+            const u32 outb = parent * F + b;
+            if (l > 0 && f0 == FJ_CHUNK) {
+                c = misc[M_SLAB_CUR] + atomicAdd(&misc[M_FLUSH], 1u); f0 = 0;
+                if (c < cap) a.out_rel[c] = ((u64)seg << 32) | n;
+                ++n;
+            }
             if (c != FJ_DIR_INVALID && c < cap) {
                 const u64 base = (u64)c * FJ_CHUNK + f0;
                 for (u32 j = 0; j < l; ++j) {
                     a.out_keys[base + j] = lo_k[b * LINE + j];
                     if (HAS_VALS) a.out_vals[base + j] = lo_v[b * LINE + j];
                 }
-                a.out_dir[c] = ((parent * F + b) << FJ_DIR_CNT_BITS) | (f0 + l);
+                a.out_dir[c] = (outb << FJ_DIR_CNT_BITS) | (f0 + l);
             }
-            left[b] = 0; fill[b] = FJ_CHUNK; cur[b] = FJ_DIR_INVALID;
+            if (n > 0) {
+                const u32 off = atomicAdd(&a.bchunks[outb], n);
+                if (seg < a.max_segs) a.seg_off[(u64)seg * F + b] = off;
+            }
+            left[b] = 0; fill[b] = FJ_CHUNK; cur[b] = FJ_DIR_INVALID; nch[b] = 0;
         }
         __syncthreads();
-        if (tid == 0) { u32 n = misc[M_FLUSH]; misc[M_SLAB_CUR] += n; misc[M_SLAB_REM] -= n; }
+        if (tid == 0) { const u32 n = misc[M_FLUSH]; misc[M_SLAB_CUR] += n; misc[M_SLAB_REM] -= n; }
         __syncthreads();
     };
 
-    while (pos < hi) {
-        // ---- tile = up to TC consecutive chunks of one parent bucket ------------------------
-        if (tid == 0) misc[M_TLEN] = (hi - pos) < TC ? (hi - pos) : TC;
+    // ---- prologue: keys of the first tile into registers, metadata of the second into LDS ----
+    u64 kn[KPT], vn[KPT];
+    u32 validn = 0, par_next = 0, par_n2 = 0, mid = 0, mcnt = 0;
+    {
+        u32 p, l;
+        get_desc(t, p, l, par_next);
+        meta_fetch(p, l, mid, mcnt);
+        if (tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }
         __syncthreads();
-        u32 parent = a.parent0;
-        if (!flat) parent = a.in_dir[a.in_list[pos]] >> FJ_DIR_CNT_BITS;
-        if (tid < TC && pos + tid < hi) {
-            const u32 c = pos + tid;
-            u32 id, cnt;
-            if (flat) {
-                id = c;
-                const u64 rem = a.n_flat - (u64)c * FJ_CHUNK;
-                cnt = rem >= FJ_CHUNK ? FJ_CHUNK : (u32)rem;
-            } else {
-                id = a.in_list[c];
-                const u32 e = a.in_dir[id];
-                cnt = e & FJ_DIR_CNT_MASK;
-                if ((e >> FJ_DIR_CNT_BITS) != parent) atomicMin(&misc[M_TLEN], tid);
-            }
-            t_chunk[tid] = id; t_cnt[tid] = cnt;
-        }
+        key_load(kn, vn, validn);
+        mid = 0; mcnt = 0;
+        if (t + 1 < thi) { get_desc(t + 1, p, l, par_n2); meta_fetch(p, l, mid, mcnt); }
+        __syncthreads();
+        if (tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }
+        __syncthreads();
+    }
+
+    u32 cur_parent = 0xFFFFFFFFu;
+    for (; t < thi; ++t) {
+        u64 k[KPT], v[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) { k[i] = kn[i]; if (HAS_VALS) v[i] = vn[i]; }
+        const u32 valid = validn, parent = par_next;
+        // keep HBM busy: tile t+1's keys and tile t+2's chunk metadata are requested now
+        if (t + 1 < thi) { key_load(kn, vn, validn); par_next = par_n2; }
+        mid = 0; mcnt = 0;
+        if (t + 2 < thi) { u32 p, l; get_desc(t + 2, p, l, par_n2); meta_fetch(p, l, mid, mcnt); }
+
         if (parent != cur_parent) {
             if (cur_parent != 0xFFFFFFFFu) flush(cur_parent);
+            if (tid == 0) {
+                const u32 seg = atomicAdd(a.seg_counter, 1u);
+                if (seg >= a.max_segs) atomicOr(a.err, FJ_ERR_POOL);
+                misc[M_SEG] = seg;
+            }
             cur_parent = parent;
         }
         for (u32 b = tid; b < F; b += NT) hist[b] = left[b];
         __syncthreads();
-        const u32 tc = misc[M_TLEN];
 
-        // ---- load (16 B per lane), hash, rank inside the tile with LDS atomics --------------
-        u64 k[KPT], v[KPT];
+        // ---- hash, rank inside the tile with LDS atomics ----------------------------------------
         u32 br[KPT];
-        u32 valid = 0;
-#pragma unroll
-        for (int i = 0; i < KPT / 2; ++i) {
-            const u32 kidx = ((u32)i * NT + tid) * 2;
-            const u32 j = kidx >> FJ_CHUNK_LOG, off = kidx & (FJ_CHUNK - 1);
-            u32 cnt = 0;
-            if (j < tc) cnt = t_cnt[j];
-            k[2 * i] = 0; k[2 * i + 1] = 0;
-            if (HAS_VALS) { v[2 * i] = 0; v[2 * i + 1] = 0; }
-            if (off < cnt) {
-                const u64 base = (u64)t_chunk[j] * FJ_CHUNK + off;
-                if (off + 1 < cnt) {
-                    const u64x2 kk = *reinterpret_cast<const u64x2*>(a.in_keys + base);
-                    k[2 * i] = kk.x; k[2 * i + 1] = kk.y;
-                    if (HAS_VALS) {
-                        const u64x2 vv = *reinterpret_cast<const u64x2*>(a.in_vals + base);
-                        v[2 * i] = vv.x; v[2 * i + 1] = vv.y;
-                    }
-                    valid |= 3u << (2 * i);
-                } else {
-                    k[2 * i] = a.in_keys[base];
-                    if (HAS_VALS) v[2 * i] = a.in_vals[base];
-                    valid |= 1u << (2 * i);
-                }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             br[i] = 0;
@@ -251,10 +298,10 @@ __global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
                 if (HAS_VALS) sorted_v[toff[b] + j] = lo_v[e];
             }
         }
-        u32 new_cur = 0, new_fill = 0, new_left = 0;
+        u32 new_cur = 0, new_fill = 0, new_left = 0, new_nch = 0;
         if (tid < F) {
             const u32 b = tid, f0 = fill[b], l0 = lineoff[b], s0 = toff[b], kb = kbase[b];
-            const u32 c0 = cur[b];
+            const u32 c0 = cur[b], n0 = nch[b];
             for (u32 q = 0; q < nf; q += LINE) {
                 const u32 pq = f0 + q, kk = pq >> FJ_CHUNK_LOG, off = pq & (FJ_CHUNK - 1);
                 const u32 id = kk == 0 ? c0 : alloc_id(kb + kk - 1);
@@ -262,13 +309,15 @@ __global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
                 line_dst[l0 + (q >> LINE_LOG)] = id < cap ? id * FJ_CHUNK + off : FJ_DIR_INVALID;
             }
             const u32 outb = (parent * F + b) << FJ_DIR_CNT_BITS;
+            const u64 segw = (u64)misc[M_SEG] << 32;
             for (u32 kk = 1; kk <= km; ++kk) {
                 const u32 id = alloc_id(kb + kk - 1);
-                if (id < cap) a.out_dir[id] = outb | FJ_CHUNK;
+                if (id < cap) { a.out_dir[id] = outb | FJ_CHUNK; a.out_rel[id] = segw | (n0 + kk - 1); }
             }
             new_cur = km ? alloc_id(kb + km - 1) : c0;
             new_fill = f0 + nf - (km << FJ_CHUNK_LOG);
             new_left = tot & (LINE - 1);
+            new_nch = n0 + km;
         }
         __syncthreads();
 
@@ -279,11 +328,11 @@ __global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
             const u32 dst = line_dst[l];
             if (dst != FJ_DIR_INVALID) {
                 const u32 src = line_src[l] + j2;
-                u64x2 kk; kk.x = sorted_k[src]; kk.y = sorted_k[src + 1];
-                *reinterpret_cast<u64x2*>(a.out_keys + (u64)dst + j2) = kk;
+                u64x2 q; q.x = sorted_k[src]; q.y = sorted_k[src + 1];
+                *reinterpret_cast<u64x2*>(a.out_keys + (u64)dst + j2) = q;
                 if (HAS_VALS) {
-                    u64x2 vv; vv.x = sorted_v[src]; vv.y = sorted_v[src + 1];
-                    *reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + j2) = vv;
+                    u64x2 w; w.x = sorted_v[src]; w.y = sorted_v[src + 1];
+                    *reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + j2) = w;
                 }
             }
         }
@@ -295,33 +344,20 @@ __global__ __launch_bounds__(NT) void fj_partition_kernel(FjPartArgs a) {
                 if (HAS_VALS) lo_v[e] = sorted_v[s];
             }
         }
-        if (tid < F) { cur[tid] = new_cur; fill[tid] = new_fill; left[tid] = new_left; }
+        if (tid < F) { cur[tid] = new_cur; fill[tid] = new_fill; left[tid] = new_left; nch[tid] = new_nch; }
+        if (tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }      // metadata of tile t+2
         if (tid == 0) {
             const u32 need = misc[M_NEED], rem = misc[M_SLAB_REM];
             if (need <= rem) { misc[M_SLAB_CUR] += need; misc[M_SLAB_REM] = rem - need; }
             else { const u32 used = need - rem; misc[M_SLAB_CUR] = misc[M_NEW_BASE] + used; misc[M_SLAB_REM] = FJ_SLAB - used; }
         }
-        pos += tc;
         __syncthreads();
     }
-    if (cur_parent != 0xFFFFFFFFu) flush(cur_parent);
+    flush(cur_parent);
 }
 
-// ---- directory grouping: (bucket|count) words -> per-bucket chunk lists ----------------------
-__global__ void fj_group_count(const u32* __restrict__ dir, const u32* __restrict__ nalloc, u32 cap,
-                               u32* __restrict__ bchunks, u64* __restrict__ bkeys) {
-    u32 n = *nalloc; if (n > cap) n = cap;
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const u32 e = dir[i];
-        if (e != FJ_DIR_INVALID) {
-            atomicAdd(&bchunks[e >> FJ_DIR_CNT_BITS], 1u);
-            atomicAdd((unsigned long long*)&bkeys[e >> FJ_DIR_CNT_BITS], (unsigned long long)(e & FJ_DIR_CNT_MASK));
-        }
-    }
-}
-
-// single-workgroup exclusive scan of u32 counts -> u32 offsets[n+1]; also zeroes a cursor array
-__global__ __launch_bounds__(1024) void fj_scan_u32(const u32* in, u32* __restrict__ out, u32 n, u32* zero_me) {
+// single-workgroup exclusive scan of u32 counts -> u32 offsets[n+1]
+__global__ __launch_bounds__(1024) void fj_scan_u32(const u32* in, u32* __restrict__ out, u32 n) {
     __shared__ u32 wtot[16];
     __shared__ u32 carry;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -337,12 +373,51 @@ __global__ __launch_bounds__(1024) void fj_scan_u32(const u32* in, u32* __restri
         __syncthreads();
         u32 woff = carry;
         for (u32 w = 0; w < wave; ++w) woff += wtot[w];
-        if (i < n) { out[i] = inc - x + woff; if (zero_me) zero_me[i] = 0; }
+        if (i < n) out[i] = inc - x + woff;
         __syncthreads();
         if (tid == 1023) carry = woff + inc;
         __syncthreads();
     }
     if (tid == 0) out[n] = carry;
+}
+
+// number of tiles of `tc` chunks per bucket (tiles never span buckets), exclusive-scanned
+__global__ __launch_bounds__(1024) void fj_tile_scan(const u32* __restrict__ boff, u32* __restrict__ toff, u32 n, u32 tc) {
+    __shared__ u32 wtot[16];
+    __shared__ u32 carry;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < n; base += 1024) {
+        const u32 i = base + tid;
+        const u32 x = i < n ? (boff[i + 1] - boff[i] + tc - 1) / tc : 0;
+        u32 inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        u32 woff = carry;
+        for (u32 w = 0; w < wave; ++w) woff += wtot[w];
+        if (i < n) toff[i] = inc - x + woff;
+        __syncthreads();
+        if (tid == 1023) carry = woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) toff[n] = carry;
+}
+
+// tile t -> (first list index, chunks, bucket)
+__global__ void fj_tile_expand(const u32* __restrict__ boff, const u32* __restrict__ toff, u32 n, u32 tc,
+                               uint4* __restrict__ tiles, u32 max_tiles) {
+    u32 total = toff[n];
+    if (total > max_tiles) total = max_tiles;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        u32 lo = 0, hi = n;                       // last p with toff[p] <= t
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
+        const u32 pos = boff[lo] + (t - toff[lo]) * tc;
+        const u32 rem = boff[lo + 1] - pos;
+        tiles[t] = make_uint4(pos, rem < tc ? rem : tc, lo, 0);
+    }
 }
 
 // same for u64 outputs (result offsets can exceed 2^32)
@@ -370,14 +445,18 @@ __global__ __launch_bounds__(1024) void fj_scan_u32_to_u64(const u32* __restrict
     if (tid == 0) out[n] = carry;
 }
 
-__global__ void fj_group_scatter(const u32* __restrict__ dir, const u32* __restrict__ nalloc, u32 cap,
-                                 const u32* __restrict__ boff, u32* __restrict__ bcur, u32* __restrict__ list) {
+// chunk lists without atomics: list[boff[bucket] + span offset of the producing segment + rank] = chunk
+__global__ void fj_list_build(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
+                              u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
+                              u32 max_segs, u32* __restrict__ list) {
     u32 n = *nalloc; if (n > cap) n = cap;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const u32 e = dir[i];
         if (e != FJ_DIR_INVALID) {
             const u32 b = e >> FJ_DIR_CNT_BITS;
-            list[boff[b] + atomicAdd(&bcur[b], 1u)] = i;
+            const u64 r = rel[i];
+            const u32 seg = (u32)(r >> 32);
+            if (seg < max_segs) list[boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r] = i;
         }
     }
 }
@@ -411,15 +490,18 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
     return launch_part<512, 8, 4, false>(a, grid, s);
 }
 
-// Group a pass's chunk directory by bucket.  cs.boff/bkeys/list are filled; cs.bchunks is scratch.
+// After a pass: per-bucket chunk counts -> offsets -> chunk lists (no atomics).
 hipError_t fj_launch_group(const FjChunkSet& cs, hipStream_t s) {
-    hipError_t e;
-    if ((e = hipMemsetAsync(cs.bchunks, 0, sizeof(u32) * cs.nb, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(cs.bkeys, 0, sizeof(u64) * cs.nb, s)) != hipSuccess) return e;
-    const u32 blocks = 512;
-    hipLaunchKernelGGL(fj_group_count, dim3(blocks), dim3(256), 0, s, cs.dir, cs.alloc, cs.cap, cs.bchunks, cs.bkeys);
-    hipLaunchKernelGGL(fj_scan_u32, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, cs.bchunks);
-    hipLaunchKernelGGL(fj_group_scatter, dim3(blocks), dim3(256), 0, s, cs.dir, cs.alloc, cs.cap, cs.boff, cs.bchunks, cs.list);
+    hipLaunchKernelGGL(fj_scan_u32, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb);
+    hipLaunchKernelGGL(fj_list_build, dim3(512), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
+                       cs.fan_mask, cs.max_segs, cs.list);
+    return hipGetLastError();
+}
+
+// Tile table of a chunk set for a consumer pass with `tc` chunks per tile.
+hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, hipStream_t s) {
+    hipLaunchKernelGGL(fj_tile_scan, dim3(1), dim3(1024), 0, s, cs.boff, toff, cs.nb, tc);
+    hipLaunchKernelGGL(fj_tile_expand, dim3(256), dim3(256), 0, s, cs.boff, toff, cs.nb, tc, tiles, max_tiles);
     return hipGetLastError();
 }
 
