@@ -97,14 +97,15 @@ int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
 
 struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; };
 
-Plan make_plan(size_t nb) {
+Plan make_plan(size_t nb, int top_bits) {
     Plan p;
     if (nb > FJ_PART_TARGET_KEYS) {
         u64 parts = (nb + FJ_PART_TARGET_KEYS - 1) / FJ_PART_TARGET_KEYS;
         while ((1ull << p.bits) < parts) ++p.bits;
     }
+    if (p.bits > top_bits - 32) p.bits = top_bits - 32;      // radix digits come from hash word 1 (32 bits)
     p.npass = (p.bits + 7) / 8;
-    for (int i = 0; i < p.npass; ++i) p.fan_log[i] = p.bits / p.npass + (i < p.bits % p.npass ? 1 : 0);
+    for (int i = 0; i < p.npass; ++i) p.fan_log[i] = p.bits / p.npass + ((getenv("FJ_SPLIT_FIRST") ? i < p.bits % p.npass : i >= p.npass - p.bits % p.npass) ? 1 : 0);   // extra bits go to the later passes
     return p;
 }
 
@@ -160,7 +161,7 @@ int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, 
         a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
         a.err = &c->d_sc->err;
         a.shift = (u32)used; a.fan_log = (u32)plan.fan_log[i];
-        const int line_log = F <= 128 ? 4 : 3;
+        const int line_log = 4;                 // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter)
         if (ev_cursor) HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor)], s));
         HIPCHK(fj_launch_partition(a, vals != nullptr, line_log, G, s));
         if (ev_cursor) { HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor) + 1], s)); ++*ev_cursor; }
@@ -262,7 +263,7 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
 // radix path: partition both relations, then one LDS-table join per final partition
 int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
                hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
-    const Plan plan = make_plan(nb);
+    const Plan plan = make_plan(nb, top_bits);
     *lds_full = false;
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
@@ -286,7 +287,33 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
     void* p;
     if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
+    ja.dbg = nullptr;
+    ja.dbg_flags = getenv("FJ_JOIN_ABLATE") ? (u32)atoi(getenv("FJ_JOIN_ABLATE")) : 0u;
+    static unsigned long long* dbg_buf = nullptr;
+    if (getenv("FJ_JOIN_STAMPS")) {
+        if (!dbg_buf) HIPCHK(hipMalloc((void**)&dbg_buf, 4096 * 8 * 8));
+        HIPCHK(hipMemsetAsync(dbg_buf, 0, 4096 * 8 * 8, s));
+        ja.dbg = dbg_buf;
+    }
     HIPCHK(fj_launch_lds_join(ja, false, s));
+    if (ja.dbg) {
+        std::vector<unsigned long long> h(4096 * 8);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+        double acc[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (int i = 0; i < 4096 && i < (int)nitems; ++i) {
+            const unsigned long long* r = &h[i * 8];
+            if (!r[0] || !r[5]) continue;
+            for (int j = 1; j <= 5; ++j) acc[j] += (double)(r[j] - r[j - 1]) * 0.01;      // 100 MHz -> us
+            if (r[0] < tmin) tmin = r[0];
+            if (r[5] > tmax) tmax = r[5];
+            ++n;
+        }
+        fprintf(stderr, "[FJ_JOIN_STAMPS] items=%d  meta+init=%.2f  issue0=%.2f  build=%.2f  buildsync=%.2f  probe=%.2f  fin=%.2f us (means); first 4096 items span %.1f us\n",
+                n, acc[1] / n, 0.0, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, (double)(tmax - tmin) * 0.01);
+        ja.dbg = nullptr;
+    }
     HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
     if (read_scalars(c, s)) return 1;
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
@@ -468,11 +495,11 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
     u64 w = 0;
     for (u32 b = 0; b < cs.nb; ++b) {
         for (u32 i = boff[b]; i < boff[b + 1]; ++i) {
-            const u32 id = list[i];
+            const u32 id = FJ_LIST_ID(list[i]);
             if (id >= cs.cap) return set_err("fj_debug_partition: list entry %u out of range", id);
             const u32 e = dir[id], cnt = e & FJ_DIR_CNT_MASK;
             if ((e >> FJ_DIR_CNT_BITS) != b) return set_err("fj_debug_partition: chunk %u listed under bucket %u but tagged %u", id, b, e >> FJ_DIR_CNT_BITS);
-            if (cnt == 0 || cnt > FJ_CHUNK) return set_err("fj_debug_partition: chunk %u has count %u", id, cnt);
+            if (cnt == 0 || cnt > FJ_CHUNK || cnt != FJ_LIST_CNT(list[i])) return set_err("fj_debug_partition: chunk %u has count %u (list says %u)", id, cnt, FJ_LIST_CNT(list[i]));
             if (w + cnt > n) return set_err("fj_debug_partition: more than %zu rows in the chunk lists", n);
             HIPCHK(hipMemcpy(ck.data(), cs.keys + (size_t)id * FJ_CHUNK, cnt * 8, hipMemcpyDeviceToHost));
             memcpy(h_out_keys + w, ck.data(), cnt * 8);

@@ -19,6 +19,9 @@ typedef uint16_t u16;
 #define FJ_DIR_INVALID 0xFFFFFFFFu
 #define FJ_DIR_CNT_BITS 9
 #define FJ_DIR_CNT_MASK 0x1FFu
+// chunk-list entry = ((count - 1) << 24) | chunk id   (ids < 2^24), so a consumer needs no directory lookup
+#define FJ_LIST_ID(e) ((e) & 0xFFFFFFu)
+#define FJ_LIST_CNT(e) (((e) >> 24) + 1u)
 #define FJ_SLAB 512u                            // chunks handed to a workgroup per allocator hit
 #define FJ_MAX_FANOUT 256u                      // buckets per partition pass (8 bits, as RADIX_BITS)
 
@@ -38,15 +41,29 @@ typedef uint16_t u16;
 // to FJ_EMPTY_KEY is never stored in a table; a per-table flag + value records it instead.
 #define FJ_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
-// Device hash: murmur3's 64-bit finaliser.  The reference hashes with CRC32C*const
-// (hash_join.cpp:40-44) which only has 32 bits of entropy; join results are hash-independent,
-// so the device uses a full-width mixer that costs a handful of VALU ops.
-__host__ __device__ __forceinline__ u64 fj_hash64(u64 k) {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
-    k ^= k >> 33;
-    return k;
+// Device hash.  The reference hashes with CRC32C*const (hash_join.cpp:40-44), 32 bits of entropy;
+// join results are hash-independent, so the device uses its own mixer.  Both hot kernels are
+// instruction-issue bound on gfx950 (PMC: profiles/r01_v2_c3_pmc_summary.txt), and a 64-bit
+// multiply costs 4+ VALU issues, so the hash is built from 32-bit multiplies only:
+//   a = lo*K1, b = hi*K2
+//   w1 = fmix32(a ^ b)                  -> owner GPU (top 16 bits) and radix digits, taken from the top
+//   w2 = fmix32(a + rotl(b,16) + K3)    -> slot inside a partition's table (low bits)
+// A kernel that needs only one word gets the other one dead-code-eliminated.
+__host__ __device__ __forceinline__ u32 fj_fmix32(u32 x) {
+    x ^= x >> 16; x *= 0x85ebca6bu;
+    x ^= x >> 13; x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
 }
+__host__ __device__ __forceinline__ u32 fj_hash_w1(u64 k) {
+    const u32 a = (u32)k * 0x9E3779B1u, b = (u32)(k >> 32) * 0x85EBCA77u;
+    return fj_fmix32(a ^ b);
+}
+__host__ __device__ __forceinline__ u32 fj_hash_w2(u64 k) {
+    const u32 a = (u32)k * 0x9E3779B1u, b = (u32)(k >> 32) * 0x85EBCA77u;
+    return fj_fmix32(a + ((b << 16) | (b >> 16)) + 0x27D4EB2Fu);
+}
+__host__ __device__ __forceinline__ u64 fj_hash64(u64 k) { return ((u64)fj_hash_w1(k) << 32) | fj_hash_w2(k); }
 
 // splitmix64-style counter hash used by the synthetic generators; identical in
 // NumPy (flash_hash_join_amd/datagen.py), C and HIP.

@@ -70,6 +70,8 @@ struct FjLdsJoinArgs {
     const u64* out_off;          // [nparts*nsplit+1] exclusive scan of part_count
     u64* out_keys;
     u64* out_vals;
+    unsigned long long* dbg;     // diagnostic: per-item phase stamps (s_memrealtime), nullptr in production
+    u32 dbg_flags;               // diagnostic ablations: 1 = skip lookups, 2 = skip inserts (results wrong on purpose)
 };
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s);
 
@@ -99,4 +101,5 @@ hipError_t fj_launch_gen_build(u64* keys, u64* vals, u64 first, u64 n, hipStream
 hipError_t fj_launch_gen_probe(u64* keys, u64 first, u64 n, u64 build_total, u64 seed, u32 hit_bp,
                                unsigned long long* expected_hits, hipStream_t s);
 
-__host__ __device__ inline u32 fj_owner_of(u64 h, u32 nranks) { return (u32)((((h >> 48) & 0xFFFFu) * nranks) >> 16); }
+// owner GPU of a key: range reduction of the top 16 bits of hash word 1
+__host__ __device__ inline u32 fj_owner_of_w1(u32 w1, u32 nranks) { return ((w1 >> 16) * nranks) >> 16; }

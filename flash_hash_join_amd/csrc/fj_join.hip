@@ -20,59 +20,169 @@ namespace {
 constexpr u32 S = FJ_LDS_SLOTS, SM = FJ_LDS_SLOTS - 1;
 
 struct JoinHdr {              // small scalars at the front of the dynamic LDS block
-    u32 cnt, has_empty, cursor, claimed, full;
-    u32 pad[3];
+    u32 cnt, has_empty, cursor, claimed, full, ovf;
+    u32 pad[2];
     u64 empty_val;
     u64 pad2;
 };
 
-__device__ __forceinline__ bool lds_lookup(const u64* __restrict__ tkeys, u64 key, u64 h, u32& where) {
-    u32 pos = ((u32)h & SM) & ~(FJ_LDS_GROUP - 1);
-    for (u32 step = 0; step < S / FJ_LDS_GROUP; ++step) {
-        const u64x2 a = *reinterpret_cast<const u64x2*>(tkeys + pos);
-        const u64x2 b = *reinterpret_cast<const u64x2*>(tkeys + pos + 2);
-        if (a.x == key) { where = pos; return true; }
-        if (a.y == key) { where = pos + 1; return true; }
-        if (b.x == key) { where = pos + 2; return true; }
-        if (b.y == key) { where = pos + 3; return true; }
-        if (a.x == FJ_EMPTY_KEY || a.y == FJ_EMPTY_KEY || b.x == FJ_EMPTY_KEY || b.y == FJ_EMPTY_KEY) return false;
-        pos = (pos + FJ_LDS_GROUP) & SM;
+// ---- LDS table: open addressing, two candidate 4-slot groups per key ---------------------------
+// With plain linear probing at load ~0.4 a few percent of the lanes must walk past their home
+// group, which means almost every 64-lane wave pays the divergent walk (measured: ~160 issued
+// instructions per 64 lookups).  So a key may live in either of two groups g1(k), g2(k) (it is
+// inserted into the emptier one); a lookup always reads exactly those 8 slots, branch-free.  Only if
+// both groups of some key were full at insert time does the table fall back to linear probing from
+// g1 for that key, and it raises a per-table flag so lookups know they may have to walk (rare: the
+// host's plan keeps the load at ~0.4, where a double-full pair is a ~1e-4 event per key).
+constexpr u32 NGRP = S / FJ_LDS_GROUP;
+__device__ __forceinline__ void lds_groups(u64 key, u32& g1, u32& g2) {
+    const u32 w = fj_hash_w2(key);
+    g1 = (w & (NGRP - 1)) * FJ_LDS_GROUP;
+    g2 = ((w >> 11) & (NGRP - 1)) * FJ_LDS_GROUP;
+}
+
+__device__ __forceinline__ u32 lds_tag(u32 w2) { const u32 t = w2 >> 24; return t ? t : 1u; }
+__device__ __forceinline__ u32 tag_matches(u32 tags, u32 pattern) {      // bit 7 of every byte that equals the tag (may over-report, never under-report)
+    const u32 x = tags ^ pattern;
+    return (x - 0x01010101u) & ~x & 0x80808080u;
+}
+
+
+template <bool MAT>
+__device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict__ tvals, unsigned char* __restrict__ ttag8,
+                                           JoinHdr* hdr, u64 key, u64 val) {
+    u32 g1, g2;
+    lds_groups(key, g1, g2);
+    const unsigned char tag = (unsigned char)lds_tag(fj_hash_w2(key));
+    for (int tries = 0; tries < 8; ++tries) {
+        const u64x2 a1 = *reinterpret_cast<const u64x2*>(tkeys + g1), b1 = *reinterpret_cast<const u64x2*>(tkeys + g1 + 2);
+        const u64x2 a2 = *reinterpret_cast<const u64x2*>(tkeys + g2), b2 = *reinterpret_cast<const u64x2*>(tkeys + g2 + 2);
+        if (a1.x == key || a1.y == key || b1.x == key || b1.y == key || a2.x == key || a2.y == key || b2.x == key || b2.y == key)
+            return false;                                  // duplicate build key: first claim wins (hash_join.cpp:125)
+        // groups fill from slot 0 upwards, so "number of empties" locates the first free slot
+        const u32 e1 = (a1.x == FJ_EMPTY_KEY) + (a1.y == FJ_EMPTY_KEY) + (b1.x == FJ_EMPTY_KEY) + (b1.y == FJ_EMPTY_KEY);
+        const u32 e2 = (a2.x == FJ_EMPTY_KEY) + (a2.y == FJ_EMPTY_KEY) + (b2.x == FJ_EMPTY_KEY) + (b2.y == FJ_EMPTY_KEY);
+        if (e1 == 0 && e2 == 0) break;
+        const u32 slot = e1 >= e2 ? g1 + (FJ_LDS_GROUP - e1) : g2 + (FJ_LDS_GROUP - e2);
+        const u64 old = atomicCAS((unsigned long long*)&tkeys[slot], (unsigned long long)FJ_EMPTY_KEY, (unsigned long long)key);
+        if (old == FJ_EMPTY_KEY) { ttag8[slot] = tag; if (MAT) tvals[slot] = val; return true; }
+        if (old == key) return false;
     }
+    // overflow: linear probing from g1, slot by slot
+    hdr->ovf = 1;
+    u32 pos = g1;
+    for (u32 step = 0; step < S; ++step) {
+        const u64 old = atomicCAS((unsigned long long*)&tkeys[pos], (unsigned long long)FJ_EMPTY_KEY, (unsigned long long)key);
+        if (old == FJ_EMPTY_KEY) { ttag8[pos] = tag; if (MAT) tvals[pos] = val; return true; }
+        if (old == key) return false;
+        pos = (pos + 1) & SM;
+    }
+    hdr->full = 1;
     return false;
 }
 
-// chunk `idx` of a chunk set: pool id and key count.  A flat array is read as a virtual chunk list.
-__device__ __forceinline__ void chunk_at(const FjChunkSet& cs, u32 idx, u32& id, u32& cnt) {
-    if (cs.list) {
-        id = cs.list[idx];
-        cnt = cs.dir[id] & FJ_DIR_CNT_MASK;
-    } else {
-        id = idx;
-        const u64 rem = cs.n_flat - (u64)idx * FJ_CHUNK;
-        cnt = rem >= FJ_CHUNK ? FJ_CHUNK : (u32)rem;
+// Lookups go through one-byte tags (one u32 = the 4 tags of a group): the kernel is LDS-bound
+// when a lookup reads all 8 candidate keys (random ds_read_b128: ~70 % of the LDS cycles are bank
+// conflicts, profiles/r01_v5_pmc), so a lookup reads the two tag words (8 B), finds the slots whose
+// tag equals the key's tag with a SWAR zero-byte test, and reads only that key (8 B).  Tag 0 = empty.
+// Probe NK keys per lane.
+//   okm[i]  : lanes whose key i is a real key          he : all-ones if the build side held FJ_EMPTY_KEY
+//   hitm[i] : lanes whose key i matched                where[i] (MAT only): matching slot
+template <bool MAT, int NK>
+__device__ __forceinline__ void lds_probe(const u64* __restrict__ tkeys, const u32* __restrict__ ttags, const u64 (&k)[NK],
+                                          const u64 (&okm)[NK], u64 he, bool ovf, u32 lane, u64 (&hitm)[NK], u32 (&where)[NK]) {
+    u32 g1[NK], g2[NK], z1[NK], z2[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const u32 w = fj_hash_w2(k[i]);
+        g1[i] = (w & (NGRP - 1)) * FJ_LDS_GROUP;
+        g2[i] = ((w >> 11) & (NGRP - 1)) * FJ_LDS_GROUP;
+        const u32 pat = lds_tag(w) * 0x01010101u;
+        z1[i] = tag_matches(ttags[g1[i] / FJ_LDS_GROUP], pat);
+        z2[i] = tag_matches(ttags[g2[i] / FJ_LDS_GROUP], pat);
+    }
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        // first candidate slot (if any), its key, compare
+        const bool in1 = z1[i] != 0;
+        const u32 z = in1 ? z1[i] : z2[i];
+        const u32 cand = (in1 ? g1[i] : g2[i]) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
+        u64 kc = ~k[i];
+        if (z) kc = tkeys[cand];
+        const bool first = kc == k[i];
+        const u64 hit1 = __ballot(first);
+        const u64 ise = __ballot(k[i] == FJ_EMPTY_KEY);      // the empty marker is never stored in the table
+        if (MAT) where[i] = cand;
+        // more candidates left?  (false-positive tags: rare)
+        const u32 r1 = in1 ? (z1[i] & (z1[i] - 1)) : 0u, r2 = in1 ? z2[i] : (z2[i] & (z2[i] - 1));
+        const u64 more = __ballot(!first && (r1 | r2) != 0) & okm[i] & ~ise;
+        u64 hit = hit1;
+        if (more) {
+            bool found = false;
+            if ((more >> lane) & 1ull) {
+                u32 ra = r1, rb = r2;
+                while (ra | rb) {
+                    const bool ina = ra != 0;
+                    const u32 zz = ina ? ra : rb;
+                    const u32 c = (ina ? g1[i] : g2[i]) + ((u32)__builtin_ctz(zz) >> 3);
+                    if (tkeys[c] == k[i]) { found = true; if (MAT) where[i] = c; break; }
+                    if (ina) ra &= ra - 1; else rb &= rb - 1;
+                }
+            }
+            hit |= __ballot(found);
+        }
+        if (ovf) {                                           // this table holds linearly probed overflow keys
+            const u64 undec = okm[i] & ~ise & ~hit;
+            bool found = false;
+            if ((undec >> lane) & 1ull) {
+                u32 p = g1[i];
+                for (u32 step = 0; step < NGRP; ++step) {
+                    const u64x2 a = *reinterpret_cast<const u64x2*>(tkeys + p);
+                    const u64x2 b = *reinterpret_cast<const u64x2*>(tkeys + p + 2);
+                    const bool m0 = a.x == k[i], m1 = a.y == k[i], m2 = b.x == k[i], m3 = b.y == k[i];
+                    if (m0 | m1 | m2 | m3) { found = true; if (MAT) where[i] = p + (m1 ? 1u : 0u) + (m2 ? 2u : 0u) + (m3 ? 3u : 0u); break; }
+                    if ((a.x == FJ_EMPTY_KEY) | (a.y == FJ_EMPTY_KEY) | (b.x == FJ_EMPTY_KEY) | (b.y == FJ_EMPTY_KEY)) break;
+                    p = (p + FJ_LDS_GROUP) & SM;
+                }
+            }
+            hit |= __ballot(found);
+        }
+        hitm[i] = okm[i] & ((hit & ~ise) | (ise & he));
     }
 }
 
-constexpr u32 JB_META = 128;    // build-side chunk metadata staged in LDS per batch
-constexpr u32 JP_META = 512;    // probe-side chunk metadata staged in LDS per batch
+// encoded chunk-list entry ((count-1) << 24 | id) of chunk `idx`; a flat array is read as a virtual chunk list
+__device__ __forceinline__ u32 chunk_entry(const FjChunkSet& cs, u32 idx) {
+    if (cs.list) return cs.list[idx];
+    const u64 rem = cs.n_flat - (u64)idx * FJ_CHUNK;
+    const u32 cnt = rem >= FJ_CHUNK ? FJ_CHUNK : (u32)rem;
+    return ((cnt - 1u) << 24) | idx;
+}
+
+constexpr u32 JB_META = 128;    // build-side chunk-list entries staged in LDS per batch
+constexpr u32 JP_META = 512;    // probe-side chunk-list entries staged in LDS per batch
 
 // grid = nparts * nsplit work items: item = (partition p, slice of p's probe chunks).  Every item
 // rebuilds p's table in LDS (cheap: the build side of a partition is <= a few thousand rows and
 // is L2 / Infinity-Cache resident), so small-build joins still fill the chip.
-// Probe keys are prefetched one round (8 keys per lane, 4 x 16-B loads) ahead; the first round is
-// requested before the table is even initialised, so HBM reads overlap the build.
+//
+// A work item lives ~25 us, so it is written against HBM *latency*: the chunk-list entries of both
+// sides are fetched together, all build keys of the partition are requested in one shot (not chunk
+// by chunk), and probe keys are prefetched two rounds (2 x 8 keys per lane) ahead; the first two
+// rounds are requested before the table is even initialised.
 template <bool MAT, int NT>
-__global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
+__global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     JoinHdr* hdr = reinterpret_cast<JoinHdr*>(smem);
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(JoinHdr));
     u64* tvals = tkeys + S;        // only present when MAT
-    u32* pm_id = reinterpret_cast<u32*>(tkeys + (MAT ? 2 * S : S));
-    u32* pm_cnt = pm_id + JP_META;
-    u32* bm_id = pm_cnt + JP_META;
-    u32* bm_cnt = bm_id + JB_META;
+    u32* ttags = reinterpret_cast<u32*>(tkeys + (MAT ? 2 * S : S));     // S one-byte tags
+    u32* pm = ttags + S / 4;
+    u32* bm = pm + JP_META;
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 item = blockIdx.x, p = item / a.nsplit, slice = item % a.nsplit;
+#define FJ_STAMP(i) do { if (a.dbg && tid == 0 && item < 4096) a.dbg[item * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    FJ_STAMP(0);
 
     u32 b0 = 0, nbc, p0 = 0, npc;
     if (a.build.list) { b0 = a.build.boff[p]; nbc = a.build.boff[p + 1] - b0; }
@@ -87,7 +197,8 @@ __global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     if (MAT && a.part_count[item] == 0) return;
 
     constexpr u32 CPL = NT / (FJ_CHUNK / 2);          // chunks covered by one 16-B load per lane
-    constexpr u32 CPR = 4 * CPL;                      // chunks per round (4 loads per lane)
+    constexpr u32 CPR = 4 * CPL;                      // chunks per round (4 loads per lane = 8 keys)
+    constexpr u32 BKPT = 4096 / NT;                   // build keys per lane and build batch (16 chunks)
     // request one round of probe keys of the current metadata batch
     auto load_round = [&](u32 r, u32 nbatch, u64 (&kk)[8], u32& okm) {
         okm = 0;
@@ -96,8 +207,8 @@ __global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
             const u32 c = r * CPR + u * CPL + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
             kk[2 * u] = 0; kk[2 * u + 1] = 0;
             if (c < nbatch) {
-                const u32 cnt = pm_cnt[c];
-                const u64 base = (u64)pm_id[c] * FJ_CHUNK + off;
+                const u32 e = pm[c], cnt = FJ_LIST_CNT(e);
+                const u64 base = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
                 if (off + 1 < cnt) {
                     const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + base);
                     kk[2 * u] = q.x; kk[2 * u + 1] = q.y; okm |= 3u << (2 * u);
@@ -107,55 +218,68 @@ __global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
             }
         }
     };
-    auto load_probe_meta = [&](u32 first, u32 nbatch) {
-        for (u32 i = tid; i < nbatch; i += NT) { u32 id, cnt; chunk_at(a.probe, p0 + first + i, id, cnt); pm_id[i] = id; pm_cnt[i] = cnt; }
-    };
 
-    // ---- first probe batch: metadata, then the first round of keys goes in flight ---------------
+    // ---- chunk-list entries of both sides, table init; then the first two probe rounds go in flight
     u32 nbatch = (s_hi - s_lo) < JP_META ? (s_hi - s_lo) : JP_META;
-    load_probe_meta(s_lo, nbatch);
+    for (u32 i = tid; i < nbatch; i += NT) pm[i] = chunk_entry(a.probe, p0 + s_lo + i);
+    u32 nbb = nbc < JB_META ? nbc : JB_META;
+    if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + tid);
     for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
-    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->cursor = 0; hdr->claimed = 0; hdr->full = 0; hdr->empty_val = 0; }
+    for (u32 i = tid; i < S / 4; i += NT) ttags[i] = 0;
+    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->cursor = 0; hdr->claimed = 0; hdr->full = 0; hdr->ovf = 0; hdr->empty_val = 0; }
     __syncthreads();
-    u64 kn[8];
-    u32 okn = 0;
-    load_round(0, nbatch, kn, okn);
+    FJ_STAMP(1);
+    u64 ka[8], kb[8];
+    u32 oka = 0, okb = 0;
+    u32 nrounds = (nbatch + CPR - 1) / CPR;
+    load_round(0, nbatch, ka, oka);
+    if (nrounds > 1) load_round(1, nbatch, kb, okb);
 
     // ---- build: first claim of a key wins, later duplicates are dropped (hash_join.cpp:125) ----
     u32 claimed = 0;
     for (u32 bb = 0; bb < nbc; bb += JB_META) {
-        const u32 nbb = (nbc - bb) < JB_META ? (nbc - bb) : JB_META;
-        if (bb) __syncthreads();
-        if (tid < nbb) { u32 id, cnt; chunk_at(a.build, b0 + bb + tid, id, cnt); bm_id[tid] = id; bm_cnt[tid] = cnt; }
-        __syncthreads();
-        for (u32 ci = 0; ci < nbb; ci += NT / FJ_CHUNK) {
-            const u32 c = ci + tid / FJ_CHUNK, off = tid % FJ_CHUNK;
-            if (c < nbb && off < bm_cnt[c]) {
-                const u64 src = (u64)bm_id[c] * FJ_CHUNK + off;
-                const u64 key = a.build.keys[src];
-                u64 val = 0;
-                if (MAT) val = a.build.vals[src];
-                if (key == FJ_EMPTY_KEY) {
-                    hdr->has_empty = 1;
-                    if (MAT) hdr->empty_val = val;
-                } else {
-                    u32 pos = ((u32)fj_hash64(key) & SM) & ~(FJ_LDS_GROUP - 1);
-                    u32 step = 0;
-                    for (; step < S; ++step) {
-                        const u64 old = atomicCAS((unsigned long long*)&tkeys[pos], (unsigned long long)FJ_EMPTY_KEY,
-                                                  (unsigned long long)key);
-                        if (old == FJ_EMPTY_KEY) { if (MAT) tvals[pos] = val; ++claimed; break; }
-                        if (old == key) break;
-                        pos = (pos + 1) & SM;
+        if (bb) {                                   // only partitions with > 128 build chunks get here
+            nbb = (nbc - bb) < JB_META ? (nbc - bb) : JB_META;
+            __syncthreads();
+            if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + bb + tid);
+            __syncthreads();
+        }
+        for (u32 c0 = 0; c0 < nbb; c0 += 16) {      // 16 chunks = 4096 keys: all requested before any insert
+            u64 bk[BKPT], bv[BKPT];
+            u32 bok = 0;
+#pragma unroll
+            for (u32 j = 0; j < BKPT; ++j) {
+                const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
+                bk[j] = 0; bv[j] = 0;
+                if (c < nbb) {
+                    const u32 e = bm[c];
+                    if (off < FJ_LIST_CNT(e)) {
+                        const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
+                        bk[j] = a.build.keys[src];
+                        if (MAT) bv[j] = a.build.vals[src];
+                        bok |= 1u << j;
                     }
-                    if (step == S) hdr->full = 1;
+                }
+            }
+#pragma unroll
+            for (u32 j = 0; j < BKPT; ++j) {
+                if (bok & (1u << j)) {
+                    const u64 key = bk[j];
+                    if (key == FJ_EMPTY_KEY) {
+                        hdr->has_empty = 1;
+                        if (MAT) hdr->empty_val = bv[j];
+                    } else if (!(a.dbg_flags & 2u)) {
+                        claimed += lds_insert<MAT>(tkeys, tvals, reinterpret_cast<unsigned char*>(ttags), hdr, key, bv[j]) ? 1u : 0u;
+                    }
                 }
             }
         }
     }
+    FJ_STAMP(2);
     claimed = fj_wave_sum(claimed);
     if (lane == 0 && claimed) atomicAdd(&hdr->claimed, claimed);
     __syncthreads();
+    FJ_STAMP(3);
     if (hdr->full || hdr->claimed > S - 64) {       // table (nearly) full: host falls back to the global-table path
         if (tid == 0) { atomicOr(a.err, FJ_ERR_LDS_FULL); if (!MAT) a.part_count[item] = 0; }
         return;
@@ -164,58 +288,61 @@ __global__ __launch_bounds__(NT) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     const u64 obase = MAT ? a.out_off[item] : 0;
 
     // ---- probe ------------------------------------------------------------------------------------
-    u32 local = 0;
+    u32 wave_hits = 0;                                        // wave-uniform
+    const u64 he = has_empty ? ~0ull : 0ull;
+    const bool ovf = hdr->ovf != 0;                          // wave-uniform: does this table need the walking lookup?
     for (u32 pb = s_lo; pb < s_hi; pb += JP_META) {
         if (pb != s_lo) {                           // later batches (only very large partitions get here)
             nbatch = (s_hi - pb) < JP_META ? (s_hi - pb) : JP_META;
             __syncthreads();
-            load_probe_meta(pb, nbatch);
+            for (u32 i = tid; i < nbatch; i += NT) pm[i] = chunk_entry(a.probe, p0 + pb + i);
             __syncthreads();
-            load_round(0, nbatch, kn, okn);
+            nrounds = (nbatch + CPR - 1) / CPR;
+            load_round(0, nbatch, ka, oka);
+            if (nrounds > 1) load_round(1, nbatch, kb, okb);
         }
-        const u32 nrounds = (nbatch + CPR - 1) / CPR;
         for (u32 r = 0; r < nrounds; ++r) {
             u64 k[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) k[i] = kn[i];
-            const u32 okm = okn;
-            if (r + 1 < nrounds) load_round(r + 1, nbatch, kn, okn);
+            for (int i = 0; i < 8; ++i) { k[i] = ka[i]; ka[i] = kb[i]; }
+            const u32 okm = oka;
+            oka = okb;
+            if (r + 2 < nrounds) load_round(r + 2, nbatch, kb, okb);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bool hit = false;
-                u64 val = 0;
-                if (okm & (1u << i)) {
-                    if (k[i] == FJ_EMPTY_KEY) {
-                        hit = has_empty;
-                        if (MAT) val = hdr->empty_val;
-                    } else {
-                        u32 where = 0;
-                        hit = lds_lookup(tkeys, k[i], fj_hash64(k[i]), where);
-                        if (MAT && hit) val = tvals[where];
-                    }
-                }
-                if (MAT) {      // wave-uniform point: ballot-rank the hits, one LDS cursor bump per wave
-                    const u64 m = __ballot(hit);
-                    if (m) {
-                        u32 wb = 0;
-                        if (lane == 0) wb = atomicAdd(&hdr->cursor, (u32)__popcll(m));
-                        wb = __shfl(wb, 0, 64);
-                        if (hit) {
-                            const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                            a.out_keys[o] = k[i];
-                            a.out_vals[o] = val;
+            for (int hgrp = 0; hgrp < 4; ++hgrp) {
+                const u64 k2[2] = {k[2 * hgrp], k[2 * hgrp + 1]};
+                u64 ok2[2], hitm[2];
+                u32 where[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ok2[i] = __ballot((okm >> (2 * hgrp + i)) & 1u);
+                if (a.dbg_flags & 1u) { hitm[0] = __ballot((k2[0] ^ k2[1]) & 1ull); hitm[1] = 0; where[0] = where[1] = 0; }
+                else lds_probe<MAT, 2>(tkeys, ttags, k2, ok2, he, ovf, lane, hitm, where);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const u64 m = hitm[i];
+                    if (MAT) {  // one LDS cursor bump per wave and key slot, lanes ranked inside the ballot
+                        if (m) {
+                            u32 wb = 0;
+                            if (lane == 0) wb = atomicAdd(&hdr->cursor, (u32)__popcll(m));
+                            wb = __shfl(wb, 0, 64);
+                            if ((m >> lane) & 1ull) {
+                                const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                                a.out_keys[o] = k2[i];
+                                a.out_vals[o] = k2[i] == FJ_EMPTY_KEY ? hdr->empty_val : tvals[where[i]];
+                            }
                         }
+                    } else {
+                        wave_hits += (u32)__popcll(m);       // scalar: the count never touches the VALU
                     }
-                } else {
-                    local += hit ? 1u : 0u;
                 }
             }
         }
     }
+    FJ_STAMP(4);
     if (!MAT) {
-        local = fj_wave_sum(local);
-        if (lane == 0 && local) atomicAdd(&hdr->cnt, local);
+        if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
         __syncthreads();
+        FJ_STAMP(5);
         if (tid == 0) {
             a.part_count[item] = hdr->cnt;
             if (hdr->cnt) atomicAdd(a.total, (unsigned long long)hdr->cnt);
@@ -352,7 +479,7 @@ __global__ __launch_bounds__(256) void fj_owner_hist_kernel(const u64* __restric
     __syncthreads();
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + tid; i < n; i += stride)
-        atomicAdd(&h[fj_owner_of(fj_hash64(keys[i]), nranks)], 1u);
+        atomicAdd(&h[fj_owner_of_w1(fj_hash_w1(keys[i]), nranks)], 1u);
     __syncthreads();
     if (tid < nranks && h[tid]) atomicAdd(&counts[tid], (unsigned long long)h[tid]);
 }
@@ -384,7 +511,7 @@ __global__ __launch_bounds__(512) void fj_owner_scatter_kernel(const u64* __rest
             if (idx < n) {
                 k[i] = keys[idx];
                 if (HAS_VALS) v[i] = vals[idx];
-                const u32 d = fj_owner_of(fj_hash64(k[i]), nranks);
+                const u32 d = fj_owner_of_w1(fj_hash_w1(k[i]), nranks);
                 dr[i] = (d << 16) | atomicAdd(&hist[d], 1u);
             }
         }
@@ -446,13 +573,13 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s) {
     const u32 nb = a.nparts * a.nsplit;
     if (materialize) {
-        const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + (JP_META + JB_META) * 8;
+        const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + (JP_META + JB_META) * 4;
         auto kern = fj_lds_join_kernel<true, 1024>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     } else {
-        const u32 lds = sizeof(JoinHdr) + S * 8 + (JP_META + JB_META) * 8;
+        const u32 lds = sizeof(JoinHdr) + S * 8 + S + (JP_META + JB_META) * 4;
         auto kern = fj_lds_join_kernel<false, 512>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -24,30 +24,21 @@ namespace {
 
 // dynamic-LDS layout, shared by kernel and host-side size computation
 struct PartLds {
-    u32 sorted_k, sorted_v, lo_k, lo_v, hist, left, fill, cur, toff, kbase, lineoff, nfull, nch;
-    u32 line_src, line_dst, t_chunk, t_cnt, wsum, misc, total;
+    u32 sorted_k, sorted_v, lo_k, lo_v, hist, toff, line_desc, t_chunk, t_cnt, wsum, misc, total;
 };
 __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool vals, u32 nwaves) {
     PartLds L;
-    u32 nsorted = T + (line - 1) * F;
-    u32 maxl = nsorted / line + 2;
+    const u32 nsorted = T + 2;                             // bucket-sorted tile (remainders stay in lo_*)
+    const u32 maxl = (T + (line - 1) * F) / line + 2;
     u32 o = 0;
     L.sorted_k = o; o += nsorted * 8;
     L.sorted_v = o; if (vals) o += nsorted * 8;
     L.lo_k = o; o += F * line * 8;
     L.lo_v = o; if (vals) o += F * line * 8;
+    L.line_desc = o; o += maxl * 8;
     L.wsum = o; o += nwaves * 8;
-    L.hist = o; o += F * 4;
-    L.left = o; o += F * 4;
-    L.fill = o; o += F * 4;
-    L.cur = o; o += F * 4;
-    L.toff = o; o += F * 4;
-    L.kbase = o; o += F * 4;
-    L.lineoff = o; o += F * 4;
-    L.nfull = o; o += F * 4;
-    L.nch = o; o += F * 4;
-    L.line_src = o; o += maxl * 4;
-    L.line_dst = o; o += maxl * 4;
+    L.hist = o; o += (F + 4) * 4;
+    L.toff = o; o += (F + 4) * 4;
     L.t_chunk = o; o += (T / FJ_CHUNK) * 4;
     L.t_cnt = o; o += (T / FJ_CHUNK) * 4;
     L.misc = o; o += 16 * 4;
@@ -57,94 +48,108 @@ __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool 
 
 enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG };
 
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS>
+// The kernel is instruction-issue bound (not HBM bound) on gfx950, so the inner phases are written
+// to minimise issued instructions per key: 32-bit-multiply hash, invalid lanes routed to a dummy
+// bucket instead of branches, per-bucket state in the registers of thread b, the bucket scan done
+// only by the waves that own buckets, 32 B per lane in the write-out.
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
 __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a) {
-    constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LPL = LINE / 2;
-    static_assert(T % FJ_CHUNK == 0 && TC <= NT, "tile geometry");
+    constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LPL = LINE / 4;
+    static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4, "tile geometry");
     const u32 F = 1u << a.fan_log, FM = F - 1;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const PartLds Lo = part_lds_layout(T, F, LINE, HAS_VALS, NW);
-    u64* sorted_k = (u64*)(smem + Lo.sorted_k);
-    u64* sorted_v = (u64*)(smem + Lo.sorted_v);
+    u64* tile_k = (u64*)(smem + Lo.sorted_k);
+    u64* tile_v = (u64*)(smem + Lo.sorted_v);
     u64* lo_k = (u64*)(smem + Lo.lo_k);
     u64* lo_v = (u64*)(smem + Lo.lo_v);
+    u64* line_desc = (u64*)(smem + Lo.line_desc);
     u64* wsum = (u64*)(smem + Lo.wsum);
     u32* hist = (u32*)(smem + Lo.hist);
-    u32* left = (u32*)(smem + Lo.left);
-    u32* fill = (u32*)(smem + Lo.fill);
-    u32* cur = (u32*)(smem + Lo.cur);
     u32* toff = (u32*)(smem + Lo.toff);
-    u32* kbase = (u32*)(smem + Lo.kbase);
-    u32* lineoff = (u32*)(smem + Lo.lineoff);
-    u32* nfull = (u32*)(smem + Lo.nfull);
-    u32* nch = (u32*)(smem + Lo.nch);
-    u32* line_src = (u32*)(smem + Lo.line_src);
-    u32* line_dst = (u32*)(smem + Lo.line_dst);
     u32* t_chunk = (u32*)(smem + Lo.t_chunk);
     u32* t_cnt = (u32*)(smem + Lo.t_cnt);
     u32* misc = (u32*)(smem + Lo.misc);
 
-    const bool flat = (a.in_list == nullptr);
-    const u32 Lc = flat ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : 0u;
-    const u32 ntiles = flat ? (Lc + TC - 1) / TC : *a.in_ntiles;
+    const u32 Lc = FLAT ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : 0u;
+    const u32 ntiles = FLAT ? (Lc + TC - 1) / TC : *a.in_ntiles;
     const u32 G = gridDim.x, g = blockIdx.x;
     u32 t = (u32)(((u64)g * ntiles) / G);
     const u32 thi = (u32)(((u64)(g + 1) * ntiles) / G);
     const u32 cap = a.cap_chunks;
     if (t >= thi) return;
 
-    // tile descriptor: first chunk (list index), number of chunks, parent bucket
-    auto get_desc = [&](u32 tt, u32& pos, u32& len, u32& parent) {
-        if (flat) { pos = tt * TC; len = (Lc - pos) < TC ? (Lc - pos) : TC; parent = a.parent0; }
-        else { const uint4 d = a.in_tiles[tt]; pos = d.x; len = d.y; parent = d.z; }
+    // ---- input side ---------------------------------------------------------------------------
+    auto get_desc = [&](u32 tt, u32& pos, u32& len, u32& parent) {      // list input: tile table row
+        const uint4 d = a.in_tiles[tt]; pos = d.x; len = d.y; parent = d.z;
     };
-    // chunk id + key count of the tile's tid-th chunk (count 0 beyond the tile)
-    auto meta_fetch = [&](u32 pos, u32 len, u32& id, u32& cnt) {
+    auto meta_fetch = [&](u32 pos, u32 len, u32& id, u32& cnt) {        // chunk id + key count of chunk tid
         id = 0; cnt = 0;
-        if (tid < len) {
-            if (flat) {
-                id = pos + tid;
-                const u64 rem = a.n_flat - (u64)id * FJ_CHUNK;
-                cnt = rem >= FJ_CHUNK ? FJ_CHUNK : (u32)rem;
-            } else {
-                id = a.in_list[pos + tid];
-                cnt = a.in_dir[id] & FJ_DIR_CNT_MASK;
-            }
-        }
+        if (tid < len) { const u32 e = a.in_list[pos + tid]; id = FJ_LIST_ID(e); cnt = FJ_LIST_CNT(e); }
     };
-    // issue the tile's loads (16 B per lane) using the chunk metadata currently in LDS
-    auto key_load = [&](u64 (&kk)[KPT], u64 (&vv)[KPT], u32& vmask) {
+    // request a tile's keys: 16 B per lane and load
+    auto key_load = [&](u32 tt, u64 (&kk)[KPT], u64 (&vv)[KPT], u32& vmask) {
         vmask = 0;
 #pragma unroll
         for (int i = 0; i < KPT / 2; ++i) {
-            const u32 kidx = ((u32)i * NT + tid) * 2;
-            const u32 j = kidx >> FJ_CHUNK_LOG, off = kidx & (FJ_CHUNK - 1);
-            const u32 cnt = t_cnt[j];
             kk[2 * i] = 0; kk[2 * i + 1] = 0;
             if (HAS_VALS) { vv[2 * i] = 0; vv[2 * i + 1] = 0; }
-            if (off < cnt) {
-                const u64 base = (u64)t_chunk[j] * FJ_CHUNK + off;
-                if (off + 1 < cnt) {
-                    const u64x2 q = *reinterpret_cast<const u64x2*>(a.in_keys + base);
-                    kk[2 * i] = q.x; kk[2 * i + 1] = q.y;
-                    if (HAS_VALS) {
-                        const u64x2 w = *reinterpret_cast<const u64x2*>(a.in_vals + base);
-                        vv[2 * i] = w.x; vv[2 * i + 1] = w.y;
-                    }
-                    vmask |= 3u << (2 * i);
-                } else {
-                    kk[2 * i] = a.in_keys[base];
-                    if (HAS_VALS) vv[2 * i] = a.in_vals[base];
-                    vmask |= 1u << (2 * i);
+            u64 base; u32 nv;                               // nv = valid keys of this pair (0..2)
+            if (FLAT) {
+                base = (u64)tt * T + ((u32)i * NT + tid) * 2;
+                nv = base + 1 < a.n_flat ? 2u : (base < a.n_flat ? 1u : 0u);
+            } else {
+                const u32 kidx = ((u32)i * NT + tid) * 2;
+                const u32 j = kidx >> FJ_CHUNK_LOG, off = kidx & (FJ_CHUNK - 1);
+                const u32 cnt = t_cnt[j];
+                base = (u64)t_chunk[j] * FJ_CHUNK + off;
+                nv = off + 1 < cnt ? 2u : (off < cnt ? 1u : 0u);
+            }
+            if (nv == 2) {
+                const u64x2 q = *reinterpret_cast<const u64x2*>(a.in_keys + base);
+                kk[2 * i] = q.x; kk[2 * i + 1] = q.y;
+                if (HAS_VALS) {
+                    const u64x2 w = *reinterpret_cast<const u64x2*>(a.in_vals + base);
+                    vv[2 * i] = w.x; vv[2 * i + 1] = w.y;
                 }
+                vmask |= 3u << (2 * i);
+            } else if (nv == 1) {
+                kk[2 * i] = a.in_keys[base];
+                if (HAS_VALS) vv[2 * i] = a.in_vals[base];
+                vmask |= 1u << (2 * i);
             }
         }
     };
 
-    for (u32 b = tid; b < F; b += NT) { left[b] = 0; fill[b] = FJ_CHUNK; cur[b] = FJ_DIR_INVALID; nch[b] = 0; }
     if (tid == 0) { misc[M_SLAB_CUR] = 0; misc[M_SLAB_REM] = 0; misc[M_NEW_BASE] = 0; misc[M_SEG] = 0; }
+    // per-bucket state lives in the registers of thread b (b < F)
+    u32 st_left = 0, st_fill = FJ_CHUNK, st_cur = FJ_DIR_INVALID, st_nch = 0;
+    u32 pend_cnt = 0, pend_nf = 0, pend_tb = 0;
+
+    // carry step of the tile that was just written: the keys of bucket b that did not fill a whole
+    // line move (or stay) in lo_*.  Runs after the tile's last barrier, before the tile region is reused.
+    auto carry = [&]() {
+        if (tid < F) {
+            const u32 b = tid, tot = st_left + pend_cnt;
+            if (pend_nf == 0) {                                   // nothing was written: append the new keys
+                for (u32 j = 0; j < pend_cnt; ++j) {
+                    lo_k[b * LINE + st_left + j] = tile_k[pend_tb + j];
+                    if (HAS_VALS) lo_v[b * LINE + st_left + j] = tile_v[pend_tb + j];
+                }
+            } else {                                              // the remainder is the tail of the new keys
+                const u32 nl2 = tot - pend_nf, src = pend_tb + (pend_nf - st_left);
+                for (u32 j = 0; j < nl2; ++j) {
+                    lo_k[b * LINE + j] = tile_k[src + j];
+                    if (HAS_VALS) lo_v[b * LINE + j] = tile_v[src + j];
+                }
+            }
+            st_left = tot - pend_nf;
+            pend_cnt = 0; pend_nf = 0;
+        }
+    };
 
     // id of the j-th chunk this workgroup allocates in the current tile
     auto alloc_id = [&](u32 j) -> u32 {
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
         }
         __syncthreads();
         if (tid < F) {
-            const u32 b = tid, l = left[b], seg = misc[M_SEG];
-            u32 f0 = fill[b], c = cur[b], n = nch[b];
+            const u32 b = tid, l = st_left, seg = misc[M_SEG];
+            u32 f0 = st_fill, c = st_cur, n = st_nch;
             const u32 outb = parent * F + b;
             if (l > 0 && f0 == FJ_CHUNK) {
                 c = misc[M_SLAB_CUR] + atomicAdd(&misc[M_FLUSH], 1u); f0 = 0;
@@ -185,29 +190,34 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
                 const u32 off = atomicAdd(&a.bchunks[outb], n);
                 if (seg < a.max_segs) a.seg_off[(u64)seg * F + b] = off;
             }
-            left[b] = 0; fill[b] = FJ_CHUNK; cur[b] = FJ_DIR_INVALID; nch[b] = 0;
+            st_left = 0; st_fill = FJ_CHUNK; st_cur = FJ_DIR_INVALID; st_nch = 0;
         }
         __syncthreads();
         if (tid == 0) { const u32 n = misc[M_FLUSH]; misc[M_SLAB_CUR] += n; misc[M_SLAB_REM] -= n; }
         __syncthreads();
     };
 
-    // ---- prologue: keys of the first tile into registers, metadata of the second into LDS ----
+    // ---- prologue: keys of the first tile into registers, metadata of the second into LDS,
+    //      descriptor of the third into registers (every dependent load is issued a tile early) ----
     u64 kn[KPT], vn[KPT];
-    u32 validn = 0, par_next = 0, par_n2 = 0, mid = 0, mcnt = 0;
-    {
+    u32 validn = 0, par_next = a.parent0, par_n2 = a.parent0, mid = 0, mcnt = 0;
+    u32 d3_pos = 0, d3_len = 0, d3_par = 0;              // descriptor of tile t+2 at the top of iteration t
+    if (FLAT) {
+        key_load(t, kn, vn, validn);
+    } else {
         u32 p, l;
         get_desc(t, p, l, par_next);
         meta_fetch(p, l, mid, mcnt);
         if (tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }
         __syncthreads();
-        key_load(kn, vn, validn);
+        key_load(t, kn, vn, validn);
         mid = 0; mcnt = 0;
         if (t + 1 < thi) { get_desc(t + 1, p, l, par_n2); meta_fetch(p, l, mid, mcnt); }
+        if (t + 2 < thi) get_desc(t + 2, d3_pos, d3_len, d3_par);
         __syncthreads();
         if (tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }
-        __syncthreads();
     }
+    __syncthreads();
 
     u32 cur_parent = 0xFFFFFFFFu;
     for (; t < thi; ++t) {
@@ -215,11 +225,15 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
 #pragma unroll
         for (int i = 0; i < KPT; ++i) { k[i] = kn[i]; if (HAS_VALS) v[i] = vn[i]; }
         const u32 valid = validn, parent = par_next;
-        // keep HBM busy: tile t+1's keys and tile t+2's chunk metadata are requested now
-        if (t + 1 < thi) { key_load(kn, vn, validn); par_next = par_n2; }
-        mid = 0; mcnt = 0;
-        if (t + 2 < thi) { u32 p, l; get_desc(t + 2, p, l, par_n2); meta_fetch(p, l, mid, mcnt); }
+        // keep HBM busy: tile t+1's keys (and tile t+2's chunk metadata) are requested now
+        if (t + 1 < thi) { key_load(t + 1, kn, vn, validn); par_next = par_n2; }
+        if (!FLAT) {
+            mid = 0; mcnt = 0;
+            if (t + 2 < thi) { par_n2 = d3_par; meta_fetch(d3_pos, d3_len, mid, mcnt); }
+            if (t + 3 < thi) get_desc(t + 3, d3_pos, d3_len, d3_par);
+        }
 
+        carry();
         if (parent != cur_parent) {
             if (cur_parent != 0xFFFFFFFFu) flush(cur_parent);
             if (tid == 0) {
@@ -229,84 +243,83 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
             }
             cur_parent = parent;
         }
-        for (u32 b = tid; b < F; b += NT) hist[b] = left[b];
+        for (u32 b = tid; b <= F; b += NT) hist[b] = 0;     // bucket F = dummy bucket for invalid lanes
         __syncthreads();
 
-        // ---- hash, rank inside the tile with LDS atomics ----------------------------------------
+        // ---- hash, rank inside the tile with LDS atomics (branch-free) --------------------------
         u32 br[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            br[i] = 0;
-            if (valid & (1u << i)) {
-                const u32 b = (u32)(fj_hash64(k[i]) >> a.shift) & FM;
-                br[i] = (b << 16) | atomicAdd(&hist[b], 1u);
-            }
+            const u32 b = (valid & (1u << i)) ? ((fj_hash_w1(k[i]) >> sh32) & FM) : F;
+            br[i] = (b << 16) | atomicAdd(&hist[b], 1u);
         }
         __syncthreads();
 
-        // ---- one packed exclusive scan over the buckets: tile offset | line offset | new chunks
-        u32 tot = 0, nf = 0, km = 0;
-        u64 x = 0;
-        if (tid < F) {
-            tot = hist[tid];
-            nf = tot & ~(LINE - 1);
-            km = nf ? ((fill[tid] + nf - 1) >> FJ_CHUNK_LOG) : 0;
-            x = (u64)tot | ((u64)(nf >> LINE_LOG) << 20) | ((u64)km << 40);
-        }
-        u64 inc = x;
+        // ---- packed exclusive scan over the buckets (only the waves that own buckets) -----------
+        //      fields: tile offset | line offset | new chunks.   A bucket's *virtual run* is its
+        //      carried remainder (lo_*, st_left keys) followed by its new keys (tile region).
+        u32 cnt = 0, tot = 0, nf = 0, km = 0, kb = 0, l0 = 0;
+        if (wave * 64 < F) {
+            u64 x = 0;
+            if (tid < F) {
+                cnt = hist[tid];
+                tot = st_left + cnt;
+                nf = tot & ~(LINE - 1);
+                km = nf ? ((st_fill + nf - 1) >> FJ_CHUNK_LOG) : 0;
+                x = (u64)cnt | ((u64)(nf >> LINE_LOG) << 20) | ((u64)km << 40);
+            }
+            u64 inc = x;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u64 y = __shfl_up(inc, d, 64);
-            if ((int)lane >= d) inc += y;
+            for (int d = 1; d < 64; d <<= 1) {
+                const u64 y = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) inc += y;
+            }
+            if (lane == 63) wsum[wave] = inc;
+            kb = (u32)((inc - x) >> 40); l0 = (u32)(((inc - x) >> 20) & 0xFFFFFu);
+            if (tid < F) toff[tid] = (u32)((inc - x) & 0xFFFFFu);      // in-wave part, completed below
         }
-        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        u64 woff = 0;
-        for (u32 w = 0; w < wave; ++w) woff += wsum[w];
-        const u64 exc = inc - x + woff;
-        if (tid < F) {
-            toff[tid] = (u32)(exc & 0xFFFFFu);
-            lineoff[tid] = (u32)((exc >> 20) & 0xFFFFFu);
-            kbase[tid] = (u32)(exc >> 40);
-            nfull[tid] = nf;
-            if (tid == F - 1) {
-                const u32 need = (u32)(exc >> 40) + km;
-                misc[M_NLINES] = (u32)((exc >> 20) & 0xFFFFFu) + (nf >> LINE_LOG);
-                misc[M_NEED] = need;
-                if (need > misc[M_SLAB_REM]) {
-                    const u32 nb = atomicAdd(a.alloc, FJ_SLAB);
-                    if (nb + FJ_SLAB > cap) atomicOr(a.err, FJ_ERR_POOL);
-                    misc[M_NEW_BASE] = nb;
+        if (wave * 64 < F) {
+            u64 woff = 0;
+            for (u32 w = 0; w < wave; ++w) woff += wsum[w];
+            if (tid < F) {
+                const u32 to = toff[tid] + (u32)(woff & 0xFFFFFu);
+                toff[tid] = to;
+                l0 += (u32)((woff >> 20) & 0xFFFFFu);
+                kb += (u32)(woff >> 40);
+                if (tid == F - 1) {
+                    toff[F] = to + cnt;                    // dummy bucket goes behind everything
+                    const u32 need = kb + km;
+                    misc[M_NLINES] = l0 + (nf >> LINE_LOG);
+                    misc[M_NEED] = need;
+                    if (need > misc[M_SLAB_REM]) {
+                        const u32 nb = atomicAdd(a.alloc, FJ_SLAB);
+                        if (nb + FJ_SLAB > cap) atomicOr(a.err, FJ_ERR_POOL);
+                        misc[M_NEW_BASE] = nb;
+                    }
                 }
             }
         }
         __syncthreads();
 
-        // ---- bucket-sort the tile in LDS; carried remainders go in front of their bucket ------
+        // ---- bucket-sort the tile's new keys in LDS ---------------------------------------------
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            if (valid & (1u << i)) {
-                const u32 d = toff[br[i] >> 16] + (br[i] & 0xFFFFu);
-                sorted_k[d] = k[i];
-                if (HAS_VALS) sorted_v[d] = v[i];
-            }
+            const u32 d = toff[br[i] >> 16] + (br[i] & 0xFFFFu);
+            tile_k[d] = k[i];
+            if (HAS_VALS) tile_v[d] = v[i];
         }
-        for (u32 e = tid; e < F * LINE; e += NT) {
-            const u32 b = e >> LINE_LOG, j = e & (LINE - 1);
-            if (j < left[b]) {
-                sorted_k[toff[b] + j] = lo_k[e];
-                if (HAS_VALS) sorted_v[toff[b] + j] = lo_v[e];
-            }
-        }
-        u32 new_cur = 0, new_fill = 0, new_left = 0, new_nch = 0;
         if (tid < F) {
-            const u32 b = tid, f0 = fill[b], l0 = lineoff[b], s0 = toff[b], kb = kbase[b];
-            const u32 c0 = cur[b], n0 = nch[b];
+            // line descriptors: dst element (32) | bucket (8) | keys of this line that still sit in lo_* (5)
+            //                   | tile index of the line's virtual key 0, biased by 32 (19)
+            const u32 b = tid, f0 = st_fill, c0 = st_cur, n0 = st_nch, tb = toff[b];
             for (u32 q = 0; q < nf; q += LINE) {
                 const u32 pq = f0 + q, kk = pq >> FJ_CHUNK_LOG, off = pq & (FJ_CHUNK - 1);
                 const u32 id = kk == 0 ? c0 : alloc_id(kb + kk - 1);
-                line_src[l0 + (q >> LINE_LOG)] = s0 + q;
-                line_dst[l0 + (q >> LINE_LOG)] = id < cap ? id * FJ_CHUNK + off : FJ_DIR_INVALID;
+                const u32 dst = id < cap ? id * FJ_CHUNK + off : FJ_DIR_INVALID;
+                const u32 lc = q == 0 ? st_left : 0u;
+                const u32 sidx = tb + q + 32u - st_left;            // tile index of virtual key q (may precede the run for line 0)
+                line_desc[l0 + (q >> LINE_LOG)] = ((u64)dst << 32) | ((u64)b << 24) | ((u64)lc << 19) | sidx;
             }
             const u32 outb = (parent * F + b) << FJ_DIR_CNT_BITS;
             const u64 segw = (u64)misc[M_SEG] << 32;
@@ -314,38 +327,44 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
                 const u32 id = alloc_id(kb + kk - 1);
                 if (id < cap) { a.out_dir[id] = outb | FJ_CHUNK; a.out_rel[id] = segw | (n0 + kk - 1); }
             }
-            new_cur = km ? alloc_id(kb + km - 1) : c0;
-            new_fill = f0 + nf - (km << FJ_CHUNK_LOG);
-            new_left = tot & (LINE - 1);
-            new_nch = n0 + km;
+            // remember what the carry step needs (it runs at the top of the next iteration)
+            pend_cnt = cnt; pend_nf = nf; pend_tb = tb;
+            st_cur = km ? alloc_id(kb + km - 1) : c0;
+            st_fill = f0 + nf - (km << FJ_CHUNK_LOG);
+            st_nch = n0 + km;
         }
         __syncthreads();
 
-        // ---- write whole lines: LINE/2 lanes x 16 B per line -------------------------------
+        // metadata of tile t+2 (fetched at the top of this iteration) -> LDS, BEFORE this tile's stores are
+        // issued: the wait for those loads must not also wait for the stores
+        if (!FLAT && tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }
+        // ---- write whole lines: 32 B (4 keys) per lane, LINE/4 lanes per line -----------------
         const u32 nl = misc[M_NLINES];
         for (u32 e = tid; e < nl * LPL; e += NT) {
-            const u32 l = e / LPL, j2 = (e % LPL) * 2;
-            const u32 dst = line_dst[l];
+            const u32 l = e / LPL, q = (e % LPL) * 4;
+            const u64 d = line_desc[l];
+            const u32 dst = (u32)(d >> 32);
             if (dst != FJ_DIR_INVALID) {
-                const u32 src = line_src[l] + j2;
-                u64x2 q; q.x = sorted_k[src]; q.y = sorted_k[src + 1];
-                *reinterpret_cast<u64x2*>(a.out_keys + (u64)dst + j2) = q;
+                const u32 w = (u32)d, b = w >> 24, lc = (w >> 19) & 31u, sidx = (w & 0x7FFFFu) - 32u;
+                u64 r[4], rv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 vi = q + i;
+                    const bool in_lo = vi < lc;
+                    const u64* sk = in_lo ? (lo_k + b * LINE + vi) : (tile_k + (sidx + vi));
+                    r[i] = *sk;
+                    if (HAS_VALS) { const u64* sv = in_lo ? (lo_v + b * LINE + vi) : (tile_v + (sidx + vi)); rv[i] = *sv; }
+                }
+                u64x2* o = reinterpret_cast<u64x2*>(a.out_keys + (u64)dst + q);
+                u64x2 r0, r1; r0.x = r[0]; r0.y = r[1]; r1.x = r[2]; r1.y = r[3];
+                o[0] = r0; o[1] = r1;
                 if (HAS_VALS) {
-                    u64x2 w; w.x = sorted_v[src]; w.y = sorted_v[src + 1];
-                    *reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + j2) = w;
+                    u64x2* ov = reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + q);
+                    u64x2 w0, w1; w0.x = rv[0]; w0.y = rv[1]; w1.x = rv[2]; w1.y = rv[3];
+                    ov[0] = w0; ov[1] = w1;
                 }
             }
         }
-        for (u32 e = tid; e < F * LINE; e += NT) {
-            const u32 b = e >> LINE_LOG, j = e & (LINE - 1);
-            if (j < (hist[b] & (LINE - 1))) {
-                const u32 s = toff[b] + nfull[b] + j;
-                lo_k[e] = sorted_k[s];
-                if (HAS_VALS) lo_v[e] = sorted_v[s];
-            }
-        }
-        if (tid < F) { cur[tid] = new_cur; fill[tid] = new_fill; left[tid] = new_left; nch[tid] = new_nch; }
-        if (tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }      // metadata of tile t+2
         if (tid == 0) {
             const u32 need = misc[M_NEED], rem = misc[M_SLAB_REM];
             if (need <= rem) { misc[M_SLAB_CUR] += need; misc[M_SLAB_REM] = rem - need; }
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
         }
         __syncthreads();
     }
+    carry();
     flush(cur_parent);
 }
 
@@ -456,20 +476,27 @@ __global__ void fj_list_build(const u32* __restrict__ dir, const u64* __restrict
             const u32 b = e >> FJ_DIR_CNT_BITS;
             const u64 r = rel[i];
             const u32 seg = (u32)(r >> 32);
-            if (seg < max_segs) list[boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r] = i;
+            if (seg < max_segs) list[boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r] = (((e & FJ_DIR_CNT_MASK) - 1u) << 24) | i;
         }
     }
 }
 
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS>
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
 hipError_t launch_part(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
     const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64);
-    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS>;
+    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, s, a);
     return hipGetLastError();
+}
+
+template <int NT, int KPT, bool HAS_VALS>
+hipError_t launch_part2(const FjPartArgs& a, int line_log, u32 grid, hipStream_t s) {
+    const bool flat = a.in_list == nullptr;
+    if (line_log == 3) return flat ? launch_part<NT, KPT, 3, HAS_VALS, true>(a, grid, s) : launch_part<NT, KPT, 3, HAS_VALS, false>(a, grid, s);
+    return flat ? launch_part<NT, KPT, 4, HAS_VALS, true>(a, grid, s) : launch_part<NT, KPT, 4, HAS_VALS, false>(a, grid, s);
 }
 
 }  // namespace
@@ -482,12 +509,9 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
 
 // One partition pass.  Keys-only tiles are 4096 keys (512 threads x 8), key+value tiles 2048.
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
-    if (vals) {
-        if (line_log == 3) return launch_part<512, 4, 3, true>(a, grid, s);
-        return launch_part<512, 4, 4, true>(a, grid, s);
-    }
-    if (line_log == 3) return launch_part<512, 8, 3, false>(a, grid, s);
-    return launch_part<512, 8, 4, false>(a, grid, s);
+    if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
+    if (vals) return launch_part2<512, 4, true>(a, line_log, grid, s);
+    return launch_part2<512, 8, false>(a, line_log, grid, s);
 }
 
 // After a pass: per-bucket chunk counts -> offsets -> chunk lists (no atomics).

@@ -106,15 +106,16 @@ def test_adaptive_threshold_both_sides(fj, oracle):
 def test_lds_overflow_falls_back_to_global_table(fj, oracle):
     """Every build key lands in ONE radix partition (> LDS table capacity): the radix path must detect
     it and the global-table path must produce the exact result."""
-    def fmix(k):
-        k = k.copy()
+    def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
+        lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
         with np.errstate(over="ignore"):
-            k ^= k >> np.uint64(33); k *= np.uint64(0xff51afd7ed558ccd)
-            k ^= k >> np.uint64(33); k *= np.uint64(0xc4ceb9fe1a85ec53)
-            k ^= k >> np.uint64(33)
-        return k
-    cand = np.arange(1, 200000, dtype=np.uint64)
-    bk = cand[(fmix(cand) >> np.uint64(60)) == 0][:9000]          # top 4 hash bits equal -> same partition for <= 16 partitions
+            x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+            x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+            x ^= x >> np.uint32(16)
+        return x
+    cand = np.arange(1, 400000, dtype=np.uint64)
+    bk = cand[(hash_w1(cand) >> np.uint32(28)) == 0][:9000]      # top 4 hash bits equal -> same partition for <= 16 partitions
     assert bk.size == 9000
     bv = bk + np.uint64(1)
     pk = np.concatenate([bk, cand[:50000]])
@@ -170,23 +171,20 @@ def test_partition_pass_in_isolation(fj, n, bits, with_vals):
                                     torch.cuda.current_stream(0).cuda_stream, ok.ctypes.data,
                                     ov.ctypes.data if with_vals else None, ob.ctypes.data, ctypes.byref(nvalid)))
     assert nvalid.value == n
-    h = keys.copy()
-    with np.errstate(over="ignore"):
-        h ^= h >> np.uint64(33); h *= np.uint64(0xff51afd7ed558ccd)
-        h ^= h >> np.uint64(33); h *= np.uint64(0xc4ceb9fe1a85ec53)
-        h ^= h >> np.uint64(33)
+    def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
+        lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+            x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+            x ^= x >> np.uint32(16)
+        return x
     if with_vals:
         assert np.array_equal(np.sort(ov), vals)                                 # permutation of the rows
         assert np.array_equal(keys[ov.astype(np.int64)], ok)                     # values travelled with their keys
-        assert np.array_equal((h >> np.uint64(64 - bits)).astype(np.uint32)[ov.astype(np.int64)], ob)
     else:
         assert np.array_equal(np.sort(ok), np.sort(keys))
-        ho = ok.copy()
-        with np.errstate(over="ignore"):
-            ho ^= ho >> np.uint64(33); ho *= np.uint64(0xff51afd7ed558ccd)
-            ho ^= ho >> np.uint64(33); ho *= np.uint64(0xc4ceb9fe1a85ec53)
-            ho ^= ho >> np.uint64(33)
-        assert np.array_equal((ho >> np.uint64(64 - bits)).astype(np.uint32), ob)
+    assert np.array_equal(hash_w1(ok) >> np.uint32(32 - bits), ob)               # every row sits in its hash's bucket
     assert np.all(np.diff(ob.astype(np.int64)) >= 0)
 
 
