@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr u32 S = FJ_LDS_SLOTS, SM = FJ_LDS_SLOTS - 1;
+constexpr u32 S = FJ_LDS_SLOTS;
 
 struct JoinHdr {              // small scalars at the front of the dynamic LDS block
     u32 cnt, has_empty, cursor, claimed, full, ovf;
@@ -42,50 +42,60 @@ __device__ __forceinline__ void lds_groups(u64 key, u32& g1, u32& g2) {
 }
 
 __device__ __forceinline__ u32 lds_tag(u32 w2) { const u32 t = w2 >> 24; return t ? t : 1u; }
-__device__ __forceinline__ u32 tag_matches(u32 tags, u32 pattern) {      // bit 7 of every byte that equals the tag (may over-report, never under-report)
-    const u32 x = tags ^ pattern;
-    return (x - 0x01010101u) & ~x & 0x80808080u;
+__device__ __forceinline__ u32 tag_zero_bytes(u32 t) {                   // bit 7 of every zero byte, exact
+    const u32 y = (t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(y | t | 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ u32 tag_matches(u32 tags, u32 pattern) {      // bit 7 of every byte that equals the tag, EXACT:
+    return tag_zero_bytes(tags ^ pattern);                                  // an empty slot (tag 0, stale key bytes) must never be a candidate
 }
 
 
 template <bool MAT>
-__device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict__ tvals, unsigned char* __restrict__ ttag8,
-                                           JoinHdr* hdr, u64 key, u64 val) {
-    u32 g1, g2;
-    lds_groups(key, g1, g2);
-    const unsigned char tag = (unsigned char)lds_tag(fj_hash_w2(key));
-    for (int tries = 0; tries < 8; ++tries) {
-        const u64x2 a1 = *reinterpret_cast<const u64x2*>(tkeys + g1), b1 = *reinterpret_cast<const u64x2*>(tkeys + g1 + 2);
-        const u64x2 a2 = *reinterpret_cast<const u64x2*>(tkeys + g2), b2 = *reinterpret_cast<const u64x2*>(tkeys + g2 + 2);
-        if (a1.x == key || a1.y == key || b1.x == key || b1.y == key || a2.x == key || a2.y == key || b2.x == key || b2.y == key)
-            return false;                                  // duplicate build key: first claim wins (hash_join.cpp:125)
-        // groups fill from slot 0 upwards, so "number of empties" locates the first free slot
-        const u32 e1 = (a1.x == FJ_EMPTY_KEY) + (a1.y == FJ_EMPTY_KEY) + (b1.x == FJ_EMPTY_KEY) + (b1.y == FJ_EMPTY_KEY);
-        const u32 e2 = (a2.x == FJ_EMPTY_KEY) + (a2.y == FJ_EMPTY_KEY) + (b2.x == FJ_EMPTY_KEY) + (b2.y == FJ_EMPTY_KEY);
-        if (e1 == 0 && e2 == 0) break;
-        const u32 slot = e1 >= e2 ? g1 + (FJ_LDS_GROUP - e1) : g2 + (FJ_LDS_GROUP - e2);
-        const u64 old = atomicCAS((unsigned long long*)&tkeys[slot], (unsigned long long)FJ_EMPTY_KEY, (unsigned long long)key);
-        if (old == FJ_EMPTY_KEY) { ttag8[slot] = tag; if (MAT) tvals[slot] = val; return true; }
-        if (old == key) return false;
-    }
-    // overflow: linear probing from g1, slot by slot
-    hdr->ovf = 1;
-    u32 pos = g1;
-    for (u32 step = 0; step < S; ++step) {
-        const u64 old = atomicCAS((unsigned long long*)&tkeys[pos], (unsigned long long)FJ_EMPTY_KEY, (unsigned long long)key);
-        if (old == FJ_EMPTY_KEY) { ttag8[pos] = tag; if (MAT) tvals[pos] = val; return true; }
-        if (old == key) return false;
-        pos = (pos + 1) & SM;
+__device__ __noinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict__ tvals, u32* __restrict__ ttags,
+                                        u32* __restrict__ gcnt, JoinHdr* hdr, u64 key, u64 val) {
+    // Tag-guided insert.  A slot is claimed with ONE 32-bit returning LDS atomic on the group's fill
+    // counter (two 16-bit counters per word) -- 64-bit ds_cmpst was measured to dominate the build
+    // phase -- then key, value and tag are plain stores.  Duplicates already visible are dropped via
+    // the tags (hash_join.cpp:125); two racing copies of one key may both be stored, which no lookup
+    // can observe (a lookup only asks whether ANY slot matches).
+    unsigned char* ttag8 = reinterpret_cast<unsigned char*>(ttags);
+    const u32 w = fj_hash_w2(key);
+    const u32 g1 = w & (NGRP - 1), g2 = (w >> 11) & (NGRP - 1);            // group indices
+    const u32 tag = lds_tag(w), pat = tag * 0x01010101u;
+    const u32 t1 = ttags[g1], t2 = ttags[g2];
+    u32 m1 = tag_matches(t1, pat), m2 = tag_matches(t2, pat);
+    while (m1) { if (tkeys[g1 * FJ_LDS_GROUP + ((u32)__builtin_ctz(m1) >> 3)] == key) return false; m1 &= m1 - 1; }
+    while (m2) { if (tkeys[g2 * FJ_LDS_GROUP + ((u32)__builtin_ctz(m2) >> 3)] == key) return false; m2 &= m2 - 1; }
+    // emptier group first, then the other one, then walk forward from g1 (linear-probing overflow)
+    const u32 e1 = (u32)__popc(tag_zero_bytes(t1)), e2 = (u32)__popc(tag_zero_bytes(t2));
+    u32 g = e1 >= e2 ? g1 : g2;
+    const u32 galt = e1 >= e2 ? g2 : g1;
+#pragma unroll 1
+    for (u32 step = 0; step < NGRP + 2; ++step) {
+        const u32 sh = (g & 1u) * 16u;
+        const u32 idx = (atomicAdd(&gcnt[g >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        if (idx < FJ_LDS_GROUP) {
+            const u32 slot = g * FJ_LDS_GROUP + idx;
+            tkeys[slot] = key;
+            if (MAT) tvals[slot] = val;
+            ttag8[slot] = (unsigned char)tag;
+            return true;
+        }
+        if (step == 0) { g = galt; continue; }
+        if (step == 1) { hdr->ovf = 1; g = g1; }           // both candidate groups full: walk from g1
+        g = (g + 1) & (NGRP - 1);
     }
     hdr->full = 1;
     return false;
 }
 
+
+
 // Lookups go through one-byte tags (one u32 = the 4 tags of a group): the kernel is LDS-bound
 // when a lookup reads all 8 candidate keys (random ds_read_b128: ~70 % of the LDS cycles are bank
 // conflicts, profiles/r01_v5_pmc), so a lookup reads the two tag words (8 B), finds the slots whose
 // tag equals the key's tag with a SWAR zero-byte test, and reads only that key (8 B).  Tag 0 = empty.
-// Probe NK keys per lane.
 //   okm[i]  : lanes whose key i is a real key          he : all-ones if the build side held FJ_EMPTY_KEY
 //   hitm[i] : lanes whose key i matched                where[i] (MAT only): matching slot
 template <bool MAT, int NK>
@@ -101,18 +111,23 @@ __device__ __forceinline__ void lds_probe(const u64* __restrict__ tkeys, const u
         z1[i] = tag_matches(ttags[g1[i] / FJ_LDS_GROUP], pat);
         z2[i] = tag_matches(ttags[g2[i] / FJ_LDS_GROUP], pat);
     }
+    u32 cand[NK];
+    u64 kc[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {                           // stage B: the first candidate's key (unconditional read keeps the
+        const bool in1 = z1[i] != 0;                         // NK reads independent and in flight together)
+        const u32 z = in1 ? z1[i] : z2[i];
+        cand[i] = (in1 ? g1[i] : g2[i]) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
+        kc[i] = tkeys[cand[i]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-        // first candidate slot (if any), its key, compare
         const bool in1 = z1[i] != 0;
-        const u32 z = in1 ? z1[i] : z2[i];
-        const u32 cand = (in1 ? g1[i] : g2[i]) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
-        u64 kc = ~k[i];
-        if (z) kc = tkeys[cand];
-        const bool first = kc == k[i];
+        const bool first = ((z1[i] | z2[i]) != 0) & (kc[i] == k[i]);
         const u64 hit1 = __ballot(first);
         const u64 ise = __ballot(k[i] == FJ_EMPTY_KEY);      // the empty marker is never stored in the table
-        if (MAT) where[i] = cand;
+        if (MAT) where[i] = cand[i];
         // more candidates left?  (false-positive tags: rare)
         const u32 r1 = in1 ? (z1[i] & (z1[i] - 1)) : 0u, r2 = in1 ? z2[i] : (z2[i] & (z2[i] - 1));
         const u64 more = __ballot(!first && (r1 | r2) != 0) & okm[i] & ~ise;
@@ -135,14 +150,17 @@ __device__ __forceinline__ void lds_probe(const u64* __restrict__ tkeys, const u
             const u64 undec = okm[i] & ~ise & ~hit;
             bool found = false;
             if ((undec >> lane) & 1ull) {
-                u32 p = g1[i];
-                for (u32 step = 0; step < NGRP; ++step) {
-                    const u64x2 a = *reinterpret_cast<const u64x2*>(tkeys + p);
-                    const u64x2 b = *reinterpret_cast<const u64x2*>(tkeys + p + 2);
-                    const bool m0 = a.x == k[i], m1 = a.y == k[i], m2 = b.x == k[i], m3 = b.y == k[i];
-                    if (m0 | m1 | m2 | m3) { found = true; if (MAT) where[i] = p + (m1 ? 1u : 0u) + (m2 ? 2u : 0u) + (m3 ? 3u : 0u); break; }
-                    if ((a.x == FJ_EMPTY_KEY) | (a.y == FJ_EMPTY_KEY) | (b.x == FJ_EMPTY_KEY) | (b.y == FJ_EMPTY_KEY)) break;
-                    p = (p + FJ_LDS_GROUP) & SM;
+                u32 g = g1[i] / FJ_LDS_GROUP;
+                for (u32 step = 0; step < NGRP; ++step) {    // an overflow key sits in the first non-full group after g1
+                    g = (g + 1) & (NGRP - 1);
+                    const u32 t = ttags[g];
+                    u32 m = tag_matches(t, lds_tag(fj_hash_w2(k[i])) * 0x01010101u);
+                    while (m) {
+                        const u32 c = g * FJ_LDS_GROUP + ((u32)__builtin_ctz(m) >> 3);
+                        if (tkeys[c] == k[i]) { found = true; if (MAT) where[i] = c; break; }
+                        m &= m - 1;
+                    }
+                    if (found || tag_zero_bytes(t)) break;
                 }
             }
             hit |= __ballot(found);
@@ -177,7 +195,8 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(JoinHdr));
     u64* tvals = tkeys + S;        // only present when MAT
     u32* ttags = reinterpret_cast<u32*>(tkeys + (MAT ? 2 * S : S));     // S one-byte tags
-    u32* pm = ttags + S / 4;
+    u32* gcnt = ttags + S / 4;                    // group fill counters, 16 bits each
+    u32* pm = gcnt + NGRP / 2;
     u32* bm = pm + JP_META;
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 item = blockIdx.x, p = item / a.nsplit, slice = item % a.nsplit;
@@ -224,8 +243,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     for (u32 i = tid; i < nbatch; i += NT) pm[i] = chunk_entry(a.probe, p0 + s_lo + i);
     u32 nbb = nbc < JB_META ? nbc : JB_META;
     if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + tid);
-    for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
-    for (u32 i = tid; i < S / 4; i += NT) ttags[i] = 0;
+    for (u32 i = tid; i < S / 4 + NGRP / 2; i += NT) ttags[i] = 0;       // tags and group counters
     if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->cursor = 0; hdr->claimed = 0; hdr->full = 0; hdr->ovf = 0; hdr->empty_val = 0; }
     __syncthreads();
     FJ_STAMP(1);
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                         hdr->has_empty = 1;
                         if (MAT) hdr->empty_val = bv[j];
                     } else if (!(a.dbg_flags & 2u)) {
-                        claimed += lds_insert<MAT>(tkeys, tvals, reinterpret_cast<unsigned char*>(ttags), hdr, key, bv[j]) ? 1u : 0u;
+                        claimed += lds_insert<MAT>(tkeys, tvals, ttags, gcnt, hdr, key, bv[j]) ? 1u : 0u;
                     }
                 }
             }
@@ -309,16 +327,16 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
             oka = okb;
             if (r + 2 < nrounds) load_round(r + 2, nbatch, kb, okb);
 #pragma unroll
-            for (int hgrp = 0; hgrp < 4; ++hgrp) {
-                const u64 k2[2] = {k[2 * hgrp], k[2 * hgrp + 1]};
-                u64 ok2[2], hitm[2];
-                u32 where[2];
+            for (int hgrp = 0; hgrp < 2; ++hgrp) {
+                const u64 k2[4] = {k[4 * hgrp], k[4 * hgrp + 1], k[4 * hgrp + 2], k[4 * hgrp + 3]};
+                u64 ok2[4], hitm[4];
+                u32 where[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) ok2[i] = __ballot((okm >> (2 * hgrp + i)) & 1u);
-                if (a.dbg_flags & 1u) { hitm[0] = __ballot((k2[0] ^ k2[1]) & 1ull); hitm[1] = 0; where[0] = where[1] = 0; }
-                else lds_probe<MAT, 2>(tkeys, ttags, k2, ok2, he, ovf, lane, hitm, where);
+                for (int i = 0; i < 4; ++i) ok2[i] = __ballot((okm >> (4 * hgrp + i)) & 1u);
+                if (a.dbg_flags & 1u) { hitm[0] = __ballot((k2[0] ^ k2[1]) & 1ull); hitm[1] = hitm[2] = hitm[3] = 0; where[0] = where[1] = where[2] = where[3] = 0; }
+                else lds_probe<MAT, 4>(tkeys, ttags, k2, ok2, he, ovf, lane, hitm, where);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < 4; ++i) {
                     const u64 m = hitm[i];
                     if (MAT) {  // one LDS cursor bump per wave and key slot, lanes ranked inside the ballot
                         if (m) {
@@ -573,13 +591,13 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s) {
     const u32 nb = a.nparts * a.nsplit;
     if (materialize) {
-        const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + (JP_META + JB_META) * 4;
+        const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
         auto kern = fj_lds_join_kernel<true, 1024>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     } else {
-        const u32 lds = sizeof(JoinHdr) + S * 8 + S + (JP_META + JB_META) * 4;
+        const u32 lds = sizeof(JoinHdr) + S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
         auto kern = fj_lds_join_kernel<false, 512>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
