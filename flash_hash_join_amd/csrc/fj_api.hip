@@ -103,6 +103,7 @@ Plan make_plan(size_t nb, int top_bits) {
         u64 parts = (nb + FJ_PART_TARGET_KEYS - 1) / FJ_PART_TARGET_KEYS;
         while ((1ull << p.bits) < parts) ++p.bits;
     }
+    if (p.bits > 0 && p.bits < 5) p.bits = 5;              // a pass with a tiny fan-out serialises on its per-bucket threads
     if (p.bits > top_bits - 32) p.bits = top_bits - 32;      // radix digits come from hash word 1 (32 bits)
     p.npass = (p.bits + 7) / 8;
     for (int i = 0; i < p.npass; ++i) p.fan_log[i] = p.bits / p.npass + ((getenv("FJ_SPLIT_FIRST") ? i < p.bits % p.npass : i >= p.npass - p.bits % p.npass) ? 1 : 0);   // extra bits go to the later passes
@@ -123,7 +124,10 @@ int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, 
     for (int i = 0; i < plan.npass; ++i) {
         const u32 F = 1u << plan.fan_log[i];
         used -= plan.fan_log[i];
-        u64 g64 = lbound / tile_chunks;
+        // workgroups: enough to fill the chip, but every (workgroup, bucket) pair ends in a partial chunk, so
+        // keep >= ~64 rows per pair or the consumers drown in tiny chunks (measured: 186 us per join item at
+        // B = 1M with 488 workgroups x 256 buckets)
+        u64 g64 = std::min<u64>(lbound / tile_chunks, (u64)n / ((u64)F * 64));
         const u32 G = (u32)std::min<u64>(512, std::max<u64>(1, g64));
         const u64 nb_out = (u64)parents * F;
         const u64 cap64 = n / FJ_CHUNK + 1 + 2ull * (G + parents) * F + (u64)(G + 1) * FJ_SLAB;
@@ -367,7 +371,9 @@ fj_ctx* fj_ctx_create(int device) {
     for (int i = 0; ok && i < E_NEV; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     if (!ok) { set_err("fj_ctx_create: allocating context scratch failed: %s", hipGetErrorString(hipGetLastError())); delete c; return nullptr; }
     const char* th = getenv("FJ_RADIX_THRESHOLD");
-    c->radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)262144;
+    // MI355X: the radix driver wins at every build size (<= 4096 rows it runs zero passes: one LDS table per
+    // workgroup over the flat inputs), so the adaptive switch point is 0 unless overridden (tools/sweep_adaptive.py)
+    c->radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)0;
     return c;
 }
 

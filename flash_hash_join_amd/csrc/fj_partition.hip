@@ -90,36 +90,45 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
         id = 0; cnt = 0;
         if (tid < len) { const u32 e = a.in_list[pos + tid]; id = FJ_LIST_ID(e); cnt = FJ_LIST_CNT(e); }
     };
-    // request a tile's keys: 16 B per lane and load
+    // request a tile's keys: 16 B per lane and load.  The loads are UNCONDITIONAL (address clamped to
+    // readable memory, validity kept in vmask) so that they form straight-line code: the compiler can
+    // then wait for the older chunk-list load with a counted vmcnt instead of draining these too.
+    const bool tiny = FLAT && a.n_flat < 2;
+    const u64 last_pair = FLAT ? ((a.n_flat - 2) & ~1ull) : 0;
     auto key_load = [&](u32 tt, u64 (&kk)[KPT], u64 (&vv)[KPT], u32& vmask) {
         vmask = 0;
 #pragma unroll
         for (int i = 0; i < KPT / 2; ++i) {
-            kk[2 * i] = 0; kk[2 * i + 1] = 0;
-            if (HAS_VALS) { vv[2 * i] = 0; vv[2 * i + 1] = 0; }
             u64 base; u32 nv;                               // nv = valid keys of this pair (0..2)
             if (FLAT) {
                 base = (u64)tt * T + ((u32)i * NT + tid) * 2;
                 nv = base + 1 < a.n_flat ? 2u : (base < a.n_flat ? 1u : 0u);
+                if (base > last_pair) base = last_pair;     // stay inside the array (tail tile only)
             } else {
                 const u32 kidx = ((u32)i * NT + tid) * 2;
                 const u32 j = kidx >> FJ_CHUNK_LOG, off = kidx & (FJ_CHUNK - 1);
                 const u32 cnt = t_cnt[j];
-                base = (u64)t_chunk[j] * FJ_CHUNK + off;
+                base = (u64)t_chunk[j] * FJ_CHUNK + off;    // chunks are fully allocated: any offset is readable
                 nv = off + 1 < cnt ? 2u : (off < cnt ? 1u : 0u);
             }
-            if (nv == 2) {
+            if (tiny) {                                      // a 1-key relation: no 16-B load possible
+                kk[2 * i] = nv ? a.in_keys[0] : 0; kk[2 * i + 1] = 0;
+                if (HAS_VALS) { vv[2 * i] = nv ? a.in_vals[0] : 0; vv[2 * i + 1] = 0; }
+            } else {
                 const u64x2 q = *reinterpret_cast<const u64x2*>(a.in_keys + base);
                 kk[2 * i] = q.x; kk[2 * i + 1] = q.y;
                 if (HAS_VALS) {
                     const u64x2 w = *reinterpret_cast<const u64x2*>(a.in_vals + base);
                     vv[2 * i] = w.x; vv[2 * i + 1] = w.y;
                 }
-                vmask |= 3u << (2 * i);
-            } else if (nv == 1) {
-                kk[2 * i] = a.in_keys[base];
-                if (HAS_VALS) vv[2 * i] = a.in_vals[base];
-                vmask |= 1u << (2 * i);
+            }
+            vmask |= (nv == 2 ? 3u : (nv == 1 ? 1u : 0u)) << (2 * i);
+        }
+        if (FLAT && !tiny && (a.n_flat & 1ull)) {            // odd length: the very last key has no pair partner
+#pragma unroll
+            for (int i = 0; i < KPT / 2; ++i) {
+                const u64 base = (u64)tt * T + ((u32)i * NT + tid) * 2;
+                if (base + 1 == a.n_flat) { kk[2 * i] = a.in_keys[base]; if (HAS_VALS) vv[2 * i] = a.in_vals[base]; }
             }
         }
     };
@@ -225,13 +234,15 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
 #pragma unroll
         for (int i = 0; i < KPT; ++i) { k[i] = kn[i]; if (HAS_VALS) v[i] = vn[i]; }
         const u32 valid = validn, parent = par_next;
-        // keep HBM busy: tile t+1's keys (and tile t+2's chunk metadata) are requested now
-        if (t + 1 < thi) { key_load(t + 1, kn, vn, validn); par_next = par_n2; }
+        // keep HBM busy: tile t+2's chunk-list entries first (so that waiting for them later does not
+        // wait for the younger key loads), then tile t+1's keys
+        const u32 par_t1 = par_n2;
         if (!FLAT) {
             mid = 0; mcnt = 0;
             if (t + 2 < thi) { par_n2 = d3_par; meta_fetch(d3_pos, d3_len, mid, mcnt); }
             if (t + 3 < thi) get_desc(t + 3, d3_pos, d3_len, d3_par);
         }
+        if (t + 1 < thi) { key_load(t + 1, kn, vn, validn); par_next = par_t1; }
 
         carry();
         if (parent != cur_parent) {

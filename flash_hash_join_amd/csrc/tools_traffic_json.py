@@ -1,0 +1,19 @@
+"""Turn a tools_pmc.sh summary into profiles/traffic_latest.json (HBM bytes per launch of the dominant kernel).
+gfx950: FETCH_SIZE counts 1/2 of wide coalesced read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact;
+both are reported in KiB and were collected in separate passes."""
+import json, re, sys
+summary, out = sys.argv[1], sys.argv[2]
+fetch, write = [], []
+for line in open(summary):
+    m = re.match(r"p\d\s+(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+launches=(\d+)\s+mean_per_launch=(\S+)", line)
+    if not m:
+        continue
+    k, c, n, v = m.group(1), m.group(2), int(m.group(3)), float(m.group(4))
+    if "fj_partition_kernel<512, 8, 4, false" in k:          # keys-only (probe-side) passes, flat and chunk-list input
+        (fetch if c == "FETCH_SIZE" else write).append(v)
+f = sum(fetch) / len(fetch) * 1024 * 2
+w = sum(write) / len(write) * 1024
+json.dump({"fj_partition_kernel_keys_bytes_per_launch": round(f + w), "read_bytes": round(f), "write_bytes": round(w),
+           "source": summary, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 half-count of wide reads); mean over the two probe-side passes"},
+          open(out, "w"), indent=1)
+print(open(out).read())
