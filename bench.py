@@ -161,35 +161,36 @@ def main() -> None:
     value = np_total * args.steps / elapsed / 1e9
     mean = lambda xs: (sum(xs) / len(xs)) if xs else 0.0
 
-    # ---- roofline of the dominant kernel: probe-side partition pass, 8 B read + 8 B written per key
-    rows_per_launch = (lt.get("partitions") and np_gpu) if world == 1 else None
+    # ---- roofline of the dominant kernel --------------------------------------------------------------
+    # radix workloads: the probe-side partition pass, 8 B read + 8 B written per key, one
+    # launch per pass over all of this rank's probe rows; its duration comes from HIP events recorded around
+    # each launch on the join's stream (fj_timings.probe_part_kernel_ms).
     roof = None
     if part_ms:
         avg_ms = mean(part_ms)
-        rows = np_gpu if world == 1 else mean([float(x) for x in [np_gpu]])
-        alg_bytes = 16.0 * rows
+        alg_bytes = 16.0 * np_gpu
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp) and world == 1 and args.workload == "c3" and args.scale == 1.0:
-            try:
+            try:      # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc.sh + tools/traffic_json.py), committed
                 traffic = json.load(open(tp)).get("fj_partition_kernel_keys_bytes_per_launch")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches,
-                "traffic": traffic}
-    elif world == 1:
-        # non-partitioned workloads: the probe kernel is the dominant one; 8 B key + one 64-B group per probe
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 16, "units_per_launch": np_gpu,
+                "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": traffic}
+    else:
+        # zero-pass / non-partitioned workloads: the join (probe) kernel dominates; 8 B per probe key
         avg_ms = mean(phase["join_ms"])
-        alg_bytes = (8.0 + 16.0) * np_gpu
+        alg_bytes = 8.0 * np_gpu
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
-        roof = {"bound": "hbm", "kernel": "fj_gt_probe_kernel (non-partitioned probe)", "achieved": round(achieved, 1),
+        roof = {"bound": "hbm", "kernel": "join kernel (no partition pass in this plan)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": args.steps,
-                "traffic": None}
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 8, "units_per_launch": np_gpu,
+                "avg_launch_ms": round(avg_ms, 4), "launches_timed": args.steps, "traffic": None}
 
     # phase-level accounting with SURVEY 8(d)'s formula for the declared k
     k = lt["passes"]

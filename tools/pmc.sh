@@ -12,4 +12,4 @@ for i in 1 2 3 4; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $R/$OUT/run$i.log 2>&1
 done
 cd $R
-python3 tools_pmc_summary.py $OUT
+python3 tools/pmc_summary.py $OUT
