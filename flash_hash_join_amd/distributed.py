@@ -20,6 +20,7 @@ test-suite with a stand-in engine; the default engine is the HIP one and has no 
 from __future__ import annotations
 
 import ctypes
+import os
 import time
 from typing import List, Optional, Tuple
 
@@ -84,8 +85,10 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     if engine is None:
         engine = HipEngine()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and os.environ.get("FJ_FORCE_EXCHANGE") and not dist.is_initialized():
+        raise RuntimeError("FJ_FORCE_EXCHANGE needs an initialised process group")
     t0 = time.perf_counter()
-    if world == 1:
+    if world == 1 and not os.environ.get("FJ_FORCE_EXCHANGE"):      # FJ_FORCE_EXCHANGE: run the full protocol on one rank (tests)
         res = engine.local_join(build_keys, build_values, probe_keys, materialize, bloom, 64, return_arrays)
         if timings is not None:
             timings.update(split_s=0.0, exchange_s=0.0, join_s=time.perf_counter() - t0)

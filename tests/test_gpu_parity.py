@@ -115,7 +115,7 @@ def test_lds_overflow_falls_back_to_global_table(fj, oracle):
             x ^= x >> np.uint32(16)
         return x
     cand = np.arange(1, 400000, dtype=np.uint64)
-    bk = cand[(hash_w1(cand) >> np.uint32(28)) == 0][:9000]      # top 4 hash bits equal -> same partition for <= 16 partitions
+    bk = cand[(hash_w1(cand) >> np.uint32(27)) == 0][:9000]      # top 5 hash bits equal -> one partition of the 32 the plan makes
     assert bk.size == 9000
     bv = bk + np.uint64(1)
     pk = np.concatenate([bk, cand[:50000]])
@@ -215,6 +215,34 @@ def test_owner_split_then_local_joins_equals_global_join(fj):
         total += n
         bo += bc[r]; po += pc[r]
     assert total == exp
+
+
+def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
+    """The whole multi-GPU step (owner split -> RCCL all_to_all_single -> join with hash_top_bits=48 -> all_reduce)
+    on a 1-rank nccl group: exercises HipEngine and the collectives; the multi-rank logic itself is covered on CPU."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import distributed_join
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        monkeypatch.setenv("FJ_FORCE_EXCHANGE", "1")
+        nb, npk = 3_000_000, 20_000_000
+        bk, bv = datagen.build_device(nb, "cuda:0")
+        pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=4, hit_bp=5000)
+        t = {}
+        n, sec = distributed_join(bk, bv, pk, timings=t)
+        assert n == exp and t["local_probe_rows"] == npk and t["local_build_rows"] == nb
+        n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
+        assert n == exp and k.numel() == exp
+        M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+        assert bool(torch.all((v + 1) * M == k))
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("nb,npk,hit_bp,fn", [
