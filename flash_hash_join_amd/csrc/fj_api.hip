@@ -118,7 +118,7 @@ int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, 
     u32 parents = 1;
     int used = top_bits;
     u64 lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
-    const u32 tile_chunks = vals ? 8 : 16;
+    const u32 tile_chunks = (vals && getenv("FJ_KV_KPT4")) ? 8 : 16;
     const uint4* tiles = nullptr;
     const u32* ntiles = nullptr;
     for (int i = 0; i < plan.npass; ++i) {

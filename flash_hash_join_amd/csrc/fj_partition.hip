@@ -19,6 +19,7 @@
 //
 // Algorithmic HBM bytes per key and pass: 8 read + 8 written (keys only), 16 + 16 with values.
 #include "fj_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -521,7 +522,7 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
 // One partition pass.  Keys-only tiles are 4096 keys (512 threads x 8), key+value tiles 2048.
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
     if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
-    if (vals) return launch_part2<512, 4, true>(a, line_log, grid, s);
+    if (vals) return getenv("FJ_KV_KPT4") ? launch_part2<512, 4, true>(a, line_log, grid, s) : launch_part2<512, 8, true>(a, line_log, grid, s);
     return launch_part2<512, 8, false>(a, line_log, grid, s);
 }
 
