@@ -368,6 +368,180 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     }
 }
 
+// ---- count-only join: cuckoo table ---------------------------------------------------------------
+// For counting, a lookup only has to answer "is the key there".  Two single-slot candidate locations
+// (cuckoo hashing with evictions at build time) make that 2 independent 8-byte LDS reads and two
+// v_cmp_eq_u64 -- about a third of the issued instructions of the tagged 2x4-slot table above, which
+// stays in use where a value must be fetched (materialising joins).  Load is ~0.37 by plan; a key
+// whose eviction chain does not terminate goes to a 32-entry stash that lookups scan only when it is
+// non-empty (a wave-uniform branch); a full stash raises FJ_ERR_LDS_FULL like a full table.
+constexpr u32 CK_STASH = 32, CK_MAXIT = 48;
+struct CkHdr { u32 cnt, has_empty, nstash, full; u64 pad[2]; u64 stash[CK_STASH]; };
+
+__device__ __noinline__ void cuckoo_insert(u64* __restrict__ tkeys, CkHdr* hdr, u64 key) {
+    u32 w = fj_hash_w2(key);
+    u32 l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+    if (tkeys[l1] == key || tkeys[l2] == key) return;            // duplicate build key already stored (hash_join.cpp:125)
+    u32 loc = l1;
+#pragma unroll 1
+    for (u32 it = 0; it < CK_MAXIT; ++it) {
+        const u64 old = atomicExch((unsigned long long*)&tkeys[loc], (unsigned long long)key);
+        if (old == FJ_EMPTY_KEY || old == key) return;            // free slot, or displaced a copy of the same key
+        key = old;                                                // carry the evicted key to its other location
+        w = fj_hash_w2(key);
+        l1 = w & (S - 1); l2 = (w >> 13) & (S - 1);
+        loc = loc == l1 ? l2 : l1;
+    }
+    const u32 sidx = atomicAdd(&hdr->nstash, 1u);
+    if (sidx < CK_STASH) hdr->stash[sidx] = key; else hdr->full = 1;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    CkHdr* hdr = reinterpret_cast<CkHdr*>(smem);
+    u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(CkHdr));
+    u32* pm = reinterpret_cast<u32*>(tkeys + S);
+    u32* bm = pm + JP_META;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 item = blockIdx.x, p = item / a.nsplit, slice = item % a.nsplit;
+    FJ_STAMP(0);
+
+    u32 b0 = 0, nbc, p0 = 0, npc;
+    if (a.build.list) { b0 = a.build.boff[p]; nbc = a.build.boff[p + 1] - b0; }
+    else nbc = (u32)((a.build.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
+    if (a.probe.list) { p0 = a.probe.boff[p]; npc = a.probe.boff[p + 1] - p0; }
+    else npc = (u32)((a.probe.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
+    const u32 s_lo = (u32)(((u64)slice * npc) / a.nsplit), s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
+    if (nbc == 0 || s_lo >= s_hi) {      // an empty side is skipped (hash_join.cpp:343, :518)
+        if (tid == 0) a.part_count[item] = 0;
+        return;
+    }
+    constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
+    auto load_round = [&](u32 r, u32 nbatch, u64 (&kk)[8], u32& okm) {
+        okm = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 c = r * CPR + u * CPL + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
+            kk[2 * u] = 0; kk[2 * u + 1] = 0;
+            if (c < nbatch) {
+                const u32 e = pm[c], cnt = FJ_LIST_CNT(e);
+                const u64 base = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
+                if (off + 1 < cnt) {
+                    const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + base);
+                    kk[2 * u] = q.x; kk[2 * u + 1] = q.y; okm |= 3u << (2 * u);
+                } else if (off < cnt) {
+                    kk[2 * u] = a.probe.keys[base]; okm |= 1u << (2 * u);
+                }
+            }
+        }
+    };
+
+    u32 nbatch = (s_hi - s_lo) < JP_META ? (s_hi - s_lo) : JP_META;
+    for (u32 i = tid; i < nbatch; i += NT) pm[i] = chunk_entry(a.probe, p0 + s_lo + i);
+    u32 nbb = nbc < JB_META ? nbc : JB_META;
+    if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + tid);
+    for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
+    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; }
+    __syncthreads();
+    FJ_STAMP(1);
+    u64 ka[8], kb[8];
+    u32 oka = 0, okb = 0;
+    u32 nrounds = (nbatch + CPR - 1) / CPR;
+    load_round(0, nbatch, ka, oka);
+    if (nrounds > 1) load_round(1, nbatch, kb, okb);
+
+    // ---- build ------------------------------------------------------------------------------------
+    for (u32 bb = 0; bb < nbc; bb += JB_META) {
+        if (bb) {
+            nbb = (nbc - bb) < JB_META ? (nbc - bb) : JB_META;
+            __syncthreads();
+            if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + bb + tid);
+            __syncthreads();
+        }
+        for (u32 c0 = 0; c0 < nbb; c0 += 16) {      // 16 chunks = 4096 keys: all requested before any insert
+            u64 bk[BKPT];
+            u32 bok = 0;
+#pragma unroll
+            for (u32 j = 0; j < BKPT; ++j) {
+                const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
+                bk[j] = 0;
+                if (c < nbb) {
+                    const u32 e = bm[c];
+                    if (off < FJ_LIST_CNT(e)) { bk[j] = a.build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off]; bok |= 1u << j; }
+                }
+            }
+#pragma unroll
+            for (u32 j = 0; j < BKPT; ++j) {
+                if (bok & (1u << j)) {
+                    if (bk[j] == FJ_EMPTY_KEY) hdr->has_empty = 1;
+                    else if (!(a.dbg_flags & 2u)) cuckoo_insert(tkeys, hdr, bk[j]);
+                }
+            }
+        }
+    }
+    FJ_STAMP(2);
+    __syncthreads();
+    FJ_STAMP(3);
+    if (hdr->full) {                                 // stash overflow: host falls back to the global-table path
+        if (tid == 0) { atomicOr(a.err, FJ_ERR_LDS_FULL); a.part_count[item] = 0; }
+        return;
+    }
+    const u64 he = hdr->has_empty ? ~0ull : 0ull;
+    const u32 nstash = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
+
+    // ---- probe ------------------------------------------------------------------------------------
+    u32 wave_hits = 0;                                        // wave-uniform, accumulated on the scalar unit
+    for (u32 pb = s_lo; pb < s_hi; pb += JP_META) {
+        if (pb != s_lo) {
+            nbatch = (s_hi - pb) < JP_META ? (s_hi - pb) : JP_META;
+            __syncthreads();
+            for (u32 i = tid; i < nbatch; i += NT) pm[i] = chunk_entry(a.probe, p0 + pb + i);
+            __syncthreads();
+            nrounds = (nbatch + CPR - 1) / CPR;
+            load_round(0, nbatch, ka, oka);
+            if (nrounds > 1) load_round(1, nbatch, kb, okb);
+        }
+        for (u32 r = 0; r < nrounds; ++r) {
+            u64 k[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { k[i] = ka[i]; ka[i] = kb[i]; }
+            const u32 okm = oka;
+            oka = okb;
+            if (r + 2 < nrounds) load_round(r + 2, nbatch, kb, okb);
+            if (a.dbg_flags & 1u) { wave_hits += (u32)__popcll(__ballot((k[0] ^ k[7]) & 1ull)); continue; }
+            u64 c1[8], c2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                    // 16 independent LDS reads in flight
+                const u32 w = fj_hash_w2(k[i]);
+                c1[i] = tkeys[w & (S - 1)];
+                c2[i] = tkeys[(w >> 13) & (S - 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u64 hit = __ballot(c1[i] == k[i]) | __ballot(c2[i] == k[i]);
+                if (nstash) {                                 // rare tables only
+                    bool f = false;
+                    for (u32 si = 0; si < nstash; ++si) f |= hdr->stash[si] == k[i];
+                    hit |= __ballot(f);
+                }
+                const u64 ise = __ballot(k[i] == FJ_EMPTY_KEY);  // the empty marker is never stored in the table
+                const u64 ok = __ballot((okm >> i) & 1u);
+                wave_hits += (u32)__popcll(ok & ((hit & ~ise) | (ise & he)));
+            }
+        }
+    }
+    FJ_STAMP(4);
+    if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
+    __syncthreads();
+    FJ_STAMP(5);
+    if (tid == 0) {
+        a.part_count[item] = hdr->cnt;
+        if (hdr->cnt) atomicAdd(a.total, (unsigned long long)hdr->cnt);
+    }
+}
+
 // =============================== global (non-partitioned) table ===============================
 __device__ __forceinline__ u32 gt_bloom_mask(u64 h) {      // 3 bits of a 32-bit word per 8-slot group
     return (1u << ((h >> 40) & 31)) | (1u << ((h >> 45) & 31)) | (1u << ((h >> 50) & 31));
@@ -597,8 +771,8 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     } else {
-        const u32 lds = sizeof(JoinHdr) + S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
-        auto kern = fj_lds_join_kernel<false, 512>;
+        const u32 lds = sizeof(CkHdr) + S * 8 + (JP_META + JB_META) * 4;
+        auto kern = fj_count_join_kernel<512>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a);
