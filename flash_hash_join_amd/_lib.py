@@ -60,6 +60,13 @@ def load() -> ctypes.CDLL:
             f"flash_hash_join_amd: HIP library {LIB_PATH} is missing. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C flash_hash_join_amd/csrc`. "
             "There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 under the same soname.  Whichever copy is loaded first
+    # serves the whole process, and torch does not find a GPU through /opt/rocm's copy; so when torch is
+    # installed, let it load its runtime before this library binds to "libamdhip64".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     u64, sz, vp, i32 = ctypes.c_uint64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
     pu64 = ctypes.POINTER(u64)

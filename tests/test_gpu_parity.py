@@ -278,3 +278,37 @@ def test_full_size_materialize_pairs_property(fj):
     assert n == exp and k.numel() == exp
     M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")      # 0x9E3779B97F4A7C15 as int64
     assert bool(torch.all((v + 1) * M == k))
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_against_oracle(fj, oracle, seed):
+    """Random sizes and key distributions (uniform, tiny domains with heavy duplication, sequential, skewed),
+    duplicate build keys carrying equal values; every count function and the radix/scalar pair sets vs the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    nb = int(rng.choice([1, 7, 300, 4096, 4097, 9000, 70000, 200000, 1200000]))
+    npk = int(rng.choice([1, 5, 1000, 33333, 250000, 1500000]))
+    kind = seed % 4
+    if kind == 0:                       # uniform 64-bit
+        bk = rng.integers(0, 2**64, size=nb, dtype=np.uint64)
+        pk = np.concatenate([rng.choice(bk, npk // 2 + 1), rng.integers(0, 2**64, size=npk // 2, dtype=np.uint64)])
+    elif kind == 1:                     # tiny domain: massive duplication on both sides
+        dom = int(rng.choice([3, 50, 5000]))
+        bk = rng.integers(0, dom, size=nb, dtype=np.uint64)
+        pk = rng.integers(0, 2 * dom, size=npk, dtype=np.uint64)
+    elif kind == 2:                     # sequential ids, probe range twice as wide
+        bk = rng.permutation(np.arange(nb, dtype=np.uint64))
+        pk = rng.integers(0, 2 * nb + 1, size=npk, dtype=np.uint64)
+    else:                               # skew: one hot key plus a uniform tail, 0 and 2^64-1 present
+        bk = np.unique(np.concatenate([rng.integers(0, 2**64, size=nb, dtype=np.uint64), np.array([0, 2**64 - 1], dtype=np.uint64)]))
+        hot = np.full(npk // 2, bk[rng.integers(0, bk.size)], dtype=np.uint64)
+        pk = np.concatenate([hot, rng.integers(0, 2**64, size=npk - npk // 2, dtype=np.uint64), np.array([0, 2**64 - 1], dtype=np.uint64)])
+    bv = bk * np.uint64(2654435761) + np.uint64(17)          # value is a function of the key: duplicates agree
+    pk = rng.permutation(pk)
+    exp, ek, ev = oracle.np_join(bk, bv, pk, return_arrays=True)
+    for fn in COUNT_FUNCS:
+        assert getattr(fj, fn)(bk, bv, pk)[0] == exp, (fn, seed, nb, npk, kind)
+    for fn in ("hash_join_radix", "hash_join", "adaptive_join_bloom"):
+        n, _, k, v = getattr(fj, fn)(bk, bv, pk, return_arrays=True)
+        assert n == exp, (fn, seed)
+        a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (fn, seed, nb, npk, kind)
