@@ -94,9 +94,15 @@ def main() -> None:
                              f"(WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # FJ_BENCH_FORCE_DIST=1 drives the multi-GPU code path (owner split -> RCCL all-to-all -> join -> all-reduce)
+    # on a single rank: a self-test of the N>1 branch on boxes with one GPU; results are identical.
+    force_dist = bool(os.environ.get("FJ_BENCH_FORCE_DIST")) and world == 1
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if force_dist:
+            os.environ["FJ_FORCE_EXCHANGE"] = "1"
 
     nb_gpu, np_gpu, hit_bp, fn_name = WORKLOADS[args.workload]
     nb_gpu, np_gpu = max(1, int(nb_gpu * args.scale)), max(1, int(np_gpu * args.scale))
@@ -113,14 +119,14 @@ def main() -> None:
         e = torch.tensor([exp_local], dtype=torch.int64, device=device)
         dist.all_reduce(e)
         exp_total = int(e.item())
-    engine = HipEngine(device) if world > 1 else None
+    engine = HipEngine(device) if (world > 1 or force_dist) else None
 
     part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": []}
     dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
 
     def step(record: bool) -> int:
         nonlocal part_launches
-        if world == 1:
+        if world == 1 and not force_dist:
             res = api.join_device(algo, bloom, materialize, bk, bv, pk, return_arrays=False)
         else:
             t = {}
@@ -137,7 +143,7 @@ def main() -> None:
         return int(res[0])
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -204,7 +210,7 @@ def main() -> None:
         "probe_phase_frac_of_hbm_peak": round((24 * k + 8) * np_gpu / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if probe_ms else None,
         "build_phase_algorithmic_bytes": (40 * k + 16) * nb_gpu,
     }
-    if world > 1:
+    if world > 1 or force_dist:
         phases.update({kk: round(mean(v) * 1e3, 3) for kk, v in (("split_ms", dtimes["split_s"]), ("exchange_ms", dtimes["exchange_s"]),
                                                                  ("local_join_ms", dtimes["join_s"]))})
 
@@ -235,7 +241,7 @@ def main() -> None:
             out["cpu_baseline"] = {"error": repr(ex)}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -67,9 +67,31 @@ class HipEngine:
         self.torch.cuda.synchronize(self.index)
 
 
-def _exchange(dist, group, engine, send, send_counts: List[int], recv_counts: List[int]):
+# RCCL moves wrong data when one peer-to-peer message of an all-to-all exceeds 4 GiB (measured here: an int64
+# all_to_all_single is exact at 0.8 GB per peer, wrong at 4.8 GB), so larger segments travel in several rounds.
+_MAX_ELEMS_PER_MESSAGE = 1 << 27          # 1 GiB of int64 per (source, destination) and round
+
+
+def _exchange(dist, group, engine, send, send_counts: List[int], recv_counts: List[int], rounds: int):
+    """One all-to-all of variable-size int64 segments. `rounds` (identical on every rank) > 1 splits every
+    segment into `rounds` near-equal pieces; piece r of every segment moves in round r, straight into its
+    final position of the receive buffer (list-based all_to_all on views: no staging copies)."""
     recv = engine.empty(sum(recv_counts))
-    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+    if rounds <= 1:
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+        return recv
+    soff = [0]
+    for c in send_counts:
+        soff.append(soff[-1] + c)
+    roff = [0]
+    for c in recv_counts:
+        roff.append(roff[-1] + c)
+    for r in range(rounds):
+        ins = [send[soff[d] + send_counts[d] * r // rounds: soff[d] + send_counts[d] * (r + 1) // rounds]
+               for d in range(len(send_counts))]
+        outs = [recv[roff[q] + recv_counts[q] * r // rounds: roff[q] + recv_counts[q] * (r + 1) // rounds]
+                for q in range(len(recv_counts))]
+        dist.all_to_all(outs, ins, group=group)
     return recv
 
 
@@ -106,9 +128,13 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     rc = recv_c.reshape(world, 2).tolist()
     b_recv = [int(x[0]) for x in rc]
     p_recv = [int(x[1]) for x in rc]
-    bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv)
-    bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv)
-    pk_r = _exchange(dist, group, engine, pk_s, p_counts, p_recv)
+    # number of rounds: the largest single message anywhere in the group decides (same value on every rank)
+    mx = engine.counts_tensor([max(b_counts + p_counts)])
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
+    bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
+    bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+    pk_r = _exchange(dist, group, engine, pk_s, p_counts, p_recv, rounds)
     engine.synchronize()
     t2 = time.perf_counter()
 
@@ -122,7 +148,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     engine.synchronize()
     t3 = time.perf_counter()
     if timings is not None:
-        timings.update(split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2,
+        timings.update(split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2, exchange_rounds=rounds,
                        local_build_rows=sum(b_recv), local_probe_rows=sum(p_recv), local_count=local_count)
     out = (int(tot.item()), t3 - t0)
     if materialize and return_arrays:
