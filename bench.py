@@ -44,6 +44,15 @@ WORKLOADS = {
 }
 
 
+def _flush_c_stdio() -> None:
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int) -> dict:
     """Oracle restatement of the reference CPU path (hash_join.cpp:498-534 radix count), all host cores,
     on a bounded sample of the same generator.  A reported baseline, not a target."""
@@ -101,6 +110,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        _flush_c_stdio()
         if force_dist:
             os.environ["FJ_FORCE_EXCHANGE"] = "1"
 
@@ -239,11 +249,12 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
         except Exception as ex:      # the baseline never blocks the GPU measurement
             out["cpu_baseline"] = {"error": repr(ex)}
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()                      # RCCL's banner sits in C stdio buffers: get it out before the result line
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

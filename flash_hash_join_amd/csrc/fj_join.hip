@@ -669,9 +669,24 @@ __global__ __launch_bounds__(256) void fj_owner_hist_kernel(const u64* __restric
     const u32 tid = threadIdx.x;
     if (tid < 64) h[tid] = 0;
     __syncthreads();
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + tid; i < n; i += stride)
-        atomicAdd(&h[fj_owner_of_w1(fj_hash_w1(keys[i]), nranks)], 1u);
+    // counts are aggregated per wave with ballots: 64 lanes hitting <= nranks LDS counters would serialise
+    const u32 lane = tid & 63;
+    const u64 stride = (u64)gridDim.x * blockDim.x, npairs = n / 2;
+    const u64 iters = (npairs + stride - 1) / stride;
+    for (u64 it = 0; it < iters; ++it) {                  // wave-uniform trip count: every lane reaches the ballots
+        const u64 i = it * stride + (u64)blockIdx.x * blockDim.x + tid;
+        u32 d0 = 0xFFFFFFFFu, d1 = 0xFFFFFFFFu;
+        if (i < npairs) {
+            const u64x2 q = *reinterpret_cast<const u64x2*>(keys + 2 * i);
+            d0 = fj_owner_of_w1(fj_hash_w1(q.x), nranks);
+            d1 = fj_owner_of_w1(fj_hash_w1(q.y), nranks);
+        }
+        for (u32 dd = 0; dd < nranks; ++dd) {
+            const u32 c = (u32)__popcll(__ballot(d0 == dd)) + (u32)__popcll(__ballot(d1 == dd));
+            if (lane == 0 && c) atomicAdd(&h[dd], c);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && tid == 0) atomicAdd(&h[fj_owner_of_w1(fj_hash_w1(keys[n - 1]), nranks)], 1u);
     __syncthreads();
     if (tid < nranks && h[tid]) atomicAdd(&counts[tid], (unsigned long long)h[tid]);
 }
@@ -697,14 +712,30 @@ __global__ __launch_bounds__(512) void fj_owner_scatter_kernel(const u64* __rest
         u64 k[KPT], v[KPT];
         u32 dr[KPT];
 #pragma unroll
-        for (u32 i = 0; i < KPT; ++i) {
-            const u64 idx = t * T + (u64)i * NT + tid;
-            dr[i] = 0xFFFFFFFFu;
-            if (idx < n) {
-                k[i] = keys[idx];
-                if (HAS_VALS) v[i] = vals[idx];
-                const u32 d = fj_owner_of_w1(fj_hash_w1(k[i]), nranks);
-                dr[i] = (d << 16) | atomicAdd(&hist[d], 1u);
+        for (u32 i = 0; i < KPT / 2; ++i) {                // 16 B per lane and load (the arrays are 16-B aligned)
+            const u64 idx = t * T + ((u64)i * NT + tid) * 2;
+            dr[2 * i] = dr[2 * i + 1] = 0xFFFFFFFFu;
+            if (idx + 1 < n) {
+                const u64x2 q = *reinterpret_cast<const u64x2*>(keys + idx);
+                k[2 * i] = q.x; k[2 * i + 1] = q.y;
+                if (HAS_VALS) { const u64x2 w = *reinterpret_cast<const u64x2*>(vals + idx); v[2 * i] = w.x; v[2 * i + 1] = w.y; }
+            } else if (idx < n) {
+                k[2 * i] = keys[idx];
+                if (HAS_VALS) v[2 * i] = vals[idx];
+            }
+#pragma unroll
+            for (u32 h = 0; h < 2; ++h) {                    // rank inside the tile: one LDS atomic per (wave, owner), lanes ranked by ballot
+                const bool ok = idx + h < n;
+                const u32 d = ok ? fj_owner_of_w1(fj_hash_w1(k[2 * i + h]), nranks) : 0xFFFFu;
+                for (u32 dd = 0; dd < nranks; ++dd) {
+                    const u64 m = __ballot(d == dd);
+                    if (m) {
+                        u32 base = 0;
+                        if ((tid & 63) == 0) base = atomicAdd(&hist[dd], (u32)__popcll(m));
+                        base = __shfl(base, 0, 64);
+                        if (d == dd) dr[2 * i + h] = (dd << 16) | (base + (u32)__popcll(m & ((1ull << (tid & 63)) - 1ull)));
+                    }
+                }
             }
         }
         __syncthreads();
