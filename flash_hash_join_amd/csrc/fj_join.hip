@@ -663,6 +663,16 @@ __global__ __launch_bounds__(256) void fj_gt_probe_kernel(FjGtArgs a) {
 }
 
 // =============================== multi-GPU owner split ========================================
+// lanes of this wave whose value d (< 2^(nbits-1), or exactly 2^(nbits-1) for "no key") equals mine: nbits ballots
+__device__ __forceinline__ u64 fj_match_any(u32 d, u32 nbits) {
+    u64 m = ~0ull;
+    for (u32 b = 0; b < nbits; ++b) {
+        const u64 bal = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(256) void fj_owner_hist_kernel(const u64* __restrict__ keys, u64 n, u32 nranks,
                                                             unsigned long long* __restrict__ counts) {
     __shared__ u32 h[64];
@@ -671,6 +681,8 @@ __global__ __launch_bounds__(256) void fj_owner_hist_kernel(const u64* __restric
     __syncthreads();
     // counts are aggregated per wave with ballots: 64 lanes hitting <= nranks LDS counters would serialise
     const u32 lane = tid & 63;
+    u32 nbits = 1; while ((1u << (nbits - 1)) < nranks) ++nbits;      // owner ids + one marker bit
+    const u32 none = 1u << (nbits - 1);
     const u64 stride = (u64)gridDim.x * blockDim.x, npairs = n / 2;
     const u64 iters = (npairs + stride - 1) / stride;
     for (u64 it = 0; it < iters; ++it) {                  // wave-uniform trip count: every lane reaches the ballots
@@ -681,10 +693,11 @@ __global__ __launch_bounds__(256) void fj_owner_hist_kernel(const u64* __restric
             d0 = fj_owner_of_w1(fj_hash_w1(q.x), nranks);
             d1 = fj_owner_of_w1(fj_hash_w1(q.y), nranks);
         }
-        for (u32 dd = 0; dd < nranks; ++dd) {
-            const u32 c = (u32)__popcll(__ballot(d0 == dd)) + (u32)__popcll(__ballot(d1 == dd));
-            if (lane == 0 && c) atomicAdd(&h[dd], c);
-        }
+        // d = none marks "no key" (top bit set): such lanes only match each other
+        { const u32 d = d0 == 0xFFFFFFFFu ? none : d0; const u64 m = fj_match_any(d, nbits);
+          if (d < none && lane == (u32)__builtin_ctzll(m)) atomicAdd(&h[d], (u32)__popcll(m)); }
+        { const u32 d = d1 == 0xFFFFFFFFu ? none : d1; const u64 m = fj_match_any(d, nbits);
+          if (d < none && lane == (u32)__builtin_ctzll(m)) atomicAdd(&h[d], (u32)__popcll(m)); }
     }
     if ((n & 1) && blockIdx.x == 0 && tid == 0) atomicAdd(&h[fj_owner_of_w1(fj_hash_w1(keys[n - 1]), nranks)], 1u);
     __syncthreads();
@@ -705,6 +718,8 @@ __global__ __launch_bounds__(512) void fj_owner_scatter_kernel(const u64* __rest
     __shared__ u32 hist[64], toff[65];
     __shared__ u64 gbase[64];
     const u32 tid = threadIdx.x;
+    u32 nbits = 1; while ((1u << (nbits - 1)) < nranks) ++nbits;
+    const u32 none = 1u << (nbits - 1);
     const u64 ntiles = (n + T - 1) / T;
     for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
         if (tid < 64) hist[tid] = 0;
@@ -726,16 +741,13 @@ __global__ __launch_bounds__(512) void fj_owner_scatter_kernel(const u64* __rest
 #pragma unroll
             for (u32 h = 0; h < 2; ++h) {                    // rank inside the tile: one LDS atomic per (wave, owner), lanes ranked by ballot
                 const bool ok = idx + h < n;
-                const u32 d = ok ? fj_owner_of_w1(fj_hash_w1(k[2 * i + h]), nranks) : 0xFFFFu;
-                for (u32 dd = 0; dd < nranks; ++dd) {
-                    const u64 m = __ballot(d == dd);
-                    if (m) {
-                        u32 base = 0;
-                        if ((tid & 63) == 0) base = atomicAdd(&hist[dd], (u32)__popcll(m));
-                        base = __shfl(base, 0, 64);
-                        if (d == dd) dr[2 * i + h] = (dd << 16) | (base + (u32)__popcll(m & ((1ull << (tid & 63)) - 1ull)));
-                    }
-                }
+                const u32 d = ok ? fj_owner_of_w1(fj_hash_w1(k[2 * i + h]), nranks) : none;
+                const u64 m = fj_match_any(d, nbits);          // lanes of this wave going to the same owner
+                const u32 leader = (u32)__builtin_ctzll(m), ln = tid & 63;
+                u32 base = 0;
+                if (ok && ln == leader) base = atomicAdd(&hist[d], (u32)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (ok) dr[2 * i + h] = (d << 16) | (base + (u32)__popcll(m & ((1ull << ln) - 1ull)));
             }
         }
         __syncthreads();
