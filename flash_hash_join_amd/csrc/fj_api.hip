@@ -66,7 +66,25 @@ struct Pending {
     u64 count = 0;
 };
 
+struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; };
+
+// iteration state over the plan's passes for one relation (see pass_prepare / pass_launch / pass_complete)
+struct PassIter {
+    int side = 0; bool has_vals = false; size_t n = 0; Plan plan; int used = 64; u32 parents = 1; u64 lbound = 0;
+    u32 tile_chunks = 16; int i = 0;
+    FjChunkSet prev{}; bool have_prev = false; const uint4* tiles = nullptr; const u32* ntiles = nullptr;
+    FjChunkSet cs{}; u32 Gmax = 1, F = 1, appends = 1;
+};
+
 }  // namespace
+
+struct StreamState {            // fj_stream_*: a join whose probe side arrives in pieces
+    bool active = false;
+    Plan plan; PassIter pit; FjLdsJoinArgs ja{};
+    int top_bits = 64, evc = 0;
+    size_t np_bound = 0, np_seen = 0;
+    u32 appends_left = 0;
+};
 
 struct fj_ctx {
     int device = 0;
@@ -75,6 +93,7 @@ struct fj_ctx {
     Scalars* d_sc = nullptr;
     Scalars* h_sc = nullptr;
     Pending pend;
+    StreamState st;
     size_t ws_bytes = 0;
     size_t radix_threshold = 0;
 };
@@ -95,7 +114,6 @@ int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
     return 0;
 }
 
-struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; };
 
 Plan make_plan(size_t nb, int top_bits) {
     Plan p;
@@ -110,81 +128,114 @@ Plan make_plan(size_t nb, int top_bits) {
     return p;
 }
 
-// run the plan's partition passes over one relation; `out` describes the final level
-int run_passes(fj_ctx* c, int side, const u64* keys, const u64* vals, size_t n, const Plan& plan, int top_bits,
-               hipStream_t s, FjChunkSet* out, int* ev_cursor) {
-    FjChunkSet prev{};
-    bool have_prev = false;
-    u32 parents = 1;
-    int used = top_bits;
-    u64 lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
-    const u32 tile_chunks = (vals && getenv("FJ_KV_KPT4")) ? 8 : 16;
-    const uint4* tiles = nullptr;
-    const u32* ntiles = nullptr;
-    for (int i = 0; i < plan.npass; ++i) {
-        const u32 F = 1u << plan.fan_log[i];
-        used -= plan.fan_log[i];
-        // workgroups: enough to fill the chip, but every (workgroup, bucket) pair ends in a partial chunk, so
-        // keep >= ~64 rows per pair or the consumers drown in tiny chunks (measured: 186 us per join item at
-        // B = 1M with 488 workgroups x 256 buckets)
-        u64 g64 = std::min<u64>(lbound / tile_chunks, (u64)n / ((u64)F * 64));
-        const u32 G = (u32)std::min<u64>(512, std::max<u64>(1, g64));
-        const u64 nb_out = (u64)parents * F;
-        const u64 cap64 = n / FJ_CHUNK + 1 + 2ull * (G + parents) * F + (u64)(G + 1) * FJ_SLAB;
-        if (cap64 >= (1ull << 24) || nb_out >= (1u << 22))
-            return set_err("relation of %zu rows is too large for one GPU's chunk directory", n);
-        FjChunkSet cs{};
-        cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0; cs.fan_mask = F - 1; cs.max_segs = G + parents + 2;
-        const int base = side * W_SIDE_STRIDE + (i & 1) * W_KINDS;
-        void* p;
-        if (get_buf(c, base + W_POOL_K, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.keys = (u64*)p;
-        cs.vals = nullptr;
-        if (vals) { if (get_buf(c, base + W_POOL_V, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.vals = (u64*)p; }
-        if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
-        if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
-        if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
-        if (get_buf(c, base + W_BCHUNKS, nb_out * 4, &p)) return 1; cs.bchunks = (u32*)p;
-        if (get_buf(c, base + W_BOFF, (nb_out + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
-        if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * F * 4, &p)) return 1; cs.seg_off = (u32*)p;
-        cs.alloc = &c->d_sc->alloc[side * 4 + i];
-        HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
-        HIPCHK(hipMemsetAsync(cs.bchunks, 0, nb_out * 4, s));
-        HIPCHK(hipMemsetAsync(cs.alloc, 0, 4, s));
-        HIPCHK(hipMemsetAsync(&c->d_sc->seg_counter[side * 4 + i], 0, 4, s));
+// ---- partition passes over one relation, as a small state machine ------------------------------
+// prepare (allocate + clear the output pool of the next pass) -> launch (once, or several times when the
+// input arrives in pieces: launches accumulate into the same pool) -> complete (chunk lists, tile table).
 
-        FjPartArgs a{};
-        if (have_prev) {
-            a.in_keys = prev.keys; a.in_vals = prev.vals; a.in_list = prev.list; a.in_dir = prev.dir;
-            a.in_tiles = tiles; a.in_ntiles = ntiles; a.n_flat = 0;
-        } else {
-            a.in_keys = keys; a.in_vals = vals; a.in_list = nullptr; a.in_dir = nullptr; a.in_tiles = nullptr; a.in_ntiles = nullptr; a.n_flat = n;
-        }
-        a.parent0 = 0;
-        a.out_keys = cs.keys; a.out_vals = cs.vals; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off;
-        a.bchunks = cs.bchunks; a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[side * 4 + i];
-        a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
-        a.err = &c->d_sc->err;
-        a.shift = (u32)used; a.fan_log = (u32)plan.fan_log[i];
-        const int line_log = 4;                 // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter)
-        if (ev_cursor) HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor)], s));
-        HIPCHK(fj_launch_partition(a, vals != nullptr, line_log, G, s));
-        if (ev_cursor) { HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor) + 1], s)); ++*ev_cursor; }
-        HIPCHK(fj_launch_group(cs, s));
-        lbound = n / FJ_CHUNK + 1 + (u64)(G + parents) * F;
-        if (i + 1 < plan.npass) {           // tile table for the next pass over this level
-            const u64 max_tiles = lbound / tile_chunks + nb_out + 1;
-            if (get_buf(c, base + W_TOFF, (nb_out + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
-            if (get_buf(c, base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1;
-            HIPCHK(fj_launch_tile_table(cs, tile_chunks, toff, (uint4*)p, (u32)max_tiles, s));
-            tiles = (const uint4*)p; ntiles = toff + nb_out;
-        }
-        prev = cs; have_prev = true;
-        parents = (u32)nb_out;
+void pass_init(PassIter& it, int side, bool has_vals, size_t n, const Plan& plan, int top_bits) {
+    it = PassIter();
+    it.side = side; it.has_vals = has_vals; it.n = n; it.plan = plan; it.used = top_bits;
+    it.lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
+    it.tile_chunks = (has_vals && getenv("FJ_KV_KPT4")) ? 8 : 16;
+}
+
+// workgroups for a launch over n rows: enough to fill the chip, but every (workgroup, bucket) pair ends in a
+// partial chunk, so keep >= ~64 rows per pair or the consumers drown in tiny chunks (measured: 186 us per join
+// item at B = 1M with 488 workgroups x 256 buckets)
+u32 pass_groups(u64 chunks, u64 rows, u32 tile_chunks, u32 F) {
+    const u64 g64 = std::min<u64>(chunks / tile_chunks, rows / ((u64)F * 64));
+    return (u32)std::min<u64>(512, std::max<u64>(1, g64));
+}
+
+int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
+    const int i = it.i;
+    it.F = 1u << it.plan.fan_log[i];
+    it.used -= it.plan.fan_log[i];
+    it.appends = appends ? appends : 1;
+    it.Gmax = pass_groups(it.lbound, it.n, it.tile_chunks, it.F);
+    const u32 F = it.F, G = it.Gmax, parents = it.parents;
+    const u64 nb_out = (u64)parents * F;
+    const u64 cap64 = it.n / FJ_CHUNK + 1 + (2ull * (G + parents) * F + (u64)(G + 1) * FJ_SLAB) * it.appends;
+    if (cap64 >= (1ull << 24) || nb_out >= (1u << 22))
+        return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
+    FjChunkSet cs{};
+    cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0; cs.fan_mask = F - 1; cs.max_segs = (G + parents + 2) * it.appends;
+    const int base = it.side * W_SIDE_STRIDE + (i & 1) * W_KINDS;
+    void* p;
+    if (get_buf(c, base + W_POOL_K, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.keys = (u64*)p;
+    cs.vals = nullptr;
+    if (it.has_vals) { if (get_buf(c, base + W_POOL_V, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.vals = (u64*)p; }
+    if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
+    if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
+    if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
+    if (get_buf(c, base + W_BCHUNKS, nb_out * 4, &p)) return 1; cs.bchunks = (u32*)p;
+    if (get_buf(c, base + W_BOFF, (nb_out + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
+    if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * F * 4, &p)) return 1; cs.seg_off = (u32*)p;
+    cs.alloc = &c->d_sc->alloc[it.side * 4 + i];
+    HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
+    HIPCHK(hipMemsetAsync(cs.bchunks, 0, nb_out * 4, s));
+    HIPCHK(hipMemsetAsync(cs.alloc, 0, 4, s));
+    HIPCHK(hipMemsetAsync(&c->d_sc->seg_counter[it.side * 4 + i], 0, 4, s));
+    it.cs = cs;
+    return 0;
+}
+
+// one launch of the prepared pass: over the previous level (keys == nullptr) or over a flat array of n rows
+int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_t n, hipStream_t s, int* ev_cursor) {
+    const FjChunkSet& cs = it.cs;
+    FjPartArgs a{};
+    u32 G = it.Gmax;
+    if (it.have_prev) {
+        a.in_keys = it.prev.keys; a.in_vals = it.prev.vals; a.in_list = it.prev.list; a.in_dir = it.prev.dir;
+        a.in_tiles = it.tiles; a.in_ntiles = it.ntiles; a.n_flat = 0;
+    } else {
+        a.in_keys = keys; a.in_vals = vals; a.in_list = nullptr; a.in_dir = nullptr; a.in_tiles = nullptr; a.in_ntiles = nullptr; a.n_flat = n;
+        G = std::min(G, pass_groups((n + FJ_CHUNK - 1) / FJ_CHUNK, n, it.tile_chunks, it.F));
     }
-    if (!have_prev) {       // no pass needed: the join kernel reads the flat arrays as virtual chunks
-        prev.keys = const_cast<u64*>(keys); prev.vals = const_cast<u64*>(vals); prev.n_flat = n; prev.list = nullptr; prev.nb = 1;
+    a.parent0 = 0;
+    a.out_keys = cs.keys; a.out_vals = cs.vals; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off;
+    a.bchunks = cs.bchunks; a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + it.i];
+    a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
+    a.err = &c->d_sc->err;
+    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i];
+    const int line_log = 4;                 // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter)
+    if (ev_cursor) HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor)], s));
+    HIPCHK(fj_launch_partition(a, it.has_vals, line_log, G, s));
+    if (ev_cursor) { HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor) + 1], s)); ++*ev_cursor; }
+    return 0;
+}
+
+int pass_complete(fj_ctx* c, PassIter& it, hipStream_t s) {
+    const FjChunkSet& cs = it.cs;
+    HIPCHK(fj_launch_group(cs, s));
+    it.lbound = it.n / FJ_CHUNK + 1 + (u64)(it.Gmax + it.parents) * it.F * it.appends;
+    if (it.i + 1 < it.plan.npass) {           // tile table for the next pass over this level
+        const int base = it.side * W_SIDE_STRIDE + (it.i & 1) * W_KINDS;
+        const u64 max_tiles = it.lbound / it.tile_chunks + cs.nb + 1;
+        void* p;
+        if (get_buf(c, base + W_TOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
+        if (get_buf(c, base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1;
+        HIPCHK(fj_launch_tile_table(cs, it.tile_chunks, toff, (uint4*)p, (u32)max_tiles, s));
+        it.tiles = (const uint4*)p; it.ntiles = toff + cs.nb;
     }
-    *out = prev;
+    it.prev = cs; it.have_prev = true;
+    it.parents = cs.nb;
+    ++it.i;
+    return 0;
+}
+
+// run every remaining pass of `it` (input of pass 0: the flat arrays); `out` describes the final level
+int run_passes(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, hipStream_t s, FjChunkSet* out, int* ev_cursor) {
+    while (it.i < it.plan.npass) {
+        if (pass_prepare(c, it, 1, s)) return 1;
+        if (pass_launch(c, it, keys, vals, it.n, s, ev_cursor)) return 1;
+        if (pass_complete(c, it, s)) return 1;
+    }
+    if (!it.have_prev) {    // no pass needed: the join kernel reads the flat arrays as virtual chunks
+        it.prev = FjChunkSet();
+        it.prev.keys = const_cast<u64*>(keys); it.prev.vals = const_cast<u64*>(vals); it.prev.n_flat = it.n; it.prev.list = nullptr; it.prev.nb = 1;
+    }
+    *out = it.prev;
     return 0;
 }
 
@@ -264,20 +315,9 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
     return 0;
 }
 
-// radix path: partition both relations, then one LDS-table join per final partition
-int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
-               hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
-    const Plan plan = make_plan(nb, top_bits);
-    *lds_full = false;
-    HIPCHK(hipEventRecord(c->ev[E_START], s));
-    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
-    FjLdsJoinArgs ja{};
-    if (run_passes(c, 0, bk, bv, nb, plan, top_bits, s, &ja.build, nullptr)) return 1;
-    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
-    int evc = 0;
-    if (run_passes(c, 1, pk, nullptr, np, plan, top_bits, s, &ja.probe, &evc)) return 1;
-    HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-
+// launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
+int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, hipStream_t s, fj_timings* t,
+                    int evc, u64* out_count, bool* lds_full) {
     ja.nparts = 1u << plan.bits;
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
     u64 nsplit = 1;
@@ -333,6 +373,27 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
     if (materialize) {
         c->pend.valid = true; c->pend.path = 0; c->pend.lds = ja; c->pend.nitems = nitems; c->pend.count = *out_count;
     }
+    return 0;
+}
+
+// radix path: partition both relations, then one LDS-table join per final partition
+int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
+               hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
+    const Plan plan = make_plan(nb, top_bits);
+    *lds_full = false;
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    FjLdsJoinArgs ja{};
+    PassIter bit, pit;
+    pass_init(bit, 0, true, nb, plan, top_bits);
+    if (run_passes(c, bit, bk, bv, s, &ja.build, nullptr)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    int evc = 0;
+    pass_init(pit, 1, false, np, plan, top_bits);
+    if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+
+    if (radix_join_tail(c, materialize, ja, plan, np, s, t, evc, out_count, lds_full)) return 1;
     return 0;
 }
 
@@ -455,6 +516,123 @@ int fj_owner_split(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, si
     return 0;
 }
 
+// ---- a join whose probe side arrives in pieces (multi-GPU: pieces of the all-to-all) ---------------------
+// begin: build-side passes + output pool of the probe side's first pass; append: one first-pass launch per piece
+// (launches accumulate into the same chunk pool); finish: remaining passes + join.  Count only.
+int fj_stream_begin(fj_ctx* c, const uint64_t* d_bk, const uint64_t* d_bv, size_t nb, size_t np_bound, int max_appends,
+                    void* stream, int hash_top_bits) {
+    if (!c) return set_err("fj_stream_begin: null context");
+    if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_stream_begin: hash_top_bits must be 64 or 48");
+    if (max_appends < 1 || max_appends > 64) return set_err("fj_stream_begin: max_appends must be 1..64");
+    if (nb && (!d_bk || !d_bv)) return set_err("fj_stream_begin: null input pointer");
+    if (((uintptr_t)d_bk | (uintptr_t)d_bv) & 15) return set_err("fj_stream_begin: input pointers must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    StreamState& st = c->st;
+    st = StreamState();
+    c->pend.valid = false;
+    st.plan = make_plan(nb, hash_top_bits);
+    st.top_bits = hash_top_bits; st.np_bound = np_bound; st.appends_left = (u32)max_appends;
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    PassIter bit;
+    pass_init(bit, 0, true, nb, st.plan, hash_top_bits);
+    if (nb && run_passes(c, bit, d_bk, d_bv, s, &st.ja.build, nullptr)) return 1;
+    if (!nb) { st.ja.build = FjChunkSet(); st.ja.build.n_flat = 0; }
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    pass_init(st.pit, 1, false, std::max<size_t>(np_bound, 1), st.plan, hash_top_bits);
+    if (st.plan.npass > 0 && pass_prepare(c, st.pit, (u32)max_appends, s)) return 1;
+    st.active = true;
+    return 0;
+}
+
+int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stream) {
+    if (!c || !c->st.active) return set_err("fj_stream_append_probe: no stream join is open on this context");
+    StreamState& st = c->st;
+    if (n == 0) return 0;
+    if (!d_pk || ((uintptr_t)d_pk & 15)) return set_err("fj_stream_append_probe: probe piece must be a 16-byte aligned device pointer");
+    if (st.appends_left == 0) return set_err("fj_stream_append_probe: more pieces than max_appends");
+    if (st.np_seen + n > st.np_bound) return set_err("fj_stream_append_probe: more probe rows than np_bound");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    --st.appends_left; st.np_seen += n;
+    if (st.plan.npass > 0) return pass_launch(c, st.pit, d_pk, nullptr, n, s, st.evc < 4 ? &st.evc : nullptr);
+    // zero-pass plan (tiny build side): join this piece right away; the device total accumulates
+    if (st.ja.build.n_flat == 0) return 0;
+    FjLdsJoinArgs ja = st.ja;
+    ja.probe = FjChunkSet(); ja.probe.keys = const_cast<u64*>(d_pk); ja.probe.n_flat = n; ja.probe.nb = 1;
+    ja.nparts = 1;
+    ja.nsplit = (u32)std::min<u64>(2048, std::max<u64>(1, ((n + FJ_CHUNK - 1) / FJ_CHUNK) / 32));
+    void* p;
+    if (get_buf(c, W_PART_COUNT, (size_t)ja.nsplit * 4, &p)) return 1; ja.part_count = (u32*)p;
+    ja.total = &c->d_sc->total; ja.err = &c->d_sc->err; ja.dbg = nullptr; ja.dbg_flags = 0;
+    HIPCHK(fj_launch_lds_join(ja, false, s));
+    return 0;
+}
+
+int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* timings) {
+    if (!c || !c->st.active) return set_err("fj_stream_finish: no stream join is open on this context");
+    StreamState& st = c->st;
+    st.active = false;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    fj_timings t; memset(&t, 0, sizeof t);
+    u64 count = 0;
+    if (st.plan.npass > 0 && st.ja.build.nb > 0 && st.np_seen > 0) {
+        if (pass_complete(c, st.pit, s)) return 1;
+        if (run_passes(c, st.pit, nullptr, nullptr, s, &st.ja.probe, nullptr)) return 1;
+        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+        bool lds_full = false;
+        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, s, &t, st.evc, &count, &lds_full)) return 1;
+        if (lds_full) return set_err("fj_stream_finish: a partition does not fit its LDS table; use fj_join_device on the whole relation");
+    } else {
+        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+        HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+        if (read_scalars(c, s)) return 1;
+        if (c->h_sc->err & FJ_ERR_LDS_FULL) return set_err("fj_stream_finish: the build side does not fit one LDS table");
+        count = c->h_sc->total;
+        t.path = 0; t.passes = 0; t.partitions = 1;
+        t.build_phase_ms = ev_ms(c, E_START, E_BUILD); t.total_ms = ev_ms(c, E_START, E_JOIN); t.probe_phase_ms = ev_ms(c, E_BUILD, E_JOIN);
+    }
+    if (out_count) *out_count = count;
+    if (timings) *timings = t;
+    g_last = t;
+    return 0;
+}
+
+// split fj_owner_split into its two halves so that a caller can size its exchange before scattering
+int fj_owner_hist(fj_ctx* c, const uint64_t* d_keys, size_t n, int nranks, uint64_t* h_counts, void* stream) {
+    if (!c) return set_err("fj_owner_hist: null context");
+    if (nranks < 1 || nranks > 64) return set_err("fj_owner_hist: nranks must be 1..64");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(c->d_sc->owner_counts, 0, sizeof(unsigned long long) * 64, s));
+    HIPCHK(fj_launch_owner_hist(d_keys, n, (u32)nranks, c->d_sc->owner_counts, s));
+    HIPCHK(hipMemcpyAsync(c->h_sc->owner_counts, c->d_sc->owner_counts, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    unsigned long long run = 0;
+    for (int r = 0; r < nranks; ++r) { h_counts[r] = c->h_sc->owner_counts[r]; run += h_counts[r]; }
+    if (run != n) return set_err("fj_owner_hist: histogram covers %llu of %zu rows", run, n);
+    return 0;
+}
+
+int fj_owner_scatter(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, int nranks, const uint64_t* h_counts,
+                     uint64_t* d_out_keys, uint64_t* d_out_vals, void* stream) {
+    if (!c) return set_err("fj_owner_scatter: null context");
+    if (nranks < 1 || nranks > 64) return set_err("fj_owner_scatter: nranks must be 1..64");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the offsets travel in a pinned slot that a previous asynchronous scatter may still be reading: drain first
+    HIPCHK(hipStreamSynchronize(s));
+    unsigned long long run = 0;
+    for (int r = 0; r < nranks; ++r) { c->h_sc->owner_offsets[r] = run; run += h_counts[r]; }
+    if (run != n) return set_err("fj_owner_scatter: counts cover %llu of %zu rows", run, n);
+    HIPCHK(hipMemcpyAsync(c->d_sc->owner_offsets, c->h_sc->owner_offsets, sizeof(unsigned long long) * 64, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_sc->owner_cursors, 0, sizeof(unsigned long long) * 64, s));
+    HIPCHK(fj_launch_owner_scatter(d_keys, d_vals, n, (u32)nranks, c->d_sc->owner_offsets, c->d_sc->owner_cursors, d_out_keys, d_out_vals, s));
+    return 0;                                         // asynchronous: ordered on `stream`
+}
+
 int fj_generate_build(fj_ctx* c, uint64_t* d_keys, uint64_t* d_vals, uint64_t first, size_t n, void* stream) {
     if (!c) return set_err("fj_generate_build: null context");
     HIPCHK(hipSetDevice(c->device));
@@ -490,7 +668,9 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
     for (int i = 0; i < plan.npass; ++i) plan.fan_log[i] = plan.bits / plan.npass + (i < plan.bits % plan.npass ? 1 : 0);
     HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
     FjChunkSet cs{};
-    if (run_passes(c, d_vals ? 0 : 1, d_keys, d_vals, n, plan, hash_top_bits, s, &cs, nullptr)) return 1;
+    PassIter dit;
+    pass_init(dit, d_vals ? 0 : 1, d_vals != nullptr, n, plan, hash_top_bits);
+    if (run_passes(c, dit, d_keys, d_vals, s, &cs, nullptr)) return 1;
     if (read_scalars(c, s)) return 1;
     if (c->h_sc->err) return set_err("fj_debug_partition: device error word 0x%x", c->h_sc->err);
     std::vector<u32> dir(cs.cap), list(cs.cap), boff(cs.nb + 1);

@@ -59,6 +59,41 @@ class HipEngine:
             t.cuda.current_stream(self.index).cuda_stream))
         return out_k, out_v, [int(counts[r]) for r in range(world)]
 
+    def owner_hist(self, keys, world: int) -> List[int]:
+        counts = (ctypes.c_uint64 * 64)()
+        self._lib.check(self.L.fj_owner_hist(self.ctx, keys.data_ptr(), keys.numel(), world, counts,
+                                             self.torch.cuda.current_stream(self.index).cuda_stream))
+        return [int(counts[r]) for r in range(world)]
+
+    def owner_scatter(self, keys, world: int, counts: List[int]):
+        """Owner-contiguous copy of `keys` given its per-owner counts; asynchronous on the current stream."""
+        out = self.empty(keys.numel())
+        c = (ctypes.c_uint64 * 64)(*counts)
+        self._lib.check(self.L.fj_owner_scatter(self.ctx, keys.data_ptr(), None, keys.numel(), world, c, out.data_ptr(), None,
+                                                self.torch.cuda.current_stream(self.index).cuda_stream))
+        return out
+
+    def stream_begin(self, bk, bv, np_bound: int, max_appends: int, hash_top_bits: int):
+        self._keep = [bk, bv]                                    # inputs must outlive the asynchronous kernels
+        self._lib.check(self.L.fj_stream_begin(self.ctx, bk.data_ptr(), bv.data_ptr(), bk.numel(), np_bound, max_appends,
+                                               self.torch.cuda.current_stream(self.index).cuda_stream, hash_top_bits))
+
+    def stream_append(self, piece):
+        self._keep.append(piece)
+        self._lib.check(self.L.fj_stream_append_probe(self.ctx, piece.data_ptr(), piece.numel(),
+                                                      self.torch.cuda.current_stream(self.index).cuda_stream))
+
+    def stream_finish(self) -> int:
+        cnt = ctypes.c_uint64(0)
+        t = self._lib.FjTimings()
+        try:
+            self._lib.check(self.L.fj_stream_finish(self.ctx, self.torch.cuda.current_stream(self.index).cuda_stream,
+                                                    ctypes.byref(cnt), ctypes.byref(t)))
+        finally:
+            self._keep = []
+        self.api._last = t
+        return int(cnt.value)
+
     def local_join(self, bk, bv, pk, materialize: bool, bloom: bool, hash_top_bits: int, return_arrays: bool):
         return self.api.join_device(self.api.ALGO_RADIX, int(bloom), int(materialize), bk, bv, pk,
                                     return_arrays=return_arrays, hash_top_bits=hash_top_bits)
@@ -95,6 +130,64 @@ def _exchange(dist, group, engine, send, send_counts: List[int], recv_counts: Li
     return recv
 
 
+def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces: int, timings: Optional[dict]):
+    """Counting join with the probe exchange cut into `pieces` rounds: the owner-scatter of piece c+1 and the first
+    partition pass over piece c-1 run while piece c is on the wire (asynchronous all-to-all)."""
+    t0 = time.perf_counter()
+    # build side: split, exchange, start the build-side passes
+    bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)
+    n = probe_keys.numel()
+    bounds = [n * c // pieces for c in range(pieces + 1)]
+    views = [probe_keys[bounds[c]: bounds[c + 1]] for c in range(pieces)]
+    p_counts = [engine.owner_hist(v, world) for v in views]                  # [piece][owner]
+    t1 = time.perf_counter()
+    # one all-to-all tells every rank what it will receive: build counts + per-piece probe counts
+    flat = []
+    for d in range(world):
+        flat += [b_counts[d]] + [p_counts[c][d] for c in range(pieces)]
+    send_c = engine.counts_tensor(flat)
+    recv_c = engine.counts_tensor([0] * len(flat))
+    dist.all_to_all_single(recv_c, send_c, group=group)
+    rc = recv_c.reshape(world, pieces + 1).tolist()
+    b_recv = [int(r[0]) for r in rc]
+    p_recv = [[int(rc[src][c + 1]) for src in range(world)] for c in range(pieces)]      # [piece][source]
+    mx = engine.counts_tensor([max([max(b_counts)] + [max(pc) for pc in p_counts])])
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
+    bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
+    bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+    np_total = sum(sum(p) for p in p_recv)
+    engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
+    keep, works, recvs = [], [], []
+    for c in range(pieces):
+        s_c = engine.owner_scatter(views[c], world, p_counts[c])
+        r_c = engine.empty(sum(p_recv[c]))
+        if rounds <= 1:
+            w = dist.all_to_all_single(r_c, s_c, output_split_sizes=p_recv[c], input_split_sizes=p_counts[c], group=group, async_op=True)
+        else:                                    # very large pieces: fall back to blocking rounds for this piece
+            r_c = _exchange(dist, group, engine, s_c, p_counts[c], p_recv[c], rounds)
+            w = None
+        keep.append(s_c); works.append(w); recvs.append(r_c)
+        if c >= 1:
+            if works[c - 1] is not None:
+                works[c - 1].wait()
+            engine.stream_append(recvs[c - 1])
+    if works[-1] is not None:
+        works[-1].wait()
+    engine.stream_append(recvs[-1])
+    t2 = time.perf_counter()
+    local_count = engine.stream_finish()
+    tot = engine.counts_tensor([local_count])
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    engine.synchronize()
+    t3 = time.perf_counter()
+    del keep
+    if timings is not None:
+        timings.update(split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2, exchange_rounds=rounds, pieces=pieces,
+                       local_build_rows=sum(b_recv), local_probe_rows=np_total, local_count=local_count)
+    return int(tot.item()), t3 - t0
+
+
 def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool = False, bloom: bool = False,
                      group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None):
     """Join relations whose rows are block-distributed over the ranks of `group`.
@@ -115,6 +208,10 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
         if timings is not None:
             timings.update(split_s=0.0, exchange_s=0.0, join_s=time.perf_counter() - t0)
         return res
+
+    pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
+    if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
+        return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings)
 
     # 1. split by owner
     bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)

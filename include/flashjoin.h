@@ -106,6 +106,25 @@ int fj_emit_pairs(fj_ctx* ctx, uint64_t* d_out_keys, uint64_t* d_out_vals, size_
 int fj_owner_split(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, int nranks,
                    uint64_t* d_out_keys, uint64_t* d_out_vals, uint64_t* h_counts, void* stream);
 
+/* The two halves of fj_owner_split: fj_owner_hist counts rows per owner (synchronous: h_counts is valid on return),
+ * fj_owner_scatter writes the owner-contiguous segments given those counts (asynchronous, ordered on `stream`). */
+int fj_owner_hist(fj_ctx* ctx, const uint64_t* d_keys, size_t n, int nranks, uint64_t* h_counts, void* stream);
+int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, int nranks, const uint64_t* h_counts,
+                     uint64_t* d_out_keys, uint64_t* d_out_vals, void* stream);
+
+/*
+ * A counting radix join whose probe side arrives in pieces (multi-GPU: the pieces of a pipelined all-to-all).
+ * fj_stream_begin partitions the build side and opens the probe side's first-pass pool for at most np_bound rows in at
+ * most max_appends pieces; every fj_stream_append_probe runs the first partition pass over one piece (asynchronous on
+ * `stream`; the piece must stay allocated until fj_stream_finish returns); fj_stream_finish runs the remaining passes
+ * and the join and returns the match count.  Same result as fj_join_device(FJ_ALGO_RADIX, 0, 0, ...) on the
+ * concatenation.  No reference counterpart.
+ */
+int fj_stream_begin(fj_ctx* ctx, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, size_t np_bound,
+                    int max_appends, void* stream, int hash_top_bits);
+int fj_stream_append_probe(fj_ctx* ctx, const uint64_t* d_probe_keys, size_t n, void* stream);
+int fj_stream_finish(fj_ctx* ctx, void* stream, uint64_t* out_count, fj_timings* timings);
+
 /*
  * Deterministic synthetic relations, generated in HBM:
  *   build_keys[i] = (first+i+1)*M, build_vals[i] = first+i, M = 0x9E3779B97F4A7C15;

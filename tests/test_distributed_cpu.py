@@ -46,6 +46,26 @@ class OracleEngine:
         ov = torch.from_numpy(vals.numpy()[order].copy()) if vals is not None else None
         return ok, ov, counts
 
+    def owner_hist(self, keys, world):
+        return self.owner_split(keys, None, world)[2]
+
+    def owner_scatter(self, keys, world, counts):
+        out, _, c = self.owner_split(keys, None, world)
+        assert c == list(counts)
+        return out
+
+    def stream_begin(self, bk, bv, np_bound, max_appends, hash_top_bits):
+        self._b = (bk, bv); self._pieces = []; self._bound = np_bound; self._max = max_appends
+
+    def stream_append(self, piece):
+        self._pieces.append(piece)
+        assert len(self._pieces) <= self._max and sum(p.numel() for p in self._pieces) <= self._bound
+
+    def stream_finish(self):
+        pk = torch.cat(self._pieces) if self._pieces else torch.empty(0, dtype=torch.int64)
+        assert pk.numel() == self._bound
+        return self.O.c_join(self._b[0].numpy(), self._b[1].numpy(), pk.numpy(), algo="radix", threads=2)[0]
+
     def local_join(self, bk, bv, pk, materialize, bloom, hash_top_bits, return_arrays):
         res = self.O.c_join(bk.numpy(), bv.numpy(), pk.numpy(), algo="radix", bloom=bloom, materialize=materialize,
                             threads=2, return_arrays=return_arrays)
@@ -71,10 +91,12 @@ def _worker(rank, world, port, nb, npk, q):
         bk, bv = datagen.build_numpy(b1 - b0, first=b0)
         pk, exp_local = datagen.probe_numpy(p1 - p0, nb, seed=1, hit_bp=5000, first=p0)
         t = {}
-        res = distributed_join(torch.from_numpy(bk.view(np.int64)), torch.from_numpy(bv.view(np.int64)),
-                               torch.from_numpy(pk.view(np.int64)), materialize=True, return_arrays=True,
-                               engine=OracleEngine(), timings=t)
+        tb, tv, tp = (torch.from_numpy(x.view(np.int64)) for x in (bk, bv, pk))
+        res = distributed_join(tb, tv, tp, materialize=True, return_arrays=True, engine=OracleEngine(), timings=t)
         exp = torch.tensor([exp_local]); dist.all_reduce(exp)
+        tc = {}
+        cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)        # counting: pipelined exchange
+        assert cnt == int(exp.item()) and tc["pieces"] == 4 and tc["local_probe_rows"] == t["local_probe_rows"]
         keys = res[2].numpy().view(np.uint64)
         # every pair this rank owns must hash to this rank
         owner = ((_fmix64(keys.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)

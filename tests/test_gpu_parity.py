@@ -280,6 +280,26 @@ def test_full_size_materialize_pairs_property(fj):
     assert bool(torch.all((v + 1) * M == k))
 
 
+@pytest.mark.parametrize("nb,npk,pieces", [(2000, 300_000, 3), (50_000, 1_000_000, 4), (1_500_000, 6_000_000, 5),
+                                           (3_000_000, 20_000_000, 4), (10, 1000, 2)])
+def test_streamed_probe_equals_one_shot(fj, nb, npk, pieces):
+    """fj_stream_begin / append_probe / finish (probe side in pieces) == the one-shot radix count, for zero-, one- and
+    two-pass plans and both hash_top_bits settings."""
+    import torch
+    from flash_hash_join_amd import datagen, api
+    from flash_hash_join_amd.distributed import HipEngine
+    bk, bv = datagen.build_device(nb, "cuda:0")
+    pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=11, hit_bp=3000)
+    eng = HipEngine("cuda:0")
+    for top in (64, 48):
+        assert api.join_device(api.ALGO_RADIX, 0, 0, bk, bv, pk, hash_top_bits=top)[0] == exp
+        eng.stream_begin(bk, bv, npk, pieces, top)
+        cuts = [npk * i // pieces for i in range(pieces + 1)]
+        for i in range(pieces):
+            eng.stream_append(pk[cuts[i]: cuts[i + 1]].clone())         # clones: 16-B aligned pieces
+        assert eng.stream_finish() == exp
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_fuzz_against_oracle(fj, oracle, seed):
     """Random sizes and key distributions (uniform, tiny domains with heavy duplication, sequential, skewed),
