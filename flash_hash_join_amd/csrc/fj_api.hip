@@ -50,7 +50,7 @@ enum Slot {
     W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_REL, W_BOFF, W_SEGOFF, W_TOFF, W_TILES, W_KINDS,
     W_SIDE_STRIDE = 2 * W_KINDS,
     W_PART_COUNT = 2 * W_SIDE_STRIDE, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
-    W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_NSLOTS
+    W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_NSLOTS
 };
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
@@ -64,6 +64,9 @@ struct Pending {
     FjGtArgs gt{};
     u32 nitems = 0, gt_grid = 0;
     u64 count = 0;
+    // duplicate build keys seen by the counting pass: the emitting pass must pick the FIRST occurrence's value
+    bool has_dups = false;
+    const u64* bk = nullptr; const u64* bv = nullptr; size_t nb = 0; int top_bits = 64;
 };
 
 struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; };
@@ -256,6 +259,18 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
         if (((uintptr_t)d_ok | (uintptr_t)d_ov) & 7) return set_err("output buffers must be 8-byte aligned");
         void* p;
         if (pd.path == 0) {
+            if (pd.has_dups) {
+                // duplicate build keys: the reference's radix path keeps the FIRST occurrence (stable partition +
+                // insert_local, hash_join.cpp:125).  Re-partition the build side with row indices as payload; the
+                // join kernel keeps the smallest index per key and fetches its value from the caller's array.
+                if (get_buf(c, W_ROWIDX, pd.nb * 8, &p)) return 1;
+                u64* rowidx = (u64*)p;
+                HIPCHK(fj_launch_iota(rowidx, pd.nb, s));
+                PassIter bit;
+                pass_init(bit, 0, true, pd.nb, make_plan(pd.nb, pd.top_bits), pd.top_bits);
+                if (run_passes(c, bit, pd.bk, rowidx, s, &pd.lds.build, nullptr)) return 1;
+                pd.lds.dedup = 1; pd.lds.orig_vals = pd.bv;
+            }
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
             HIPCHK(fj_launch_scan_u32_to_u64(pd.lds.part_count, (u64*)p, pd.nitems, s));
             pd.lds.out_off = (const u64*)p; pd.lds.out_keys = d_ok; pd.lds.out_vals = d_ov;
@@ -331,6 +346,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     void* p;
     if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
+    ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr;
     ja.dbg = nullptr;
     ja.dbg_flags = getenv("FJ_JOIN_ABLATE") ? (u32)atoi(getenv("FJ_JOIN_ABLATE")) : 0u;
     static unsigned long long* dbg_buf = nullptr;
@@ -372,6 +388,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     c->pend.valid = false;
     if (materialize) {
         c->pend.valid = true; c->pend.path = 0; c->pend.lds = ja; c->pend.nitems = nitems; c->pend.count = *out_count;
+        c->pend.has_dups = (c->h_sc->err & FJ_STAT_DUPS) != 0;
     }
     return 0;
 }
@@ -394,6 +411,7 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
     HIPCHK(hipEventRecord(c->ev[E_PPART], s));
 
     if (radix_join_tail(c, materialize, ja, plan, np, s, t, evc, out_count, lds_full)) return 1;
+    if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
     return 0;
 }
 
@@ -566,6 +584,7 @@ int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stre
     void* p;
     if (get_buf(c, W_PART_COUNT, (size_t)ja.nsplit * 4, &p)) return 1; ja.part_count = (u32*)p;
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err; ja.dbg = nullptr; ja.dbg_flags = 0;
+    ja.want_dups = 0; ja.dedup = 0; ja.orig_vals = nullptr;
     HIPCHK(fj_launch_lds_join(ja, false, s));
     return 0;
 }

@@ -5,6 +5,7 @@
 // device error word bits
 #define FJ_ERR_POOL 1u       // chunk pool exhausted (sizing bug) -> call fails
 #define FJ_ERR_LDS_FULL 2u   // a final partition does not fit its LDS table -> global-table fallback
+#define FJ_STAT_DUPS 4u      // (status, not an error) the build side holds duplicate keys
 
 // ---- partition pass ---------------------------------------------------------------------------
 struct FjPartArgs {
@@ -70,6 +71,9 @@ struct FjLdsJoinArgs {
     const u64* out_off;          // [nparts*nsplit+1] exclusive scan of part_count
     u64* out_keys;
     u64* out_vals;
+    u32 want_dups;               // counting pass of a materialising join: report duplicate build keys (FJ_STAT_DUPS)
+    u32 dedup;                   // materialising pass: build 'values' are row indices, the smallest wins, then orig_vals[idx]
+    const u64* orig_vals;        // the caller's build_values (dedup only)
     unsigned long long* dbg;     // diagnostic: per-item phase stamps (s_memrealtime), nullptr in production
     u32 dbg_flags;               // diagnostic ablations: 1 = skip lookups, 2 = skip inserts (results wrong on purpose)
 };
@@ -97,6 +101,7 @@ hipError_t fj_launch_owner_scatter(const u64* keys, const u64* vals, u64 n, u32 
                                    u64* out_keys, u64* out_vals, hipStream_t s);
 
 // ---- synthetic data ---------------------------------------------------------------------------
+hipError_t fj_launch_iota(u64* out, u64 n, hipStream_t s);
 hipError_t fj_launch_gen_build(u64* keys, u64* vals, u64 first, u64 n, hipStream_t s);
 hipError_t fj_launch_gen_probe(u64* keys, u64 first, u64 n, u64 build_total, u64 seed, u32 hit_bp,
                                unsigned long long* expected_hits, hipStream_t s);

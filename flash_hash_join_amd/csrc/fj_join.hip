@@ -53,7 +53,7 @@ __device__ __forceinline__ u32 tag_matches(u32 tags, u32 pattern) {      // bit 
 
 template <bool MAT>
 __device__ __noinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict__ tvals, u32* __restrict__ ttags,
-                                        u32* __restrict__ gcnt, JoinHdr* hdr, u64 key, u64 val) {
+                                        u32* __restrict__ gcnt, JoinHdr* hdr, u64 key, u64 val, bool dedup) {
     // Tag-guided insert.  A slot is claimed with ONE 32-bit returning LDS atomic on the group's fill
     // counter (two 16-bit counters per word) -- 64-bit ds_cmpst was measured to dominate the build
     // phase -- then key, value and tag are plain stores.  Duplicates already visible are dropped via
@@ -65,8 +65,11 @@ __device__ __noinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict
     const u32 tag = lds_tag(w), pat = tag * 0x01010101u;
     const u32 t1 = ttags[g1], t2 = ttags[g2];
     u32 m1 = tag_matches(t1, pat), m2 = tag_matches(t2, pat);
-    while (m1) { if (tkeys[g1 * FJ_LDS_GROUP + ((u32)__builtin_ctz(m1) >> 3)] == key) return false; m1 &= m1 - 1; }
-    while (m2) { if (tkeys[g2 * FJ_LDS_GROUP + ((u32)__builtin_ctz(m2) >> 3)] == key) return false; m2 &= m2 - 1; }
+    // (dedup: the "value" is the original row index and the smallest one must win -> ds_min_u64 on the existing copy)
+    while (m1) { const u32 c = g1 * FJ_LDS_GROUP + ((u32)__builtin_ctz(m1) >> 3);
+                 if (tkeys[c] == key) { if (MAT && dedup) atomicMin((unsigned long long*)&tvals[c], (unsigned long long)val); return false; } m1 &= m1 - 1; }
+    while (m2) { const u32 c = g2 * FJ_LDS_GROUP + ((u32)__builtin_ctz(m2) >> 3);
+                 if (tkeys[c] == key) { if (MAT && dedup) atomicMin((unsigned long long*)&tvals[c], (unsigned long long)val); return false; } m2 &= m2 - 1; }
     // emptier group first, then the other one, then walk forward from g1 (linear-probing overflow)
     const u32 e1 = (u32)__popc(tag_zero_bytes(t1)), e2 = (u32)__popc(tag_zero_bytes(t2));
     u32 g = e1 >= e2 ? g1 : g2;
@@ -78,7 +81,7 @@ __device__ __noinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict
         if (idx < FJ_LDS_GROUP) {
             const u32 slot = g * FJ_LDS_GROUP + idx;
             tkeys[slot] = key;
-            if (MAT) tvals[slot] = val;
+            if (MAT) { if (dedup) atomicMin((unsigned long long*)&tvals[slot], (unsigned long long)val); else tvals[slot] = val; }
             ttag8[slot] = (unsigned char)tag;
             return true;
         }
@@ -244,7 +247,9 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     u32 nbb = nbc < JB_META ? nbc : JB_META;
     if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + tid);
     for (u32 i = tid; i < S / 4 + NGRP / 2; i += NT) ttags[i] = 0;       // tags and group counters
-    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->cursor = 0; hdr->claimed = 0; hdr->full = 0; hdr->ovf = 0; hdr->empty_val = 0; }
+    const bool dedup = MAT && a.dedup != 0;
+    if (dedup) for (u32 i = tid; i < S; i += NT) tvals[i] = ~0ull;        // row indices: the minimum wins
+    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->cursor = 0; hdr->claimed = 0; hdr->full = 0; hdr->ovf = 0; hdr->empty_val = (MAT && a.dedup) ? ~0ull : 0ull; }
     __syncthreads();
     FJ_STAMP(1);
     u64 ka[8], kb[8];
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                         hdr->has_empty = 1;
                         if (MAT) hdr->empty_val = bv[j];
                     } else if (!(a.dbg_flags & 2u)) {
-                        claimed += lds_insert<MAT>(tkeys, tvals, ttags, gcnt, hdr, key, bv[j]) ? 1u : 0u;
+                        claimed += lds_insert<MAT>(tkeys, tvals, ttags, gcnt, hdr, key, bv[j], dedup) ? 1u : 0u;
                     }
                 }
             }
@@ -301,6 +306,36 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     if (hdr->full || hdr->claimed > S - 64) {       // table (nearly) full: host falls back to the global-table path
         if (tid == 0) { atomicOr(a.err, FJ_ERR_LDS_FULL); if (!MAT) a.part_count[item] = 0; }
         return;
+    }
+    if (dedup) {
+        // Two racing copies of one key may both have been stored, each with the smallest row index IT saw: give every
+        // copy the minimum over all copies (every copy lives in g1, g2 or, for overflow keys, the walk from g1), then
+        // turn the winning row index into its value with one gather from the caller's build_values.
+        const bool ovf0 = hdr->ovf != 0;
+        for (u32 sl = tid; sl < S; sl += NT) {
+            if (reinterpret_cast<const unsigned char*>(ttags)[sl] == 0) continue;
+            const u64 key = tkeys[sl];
+            const u32 w = fj_hash_w2(key), pat = lds_tag(w) * 0x01010101u;
+            u32 g = w & (NGRP - 1);
+            const u32 g2 = (w >> 11) & (NGRP - 1);
+            u64 best = tvals[sl];
+            for (u32 step = 0; step < NGRP + 2; ++step) {
+                const u32 t = ttags[g];
+                u32 m = tag_matches(t, pat);
+                while (m) { const u32 c = g * FJ_LDS_GROUP + ((u32)__builtin_ctz(m) >> 3); if (c != sl && tkeys[c] == key) { const u64 o = tvals[c]; best = o < best ? o : best; } m &= m - 1; }
+                if (step == 0) { g = g2; continue; }                     // second candidate group
+                if (!ovf0) break;
+                if (step == 1) g = w & (NGRP - 1);                      // then the overflow walk from g1 + 1
+                else if (tag_zero_bytes(t)) break;                       // a non-full group ends the walk
+                g = (g + 1) & (NGRP - 1);
+            }
+            atomicMin((unsigned long long*)&tvals[sl], (unsigned long long)best);
+        }
+        __syncthreads();
+        for (u32 sl = tid; sl < S; sl += NT)
+            if (reinterpret_cast<const unsigned char*>(ttags)[sl] != 0) tvals[sl] = a.orig_vals[tvals[sl]];
+        if (tid == 0 && hdr->has_empty) hdr->empty_val = a.orig_vals[hdr->empty_val];
+        __syncthreads();
     }
     const bool has_empty = hdr->has_empty != 0;
     const u64 obase = MAT ? a.out_off[item] : 0;
@@ -376,16 +411,17 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
 // whose eviction chain does not terminate goes to a 32-entry stash that lookups scan only when it is
 // non-empty (a wave-uniform branch); a full stash raises FJ_ERR_LDS_FULL like a full table.
 constexpr u32 CK_STASH = 32, CK_MAXIT = 48;
-struct CkHdr { u32 cnt, has_empty, nstash, full; u64 pad[2]; u64 stash[CK_STASH]; };
+struct CkHdr { u32 cnt, has_empty, nstash, full, dups, empties, pad1[2]; u64 pad[1]; u64 stash[CK_STASH]; };
 
 __device__ __noinline__ void cuckoo_insert(u64* __restrict__ tkeys, CkHdr* hdr, u64 key) {
     u32 w = fj_hash_w2(key);
     u32 l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
-    if (tkeys[l1] == key || tkeys[l2] == key) return;            // duplicate build key already stored (hash_join.cpp:125)
+    if (tkeys[l1] == key || tkeys[l2] == key) { hdr->dups = 1; return; }   // duplicate build key already stored (hash_join.cpp:125)
     u32 loc = l1;
 #pragma unroll 1
     for (u32 it = 0; it < CK_MAXIT; ++it) {
         const u64 old = atomicExch((unsigned long long*)&tkeys[loc], (unsigned long long)key);
+        if (old == key) hdr->dups = 1;
         if (old == FJ_EMPTY_KEY || old == key) return;            // free slot, or displaced a copy of the same key
         key = old;                                                // carry the evicted key to its other location
         w = fj_hash_w2(key);
@@ -442,7 +478,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     u32 nbb = nbc < JB_META ? nbc : JB_META;
     if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + tid);
     for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
-    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; }
+    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->empties = 0; }
     __syncthreads();
     FJ_STAMP(1);
     u64 ka[8], kb[8];
@@ -474,7 +510,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
 #pragma unroll
             for (u32 j = 0; j < BKPT; ++j) {
                 if (bok & (1u << j)) {
-                    if (bk[j] == FJ_EMPTY_KEY) hdr->has_empty = 1;
+                    if (bk[j] == FJ_EMPTY_KEY) { hdr->has_empty = 1; if (a.want_dups && atomicAdd(&hdr->empties, 1u) > 0) hdr->dups = 1; }
                     else if (!(a.dbg_flags & 2u)) cuckoo_insert(tkeys, hdr, bk[j]);
                 }
             }
@@ -489,6 +525,22 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     }
     const u64 he = hdr->has_empty ? ~0ull : 0ull;
     const u32 nstash = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
+    if (a.want_dups) {
+        // exact duplicate report for the materialising pass that follows: a second copy of a key was either noticed
+        // by its insert (dups flag) or it raced past the check and the key now sits in both of its slots / the stash
+        for (u32 sl = tid; sl < S; sl += NT) {
+            const u64 key = tkeys[sl];
+            if (key == FJ_EMPTY_KEY) continue;
+            const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+            const u32 other = sl == l1 ? l2 : l1;
+            if (other != sl && tkeys[other] == key) hdr->dups = 1;
+            for (u32 si = 0; si < nstash; ++si) if (hdr->stash[si] == key) hdr->dups = 1;
+        }
+        for (u32 si = tid; si < nstash; si += NT)
+            for (u32 sj = si + 1; sj < nstash; ++sj) if (hdr->stash[si] == hdr->stash[sj]) hdr->dups = 1;
+        __syncthreads();
+        if (tid == 0 && hdr->dups) atomicOr(a.err, FJ_STAT_DUPS);
+    }
 
     // ---- probe ------------------------------------------------------------------------------------
     u32 wave_hits = 0;                                        // wave-uniform, accumulated on the scalar unit
@@ -781,6 +833,10 @@ __global__ __launch_bounds__(512) void fj_owner_scatter_kernel(const u64* __rest
 }
 
 // =============================== synthetic data ==============================
+__global__ void fj_iota_kernel(u64* __restrict__ out, u64 n) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = i;
+}
 __global__ void fj_gen_build_kernel(u64* __restrict__ keys, u64* __restrict__ vals, u64 first, u64 n) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -863,6 +919,11 @@ hipError_t fj_launch_owner_scatter(const u64* keys, const u64* vals, u64 n, u32 
     return hipGetLastError();
 }
 
+hipError_t fj_launch_iota(u64* out, u64 n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fj_iota_kernel, dim3(2048), dim3(256), 0, s, out, n);
+    return hipGetLastError();
+}
 hipError_t fj_launch_gen_build(u64* keys, u64* vals, u64 first, u64 n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(fj_gen_build_kernel, dim3(2048), dim3(256), 0, s, keys, vals, first, n);

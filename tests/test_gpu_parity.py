@@ -332,3 +332,25 @@ def test_fuzz_against_oracle(fj, oracle, seed):
         assert n == exp, (fn, seed)
         a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (fn, seed, nb, npk, kind)
+
+
+@pytest.mark.parametrize("nb,dom,npk", [(3000, 700, 20000), (60000, 9000, 200000), (500000, 120000, 900000), (3000000, 1000000, 4000000)])
+def test_duplicate_build_keys_first_occurrence_wins(fj, oracle, nb, dom, npk):
+    """Duplicate build keys with DIFFERENT values: the radix/adaptive joins must emit the value of the FIRST occurrence
+    (the reference's radix path: stable partition + insert_local, hash_join.cpp:125 / SURVEY App. B); the scalar path is
+    racy in the reference too, there any occurrence's value is acceptable."""
+    rng = np.random.default_rng(nb)
+    ids = rng.integers(0, dom, size=nb, dtype=np.uint64)
+    bk = ids * np.uint64(0x9E3779B97F4A7C15) + np.uint64(3)
+    bv = np.arange(nb, dtype=np.uint64) + np.uint64(10**12)                 # value = row id: every occurrence differs
+    pk = rng.integers(0, 2 * dom, size=npk, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(3)
+    exp, ek, ev = oracle.np_join(bk, bv, pk, return_arrays=True)            # first occurrence wins
+    ref = oracle.canon_pairs(ek, ev)
+    for fn in ("hash_join_radix", "adaptive_join", "hash_join_radix_bloom", "adaptive_join_bloom"):
+        n, _, k, v = getattr(fj, fn)(bk, bv, pk, return_arrays=True)
+        got = oracle.canon_pairs(k, v)
+        assert n == exp and np.array_equal(got[0], ref[0]), fn
+        assert np.array_equal(got[1], ref[1]), (fn, "value of a duplicated build key is not its first occurrence's")
+    n, _, k, v = fj.hash_join(bk, bv, pk, return_arrays=True)               # scalar path: some occurrence of the right key
+    assert n == exp and np.array_equal(np.sort(k), ref[0])
+    assert np.array_equal(bk[(v - np.uint64(10**12)).astype(np.int64)], k)
