@@ -201,6 +201,7 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
     a.err = &c->d_sc->err;
     a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i];
+    a.interleave = getenv("FJ_INTERLEAVE") ? (u32)atoi(getenv("FJ_INTERLEAVE")) : 0u;
     const int line_log = 4;                 // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter)
     if (ev_cursor) HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor)], s));
     HIPCHK(fj_launch_partition(a, it.has_vals, line_log, G, s));

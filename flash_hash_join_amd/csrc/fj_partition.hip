@@ -78,14 +78,19 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
     const u32 Lc = FLAT ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : 0u;
     const u32 ntiles = FLAT ? (Lc + TC - 1) / TC : *a.in_ntiles;
     const u32 G = gridDim.x, g = blockIdx.x;
-    u32 t = (u32)(((u64)g * ntiles) / G);
-    const u32 thi = (u32)(((u64)(g + 1) * ntiles) / G);
+    // tile index space of this workgroup: j = 0..nmine-1 -> tile t0 + j * tstep
+    const bool il = FLAT && a.interleave;
+    const u32 t0 = il ? g : (u32)(((u64)g * ntiles) / G);
+    const u32 tstep = il ? G : 1u;
+    const u32 nmine = il ? (g < ntiles ? (ntiles - g + G - 1) / G : 0u) : (u32)(((u64)(g + 1) * ntiles) / G) - t0;
+    u32 t = 0;
+    const u32 thi = nmine;
     const u32 cap = a.cap_chunks;
     if (t >= thi) return;
 
     // ---- input side ---------------------------------------------------------------------------
     auto get_desc = [&](u32 tt, u32& pos, u32& len, u32& parent) {      // list input: tile table row
-        const uint4 d = a.in_tiles[tt]; pos = d.x; len = d.y; parent = d.z;
+        const uint4 d = a.in_tiles[t0 + tt]; pos = d.x; len = d.y; parent = d.z;
     };
     auto meta_fetch = [&](u32 pos, u32 len, u32& id, u32& cnt) {        // chunk id + key count of chunk tid
         id = 0; cnt = 0;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
         for (int i = 0; i < KPT / 2; ++i) {
             u64 base; u32 nv;                               // nv = valid keys of this pair (0..2)
             if (FLAT) {
-                base = (u64)tt * T + ((u32)i * NT + tid) * 2;
+                base = (u64)(t0 + tt * tstep) * T + ((u32)i * NT + tid) * 2;
                 nv = base + 1 < a.n_flat ? 2u : (base < a.n_flat ? 1u : 0u);
                 if (base > last_pair) base = last_pair;     // stay inside the array (tail tile only)
             } else {
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a
         if (FLAT && !tiny && (a.n_flat & 1ull)) {            // odd length: the very last key has no pair partner
 #pragma unroll
             for (int i = 0; i < KPT / 2; ++i) {
-                const u64 base = (u64)tt * T + ((u32)i * NT + tid) * 2;
+                const u64 base = (u64)(t0 + tt * tstep) * T + ((u32)i * NT + tid) * 2;
                 if (base + 1 == a.n_flat) { kk[2 * i] = a.in_keys[base]; if (HAS_VALS) vv[2 * i] = a.in_vals[base]; }
             }
         }
