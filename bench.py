@@ -131,6 +131,7 @@ def main() -> None:
         exp_total = int(e.item())
     engine = HipEngine(device) if (world > 1 or force_dist) else None
 
+    units_per_launch = [float(np_gpu)]
     part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": []}
     dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
 
@@ -146,7 +147,12 @@ def main() -> None:
                     dtimes[k].append(t.get(k, 0.0))
         if record:
             lt = api.last_timings()
-            for i in range(lt["passes"]):
+            if world == 1 and not force_dist:
+                npart = lt["passes"]                       # one launch per pass over all probe rows
+            else:
+                npart = min(4, int(t.get("pieces", 0)))    # pipelined exchange: first-pass launches, one per received piece
+                units_per_launch[0] = t.get("local_probe_rows", np_gpu) / max(1, int(t.get("pieces", 1)))
+            for i in range(npart):
                 part_ms.append(lt["probe_part_kernel_ms"][i]); part_launches += 1
             phase["build_ms"].append(lt["build_phase_ms"]); phase["probe_ms"].append(lt["probe_phase_ms"])
             phase["join_ms"].append(lt["join_ms"]); phase["total_ms"].append(lt["total_ms"]); phase["emit_ms"].append(lt["emit_ms"])
@@ -184,11 +190,11 @@ def main() -> None:
     roof = None
     if part_ms:
         avg_ms = mean(part_ms)
-        alg_bytes = 16.0 * np_gpu
+        alg_bytes = 16.0 * units_per_launch[0]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp) and world == 1 and args.workload == "c3" and args.scale == 1.0:
+        if os.path.exists(tp) and world == 1 and not force_dist and args.workload == "c3" and args.scale == 1.0:
             try:      # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc.sh + tools/traffic_json.py), committed
                 traffic = json.load(open(tp)).get("fj_partition_kernel_keys_bytes_per_launch")
             except Exception:
@@ -196,7 +202,7 @@ def main() -> None:
         roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
-                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 16, "units_per_launch": np_gpu,
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 16, "units_per_launch": units_per_launch[0],
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": traffic}
     else:
         # zero-pass / non-partitioned workloads: the join (probe) kernel dominates; 8 B per probe key
