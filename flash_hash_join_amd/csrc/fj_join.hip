@@ -1,18 +1,23 @@
 // fj_join.hip -- build + probe kernels for MI355X (gfx950).
 //
-//  * fj_lds_join_kernel : one workgroup per final radix partition.  Linear-probing open-address
-//    build into an LDS table (ds_cmpst_rtn_b64 claims a slot), then the partition's probe keys
-//    are streamed through it.  Mirrors insert_local + probe_vectorized of the reference
-//    (hash_join.cpp:112-128, :153-182) inside _hash_join_radix_{count,materialize} (:315-381,
-//    :498-534).  The home slot is aligned to a 4-slot group and the probe compares 4 keys per
-//    step, so almost every probe resolves with one LDS access pair and wave divergence stays low.
-//  * fj_gt_*            : non-partitioned table in HBM / Infinity Cache (hash_join.cpp:130-151
-//    insert_concurrent, :383-496 / :536-567 scalar drivers), 8-key (64-B) groups, optional
-//    bloom word per group (role of the reference's bloom directory, :183-189).
+// Per final radix partition (one workgroup per (partition, probe slice) work item), mirroring insert_local +
+// probe_vectorized of the reference (hash_join.cpp:112-128, :153-182) inside _hash_join_radix_{count,materialize}
+// (:315-381, :498-534):
+//  * fj_count_join_kernel      : counting joins.  Cuckoo table of bare keys in LDS: a lookup is two independent 8-byte
+//    reads and two v_cmp_eq_u64, hit masks and the count live in SGPRs.
+//  * fj_lds_join_kernel<MAT>   : materialising joins (a value must be fetched).  Open addressing with two candidate
+//    4-slot groups per key, one-byte tags, slot claims by a 32-bit LDS atomic, linear probing as the overflow path.
+//    Duplicate build keys: optional row-index dedup so the FIRST occurrence's value is emitted (hash_join.cpp:125).
+// Both were shaped by measurements (in-kernel stamps, PMC, ablations): plain linear probing with
+// 64-bit ds_cmpst was issue-, LDS-bank-conflict- and atomic-bound in turn.
+//  * fj_gt_*                   : non-partitioned table in HBM / Infinity Cache (hash_join.cpp:130-151 insert_concurrent,
+//    :383-496 / :536-567 scalar drivers), 8-key (64-B) groups, linear probing over groups, optional bloom word per
+//    group (role of the reference's bloom directory, :183-189).
+//  * fj_owner_*                : multi-GPU owner split.      * fj_gen_* : synthetic relations.
 //
-// Materialisation is two-pass like the reference's small-table strategy (hash_join.cpp:394-444):
-// count per work item -> exclusive scan -> re-probe and write at exact offsets, so the output
-// arrays have exactly `count` rows and no global cursor is contended.
+// Materialisation is two-pass like the reference's small-table strategy (hash_join.cpp:394-444): count per work item
+// -> exclusive scan -> re-probe and write at exact offsets, so the output arrays have exactly `count` rows and no
+// global cursor is contended.
 #include "fj_internal.h"
 
 namespace {
