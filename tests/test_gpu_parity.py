@@ -250,6 +250,8 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
     (1_000_000, 100_000_000, 5000, "hash_join_count_radix"),
     (100_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),  # BASELINE config 3
     (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom"),   # BASELINE config 4 (radix form)
+    (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),         # BASELINE config 4 as named: non-partitioned + bloom precheck
+    (1_000_000, 10_000_000, 5000, "adaptive_join_count"),               # BASELINE config 1 sizes on the device
 ])
 def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn):
     """BASELINE.json's full sizes, checked through the size-independent property of the generator:

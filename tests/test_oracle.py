@@ -126,3 +126,15 @@ def test_adaptive_threshold(oracle):
         bk = np.arange(1, nb + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
         pk = np.concatenate([bk[:5000], rng.integers(0, 2**64, size=5000, dtype=np.uint64)])
         assert oracle.c_join(bk, bk, pk, algo="adaptive")[0] == oracle.np_join(bk, bk, pk)
+
+
+def test_baseline_config1_on_cpu(oracle):
+    """BASELINE.json configs[0]: scalar path on CPU, 1M build x 10M probe int64 keys, 50 % hit rate (plumbing, no GPU):
+    the oracle's restatement, every variant, against the generator's closed-form count."""
+    from flash_hash_join_amd import datagen
+    bk, bv = datagen.build_numpy(1_000_000)
+    pk, exp = datagen.probe_numpy(10_000_000, 1_000_000, seed=1, hit_bp=5000)
+    assert abs(exp - 5_000_000) < 20_000
+    for algo in ("scalar", "radix", "adaptive"):
+        for bloom in (False, True):
+            assert oracle.c_join(bk.view(np.int64), bv, pk, algo=algo, bloom=bloom)[0] == exp
