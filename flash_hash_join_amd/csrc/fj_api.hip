@@ -139,7 +139,7 @@ void pass_init(PassIter& it, int side, bool has_vals, size_t n, const Plan& plan
     it = PassIter();
     it.side = side; it.has_vals = has_vals; it.n = n; it.plan = plan; it.used = top_bits;
     it.lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
-    it.tile_chunks = (has_vals && getenv("FJ_KV_KPT4")) ? 8 : 16;
+    it.tile_chunks = (!has_vals && getenv("FJ_K_NT1024")) ? 32 : 16;        // chunks per tile of the pass kernel that will read this level
 }
 
 // workgroups for a launch over n rows: enough to fill the chip, but every (workgroup, bucket) pair ends in a

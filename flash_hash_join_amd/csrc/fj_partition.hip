@@ -54,7 +54,7 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG 
 // bucket instead of branches, per-bucket state in the registers of thread b, the bucket scan done
 // only by the waves that own buckets, 32 B per lane in the write-out.
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
-__global__ __launch_bounds__(NT, NT / 128) void fj_partition_kernel(FjPartArgs a) {
+__global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LPL = LINE / 4;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4, "tile geometry");
     const u32 F = 1u << a.fan_log, FM = F - 1;
@@ -527,7 +527,12 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
 // One partition pass.  Keys-only tiles are 4096 keys (512 threads x 8), key+value tiles 2048.
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
     if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
-    if (vals) return getenv("FJ_KV_KPT4") ? launch_part2<512, 4, true>(a, line_log, grid, s) : launch_part2<512, 8, true>(a, line_log, grid, s);
+    if (vals) {
+        // 1024 threads x 4 rows: one workgroup per CU (LDS), but 16 waves of it: 1.63 -> 1.42 ms build phase at c3
+        if (getenv("FJ_KV_NT512")) return launch_part2<512, 8, true>(a, line_log, grid, s);
+        return launch_part2<1024, 4, true>(a, line_log, grid, s);
+    }
+    if (getenv("FJ_K_NT1024")) return launch_part2<1024, 8, false>(a, line_log, grid, s);
     return launch_part2<512, 8, false>(a, line_log, grid, s);
 }
 
