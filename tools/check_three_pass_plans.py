@@ -1,3 +1,4 @@
+"""Three-pass plans (build sides > 268M rows): count and materialised pairs against the generator's closed form."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flash_hash_join_amd import api, datagen
