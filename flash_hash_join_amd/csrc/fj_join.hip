@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
 constexpr u32 CK_STASH = 32, CK_MAXIT = 48;
 struct CkHdr { u32 cnt, has_empty, nstash, full, dups, empties, pad1[2]; u64 pad[1]; u64 stash[CK_STASH]; };
 
-__device__ __noinline__ void cuckoo_insert(u64* __restrict__ tkeys, CkHdr* hdr, u64 key) {
+__device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, CkHdr* hdr, u64 key) {
     u32 w = fj_hash_w2(key);
     u32 l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
     if (tkeys[l1] == key || tkeys[l2] == key) { hdr->dups = 1; return; }   // duplicate build key already stored (hash_join.cpp:125)
@@ -437,7 +437,7 @@ __device__ __noinline__ void cuckoo_insert(u64* __restrict__ tkeys, CkHdr* hdr, 
     if (sidx < CK_STASH) hdr->stash[sidx] = key; else hdr->full = 1;
 }
 
-template <int NT>
+template <int NT, bool LIST>
 __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     CkHdr* hdr = reinterpret_cast<CkHdr*>(smem);
@@ -459,11 +459,21 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
         return;
     }
     constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
+    // Chunk-list inputs live in whole 2-KiB pool chunks, so their loads are issued unconditionally (validity is a mask):
+    // straight-line loads let the compiler count outstanding requests instead of draining them all at the first use.
+    constexpr bool plist = LIST, blist = LIST;       // LIST: both sides are chunk lists (every partitioned plan)
     auto load_round = [&](u32 r, u32 nbatch, u64 (&kk)[8], u32& okm) {
         okm = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const u32 c = r * CPR + u * CPL + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
+            if (plist) {
+                const u32 e = pm[c < nbatch ? c : nbatch - 1], cnt = c < nbatch ? FJ_LIST_CNT(e) : 0;
+                const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + off);
+                kk[2 * u] = q.x; kk[2 * u + 1] = q.y;
+                okm |= ((off < cnt ? 1u : 0u) | (off + 1 < cnt ? 2u : 0u)) << (2 * u);
+                continue;
+            }
             kk[2 * u] = 0; kk[2 * u + 1] = 0;
             if (c < nbatch) {
                 const u32 e = pm[c], cnt = FJ_LIST_CNT(e);
@@ -474,6 +484,26 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
                 } else if (off < cnt) {
                     kk[2 * u] = a.probe.keys[base]; okm |= 1u << (2 * u);
                 }
+            }
+        }
+    };
+    u64 bk[BKPT];
+    u32 bok = 0;
+    auto load_build = [&](u32 c0, u32 nbb) {                // 16 chunks = 4096 keys requested at once
+        bok = 0;
+#pragma unroll
+        for (u32 j = 0; j < BKPT; ++j) {
+            const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
+            if (blist) {
+                const u32 e = bm[c < nbb ? c : nbb - 1];
+                bk[j] = a.build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off];
+                bok |= (c < nbb && off < FJ_LIST_CNT(e) ? 1u : 0u) << j;
+                continue;
+            }
+            bk[j] = 0;
+            if (c < nbb) {
+                const u32 e = bm[c];
+                if (off < FJ_LIST_CNT(e)) { bk[j] = a.build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off]; bok |= 1u << j; }
             }
         }
     };
@@ -489,6 +519,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     u64 ka[8], kb[8];
     u32 oka = 0, okb = 0;
     u32 nrounds = (nbatch + CPR - 1) / CPR;
+    load_build(0, nbb);                              // build keys first: their inserts start while the probe keys fly
     load_round(0, nbatch, ka, oka);
     if (nrounds > 1) load_round(1, nbatch, kb, okb);
 
@@ -500,18 +531,8 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
             if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + bb + tid);
             __syncthreads();
         }
-        for (u32 c0 = 0; c0 < nbb; c0 += 16) {      // 16 chunks = 4096 keys: all requested before any insert
-            u64 bk[BKPT];
-            u32 bok = 0;
-#pragma unroll
-            for (u32 j = 0; j < BKPT; ++j) {
-                const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
-                bk[j] = 0;
-                if (c < nbb) {
-                    const u32 e = bm[c];
-                    if (off < FJ_LIST_CNT(e)) { bk[j] = a.build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off]; bok |= 1u << j; }
-                }
-            }
+        for (u32 c0 = 0; c0 < nbb; c0 += 16) {
+            if (bb | c0) load_build(c0, nbb);
 #pragma unroll
             for (u32 j = 0; j < BKPT; ++j) {
                 if (bok & (1u << j)) {
@@ -876,7 +897,8 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     } else {
         const u32 lds = sizeof(CkHdr) + S * 8 + (JP_META + JB_META) * 4;
-        auto kern = fj_count_join_kernel<512>;
+        const bool lists = a.build.list && a.probe.list;
+        auto kern = lists ? fj_count_join_kernel<512, true> : fj_count_join_kernel<512, false>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a);
