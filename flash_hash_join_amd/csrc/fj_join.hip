@@ -57,7 +57,7 @@ __device__ __forceinline__ u32 tag_matches(u32 tags, u32 pattern) {      // bit 
 
 
 template <bool MAT>
-__device__ __noinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict__ tvals, u32* __restrict__ ttags,
+__device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict__ tvals, u32* __restrict__ ttags,
                                         u32* __restrict__ gcnt, JoinHdr* hdr, u64 key, u64 val, bool dedup) {
     // Tag-guided insert.  A slot is claimed with ONE 32-bit returning LDS atomic on the group's fill
     // counter (two 16-bit counters per word) -- 64-bit ds_cmpst was measured to dominate the build
@@ -196,7 +196,7 @@ constexpr u32 JP_META = 512;    // probe-side chunk-list entries staged in LDS p
 // sides are fetched together, all build keys of the partition are requested in one shot (not chunk
 // by chunk), and probe keys are prefetched two rounds (2 x 8 keys per lane) ahead; the first two
 // rounds are requested before the table is even initialised.
-template <bool MAT, int NT>
+template <bool MAT, int NT, bool LIST>
 __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     JoinHdr* hdr = reinterpret_cast<JoinHdr*>(smem);
@@ -227,11 +227,20 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     constexpr u32 CPR = 4 * CPL;                      // chunks per round (4 loads per lane = 8 keys)
     constexpr u32 BKPT = 4096 / NT;                   // build keys per lane and build batch (16 chunks)
     // request one round of probe keys of the current metadata batch
+    // LIST: both sides are chunk lists (every partitioned plan).  Their chunks are whole 2-KiB pool blocks, so the loads
+    // are issued unconditionally (validity is a mask) -- straight-line loads let the waits be counted.
     auto load_round = [&](u32 r, u32 nbatch, u64 (&kk)[8], u32& okm) {
         okm = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const u32 c = r * CPR + u * CPL + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
+            if (LIST) {
+                const u32 e = pm[c < nbatch ? c : nbatch - 1], cnt = c < nbatch ? FJ_LIST_CNT(e) : 0;
+                const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + off);
+                kk[2 * u] = q.x; kk[2 * u + 1] = q.y;
+                okm |= ((off < cnt ? 1u : 0u) | (off + 1 < cnt ? 2u : 0u)) << (2 * u);
+                continue;
+            }
             kk[2 * u] = 0; kk[2 * u + 1] = 0;
             if (c < nbatch) {
                 const u32 e = pm[c], cnt = FJ_LIST_CNT(e);
@@ -241,6 +250,33 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                     kk[2 * u] = q.x; kk[2 * u + 1] = q.y; okm |= 3u << (2 * u);
                 } else if (off < cnt) {
                     kk[2 * u] = a.probe.keys[base]; okm |= 1u << (2 * u);
+                }
+            }
+        }
+    };
+    u64 bk[BKPT], bv[BKPT];
+    u32 bok = 0;
+    auto load_build = [&](u32 c0, u32 nbb) {                // 16 chunks = 4096 rows requested at once
+        bok = 0;
+#pragma unroll
+        for (u32 j = 0; j < BKPT; ++j) {
+            const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
+            if (LIST) {
+                const u32 e = bm[c < nbb ? c : nbb - 1];
+                const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
+                bk[j] = a.build.keys[src];
+                bv[j] = MAT ? a.build.vals[src] : 0;
+                bok |= (c < nbb && off < FJ_LIST_CNT(e) ? 1u : 0u) << j;
+                continue;
+            }
+            bk[j] = 0; bv[j] = 0;
+            if (c < nbb) {
+                const u32 e = bm[c];
+                if (off < FJ_LIST_CNT(e)) {
+                    const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
+                    bk[j] = a.build.keys[src];
+                    if (MAT) bv[j] = a.build.vals[src];
+                    bok |= 1u << j;
                 }
             }
         }
@@ -260,6 +296,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     u64 ka[8], kb[8];
     u32 oka = 0, okb = 0;
     u32 nrounds = (nbatch + CPR - 1) / CPR;
+    load_build(0, nbb);                              // build rows first: their inserts start while the probe keys fly
     load_round(0, nbatch, ka, oka);
     if (nrounds > 1) load_round(1, nbatch, kb, okb);
 
@@ -272,23 +309,8 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
             if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + bb + tid);
             __syncthreads();
         }
-        for (u32 c0 = 0; c0 < nbb; c0 += 16) {      // 16 chunks = 4096 keys: all requested before any insert
-            u64 bk[BKPT], bv[BKPT];
-            u32 bok = 0;
-#pragma unroll
-            for (u32 j = 0; j < BKPT; ++j) {
-                const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
-                bk[j] = 0; bv[j] = 0;
-                if (c < nbb) {
-                    const u32 e = bm[c];
-                    if (off < FJ_LIST_CNT(e)) {
-                        const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
-                        bk[j] = a.build.keys[src];
-                        if (MAT) bv[j] = a.build.vals[src];
-                        bok |= 1u << j;
-                    }
-                }
-            }
+        for (u32 c0 = 0; c0 < nbb; c0 += 16) {
+            if (bb | c0) load_build(c0, nbb);
 #pragma unroll
             for (u32 j = 0; j < BKPT; ++j) {
                 if (bok & (1u << j)) {
@@ -891,7 +913,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
     const u32 nb = a.nparts * a.nsplit;
     if (materialize) {
         const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
-        auto kern = fj_lds_join_kernel<true, 1024>;
+        auto kern = (a.build.list && a.probe.list) ? fj_lds_join_kernel<true, 1024, true> : fj_lds_join_kernel<true, 1024, false>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
