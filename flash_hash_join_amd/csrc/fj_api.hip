@@ -403,8 +403,9 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
     HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
     FjLdsJoinArgs ja{};
     PassIter bit, pit;
-    pass_init(bit, 0, true, nb, plan, top_bits);
-    if (run_passes(c, bit, bk, bv, s, &ja.build, nullptr)) return 1;
+    // a counting join never looks at a value: its build side moves keys only (half the build-phase bytes)
+    pass_init(bit, 0, materialize != 0, nb, plan, top_bits);
+    if (run_passes(c, bit, bk, materialize ? bv : nullptr, s, &ja.build, nullptr)) return 1;
     HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
     int evc = 0;
     pass_init(pit, 1, false, np, plan, top_bits);
@@ -555,8 +556,8 @@ int fj_stream_begin(fj_ctx* c, const uint64_t* d_bk, const uint64_t* d_bv, size_
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
     PassIter bit;
-    pass_init(bit, 0, true, nb, st.plan, hash_top_bits);
-    if (nb && run_passes(c, bit, d_bk, d_bv, s, &st.ja.build, nullptr)) return 1;
+    pass_init(bit, 0, false, nb, st.plan, hash_top_bits);        // count only: the build side moves keys only
+    if (nb && run_passes(c, bit, d_bk, nullptr, s, &st.ja.build, nullptr)) return 1;
     if (!nb) { st.ja.build = FjChunkSet(); st.ja.build.n_flat = 0; }
     HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
     pass_init(st.pit, 1, false, std::max<size_t>(np_bound, 1), st.plan, hash_top_bits);
