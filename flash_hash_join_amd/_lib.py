@@ -19,6 +19,7 @@ SYMBOLS = [
     "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes",
     "fj_join_host", "fj_free_host", "fj_last_timings",
     "fj_join_device", "fj_emit_pairs", "fj_owner_split", "fj_owner_hist", "fj_owner_scatter",
+    "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe",
     "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
     "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h",
@@ -92,6 +93,9 @@ def load() -> ctypes.CDLL:
     L.fj_owner_split.argtypes = [vp, vp, vp, sz, i32, vp, vp, pu64, vp]
     L.fj_owner_hist.restype = i32; L.fj_owner_hist.argtypes = [vp, vp, sz, i32, pu64, vp]
     L.fj_owner_scatter.restype = i32; L.fj_owner_scatter.argtypes = [vp, vp, vp, sz, i32, pu64, vp, vp, vp]
+    L.fj_stream_open.restype = i32; L.fj_stream_open.argtypes = [vp, sz, i32, sz, i32, vp, i32]
+    L.fj_stream_append_build.restype = i32; L.fj_stream_append_build.argtypes = [vp, vp, sz, vp]
+    L.fj_stream_advance_probe.restype = i32; L.fj_stream_advance_probe.argtypes = [vp, vp]
     L.fj_stream_begin.restype = i32; L.fj_stream_begin.argtypes = [vp, vp, vp, sz, sz, i32, vp, i32]
     L.fj_stream_append_probe.restype = i32; L.fj_stream_append_probe.argtypes = [vp, vp, sz, vp]
     L.fj_stream_finish.restype = i32; L.fj_stream_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]

@@ -55,7 +55,7 @@ enum Slot {
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
 
-enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_PK0, E_NEV = E_PK0 + 8 };
+enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_SB0, E_SB1, E_PK0, E_NEV = E_PK0 + 8 };
 
 struct Pending {
     bool valid = false;
@@ -81,12 +81,16 @@ struct PassIter {
 
 }  // namespace
 
-struct StreamState {            // fj_stream_*: a join whose probe side arrives in pieces
+struct StreamState {            // fj_stream_*: a counting join whose relations arrive in pieces
     bool active = false;
-    Plan plan; PassIter pit; FjLdsJoinArgs ja{};
+    Plan plan; PassIter pit, bit; FjLdsJoinArgs ja{};
     int top_bits = 64, evc = 0;
-    size_t np_bound = 0, np_seen = 0;
-    u32 appends_left = 0;
+    size_t np_bound = 0, np_seen = 0, nb_bound = 0, nb_seen = 0;
+    u32 p_appends_left = 0, b_appends_left = 0;
+    bool probe_done = false, build_done = false;
+    // zero-pass plans (build side <= one LDS table): the pieces are joined as flat arrays
+    const u64* flat_build = nullptr;
+    const u64* flat_probe[64]; size_t flat_np[64]; u32 nflat = 0;
 };
 
 struct fj_ctx {
@@ -536,49 +540,13 @@ int fj_owner_split(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, si
     return 0;
 }
 
-// ---- a join whose probe side arrives in pieces (multi-GPU: pieces of the all-to-all) ---------------------
-// begin: build-side passes + output pool of the probe side's first pass; append: one first-pass launch per piece
-// (launches accumulate into the same chunk pool); finish: remaining passes + join.  Count only.
-int fj_stream_begin(fj_ctx* c, const uint64_t* d_bk, const uint64_t* d_bv, size_t nb, size_t np_bound, int max_appends,
-                    void* stream, int hash_top_bits) {
-    if (!c) return set_err("fj_stream_begin: null context");
-    if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_stream_begin: hash_top_bits must be 64 or 48");
-    if (max_appends < 1 || max_appends > 64) return set_err("fj_stream_begin: max_appends must be 1..64");
-    if (nb && (!d_bk || !d_bv)) return set_err("fj_stream_begin: null input pointer");
-    if (((uintptr_t)d_bk | (uintptr_t)d_bv) & 15) return set_err("fj_stream_begin: input pointers must be 16-byte aligned");
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
-    StreamState& st = c->st;
-    st = StreamState();
-    c->pend.valid = false;
-    st.plan = make_plan(nb, hash_top_bits);
-    st.top_bits = hash_top_bits; st.np_bound = np_bound; st.appends_left = (u32)max_appends;
-    HIPCHK(hipEventRecord(c->ev[E_START], s));
-    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
-    PassIter bit;
-    pass_init(bit, 0, false, nb, st.plan, hash_top_bits);        // count only: the build side moves keys only
-    if (nb && run_passes(c, bit, d_bk, nullptr, s, &st.ja.build, nullptr)) return 1;
-    if (!nb) { st.ja.build = FjChunkSet(); st.ja.build.n_flat = 0; }
-    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
-    pass_init(st.pit, 1, false, std::max<size_t>(np_bound, 1), st.plan, hash_top_bits);
-    if (st.plan.npass > 0 && pass_prepare(c, st.pit, (u32)max_appends, s)) return 1;
-    st.active = true;
-    return 0;
-}
+// ---- a counting join whose relations arrive in pieces (multi-GPU: pieces of an exchange) -----------------
+// open: plan + first-pass pools of both sides; append_*: one first-pass launch per piece (launches accumulate
+// into the same chunk pool); advance_probe: the probe side's remaining passes (so that they can overlap an
+// exchange of the build side); finish: whatever remains + join.
+namespace {
 
-int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stream) {
-    if (!c || !c->st.active) return set_err("fj_stream_append_probe: no stream join is open on this context");
-    StreamState& st = c->st;
-    if (n == 0) return 0;
-    if (!d_pk || ((uintptr_t)d_pk & 15)) return set_err("fj_stream_append_probe: probe piece must be a 16-byte aligned device pointer");
-    if (st.appends_left == 0) return set_err("fj_stream_append_probe: more pieces than max_appends");
-    if (st.np_seen + n > st.np_bound) return set_err("fj_stream_append_probe: more probe rows than np_bound");
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
-    --st.appends_left; st.np_seen += n;
-    if (st.plan.npass > 0) return pass_launch(c, st.pit, d_pk, nullptr, n, s, st.evc < 4 ? &st.evc : nullptr);
-    // zero-pass plan (tiny build side): join this piece right away; the device total accumulates
-    if (st.ja.build.n_flat == 0) return 0;
+int stream_flat_join(fj_ctx* c, StreamState& st, const u64* d_pk, size_t n, hipStream_t s) {
     FjLdsJoinArgs ja = st.ja;
     ja.probe = FjChunkSet(); ja.probe.keys = const_cast<u64*>(d_pk); ja.probe.n_flat = n; ja.probe.nb = 1;
     ja.nparts = 1;
@@ -591,6 +559,121 @@ int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stre
     return 0;
 }
 
+// the build side is complete: run its remaining passes (or fix the flat table input of a zero-pass plan)
+int stream_flush_build(fj_ctx* c, StreamState& st, hipStream_t s) {
+    if (st.build_done) return 0;
+    st.build_done = true;
+    HIPCHK(hipEventRecord(c->ev[E_SB0], s));
+    if (st.plan.npass > 0) {
+        if (st.nb_seen > 0) {
+            if (pass_complete(c, st.bit, s)) return 1;
+            if (run_passes(c, st.bit, nullptr, nullptr, s, &st.ja.build, nullptr)) return 1;
+        } else { st.ja.build = FjChunkSet(); st.ja.build.n_flat = 0; }
+    } else {
+        st.ja.build = FjChunkSet();
+        st.ja.build.keys = const_cast<u64*>(st.flat_build); st.ja.build.n_flat = st.nb_seen; st.ja.build.list = nullptr; st.ja.build.nb = 1;
+    }
+    HIPCHK(hipEventRecord(c->ev[E_SB1], s));
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    return 0;
+}
+
+int stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends, hipStream_t s, int top_bits) {
+    StreamState& st = c->st;
+    st = StreamState();
+    c->pend.valid = false;
+    st.plan = make_plan(nb_bound, top_bits);
+    st.top_bits = top_bits; st.np_bound = np_bound; st.nb_bound = nb_bound;
+    st.p_appends_left = (u32)probe_appends; st.b_appends_left = (u32)build_appends;
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    if (st.plan.npass > 0) {
+        pass_init(st.bit, 0, false, std::max<size_t>(nb_bound, 1), st.plan, top_bits);     // count only: keys
+        if (pass_prepare(c, st.bit, (u32)build_appends, s)) return 1;
+        pass_init(st.pit, 1, false, std::max<size_t>(np_bound, 1), st.plan, top_bits);
+        if (pass_prepare(c, st.pit, (u32)probe_appends, s)) return 1;
+    }
+    st.active = true;
+    return 0;
+}
+
+int stream_append_build(fj_ctx* c, const u64* d_bk, size_t n, hipStream_t s) {
+    StreamState& st = c->st;
+    if (n == 0) return 0;
+    if (st.build_done) return set_err("fj_stream_append_build: the build side is already closed");
+    if (!d_bk || ((uintptr_t)d_bk & 15)) return set_err("fj_stream_append_build: build piece must be a 16-byte aligned device pointer");
+    if (st.b_appends_left == 0) return set_err("fj_stream_append_build: more pieces than build_appends");
+    if (st.nb_seen + n > st.nb_bound) return set_err("fj_stream_append_build: more build rows than nb_bound");
+    --st.b_appends_left; st.nb_seen += n;
+    if (st.plan.npass > 0) return pass_launch(c, st.bit, d_bk, nullptr, n, s, nullptr);
+    if (st.flat_build) return set_err("fj_stream_append_build: a build side of <= %d rows must arrive in one piece", (int)FJ_PART_TARGET_KEYS);
+    st.flat_build = d_bk;
+    return 0;
+}
+
+}  // namespace
+
+int fj_stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends, void* stream, int hash_top_bits) {
+    if (!c) return set_err("fj_stream_open: null context");
+    if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_stream_open: hash_top_bits must be 64 or 48");
+    if (build_appends < 1 || build_appends > 64 || probe_appends < 1 || probe_appends > 64)
+        return set_err("fj_stream_open: build_appends and probe_appends must be 1..64");
+    HIPCHK(hipSetDevice(c->device));
+    return stream_open(c, nb_bound, build_appends, np_bound, probe_appends, (hipStream_t)stream, hash_top_bits);
+}
+
+int fj_stream_append_build(fj_ctx* c, const uint64_t* d_bk, size_t n, void* stream) {
+    if (!c || !c->st.active) return set_err("fj_stream_append_build: no stream join is open on this context");
+    HIPCHK(hipSetDevice(c->device));
+    return stream_append_build(c, (const u64*)d_bk, n, (hipStream_t)stream);
+}
+
+int fj_stream_begin(fj_ctx* c, const uint64_t* d_bk, const uint64_t* d_bv, size_t nb, size_t np_bound, int max_appends,
+                    void* stream, int hash_top_bits) {
+    if (!c) return set_err("fj_stream_begin: null context");
+    if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_stream_begin: hash_top_bits must be 64 or 48");
+    if (max_appends < 1 || max_appends > 64) return set_err("fj_stream_begin: max_appends must be 1..64");
+    if (nb && (!d_bk || !d_bv)) return set_err("fj_stream_begin: null input pointer");
+    if (((uintptr_t)d_bk | (uintptr_t)d_bv) & 15) return set_err("fj_stream_begin: input pointers must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (stream_open(c, nb, 1, np_bound, max_appends, s, hash_top_bits)) return 1;
+    if (stream_append_build(c, (const u64*)d_bk, nb, s)) return 1;
+    return stream_flush_build(c, c->st, s);
+}
+
+int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stream) {
+    if (!c || !c->st.active) return set_err("fj_stream_append_probe: no stream join is open on this context");
+    StreamState& st = c->st;
+    if (n == 0) return 0;
+    if (st.probe_done) return set_err("fj_stream_append_probe: the probe side is already closed");
+    if (!d_pk || ((uintptr_t)d_pk & 15)) return set_err("fj_stream_append_probe: probe piece must be a 16-byte aligned device pointer");
+    if (st.p_appends_left == 0) return set_err("fj_stream_append_probe: more pieces than probe_appends");
+    if (st.np_seen + n > st.np_bound) return set_err("fj_stream_append_probe: more probe rows than np_bound");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    --st.p_appends_left; st.np_seen += n;
+    if (st.plan.npass > 0) return pass_launch(c, st.pit, d_pk, nullptr, n, s, st.evc < 4 ? &st.evc : nullptr);
+    // zero-pass plan (tiny build side): join this piece right away when the build side is known, else at finish
+    if (st.build_done) return st.ja.build.n_flat == 0 ? 0 : stream_flat_join(c, st, d_pk, n, s);
+    st.flat_probe[st.nflat] = d_pk; st.flat_np[st.nflat] = n; ++st.nflat;
+    return 0;
+}
+
+int fj_stream_advance_probe(fj_ctx* c, void* stream) {
+    if (!c || !c->st.active) return set_err("fj_stream_advance_probe: no stream join is open on this context");
+    StreamState& st = c->st;
+    if (st.probe_done) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    st.probe_done = true;
+    if (st.plan.npass > 0 && st.np_seen > 0) {
+        if (pass_complete(c, st.pit, s)) return 1;
+        if (run_passes(c, st.pit, nullptr, nullptr, s, &st.ja.probe, nullptr)) return 1;
+    }
+    return 0;
+}
+
 int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* timings) {
     if (!c || !c->st.active) return set_err("fj_stream_finish: no stream join is open on this context");
     StreamState& st = c->st;
@@ -599,22 +682,30 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
     hipStream_t s = (hipStream_t)stream;
     fj_timings t; memset(&t, 0, sizeof t);
     u64 count = 0;
-    if (st.plan.npass > 0 && st.ja.build.nb > 0 && st.np_seen > 0) {
-        if (pass_complete(c, st.pit, s)) return 1;
-        if (run_passes(c, st.pit, nullptr, nullptr, s, &st.ja.probe, nullptr)) return 1;
+    if (stream_flush_build(c, st, s)) return 1;
+    if (st.plan.npass > 0 && st.nb_seen > 0 && st.np_seen > 0) {
+        if (!st.probe_done) {
+            st.probe_done = true;
+            if (pass_complete(c, st.pit, s)) return 1;
+            if (run_passes(c, st.pit, nullptr, nullptr, s, &st.ja.probe, nullptr)) return 1;
+        }
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
         if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, s, &t, st.evc, &count, &lds_full)) return 1;
         if (lds_full) return set_err("fj_stream_finish: a partition does not fit its LDS table; use fj_join_device on the whole relation");
     } else {
+        if (st.plan.npass == 0 && st.nb_seen > 0)
+            for (u32 i = 0; i < st.nflat; ++i) if (stream_flat_join(c, st, st.flat_probe[i], st.flat_np[i], s)) return 1;
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
         if (read_scalars(c, s)) return 1;
         if (c->h_sc->err & FJ_ERR_LDS_FULL) return set_err("fj_stream_finish: the build side does not fit one LDS table");
         count = c->h_sc->total;
         t.path = 0; t.passes = 0; t.partitions = 1;
-        t.build_phase_ms = ev_ms(c, E_START, E_BUILD); t.total_ms = ev_ms(c, E_START, E_JOIN); t.probe_phase_ms = ev_ms(c, E_BUILD, E_JOIN);
+        t.total_ms = ev_ms(c, E_START, E_JOIN);
     }
+    t.build_phase_ms = ev_ms(c, E_SB0, E_SB1);                  // the two sides may have run in either order
+    t.probe_phase_ms = t.total_ms - t.build_phase_ms;
     if (out_count) *out_count = count;
     if (timings) *timings = t;
     g_last = t;

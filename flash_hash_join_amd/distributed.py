@@ -1,15 +1,24 @@
-"""Multi-GPU radix join: one process per GPU, one exchange step over RCCL/xGMI.
+"""Multi-GPU radix join: one process per GPU over RCCL/xGMI.
 
-The reference is single-process; this is new design.  Radix partitions are
-independent join units (hash_join.cpp:340-356, :515-525), so the level-0 digit is the owner GPU:
+The reference is single-process; this is new design.  Two exchange strategies, chosen per call
+by a per-link byte + local-work cost model (choose_strategy; FJ_DIST_STRATEGY=shuffle|replicate overrides):
 
-    owner(key) = (top 16 bits of hash(key) * world) >> 16
+replicate -- every rank all-gathers the build KEYS (and values when materialising) and joins its own probe rows
+  against all of them; probe rows never move, their partition passes run while the build keys are on the wire
+  (fj_stream_open / append_probe / advance_probe, then append_build / finish).  An xGMI mesh has one link per peer,
+  so an exchange is bound by bytes per link: B*8 here against (P*8 + B*16)/N for the shuffle -- fewer up to
+  N = 12 for the probe-heavy (P = 10 B) joins this path is built for, 6x fewer at N = 2.  Cost: every rank
+  partitions all N*B build keys.  Global count = sum of local counts; pairs stay with their probe row.
+
+shuffle -- radix partitions are independent join units (hash_join.cpp:340-356, :515-525), so the level-0 digit is
+  the owner GPU:   owner(key) = (top 16 bits of hash(key) * world) >> 16
 
   1. every rank splits its local rows of both relations by owner (fj_owner_split: LDS counting
      sort per tile, contiguous per-owner segments);
   2. ONE all-to-all per relation moves each segment to its owner (torch.distributed
      all_to_all_single, backend "nccl" == RCCL on ROCm; a fully connected xGMI mesh carries one
-     peer per link);
+     peer per link); counting joins cut the probe exchange into pieces and overlap it with the split of the
+     next piece and the first partition pass of the previous one;
   3. each rank joins what it owns with the single-GPU radix join (hash_top_bits = 48: the owner
      digit is already consumed);
   4. the global count is one all-reduce of a single int64.  Materialised pairs stay sharded by owner.
@@ -77,6 +86,19 @@ class HipEngine:
         self._keep = [bk, bv]                                    # inputs must outlive the asynchronous kernels
         self._lib.check(self.L.fj_stream_begin(self.ctx, bk.data_ptr(), bv.data_ptr(), bk.numel(), np_bound, max_appends,
                                                self.torch.cuda.current_stream(self.index).cuda_stream, hash_top_bits))
+
+    def stream_open(self, nb_bound: int, build_appends: int, np_bound: int, probe_appends: int, hash_top_bits: int):
+        self._keep = []
+        self._lib.check(self.L.fj_stream_open(self.ctx, nb_bound, build_appends, np_bound, probe_appends,
+                                              self.torch.cuda.current_stream(self.index).cuda_stream, hash_top_bits))
+
+    def stream_append_build(self, piece):
+        self._keep.append(piece)
+        self._lib.check(self.L.fj_stream_append_build(self.ctx, piece.data_ptr(), piece.numel(),
+                                                      self.torch.cuda.current_stream(self.index).cuda_stream))
+
+    def stream_advance_probe(self):
+        self._lib.check(self.L.fj_stream_advance_probe(self.ctx, self.torch.cuda.current_stream(self.index).cuda_stream))
 
     def stream_append(self, piece):
         self._keep.append(piece)
@@ -188,6 +210,110 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
     return int(tot.item()), t3 - t0
 
 
+# ---- strategy 2: replicate the build side ------------------------------------------------------------------
+# xGMI is a point-to-point mesh: a GPU has ONE link to each peer, so what bounds an exchange is the bytes per link.
+# The owner shuffle puts (P*8 + B*16)/N bytes on every link (P, B = local probe / build rows); sending every rank's
+# build KEYS to every peer puts B*8 there (B*16 with values).  For the probe-heavy joins this path is built for
+# (P = 10 B) that is fewer bytes up to N = 12 -- 6x fewer at N = 2 -- and the probe side never moves: its partition
+# passes run while the build keys are on the wire.  The price is local: every rank partitions all N*B build keys.
+_LINK_BYTES_PER_S = 45e9          # one xGMI link, one direction, effective (153.6 GB/s bidirectional raw)
+_HBM_BYTES_PER_S = 4.5e12         # partition-pass rate of this library (read + write)
+
+
+def _plan_passes(nb: int) -> int:
+    """Partition passes of the single-GPU plan for a build side of nb rows (csrc/fj_api.hip make_plan)."""
+    if nb <= 4096:
+        return 0
+    bits = max(5, (-(-nb // 4096) - 1).bit_length())
+    return -(-bits // 8)
+
+
+def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
+    """'replicate' or 'shuffle' for per-rank relation sizes nb x np_ (the maxima over the ranks)."""
+    forced = os.environ.get("FJ_DIST_STRATEGY", "auto")
+    if forced in ("replicate", "shuffle"):
+        return forced
+    if world * nb >= (1 << 31):               # replicated build side must stay inside one GPU's chunk directory
+        return "shuffle"
+    kb = 16 if materialize else 8
+    t_shuffle = (np_ * 8 + nb * 16) / world / _LINK_BYTES_PER_S + (np_ * 16 + nb * 32) / _HBM_BYTES_PER_S
+    p_all, p_loc = _plan_passes(world * nb), _plan_passes(nb)
+    t_replicate = (nb * kb / _LINK_BYTES_PER_S + (world - 1) * nb * 2 * kb * p_all / _HBM_BYTES_PER_S
+                   + np_ * 16 * (p_all - p_loc) / _HBM_BYTES_PER_S)
+    return "replicate" if t_replicate <= t_shuffle else "shuffle"
+
+
+def _gather_rows(dist, group, engine, world, t, sizes: List[int], lo_frac=(0, 1), async_op=False):
+    """All ranks' slice [n*a/b, n*(a+1)/b) of their tensor `t`, concatenated in rank order.  Returns (work, out, fix)
+    where fix(out) compacts the result when the slices are not all the same length."""
+    a, b = lo_frac
+    lens = [n * (a + 1) // b - n * a // b for n in sizes]
+    me = dist.get_rank(group)
+    mine = t[sizes[me] * a // b: sizes[me] * (a + 1) // b]
+    mx = max(lens)
+    if min(lens) == mx:
+        out = engine.empty(mx * world)
+        w = dist.all_gather_into_tensor(out, mine.contiguous(), group=group, async_op=async_op)
+        return w, out, None
+    pad = engine.empty(mx)
+    pad[: lens[me]] = mine
+    out = engine.empty(mx * world)
+    w = dist.all_gather_into_tensor(out, pad, group=group, async_op=async_op)
+
+    def fix(o):
+        import torch
+        return torch.cat([o[r * mx: r * mx + lens[r]] for r in range(world)])
+    return w, out, fix
+
+
+def _replicated_join(dist, group, engine, world, build_keys, build_values, probe_keys, sizes_b: List[int], materialize: bool,
+                     bloom: bool, return_arrays: bool, pieces: int, timings: Optional[dict]):
+    """Every rank joins ITS probe rows against ALL build rows: build keys (and values when materialising) are
+    all-gathered, probe rows never leave their GPU.  The global count is the sum of the local counts; materialised
+    pairs stay on the rank that holds the probe row."""
+    t0 = time.perf_counter()
+    nb_total = sum(sizes_b)
+    if materialize or not hasattr(engine, "stream_open"):
+        _, bk_all, fix = _gather_rows(dist, group, engine, world, build_keys, sizes_b)
+        if fix: bk_all = fix(bk_all)
+        _, bv_all, fix = _gather_rows(dist, group, engine, world, build_values, sizes_b)
+        if fix: bv_all = fix(bv_all)
+        engine.synchronize()
+        t1 = time.perf_counter()
+        res = engine.local_join(bk_all, bv_all, probe_keys, materialize, bloom, 64, return_arrays)
+        local_count = int(res[0])
+    else:
+        # counting: keys only, in `pieces` asynchronous all-gathers; the probe side is partitioned meanwhile
+        if nb_total <= 8192 or min(sizes_b) < pieces or min(sizes_b) != max(sizes_b):    # (a zero-pass build side is one piece)
+            pieces = 1
+        gathers = [_gather_rows(dist, group, engine, world, build_keys, sizes_b, (c, pieces), async_op=True) for c in range(pieces)]
+        engine.stream_open(nb_total, pieces, probe_keys.numel(), 1, 64)
+        engine.stream_append(probe_keys)
+        engine.stream_advance_probe()
+        keep = []
+        for w, out, fix in gathers:
+            if w is not None:
+                w.wait()
+            if fix: out = fix(out)
+            keep.append(out)
+            engine.stream_append_build(out)
+        t1 = time.perf_counter()
+        local_count = engine.stream_finish()
+        res = None
+        del keep
+    tot = engine.counts_tensor([local_count])
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    engine.synchronize()
+    t2 = time.perf_counter()
+    if timings is not None:
+        timings.update(strategy="replicate", split_s=0.0, exchange_s=t1 - t0, join_s=t2 - t1, exchange_rounds=1, pieces=pieces,
+                       local_build_rows=nb_total, local_probe_rows=probe_keys.numel(), local_count=local_count)
+    out = (int(tot.item()), t2 - t0)
+    if materialize and return_arrays:
+        return out + (res[2], res[3])
+    return out
+
+
 def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool = False, bloom: bool = False,
                      group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None):
     """Join relations whose rows are block-distributed over the ranks of `group`.
@@ -210,6 +336,18 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
         return res
 
     pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
+    # relation sizes of every rank: one tiny all-gather decides the strategy identically everywhere
+    mine = engine.counts_tensor([build_keys.numel(), probe_keys.numel()])
+    allsz = engine.counts_tensor([0] * (2 * world))
+    dist.all_gather_into_tensor(allsz, mine, group=group)
+    allsz = allsz.reshape(world, 2).tolist()
+    sizes_b = [int(x[0]) for x in allsz]
+    strategy = choose_strategy(world, max(sizes_b), max(int(x[1]) for x in allsz), materialize)
+    if strategy == "replicate":
+        return _replicated_join(dist, group, engine, world, build_keys, build_values, probe_keys, sizes_b, materialize, bloom,
+                                return_arrays, int(os.environ.get("FJ_REPLICATE_PIECES", "1")), timings)
+    if timings is not None:
+        timings["strategy"] = "shuffle"
     if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
         return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings)
 

@@ -113,13 +113,23 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
                      uint64_t* d_out_keys, uint64_t* d_out_vals, void* stream);
 
 /*
- * A counting radix join whose probe side arrives in pieces (multi-GPU: the pieces of a pipelined all-to-all).
- * fj_stream_begin partitions the build side and opens the probe side's first-pass pool for at most np_bound rows in at
- * most max_appends pieces; every fj_stream_append_probe runs the first partition pass over one piece (asynchronous on
- * `stream`; the piece must stay allocated until fj_stream_finish returns); fj_stream_finish runs the remaining passes
- * and the join and returns the match count.  Same result as fj_join_device(FJ_ALGO_RADIX, 0, 0, ...) on the
- * concatenation.  No reference counterpart.
+ * A counting radix join whose relations arrive in pieces (multi-GPU: the pieces of an exchange).  No reference
+ * counterpart; same result as fj_join_device(FJ_ALGO_RADIX, 0, 0, ...) on the concatenations.
+ *
+ * fj_stream_open sizes the plan for at most nb_bound build rows (in <= build_appends pieces) and np_bound probe rows
+ * (in <= probe_appends pieces).  Every fj_stream_append_build / fj_stream_append_probe runs the first partition pass
+ * over one piece (asynchronous on `stream`; a piece must stay allocated until fj_stream_finish returns); the two
+ * sides may be appended in any order.  fj_stream_advance_probe closes the probe side and runs its remaining passes at
+ * once, so that they overlap an exchange of the build side.  fj_stream_finish runs whatever remains, then the join,
+ * and returns the match count.  A build side of <= 4096 rows (zero-pass plan) must arrive in one piece.
+ *
+ * fj_stream_begin = fj_stream_open + one fj_stream_append_build of the whole build side + its remaining passes
+ * (the build side is complete before the probe pieces arrive: the owner-shuffle exchange).
  */
+int fj_stream_open(fj_ctx* ctx, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends, void* stream,
+                   int hash_top_bits);
+int fj_stream_append_build(fj_ctx* ctx, const uint64_t* d_build_keys, size_t n, void* stream);
+int fj_stream_advance_probe(fj_ctx* ctx, void* stream);
 int fj_stream_begin(fj_ctx* ctx, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, size_t np_bound,
                     int max_appends, void* stream, int hash_top_bits);
 int fj_stream_append_probe(fj_ctx* ctx, const uint64_t* d_probe_keys, size_t n, void* stream);

@@ -55,15 +55,32 @@ class OracleEngine:
         return out
 
     def stream_begin(self, bk, bv, np_bound, max_appends, hash_top_bits):
-        self._b = (bk, bv); self._pieces = []; self._bound = np_bound; self._max = max_appends
+        self._b = (bk, bv); self._pieces = []; self._bound = np_bound; self._max = max_appends; self._closed = False
+
+    def stream_open(self, nb_bound, build_appends, np_bound, probe_appends, hash_top_bits):
+        assert hash_top_bits == 64
+        self._b = None; self._bp = []; self._bb = nb_bound; self._bmax = build_appends
+        self._pieces = []; self._bound = np_bound; self._max = probe_appends; self._closed = False
+
+    def stream_append_build(self, piece):
+        self._bp.append(piece)
+        assert len(self._bp) <= self._bmax and sum(p.numel() for p in self._bp) <= self._bb
+
+    def stream_advance_probe(self):
+        self._closed = True
 
     def stream_append(self, piece):
+        assert not getattr(self, "_closed", False)
         self._pieces.append(piece)
         assert len(self._pieces) <= self._max and sum(p.numel() for p in self._pieces) <= self._bound
 
     def stream_finish(self):
         pk = torch.cat(self._pieces) if self._pieces else torch.empty(0, dtype=torch.int64)
         assert pk.numel() == self._bound
+        if self._b is None:                     # replicate strategy: build keys arrived in pieces, no values
+            bk = torch.cat(self._bp)
+            assert bk.numel() == self._bb
+            self._b = (bk, torch.zeros_like(bk))
         return self.O.c_join(self._b[0].numpy(), self._b[1].numpy(), pk.numpy(), algo="radix", threads=2)[0]
 
     def local_join(self, bk, bv, pk, materialize, bloom, hash_top_bits, return_arrays):
@@ -77,10 +94,13 @@ class OracleEngine:
         pass
 
 
-def _worker(rank, world, port, nb, npk, q):
+def _worker(rank, world, port, nb, npk, q, strategy):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["FJ_DIST_STRATEGY"] = strategy
+    if strategy == "replicate":
+        os.environ["FJ_REPLICATE_PIECES"] = "3"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from flash_hash_join_amd import datagen
@@ -96,11 +116,19 @@ def _worker(rank, world, port, nb, npk, q):
         exp = torch.tensor([exp_local]); dist.all_reduce(exp)
         tc = {}
         cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)        # counting: pipelined exchange
-        assert cnt == int(exp.item()) and tc["pieces"] == 4 and tc["local_probe_rows"] == t["local_probe_rows"]
+        assert cnt == int(exp.item()) and tc["strategy"] == t["strategy"] == strategy
+        assert tc["local_probe_rows"] == t["local_probe_rows"]
         keys = res[2].numpy().view(np.uint64)
-        # every pair this rank owns must hash to this rank
-        owner = ((_fmix64(keys.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)
-        q.put((rank, int(res[0]), int(exp.item()), int(res[2].numel()), bool(np.all(owner == rank)), t.get("local_count")))
+        if strategy == "shuffle":
+            assert tc["pieces"] == 4
+            # every pair this rank owns must hash to this rank
+            owner = ((_fmix64(keys.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)
+            owned = bool(np.all(owner == rank))
+        else:
+            # pairs stay with the probe row: every emitted key is one of this rank's probe keys, every build row was here
+            assert tc["pieces"] == (3 if nb % world == 0 else 1) and t["local_build_rows"] == nb
+            owned = bool(np.isin(keys, pk).all()) and t["local_probe_rows"] == p1 - p0
+        q.put((rank, int(res[0]), int(exp.item()), int(res[2].numel()), owned, t.get("local_count")))
     finally:
         dist.destroy_process_group()
 
@@ -109,13 +137,14 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+@pytest.mark.parametrize("strategy", ["shuffle", "replicate"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_distributed_join_gloo(world, oracle):
+def test_distributed_join_gloo(world, strategy, oracle):
     nb, npk = 20000, 90000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nb, npk, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nb, npk, q, strategy)) for r in range(world)]
     for p in procs:
         p.start()
     rows = [q.get(timeout=180) for _ in range(world)]

@@ -218,8 +218,9 @@ def test_owner_split_then_local_joins_equals_global_join(fj):
 
 
 def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
-    """The whole multi-GPU step (owner split -> RCCL all_to_all_single -> join with hash_top_bits=48 -> all_reduce)
-    on a 1-rank nccl group: exercises HipEngine and the collectives; the multi-rank logic itself is covered on CPU."""
+    """The whole multi-GPU step on a 1-rank nccl group, both strategies: owner split -> RCCL all_to_all_single -> join
+    with hash_top_bits=48 -> all_reduce, and all-gather of the build keys overlapped with the probe passes -> join ->
+    all_reduce.  Exercises HipEngine and the collectives; the multi-rank logic itself is covered on CPU."""
     import socket
     import torch
     import torch.distributed as dist
@@ -234,13 +235,18 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
         nb, npk = 3_000_000, 20_000_000
         bk, bv = datagen.build_device(nb, "cuda:0")
         pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=4, hit_bp=5000)
-        t = {}
-        n, sec = distributed_join(bk, bv, pk, timings=t)
-        assert n == exp and t["local_probe_rows"] == npk and t["local_build_rows"] == nb
-        n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
-        assert n == exp and k.numel() == exp
         M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
-        assert bool(torch.all((v + 1) * M == k))
+        for strategy, rp in (("shuffle", "1"), ("replicate", "1"), ("replicate", "3")):
+            monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
+            monkeypatch.setenv("FJ_REPLICATE_PIECES", rp)
+            t = {}
+            n, sec = distributed_join(bk, bv, pk, timings=t)
+            assert n == exp and t["local_probe_rows"] == npk and t["local_build_rows"] == nb and t["strategy"] == strategy
+            if strategy == "replicate":
+                assert t["pieces"] == int(rp)
+            n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
+            assert n == exp and k.numel() == exp
+            assert bool(torch.all((v + 1) * M == k))
     finally:
         dist.destroy_process_group()
 
@@ -300,6 +306,52 @@ def test_streamed_probe_equals_one_shot(fj, nb, npk, pieces):
         for i in range(pieces):
             eng.stream_append(pk[cuts[i]: cuts[i + 1]].clone())         # clones: 16-B aligned pieces
         assert eng.stream_finish() == exp
+
+
+@pytest.mark.parametrize("nb,npk,bpieces,ppieces", [(2000, 300_000, 1, 3), (50_000, 1_000_000, 4, 2), (1_500_000, 6_000_000, 5, 1),
+                                                    (3_000_000, 20_000_000, 3, 4), (10, 1000, 1, 2), (20_000_000, 30_000_000, 8, 1)])
+def test_stream_join_with_both_sides_in_pieces(fj, nb, npk, bpieces, ppieces):
+    """fj_stream_open / append_build / append_probe / advance_probe / finish == the one-shot radix count, with the
+    probe side closed BEFORE the build side arrives (the replicate-build exchange order) and after it."""
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    bk, bv = datagen.build_device(nb, "cuda:0")
+    pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=12, hit_bp=4000)
+    eng = HipEngine("cuda:0")
+    bcuts = [nb * i // bpieces for i in range(bpieces + 1)]
+    pcuts = [npk * i // ppieces for i in range(ppieces + 1)]
+    for probe_first in (True, False):
+        eng.stream_open(nb, bpieces, npk, ppieces, 64)
+        if probe_first:
+            for i in range(ppieces):
+                eng.stream_append(pk[pcuts[i]: pcuts[i + 1]].clone())
+            eng.stream_advance_probe()
+        for i in range(bpieces):
+            eng.stream_append_build(bk[bcuts[i]: bcuts[i + 1]].clone())
+        if not probe_first:
+            for i in range(ppieces):
+                eng.stream_append(pk[pcuts[i]: pcuts[i + 1]].clone())
+        assert eng.stream_finish() == exp
+
+
+def test_stream_join_rejects_misuse(fj):
+    import torch
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    bk, bv = datagen.build_device(100_000, "cuda:0")
+    pk, exp = datagen.probe_device(100_000, 100_000, "cuda:0", seed=1, hit_bp=5000)
+    eng = HipEngine("cuda:0")
+    eng.stream_open(100_000, 1, 100_000, 1, 64)
+    eng.stream_append_build(bk)
+    with pytest.raises(RuntimeError, match="more pieces"):
+        eng.stream_append_build(bk)
+    eng.stream_append(pk)
+    eng.stream_advance_probe()
+    with pytest.raises(RuntimeError, match="closed"):
+        eng.stream_append(pk)
+    assert eng.stream_finish() == exp
+    with pytest.raises(RuntimeError, match="no stream join"):
+        eng.stream_append(pk)
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
