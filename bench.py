@@ -41,6 +41,10 @@ WORKLOADS = {
     "c4_scalar_bloom": (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),
     "c3_mat": (100_000_000, 1_000_000_000, 5000, "hash_join_radix"),
     "small": (1_000_000, 10_000_000, 5000, "hash_join_count_radix"),
+    # what ONE rank joins locally under the replicate-build multi-GPU strategy at N = 2, 4, 8 (c3 rows per GPU)
+    "rep2": (200_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
+    "rep4": (400_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
+    "rep8": (800_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
 }
 
 

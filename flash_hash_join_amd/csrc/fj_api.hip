@@ -122,6 +122,16 @@ int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
 }
 
 
+// passes for `bits` radix bits: 8-bit passes (256 buckets, 128-B lines, two workgroups per CU) while two of them
+// reach, 9-bit passes (512 buckets) beyond 16 bits -- a wider pass is slower per row but cheaper than a third pass
+void plan_passes(Plan& p, bool extra_first) {
+    p.npass = p.bits <= 16 ? (p.bits + 7) / 8 : (p.bits + FJ_MAX_FAN_LOG - 1) / FJ_MAX_FAN_LOG;
+    for (int i = 0; i < p.npass; ++i) {
+        const int rem = p.bits % p.npass;
+        p.fan_log[i] = p.bits / p.npass + ((extra_first ? i < rem : i >= p.npass - rem) ? 1 : 0);
+    }
+}
+
 Plan make_plan(size_t nb, int top_bits) {
     Plan p;
     if (nb > FJ_PART_TARGET_KEYS) {
@@ -130,8 +140,7 @@ Plan make_plan(size_t nb, int top_bits) {
     }
     if (p.bits > 0 && p.bits < 5) p.bits = 5;              // a pass with a tiny fan-out serialises on its per-bucket threads
     if (p.bits > top_bits - 32) p.bits = top_bits - 32;      // radix digits come from hash word 1 (32 bits)
-    p.npass = (p.bits + 7) / 8;
-    for (int i = 0; i < p.npass; ++i) p.fan_log[i] = p.bits / p.npass + ((getenv("FJ_SPLIT_FIRST") ? i < p.bits % p.npass : i >= p.npass - p.bits % p.npass) ? 1 : 0);   // extra bits go to the later passes
+    plan_passes(p, getenv("FJ_SPLIT_FIRST") != nullptr);     // extra bits go to the later passes
     return p;
 }
 
@@ -162,7 +171,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     it.Gmax = pass_groups(it.lbound, it.n, it.tile_chunks, it.F);
     const u32 F = it.F, G = it.Gmax, parents = it.parents;
     const u64 nb_out = (u64)parents * F;
-    const u64 cap64 = it.n / FJ_CHUNK + 1 + (2ull * (G + parents) * F + (u64)(G + 1) * FJ_SLAB) * it.appends;
+    const u64 cap64 = it.n / FJ_CHUNK + 1 + (2ull * (G + parents) * F + (u64)(G + 1) * fj_slab_for(F)) * it.appends;
     if (cap64 >= (1ull << 24) || nb_out >= (1u << 22))
         return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
     FjChunkSet cs{};
@@ -204,9 +213,11 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     a.bchunks = cs.bchunks; a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + it.i];
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
     a.err = &c->d_sc->err;
-    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i];
+    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.F);
     a.interleave = getenv("FJ_INTERLEAVE") ? (u32)atoi(getenv("FJ_INTERLEAVE")) : 0u;
-    const int line_log = 4;                 // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter)
+    // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter); only a 512-bucket pass that
+    // also carries values has to fall back to them (LDS)
+    const int line_log = (it.has_vals && it.F > 256) ? 3 : 4;
     if (ev_cursor) HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor)], s));
     HIPCHK(fj_launch_partition(a, it.has_vals, line_log, G, s));
     if (ev_cursor) { HIPCHK(hipEventRecord(c->ev[E_PK0 + 2 * (*ev_cursor) + 1], s)); ++*ev_cursor; }
@@ -776,8 +787,8 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
     if (total_bits < 1 || total_bits > 24) return set_err("fj_debug_partition: total_bits must be 1..24");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    Plan plan; plan.bits = total_bits; plan.npass = (total_bits + 7) / 8;
-    for (int i = 0; i < plan.npass; ++i) plan.fan_log[i] = plan.bits / plan.npass + (i < plan.bits % plan.npass ? 1 : 0);
+    Plan plan; plan.bits = total_bits;
+    plan_passes(plan, true);
     HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
     FjChunkSet cs{};
     PassIter dit;

@@ -22,7 +22,9 @@ typedef uint16_t u16;
 // chunk-list entry = ((count - 1) << 24) | chunk id   (ids < 2^24), so a consumer needs no directory lookup
 #define FJ_LIST_ID(e) ((e) & 0xFFFFFFu)
 #define FJ_LIST_CNT(e) (((e) >> 24) + 1u)
-#define FJ_SLAB 512u                            // chunks handed to a workgroup per allocator hit
+#define FJ_SLAB 512u                            // chunks handed to a workgroup per allocator hit (fan-out <= 256)
+#define FJ_MAX_FAN_LOG 9                         // widest pass: 512 buckets
+static inline unsigned fj_slab_for(unsigned fan) { return fan > 256u ? 2u * FJ_SLAB : FJ_SLAB; }   // one tile starts <= (T + 15 fan)/256 + fan chunks
 #define FJ_MAX_FANOUT 256u                      // buckets per partition pass (8 bits, as RADIX_BITS)
 
 // LDS-resident join table (per final partition): 8192 slots, 8-B keys (+ 8-B values when

@@ -56,7 +56,7 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG 
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
 __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LPL = LINE / 4;
-    static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4, "tile geometry");
+    static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
     const u32 F = 1u << a.fan_log, FM = F - 1;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     auto flush = [&](u32 parent) {
         if (tid == 0) {
             if (misc[M_SLAB_REM] < F) {
-                const u32 nb = atomicAdd(a.alloc, FJ_SLAB);
-                if (nb + FJ_SLAB > cap) atomicOr(a.err, FJ_ERR_POOL);
-                misc[M_SLAB_CUR] = nb; misc[M_SLAB_REM] = FJ_SLAB;
+                const u32 nb = atomicAdd(a.alloc, a.slab);
+                if (nb + a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
+                misc[M_SLAB_CUR] = nb; misc[M_SLAB_REM] = a.slab;
             }
             misc[M_FLUSH] = 0;
         }
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                     misc[M_NLINES] = l0 + (nf >> LINE_LOG);
                     misc[M_NEED] = need;
                     if (need > misc[M_SLAB_REM]) {
-                        const u32 nb = atomicAdd(a.alloc, FJ_SLAB);
-                        if (nb + FJ_SLAB > cap) atomicOr(a.err, FJ_ERR_POOL);
+                        const u32 nb = atomicAdd(a.alloc, a.slab);
+                        if (nb + a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
                         misc[M_NEW_BASE] = nb;
                     }
                 }
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             if (HAS_VALS) tile_v[d] = v[i];
         }
         if (tid < F) {
-            // line descriptors: dst element (32) | bucket (8) | keys of this line that still sit in lo_* (5)
-            //                   | tile index of the line's virtual key 0, biased by 32 (19)
+            // line descriptors: dst element (32) | bucket (10) | keys of this line that still sit in lo_* (5)
+            //                   | tile index of the line's virtual key 0, biased by 32 (17)
             const u32 b = tid, f0 = st_fill, c0 = st_cur, n0 = st_nch, tb = toff[b];
             for (u32 q = 0; q < nf; q += LINE) {
                 const u32 pq = f0 + q, kk = pq >> FJ_CHUNK_LOG, off = pq & (FJ_CHUNK - 1);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 const u32 dst = id < cap ? id * FJ_CHUNK + off : FJ_DIR_INVALID;
                 const u32 lc = q == 0 ? st_left : 0u;
                 const u32 sidx = tb + q + 32u - st_left;            // tile index of virtual key q (may precede the run for line 0)
-                line_desc[l0 + (q >> LINE_LOG)] = ((u64)dst << 32) | ((u64)b << 24) | ((u64)lc << 19) | sidx;
+                line_desc[l0 + (q >> LINE_LOG)] = ((u64)dst << 32) | ((u64)b << 22) | ((u64)lc << 17) | sidx;
             }
             const u32 outb = (parent * F + b) << FJ_DIR_CNT_BITS;
             const u64 segw = (u64)misc[M_SEG] << 32;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u64 d = line_desc[l];
             const u32 dst = (u32)(d >> 32);
             if (dst != FJ_DIR_INVALID) {
-                const u32 w = (u32)d, b = w >> 24, lc = (w >> 19) & 31u, sidx = (w & 0x7FFFFu) - 32u;
+                const u32 w = (u32)d, b = w >> 22, lc = (w >> 17) & 31u, sidx = (w & 0x1FFFFu) - 32u;
                 u64 r[4], rv[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         if (tid == 0) {
             const u32 need = misc[M_NEED], rem = misc[M_SLAB_REM];
             if (need <= rem) { misc[M_SLAB_CUR] += need; misc[M_SLAB_REM] = rem - need; }
-            else { const u32 used = need - rem; misc[M_SLAB_CUR] = misc[M_NEW_BASE] + used; misc[M_SLAB_REM] = FJ_SLAB - used; }
+            else { const u32 used = need - rem; misc[M_SLAB_CUR] = misc[M_NEW_BASE] + used; misc[M_SLAB_REM] = a.slab - used; }
         }
         __syncthreads();
     }
@@ -527,6 +527,13 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
 // One partition pass.  Keys-only tiles are 4096 keys (512 threads x 8), key+value tiles 2048.
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
     if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
+    if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < 48 + (1u << a.fan_log)) return hipErrorInvalidValue;
+    if (a.fan_log == 9) {
+        // 512 buckets: one bucket per thread needs >= 512 threads and the open lines take 64 KiB (keys) -- one
+        // 1024-thread workgroup per CU; with values the lines shrink to 64 B so that both payloads still fit
+        if (vals) return line_log == 3 ? launch_part2<1024, 4, true>(a, 3, grid, s) : hipErrorInvalidValue;
+        return launch_part2<1024, 4, false>(a, line_log, grid, s);
+    }
     if (vals) {
         // 1024 threads x 4 rows: one workgroup per CU (LDS), but 16 waves of it: 1.63 -> 1.42 ms build phase at c3
         if (getenv("FJ_KV_NT512")) return launch_part2<512, 8, true>(a, line_log, grid, s);

@@ -217,7 +217,11 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
 # (P = 10 B) that is fewer bytes up to N = 12 -- 6x fewer at N = 2 -- and the probe side never moves: its partition
 # passes run while the build keys are on the wire.  The price is local: every rank partitions all N*B build keys.
 _LINK_BYTES_PER_S = 45e9          # one xGMI link, one direction, effective (153.6 GB/s bidirectional raw)
-_HBM_BYTES_PER_S = 4.5e12         # partition-pass rate of this library (read + write)
+# local work, measured on one MI355X (profiles/r01_replicate_local.txt; c3 = 100M x 1B rows per GPU):
+_PROBE_PASS_S_PER_ROW = 3.4e-12    # one probe-side partition pass
+_BUILD_S_PER_ROW = 18e-12          # a build row's share of passes + table build, counting join (800M rows: 8.2 + 5.4 ms)
+_SPLIT_S_PER_ROW = 2.7e-12         # shuffle: owner histogram + the un-overlapped first owner scatter
+_JOIN_S_PER_ROW = 2.0e-12          # per-partition join, per probe row
 
 
 def _plan_passes(nb: int) -> int:
@@ -225,7 +229,21 @@ def _plan_passes(nb: int) -> int:
     if nb <= 4096:
         return 0
     bits = max(5, (-(-nb // 4096) - 1).bit_length())
-    return -(-bits // 8)
+    return -(-bits // 8) if bits <= 16 else -(-bits // 9)
+
+
+def strategy_costs(world: int, nb: int, np_: int, materialize: bool) -> dict:
+    """Modelled seconds of one step for per-rank relation sizes nb x np_ under both strategies."""
+    kb = 2 if materialize else 1
+    # shuffle: exchange of 1/N of every relation per link; the probe exchange hides the splits and the first pass
+    x_sh = (np_ * 8 + nb * 16) / world / _LINK_BYTES_PER_S
+    t_shuffle = (_SPLIT_S_PER_ROW * np_ + x_sh + (_plan_passes(nb) - 1) * _PROBE_PASS_S_PER_ROW * np_
+                 + _JOIN_S_PER_ROW * np_ + _BUILD_S_PER_ROW * nb * kb)
+    # replicate: the build keys of one peer per link; the probe passes hide under it, the N-fold build work does not
+    x_rep = nb * 8 * kb / _LINK_BYTES_PER_S
+    t_replicate = (max(x_rep, _plan_passes(world * nb) * _PROBE_PASS_S_PER_ROW * np_)
+                   + _BUILD_S_PER_ROW * world * nb * kb + _JOIN_S_PER_ROW * np_)
+    return {"shuffle": t_shuffle, "replicate": t_replicate}
 
 
 def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
@@ -235,12 +253,8 @@ def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
         return forced
     if world * nb >= (1 << 31):               # replicated build side must stay inside one GPU's chunk directory
         return "shuffle"
-    kb = 16 if materialize else 8
-    t_shuffle = (np_ * 8 + nb * 16) / world / _LINK_BYTES_PER_S + (np_ * 16 + nb * 32) / _HBM_BYTES_PER_S
-    p_all, p_loc = _plan_passes(world * nb), _plan_passes(nb)
-    t_replicate = (nb * kb / _LINK_BYTES_PER_S + (world - 1) * nb * 2 * kb * p_all / _HBM_BYTES_PER_S
-                   + np_ * 16 * (p_all - p_loc) / _HBM_BYTES_PER_S)
-    return "replicate" if t_replicate <= t_shuffle else "shuffle"
+    c = strategy_costs(world, nb, np_, materialize)
+    return "replicate" if c["replicate"] <= c["shuffle"] else "shuffle"
 
 
 def _gather_rows(dist, group, engine, world, t, sizes: List[int], lo_frac=(0, 1), async_op=False):

@@ -151,10 +151,13 @@ def test_device_tensor_inputs_and_device_generators(fj, oracle):
 
 
 @pytest.mark.parametrize("n,bits,with_vals", [(1000, 3, True), (100_000, 8, False), (300_000, 7, True),
-                                                (2_000_000, 13, False), (1_500_000, 10, True), (700_001, 16, False)])
+                                                (2_000_000, 13, False), (1_500_000, 10, True), (700_001, 16, False),
+                                                (2_000_000, 17, False), (1_200_000, 17, True), (3_000_000, 18, False),
+                                                (2_500_000, 18, True), (1_000_000, 20, False)])
 def test_partition_pass_in_isolation(fj, n, bits, with_vals):
     """fj_debug_partition: the chunk lists are a permutation of the input and every row sits in the
-    bucket named by the top `bits` bits of its hash (1 pass for bits <= 8, 2 passes above)."""
+    bucket named by the top `bits` bits of its hash (1 pass for bits <= 8, 2 passes up to 18 bits -- 512-bucket passes
+    above 16 --, 3 passes above)."""
     import ctypes
     import torch
     from flash_hash_join_amd import _lib, api
@@ -258,6 +261,8 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
     (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom"),   # BASELINE config 4 (radix form)
     (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),         # BASELINE config 4 as named: non-partitioned + bloom precheck
     (1_000_000, 10_000_000, 5000, "adaptive_join_count"),               # BASELINE config 1 sizes on the device
+    (300_000_000, 300_000_000, 5000, "hash_join_count_radix"),          # 17 radix bits: an 8-bit and a 9-bit pass
+    (800_000_000, 200_000_000, 5000, "hash_join_count_radix"),          # 18 bits (9 + 9): the replicated build side of 8 GPUs
 ])
 def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn):
     """BASELINE.json's full sizes, checked through the size-independent property of the generator:
@@ -275,11 +280,12 @@ def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn):
     torch.cuda.empty_cache()
 
 
-def test_full_size_materialize_pairs_property(fj):
-    """10M x 100M materialise: every emitted pair satisfies key == (value+1)*M, count is closed-form."""
+@pytest.mark.parametrize("nb,npk", [(10_000_000, 100_000_000), (300_000_000, 50_000_000)])
+def test_full_size_materialize_pairs_property(fj, nb, npk):
+    """10M x 100M materialise (and 300M x 50M: a 512-bucket pass that carries values): every emitted pair satisfies
+    key == (value+1)*M, count is closed-form."""
     import torch
     from flash_hash_join_amd import datagen
-    nb, npk = 10_000_000, 100_000_000
     dbk, dbv = datagen.build_device(nb, "cuda:0")
     dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=9, hit_bp=5000)
     n, sec, k, v = fj.hash_join_radix(dbk, dbv, dpk, return_arrays=True)
