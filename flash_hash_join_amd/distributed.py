@@ -287,18 +287,31 @@ def _replicated_join(dist, group, engine, world, build_keys, build_values, probe
     pairs stay on the rank that holds the probe row."""
     t0 = time.perf_counter()
     nb_total = sum(sizes_b)
+    need = max(1, -(-max(sizes_b) // _MAX_ELEMS_PER_MESSAGE))        # keep every rank's contribution to one collective <= 1 GiB
     if materialize or not hasattr(engine, "stream_open"):
-        _, bk_all, fix = _gather_rows(dist, group, engine, world, build_keys, sizes_b)
-        if fix: bk_all = fix(bk_all)
-        _, bv_all, fix = _gather_rows(dist, group, engine, world, build_values, sizes_b)
-        if fix: bv_all = fix(bv_all)
+        import torch
+
+        def gather_all(t):
+            parts = []
+            for c in range(need):
+                _, o, fix = _gather_rows(dist, group, engine, world, t, sizes_b, (c, need))
+                parts.append(fix(o) if fix else o)
+            if need == 1:
+                return parts[0]
+            # piece-major -> rank-major, so that the first occurrence of a duplicate key is the one of the lowest rank
+            lens = [[n * (c + 1) // need - n * c // need for n in sizes_b] for c in range(need)]
+            offs = [[sum(l[:r]) for r in range(world)] for l in lens]
+            return torch.cat([parts[c][offs[c][r]: offs[c][r] + lens[c][r]] for r in range(world) for c in range(need)])
+        bk_all = gather_all(build_keys)
+        bv_all = gather_all(build_values)
         engine.synchronize()
         t1 = time.perf_counter()
         res = engine.local_join(bk_all, bv_all, probe_keys, materialize, bloom, 64, return_arrays)
         local_count = int(res[0])
     else:
         # counting: keys only, in `pieces` asynchronous all-gathers; the probe side is partitioned meanwhile
-        if nb_total <= 8192 or min(sizes_b) < pieces or min(sizes_b) != max(sizes_b):    # (a zero-pass build side is one piece)
+        pieces = max(pieces, need)
+        if nb_total <= 8192 or min(sizes_b) < pieces:        # (a zero-pass build side must arrive as one piece)
             pieces = 1
         gathers = [_gather_rows(dist, group, engine, world, build_keys, sizes_b, (c, pieces), async_op=True) for c in range(pieces)]
         engine.stream_open(nb_total, pieces, probe_keys.numel(), 1, 64)

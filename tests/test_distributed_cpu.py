@@ -98,6 +98,8 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    small_messages = strategy == "replicate_small_messages"
+    strategy = strategy.split("_")[0]
     os.environ["FJ_DIST_STRATEGY"] = strategy
     if strategy == "replicate":
         os.environ["FJ_REPLICATE_PIECES"] = "3"
@@ -105,6 +107,9 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     try:
         from flash_hash_join_amd import datagen
         from flash_hash_join_amd.distributed import distributed_join
+        if small_messages:                      # every collective carries <= 3000 rows per rank: 4 pieces, reordered rank-major
+            import flash_hash_join_amd.distributed as D
+            D._MAX_ELEMS_PER_MESSAGE = 3000
         # block distribution of the global relation (GPU g holds rows [g*N/G, (g+1)*N/G))
         b0, b1 = rank * nb // world, (rank + 1) * nb // world
         p0, p1 = rank * npk // world, (rank + 1) * npk // world
@@ -126,7 +131,8 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             owned = bool(np.all(owner == rank))
         else:
             # pairs stay with the probe row: every emitted key is one of this rank's probe keys, every build row was here
-            assert tc["pieces"] == (3 if nb % world == 0 else 1) and t["local_build_rows"] == nb
+            per_rank = -(-nb // world)
+            assert tc["pieces"] == (max(3, -(-per_rank // 3000)) if small_messages else 3) and t["local_build_rows"] == nb
             owned = bool(np.isin(keys, pk).all()) and t["local_probe_rows"] == p1 - p0
         q.put((rank, int(res[0]), int(exp.item()), int(res[2].numel()), owned, t.get("local_count")))
     finally:
@@ -137,7 +143,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "replicate"])
+@pytest.mark.parametrize("strategy", ["shuffle", "replicate", "replicate_small_messages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):
     nb, npk = 20000, 90000
