@@ -213,7 +213,7 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     a.bchunks = cs.bchunks; a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + it.i];
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
     a.err = &c->d_sc->err;
-    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.F);
+    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.F); a.side = (u32)it.side;
     a.interleave = getenv("FJ_INTERLEAVE") ? (u32)atoi(getenv("FJ_INTERLEAVE")) : 0u;
     // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter); only a 512-bucket pass that
     // also carries values has to fall back to them (LDS)

@@ -53,7 +53,9 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG 
 // to minimise issued instructions per key: 32-bit-multiply hash, invalid lanes routed to a dummy
 // bucket instead of branches, per-bucket state in the registers of thread b, the bucket scan done
 // only by the waves that own buckets, 32 B per lane in the write-out.
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
+// PROBE_SIDE only names the instantiation (identical code): a counting join runs the keys-only kernel over both
+// relations, and per-kernel profiler statistics should not average 100M-row and 1B-row launches together.
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE>
 __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LPL = LINE / 4;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
@@ -498,15 +500,23 @@ __global__ void fj_list_build(const u32* __restrict__ dir, const u64* __restrict
     }
 }
 
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
-hipError_t launch_part(const FjPartArgs& a, u32 grid, hipStream_t s) {
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE>
+hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
     const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64);
-    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT>;
+    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, s, a);
     return hipGetLastError();
+}
+
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
+hipError_t launch_part(const FjPartArgs& a, u32 grid, hipStream_t s) {
+    if constexpr (!HAS_VALS && NT == 512) {
+        if (a.side == 0) return launch_part1<NT, KPT, LINE_LOG, HAS_VALS, FLAT, false>(a, grid, s);
+    }
+    return launch_part1<NT, KPT, LINE_LOG, HAS_VALS, FLAT, true>(a, grid, s);
 }
 
 template <int NT, int KPT, bool HAS_VALS>
