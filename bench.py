@@ -35,10 +35,12 @@ HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide
 WORKLOADS = {
     # name: (build rows per GPU, probe rows per GPU, hit rate in basis points, function)
     "c2": (1_000_000, 100_000_000, 5000, "hash_join_count"),
+    "c2_hbm_table": (1_000_000, 100_000_000, 5000, "hash_join_count"),           # literal one-table algorithm (option)
     "c2_radix": (1_000_000, 100_000_000, 5000, "hash_join_count_radix"),
     "c3": (100_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
     "c4": (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom"),
     "c4_scalar_bloom": (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),
+    "c4_hbm_table_bloom": (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),   # literal one-table algorithm + bloom precheck
     "c3_mat": (100_000_000, 1_000_000_000, 5000, "hash_join_radix"),
     "small": (1_000_000, 10_000_000, 5000, "hash_join_count_radix"),
     # what ONE rank joins locally under the replicate-build multi-GPU strategy at N = 2, 4, 8 (c3 rows per GPU)
@@ -126,6 +128,7 @@ def main() -> None:
     materialize = int(fn_name in ("hash_join_radix", "hash_join"))
 
     api.initialize() if local_rank == 0 else api.context(local_rank)
+    api.set_option("scalar_hbm_table", int("hbm_table" in args.workload))
     bk, bv = datagen.build_device(nb_gpu, device, first=rank * nb_gpu)
     pk, exp_local = datagen.probe_device(np_gpu, nb_total, device, seed=1, hit_bp=hit_bp, first=rank * np_gpu)
     exp_total = exp_local

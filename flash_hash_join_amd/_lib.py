@@ -19,6 +19,7 @@ SYMBOLS = [
     "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes",
     "fj_join_host", "fj_free_host", "fj_last_timings",
     "fj_join_device", "fj_emit_pairs", "fj_owner_split", "fj_owner_hist", "fj_owner_scatter",
+    "fj_set_option", "fj_get_option",
     "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe",
     "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
@@ -93,6 +94,8 @@ def load() -> ctypes.CDLL:
     L.fj_owner_split.argtypes = [vp, vp, vp, sz, i32, vp, vp, pu64, vp]
     L.fj_owner_hist.restype = i32; L.fj_owner_hist.argtypes = [vp, vp, sz, i32, pu64, vp]
     L.fj_owner_scatter.restype = i32; L.fj_owner_scatter.argtypes = [vp, vp, vp, sz, i32, pu64, vp, vp, vp]
+    L.fj_set_option.restype = i32; L.fj_set_option.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+    L.fj_get_option.restype = ctypes.c_longlong; L.fj_get_option.argtypes = [ctypes.c_char_p]
     L.fj_stream_open.restype = i32; L.fj_stream_open.argtypes = [vp, sz, i32, sz, i32, vp, i32]
     L.fj_stream_append_build.restype = i32; L.fj_stream_append_build.argtypes = [vp, vp, sz, vp]
     L.fj_stream_advance_probe.restype = i32; L.fj_stream_advance_probe.argtypes = [vp, vp]

@@ -12,7 +12,12 @@ Differences from the reference, all deliberate:
     are reported separately in `last_timings()`;
   * opt-in `return_arrays=True` returns the materialised pairs the reference computes and drops
     (hash_join.cpp:365-380): `(count, seconds, keys, values)`;
-  * torch tensors that already live on a ROCm device are joined in place (no PCIe).
+  * torch tensors that already live on a ROCm device are joined in place (no PCIe);
+  * the "scalar" functions (`hash_join*`: ONE table for the whole build side) run the partitioned plan by default:
+    a table that does not fit LDS costs a cache-missing 64-B access per probe in HBM, more traffic than two
+    streaming partition passes, so on MI355X it is the slower way to the same result at every size.
+    `set_option("scalar_hbm_table", 1)` restores the literal algorithm (HBM table with linear probing over 8-slot
+    groups, bloom word per group for the `_bloom` variants); it is also the fallback when a partition overflows LDS.
 """
 from __future__ import annotations
 
@@ -59,6 +64,18 @@ def context(device: int) -> int:
             raise RuntimeError(_lib.last_error())
         _ctxs[device] = h
     return _ctxs[device]
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide dispatch option of the native library: "radix_threshold", "scalar_hbm_table" (include/flashjoin.h)."""
+    check(_lib.load().fj_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = int(_lib.load().fj_get_option(name.encode()))
+    if v < 0:
+        raise KeyError(_lib.last_error())
+    return v
 
 
 def last_timings() -> Optional[dict]:
@@ -232,4 +249,4 @@ REFERENCE_EXPORTS = [
     "initialize",
 ]
 ALIASES = ["flash_join", "flash_join_radix", "flash_join_bloom", "flash_join_radix_bloom", "adaptive_bloom"]
-__all__ = REFERENCE_EXPORTS + ALIASES + ["last_timings", "join_device", "context"]
+__all__ = REFERENCE_EXPORTS + ALIASES + ["last_timings", "join_device", "context", "set_option", "get_option"]

@@ -102,7 +102,6 @@ struct fj_ctx {
     Pending pend;
     StreamState st;
     size_t ws_bytes = 0;
-    size_t radix_threshold = 0;
 };
 
 namespace {
@@ -434,12 +433,46 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
 
 fj_ctx* g_host_ctx = nullptr;
 
+// Process-wide dispatch options (fj_set_option; initial values from the environment).
+//   radix_threshold  : adaptive joins take the non-partitioned HBM table below this many build rows.  MI355X: the
+//                      partitioned driver wins at every build size (<= 4096 rows it runs zero passes: one LDS table per
+//                      workgroup over the flat inputs), so the switch point is 0 (tools/sweep_adaptive.py).
+//   scalar_hbm_table : 1 = the reference's "scalar" functions (hash_join*, one table for the whole build side) use the
+//                      non-partitioned HBM table at every size; 0 (default) = they use it only as the fallback and
+//                      otherwise run the partitioned plan.  One table for B rows means one cache-missing 64-B access
+//                      per probe in HBM -- more traffic than the 40 B per probe the two streaming passes + LDS join
+//                      move -- so on this machine "scalar" is the slower way to the same result at every size.
+struct Options {
+    size_t radix_threshold; int scalar_hbm_table;
+    Options() {
+        const char* th = getenv("FJ_RADIX_THRESHOLD");
+        radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)0;
+        const char* sg = getenv("FJ_SCALAR_HBM_TABLE");
+        scalar_hbm_table = sg ? atoi(sg) : 0;
+    }
+};
+Options& options() { static Options o; return o; }
+
 }  // namespace
 
 extern "C" {
 
 const char* fj_last_error(void) { return g_err.c_str(); }
 const char* fj_version(void) { return "flash_hash_join_amd 0.1 (gfx950)"; }
+
+int fj_set_option(const char* name, long long value) {
+    if (!name) return set_err("fj_set_option: null name");
+    if (!strcmp(name, "radix_threshold")) { if (value < 0) return set_err("fj_set_option: radix_threshold must be >= 0"); options().radix_threshold = (size_t)value; return 0; }
+    if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
+    return set_err("fj_set_option: unknown option '%s'", name);
+}
+
+long long fj_get_option(const char* name) {
+    if (name && !strcmp(name, "radix_threshold")) return (long long)options().radix_threshold;
+    if (name && !strcmp(name, "scalar_hbm_table")) return options().scalar_hbm_table;
+    set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
+    return -1;
+}
 
 int fj_device_count(void) {
     int n = 0;
@@ -466,10 +499,6 @@ fj_ctx* fj_ctx_create(int device) {
               hipMemset(c->d_sc, 0, sizeof(Scalars)) == hipSuccess;
     for (int i = 0; ok && i < E_NEV; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     if (!ok) { set_err("fj_ctx_create: allocating context scratch failed: %s", hipGetErrorString(hipGetLastError())); delete c; return nullptr; }
-    const char* th = getenv("FJ_RADIX_THRESHOLD");
-    // MI355X: the radix driver wins at every build size (<= 4096 rows it runs zero passes: one LDS table per
-    // workgroup over the flat inputs), so the adaptive switch point is 0 unless overridden (tools/sweep_adaptive.py)
-    c->radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)0;
     return c;
 }
 
@@ -499,7 +528,9 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
     fj_timings t; memset(&t, 0, sizeof t);
     u64 count = 0;
     c->pend.valid = false;
-    bool use_radix = algo == FJ_ALGO_RADIX || (algo == FJ_ALGO_ADAPTIVE && nb >= c->radix_threshold);
+    const Options& opt = options();
+    bool use_radix = algo == FJ_ALGO_RADIX || (algo == FJ_ALGO_ADAPTIVE && nb >= opt.radix_threshold) ||
+                     (algo == FJ_ALGO_SCALAR && !opt.scalar_hbm_table);
     if (nb == 0 || np == 0) {                   // empty side: (0, t), hash_join.cpp behaviour for empty inputs
         count = 0;
     } else if (use_radix) {

@@ -54,6 +54,17 @@ const char* fj_last_error(void);
 int fj_device_count(void);
 const char* fj_version(void);
 
+/* Process-wide dispatch options (no reference counterpart; the reference hard-codes 1'000'000 at hash_join.cpp:576):
+ *   "radix_threshold"  - adaptive_* joins use the non-partitioned HBM table below this many build rows (default 0:
+ *                        the partitioned driver wins at every size on MI355X; env FJ_RADIX_THRESHOLD);
+ *   "scalar_hbm_table" - 1: the "scalar" functions (FJ_ALGO_SCALAR: hash_join*, hash_join.cpp:383-496, :536-567) keep
+ *                        ONE table for the whole build side in HBM, as the reference does in DRAM; 0 (default): they
+ *                        run the same partitioned plan as the radix functions (identical results, 2-4x faster here)
+ *                        and the HBM table is only the overflow fallback (env FJ_SCALAR_HBM_TABLE).
+ * fj_get_option returns -1 for an unknown name. */
+int fj_set_option(const char* name, long long value);
+long long fj_get_option(const char* name);
+
 /* One context per (process, device): owns the grow-only workspace, events and scratch words. */
 fj_ctx* fj_ctx_create(int device);
 void fj_ctx_destroy(fj_ctx* ctx);

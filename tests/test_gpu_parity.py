@@ -28,6 +28,15 @@ def fj():
     return flash_join
 
 
+@pytest.fixture(params=[0, 1], ids=["scalar=planned", "scalar=hbm_table"])
+def scalar_mode(request, fj):
+    """Run a test under both settings of the "scalar_hbm_table" option: the hash_join* functions served by the
+    partitioned plan (default) and by the literal one-table-in-HBM algorithm (linear probing, bloom word per group)."""
+    fj.set_option("scalar_hbm_table", request.param)
+    yield request.param
+    fj.set_option("scalar_hbm_table", 0)
+
+
 def _digest(oracle, k, v):
     k, v = oracle.canon_pairs(k, v)
     return hashlib.sha256(k.tobytes() + v.tobytes()).hexdigest()
@@ -39,7 +48,7 @@ def _golden():
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_all_twelve_functions_match_golden_vectors(fj, oracle, name):
+def test_all_twelve_functions_match_golden_vectors(fj, oracle, name, scalar_mode):
     g = _golden()[name]
     bk, bv, pk = make_case(name)
     for fn in COUNT_FUNCS + MAT_FUNCS:
@@ -53,7 +62,7 @@ def test_all_twelve_functions_match_golden_vectors(fj, oracle, name):
         assert _digest(oracle, k, v) == g["pairs_sha256"], fn
 
 
-def test_against_c_oracle_on_fresh_random_inputs(fj, oracle):
+def test_against_c_oracle_on_fresh_random_inputs(fj, oracle, scalar_mode):
     rng = np.random.default_rng(2024)
     for nb, npk in [(1, 1), (2, 3), (255, 1000), (4096, 50000), (4097, 50000), (30000, 1), (123457, 654321)]:
         bk = np.unique(rng.integers(0, 2**64, size=nb, dtype=np.uint64))
@@ -70,7 +79,7 @@ def test_against_c_oracle_on_fresh_random_inputs(fj, oracle):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (fn, nb, npk)
 
 
-def test_empty_inputs_return_zero(fj):
+def test_empty_inputs_return_zero(fj, scalar_mode):
     e = np.empty(0, dtype=np.uint64)
     one = np.array([7], dtype=np.uint64)
     for fn in COUNT_FUNCS + MAT_FUNCS:
@@ -80,7 +89,7 @@ def test_empty_inputs_return_zero(fj):
     assert n == 0 and k.size == 0 and v.size == 0
 
 
-def test_int64_inputs_and_duplicates(fj, oracle):
+def test_int64_inputs_and_duplicates(fj, oracle, scalar_mode):
     bk = np.array([-1, -2, 5, 5, 5, 0], dtype=np.int64)
     bv = np.array([1, 2, 3, 3, 3, 9], dtype=np.int64)
     pk = np.array([-1, 5, 5, -3, 0, 2**63 - 1, -2], dtype=np.int64)
@@ -254,21 +263,24 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nb,npk,hit_bp,fn", [
-    (1_000_000, 100_000_000, 5000, "hash_join_count"),            # BASELINE config 2
-    (1_000_000, 100_000_000, 5000, "hash_join_count_radix"),
-    (100_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),  # BASELINE config 3
-    (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom"),   # BASELINE config 4 (radix form)
-    (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),         # BASELINE config 4 as named: non-partitioned + bloom precheck
-    (1_000_000, 10_000_000, 5000, "adaptive_join_count"),               # BASELINE config 1 sizes on the device
-    (300_000_000, 300_000_000, 5000, "hash_join_count_radix"),          # 17 radix bits: an 8-bit and a 9-bit pass
-    (800_000_000, 200_000_000, 5000, "hash_join_count_radix"),          # 18 bits (9 + 9): the replicated build side of 8 GPUs
+@pytest.mark.parametrize("nb,npk,hit_bp,fn,hbm", [
+    (1_000_000, 100_000_000, 5000, "hash_join_count", 0),            # BASELINE config 2
+    (1_000_000, 100_000_000, 5000, "hash_join_count", 1),            # ... with the literal one-table algorithm
+    (1_000_000, 100_000_000, 5000, "hash_join_count_radix", 0),
+    (100_000_000, 1_000_000_000, 5000, "hash_join_count_radix", 0),  # BASELINE config 3
+    (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom", 0),   # BASELINE config 4 (radix form)
+    (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom", 0),         # BASELINE config 4 as named
+    (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom", 1),         # ... non-partitioned HBM table + bloom precheck
+    (1_000_000, 10_000_000, 5000, "adaptive_join_count", 0),               # BASELINE config 1 sizes on the device
+    (300_000_000, 300_000_000, 5000, "hash_join_count_radix", 0),          # 17 radix bits: an 8-bit and a 9-bit pass
+    (800_000_000, 200_000_000, 5000, "hash_join_count_radix", 0),          # 18 bits (9 + 9): the replicated build side of 8 GPUs
 ])
-def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn):
+def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn, hbm):
     """BASELINE.json's full sizes, checked through the size-independent property of the generator:
     the match count equals the number of generated hits."""
     import torch
     from flash_hash_join_amd import datagen
+    fj.set_option("scalar_hbm_table", hbm)
     dbk, dbv = datagen.build_device(nb, "cuda:0")
     dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=1, hit_bp=hit_bp)
     assert abs(exp - npk * hit_bp / 10000) < 6 * (npk ** 0.5)
@@ -276,6 +288,8 @@ def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn):
     assert n == exp
     n2, _ = getattr(fj, fn)(dbk, dbv, dpk)                                         # idempotent, workspace reuse
     assert n2 == exp
+    assert fj.last_timings()["path"] == (1 if hbm else 0)
+    fj.set_option("scalar_hbm_table", 0)
     del dbk, dbv, dpk
     torch.cuda.empty_cache()
 
@@ -361,7 +375,7 @@ def test_stream_join_rejects_misuse(fj):
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_fuzz_against_oracle(fj, oracle, seed):
+def test_fuzz_against_oracle(fj, oracle, seed, scalar_mode):
     """Random sizes and key distributions (uniform, tiny domains with heavy duplication, sequential, skewed),
     duplicate build keys carrying equal values; every count function and the radix/scalar pair sets vs the oracle."""
     rng = np.random.default_rng(9000 + seed)
@@ -395,7 +409,7 @@ def test_fuzz_against_oracle(fj, oracle, seed):
 
 
 @pytest.mark.parametrize("nb,dom,npk", [(3000, 700, 20000), (60000, 9000, 200000), (500000, 120000, 900000), (3000000, 1000000, 4000000)])
-def test_duplicate_build_keys_first_occurrence_wins(fj, oracle, nb, dom, npk):
+def test_duplicate_build_keys_first_occurrence_wins(fj, oracle, nb, dom, npk, scalar_mode):
     """Duplicate build keys with DIFFERENT values: the radix/adaptive joins must emit the value of the FIRST occurrence
     (the reference's radix path: stable partition + insert_local, hash_join.cpp:125 / SURVEY App. B); the scalar path is
     racy in the reference too, there any occurrence's value is acceptable."""

@@ -5,6 +5,7 @@ import torch
 from flash_hash_join_amd import api, datagen
 
 api.initialize()
+api.set_option("scalar_hbm_table", 1)          # ALGO_SCALAR = the literal one-table algorithm (default: the partitioned plan)
 P = int(os.environ.get("P", 100_000_000))
 print("B,P,algo,bloom,count_ok,total_ms,build_ms,probe_ms,passes,partitions")
 for B in [1000, 4096, 8192, 32768, 131072, 262144, 524288, 1_000_000, 2_000_000, 4_000_000, 10_000_000, 30_000_000]:
