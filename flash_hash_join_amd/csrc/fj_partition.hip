@@ -488,15 +488,28 @@ __global__ __launch_bounds__(1024) void fj_scan_u32_to_u64(const u32* __restrict
 __global__ void fj_list_build(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
                               u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
                               u32 max_segs, u32* __restrict__ list) {
+    // a chain of dependent loads per chunk (dir/rel -> boff/seg_off -> store): four chunks per thread and step keep
+    // four chains in flight (the kernel is latency-bound: ~4M chunks at c3)
     u32 n = *nalloc; if (n > cap) n = cap;
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const u32 e = dir[i];
-        if (e != FJ_DIR_INVALID) {
-            const u32 b = e >> FJ_DIR_CNT_BITS;
-            const u64 r = rel[i];
-            const u32 seg = (u32)(r >> 32);
-            if (seg < max_segs) list[boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r] = (((e & FJ_DIR_CNT_MASK) - 1u) << 24) | i;
+    const u32 stride = gridDim.x * blockDim.x;
+    for (u32 i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        u32 e[4]; u64 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 i = i0 + u * stride;
+            e[u] = i < n ? dir[i] : FJ_DIR_INVALID;
+            r[u] = i < n ? rel[i] : 0;
         }
+        u32 pos[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 b = e[u] >> FJ_DIR_CNT_BITS, seg = (u32)(r[u] >> 32);
+            ok[u] = e[u] != FJ_DIR_INVALID && seg < max_segs;
+            pos[u] = ok[u] ? boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r[u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) list[pos[u]] = (((e[u] & FJ_DIR_CNT_MASK) - 1u) << 24) | (i0 + u * stride);
     }
 }
 
