@@ -43,6 +43,7 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     u32 alloc[8];                      // [side*4 + pass] chunk allocators
     u32 seg_counter[8];                // [side*4 + pass] segment ids
     unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
+    u32 next_item;                     // work counter of the persistent join kernel
 };
 
 enum Slot {
@@ -370,7 +371,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
         HIPCHK(hipMemsetAsync(dbg_buf, 0, 4096 * 8 * 8, s));
         ja.dbg = dbg_buf;
     }
-    HIPCHK(fj_launch_lds_join(ja, false, s));
+    HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item));
     if (ja.dbg) {
         std::vector<unsigned long long> h(4096 * 8);
         HIPCHK(hipStreamSynchronize(s));

@@ -642,6 +642,219 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     }
 }
 
+// ---- count-only join over chunk lists, persistent form ----------------------------------------------
+// Same table and lookups as fj_count_join_kernel, but a workgroup stays resident and takes items from a global
+// counter, so that the dependent-load latencies of an item (list entries -> build keys) are paid while the PREVIOUS
+// item is being probed: after the build barrier of item i the list entries of item i+1 are requested, after the
+// first probe round they are parked in the second half of the LDS staging arrays, and right after the last probe
+// round the build keys of item i+1 are requested into registers (holding them across the probe loop would spill).
+// Item i+1 then starts with a table memset, its first probe rounds' loads, and inserts.
+// Measured at c3 (32768 items of ~3052 build / ~30518 probe keys): see DESIGN.md section 5.
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs a, u32* __restrict__ next_item) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    CkHdr* hdr = reinterpret_cast<CkHdr*>(smem);
+    u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(CkHdr));
+    u32* pm0 = reinterpret_cast<u32*>(tkeys + S);          // [2][JP_META] probe-side list entries
+    u32* bm0 = pm0 + 2 * JP_META;                            // [2][JB_META] build-side list entries
+    u32* s_next = bm0 + 2 * JB_META;                         // [2] item ids handed out by the global counter
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 nitems = a.nparts * a.nsplit;
+    constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
+    static_assert(JP_META <= NT && JB_META <= NT, "one staged list entry per thread");
+
+    struct Desc { u32 item, b0, nbc, p0, s_lo, s_hi; };
+    auto describe = [&](u32 item) -> Desc {                  // wave-uniform scalar loads
+        Desc d; d.item = item; d.b0 = 0; d.nbc = 0; d.p0 = 0; d.s_lo = 0; d.s_hi = 0;
+        if (item >= nitems) return d;
+        const u32 p = item / a.nsplit, slice = item % a.nsplit;
+        d.b0 = a.build.boff[p]; d.nbc = a.build.boff[p + 1] - d.b0;
+        d.p0 = a.probe.boff[p];
+        const u32 npc = a.probe.boff[p + 1] - d.p0;
+        d.s_lo = (u32)(((u64)slice * npc) / a.nsplit); d.s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
+        return d;
+    };
+    auto live = [&](const Desc& d) { return d.item < nitems && d.nbc > 0 && d.s_lo < d.s_hi; };
+
+    u64 bk[BKPT];
+    u32 bok = 0;
+    auto load_build = [&](const u32* bm, u32 c0, u32 nbb) {  // 16 chunks = 4096 keys requested at once, unconditionally
+        bok = 0;
+#pragma unroll
+        for (u32 j = 0; j < BKPT; ++j) {
+            const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
+            const u32 e = bm[c < nbb ? c : nbb - 1];
+            bk[j] = a.build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off];
+            bok |= (c < nbb && off < FJ_LIST_CNT(e) ? 1u : 0u) << j;
+        }
+    };
+    auto load_round = [&](const u32* pm, u32 r, u32 nbatch, u64 (&kk)[8], u32& okm) {
+        okm = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 c = r * CPR + u * CPL + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
+            const u32 e = pm[c < nbatch ? c : nbatch - 1], cnt = c < nbatch ? FJ_LIST_CNT(e) : 0;
+            const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + off);
+            kk[2 * u] = q.x; kk[2 * u + 1] = q.y;
+            okm |= ((off < cnt ? 1u : 0u) | (off + 1 < cnt ? 2u : 0u)) << (2 * u);
+        }
+    };
+    auto reset_table = [&]() {
+        for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
+        if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->empties = 0; }
+    };
+
+    // ---- prologue: first item (static), its list entries, its first build batch ----
+    Desc d = describe(blockIdx.x);
+    if (d.item >= nitems) return;
+    u32 buf = 0;
+    {
+        const bool lv = live(d);
+        const u32 nb0 = (d.s_hi - d.s_lo) < JP_META ? (d.s_hi - d.s_lo) : JP_META;
+        if (lv && tid < nb0) pm0[tid] = a.probe.list[d.p0 + d.s_lo + tid];
+        const u32 nbb0 = d.nbc < JB_META ? d.nbc : JB_META;
+        if (lv && tid < nbb0) bm0[tid] = a.build.list[d.b0 + tid];
+        reset_table();
+        if (tid == 0) s_next[0] = atomicAdd(next_item, 1u) + gridDim.x;
+        __syncthreads();
+        if (lv) load_build(bm0, 0, nbb0);
+    }
+
+    for (;;) {
+        // invariant: table empty, hdr reset, pm/bm[buf] hold d's first batches, bk[] = d's first build batch (in flight),
+        // s_next[buf] = id of the item after d
+        u32* pm = pm0 + buf * JP_META; u32* bm = bm0 + buf * JB_META;
+        u32* pmn = pm0 + (buf ^ 1) * JP_META; u32* bmn = bm0 + (buf ^ 1) * JB_META;
+        const bool lv = live(d);
+        u64 ka[8], kb[8];
+        u32 oka = 0, okb = 0;
+        u32 nbatch = (d.s_hi - d.s_lo) < JP_META ? (d.s_hi - d.s_lo) : JP_META;
+        u32 nrounds = (nbatch + CPR - 1) / CPR;
+        if (lv) {
+            load_round(pm, 0, nbatch, ka, oka);
+            if (nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
+            // ---- build ----
+            u32 nbb = d.nbc < JB_META ? d.nbc : JB_META;
+            for (u32 bb = 0; bb < d.nbc; bb += JB_META) {
+                if (bb) {
+                    nbb = (d.nbc - bb) < JB_META ? (d.nbc - bb) : JB_META;
+                    __syncthreads();
+                    if (tid < nbb) bm[tid] = a.build.list[d.b0 + bb + tid];
+                    __syncthreads();
+                }
+                for (u32 c0 = 0; c0 < nbb; c0 += 16) {
+                    if (bb | c0) load_build(bm, c0, nbb);
+#pragma unroll
+                    for (u32 j = 0; j < BKPT; ++j) {
+                        if (bok & (1u << j)) {
+                            if (bk[j] == FJ_EMPTY_KEY) { hdr->has_empty = 1; if (a.want_dups && atomicAdd(&hdr->empties, 1u) > 0) hdr->dups = 1; }
+                            else cuckoo_insert(tkeys, hdr, bk[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                     // table complete; s_next[buf] visible
+        // ---- P1: request the next item's list entries ----
+        const Desc dn = describe(__builtin_amdgcn_readfirstlane(s_next[buf]));   // uniform: keeps the descriptor in SGPRs
+        const bool lvn = live(dn);
+        const u32 nbn = (dn.s_hi - dn.s_lo) < JP_META ? (dn.s_hi - dn.s_lo) : JP_META;
+        const u32 nbbn = dn.nbc < JB_META ? dn.nbc : JB_META;
+        u32 mp = 0, mb = 0;
+        if (lvn && tid < nbn) mp = a.probe.list[dn.p0 + dn.s_lo + tid];
+        if (lvn && tid < nbbn) mb = a.build.list[dn.b0 + tid];
+        bool parked = false;                                  // next item's list entries still in registers?
+        auto park = [&]() {
+            if (tid < nbn) pmn[tid] = mp;
+            if (tid < nbbn) bmn[tid] = mb;
+            if (tid == 0) s_next[buf ^ 1] = atomicAdd(next_item, 1u) + gridDim.x;
+            parked = true;
+        };
+
+        u32 wave_hits = 0;
+        bool full = false;
+        if (lv) {
+            full = hdr->full != 0;
+            const u64 he = hdr->has_empty ? ~0ull : 0ull;
+            const u32 nstash = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
+            if (a.want_dups && !full) {
+                for (u32 sl = tid; sl < S; sl += NT) {
+                    const u64 key = tkeys[sl];
+                    if (key == FJ_EMPTY_KEY) continue;
+                    const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+                    const u32 other = sl == l1 ? l2 : l1;
+                    if (other != sl && tkeys[other] == key) hdr->dups = 1;
+                    for (u32 si = 0; si < nstash; ++si) if (hdr->stash[si] == key) hdr->dups = 1;
+                }
+                for (u32 si = tid; si < nstash; si += NT)
+                    for (u32 sj = si + 1; sj < nstash; ++sj) if (hdr->stash[si] == hdr->stash[sj]) hdr->dups = 1;
+                __syncthreads();
+                if (tid == 0 && hdr->dups) atomicOr(a.err, FJ_STAT_DUPS);
+            }
+            // ---- probe ----
+            if (!full) for (u32 pb = d.s_lo; pb < d.s_hi; pb += JP_META) {
+                if (pb != d.s_lo) {
+                    nbatch = (d.s_hi - pb) < JP_META ? (d.s_hi - pb) : JP_META;
+                    __syncthreads();
+                    if (tid < nbatch) pm[tid] = a.probe.list[d.p0 + pb + tid];
+                    __syncthreads();
+                    nrounds = (nbatch + CPR - 1) / CPR;
+                    load_round(pm, 0, nbatch, ka, oka);
+                    if (nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
+                }
+                for (u32 r = 0; r < nrounds; ++r) {
+                    u64 k[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { k[i] = ka[i]; ka[i] = kb[i]; }
+                    const u32 okm = oka;
+                    oka = okb;
+                    if (r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4) {              // two halves of 4 keys: 8 LDS reads in flight per lane
+                        u64 c1[4], c2[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32 w = fj_hash_w2(k[h + i]);
+                            c1[i] = tkeys[w & (S - 1)];
+                            c2[i] = tkeys[(w >> 13) & (S - 1)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            u64 hit = __ballot(c1[i] == k[h + i]) | __ballot(c2[i] == k[h + i]);
+                            if (nstash) {
+                                bool f = false;
+                                for (u32 si = 0; si < nstash; ++si) f |= hdr->stash[si] == k[h + i];
+                                hit |= __ballot(f);
+                            }
+                            const u64 ise = __ballot(k[h + i] == FJ_EMPTY_KEY);
+                            const u64 ok = __ballot((okm >> (h + i)) & 1u);
+                            wave_hits += (u32)__popcll(ok & ((hit & ~ise) | (ise & he)));
+                        }
+                    }
+                    if (!parked) park();                      // after the first round: the entries have long arrived
+                }
+            }
+        }
+        if (!parked) park();                                  // skipped probe loop
+        // ---- finish item d; request the next item's build keys as soon as its entries are visible ----
+        if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
+        __syncthreads();
+        if (lvn) load_build(bmn, 0, nbbn); else bok = 0;
+        if (tid == 0) {
+            const u32 cnt = (lv && !full) ? hdr->cnt : 0u;
+            if (full) atomicOr(a.err, FJ_ERR_LDS_FULL);     // stash overflow: host falls back to the global-table path
+            a.part_count[d.item] = cnt;
+            if (cnt) atomicAdd(a.total, (unsigned long long)cnt);
+        }
+        if (dn.item >= nitems) break;
+        __syncthreads();                                     // hdr->cnt read before the reset
+        reset_table();
+        __syncthreads();
+        d = dn; buf ^= 1;
+    }
+}
+
 // =============================== global (non-partitioned) table ===============================
 __device__ __forceinline__ u32 gt_bloom_mask(u64 h) {      // 3 bits of a 32-bit word per 8-slot group
     return (1u << ((h >> 40) & 31)) | (1u << ((h >> 45) & 31)) | (1u << ((h >> 50) & 31));
@@ -909,7 +1122,7 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 
 }  // namespace
 
-hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s) {
+hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item) {
     const u32 nb = a.nparts * a.nsplit;
     if (materialize) {
         const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
@@ -920,6 +1133,19 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
     } else {
         const u32 lds = sizeof(CkHdr) + S * 8 + (JP_META + JB_META) * 4;
         const bool lists = a.build.list && a.probe.list;
+        // many items: resident workgroups that prefetch the next item's lists and build keys (join -3 % at c3, -3.5 % at
+        // 262144 items); few items (c2: 2048): one workgroup per item balances better
+        if (lists && next_item && nb >= 8192 && !a.dbg && !a.dbg_flags && !getenv("FJ_JOIN_PER_ITEM")) {
+            const u32 ldsp = sizeof(CkHdr) + S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
+            auto pk = fj_count_join_persistent<512>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+            if (e != hipSuccess) return e;
+            e = hipMemsetAsync(next_item, 0, 4, s);
+            if (e != hipSuccess) return e;
+            const u32 grid = nb < 512 ? nb : 512;            // two resident workgroups per CU
+            hipLaunchKernelGGL(pk, dim3(grid), dim3(512), ldsp, s, a, next_item);
+            return hipGetLastError();
+        }
         auto kern = lists ? fj_count_join_kernel<512, true> : fj_count_join_kernel<512, false>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
