@@ -107,6 +107,30 @@ struct fj_ctx {
 
 namespace {
 
+// Process-wide dispatch options (fj_set_option; initial values from the environment).
+//   radix_threshold  : adaptive joins take the non-partitioned HBM table below this many build rows.  MI355X: the
+//                      partitioned driver wins at every build size (<= 4096 rows it runs zero passes: one LDS table per
+//                      workgroup over the flat inputs), so the switch point is 0 (tools/sweep_adaptive.py).
+//   persistent_min_items : counting joins with at least this many (partition, slice) items run the persistent join
+//                      kernel (resident workgroups that prefetch the next item); below it one workgroup per item.
+//   scalar_hbm_table : 1 = the reference's "scalar" functions (hash_join*, one table for the whole build side) use the
+//                      non-partitioned HBM table at every size; 0 (default) = they use it only as the fallback and
+//                      otherwise run the partitioned plan.  One table for B rows means one cache-missing 64-B access
+//                      per probe in HBM -- more traffic than the 40 B per probe the two streaming passes + LDS join
+//                      move -- so on this machine "scalar" is the slower way to the same result at every size.
+struct Options {
+    size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items;
+    Options() {
+        const char* th = getenv("FJ_RADIX_THRESHOLD");
+        radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)0;
+        const char* sg = getenv("FJ_SCALAR_HBM_TABLE");
+        scalar_hbm_table = sg ? atoi(sg) : 0;
+        const char* pm = getenv("FJ_PERSISTENT_MIN_ITEMS");
+        persistent_min_items = pm ? (u32)strtoul(pm, nullptr, 10) : 8192u;
+    }
+};
+Options& options() { static Options o; return o; }
+
 int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
     Buf& b = c->bufs[slot];
     if (bytes == 0) bytes = 16;
@@ -371,7 +395,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
         HIPCHK(hipMemsetAsync(dbg_buf, 0, 4096 * 8 * 8, s));
         ja.dbg = dbg_buf;
     }
-    HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item));
+    HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item, options().persistent_min_items));
     if (ja.dbg) {
         std::vector<unsigned long long> h(4096 * 8);
         HIPCHK(hipStreamSynchronize(s));
@@ -434,25 +458,6 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
 
 fj_ctx* g_host_ctx = nullptr;
 
-// Process-wide dispatch options (fj_set_option; initial values from the environment).
-//   radix_threshold  : adaptive joins take the non-partitioned HBM table below this many build rows.  MI355X: the
-//                      partitioned driver wins at every build size (<= 4096 rows it runs zero passes: one LDS table per
-//                      workgroup over the flat inputs), so the switch point is 0 (tools/sweep_adaptive.py).
-//   scalar_hbm_table : 1 = the reference's "scalar" functions (hash_join*, one table for the whole build side) use the
-//                      non-partitioned HBM table at every size; 0 (default) = they use it only as the fallback and
-//                      otherwise run the partitioned plan.  One table for B rows means one cache-missing 64-B access
-//                      per probe in HBM -- more traffic than the 40 B per probe the two streaming passes + LDS join
-//                      move -- so on this machine "scalar" is the slower way to the same result at every size.
-struct Options {
-    size_t radix_threshold; int scalar_hbm_table;
-    Options() {
-        const char* th = getenv("FJ_RADIX_THRESHOLD");
-        radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)0;
-        const char* sg = getenv("FJ_SCALAR_HBM_TABLE");
-        scalar_hbm_table = sg ? atoi(sg) : 0;
-    }
-};
-Options& options() { static Options o; return o; }
 
 }  // namespace
 
@@ -465,12 +470,14 @@ int fj_set_option(const char* name, long long value) {
     if (!name) return set_err("fj_set_option: null name");
     if (!strcmp(name, "radix_threshold")) { if (value < 0) return set_err("fj_set_option: radix_threshold must be >= 0"); options().radix_threshold = (size_t)value; return 0; }
     if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
+    if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
     return set_err("fj_set_option: unknown option '%s'", name);
 }
 
 long long fj_get_option(const char* name) {
     if (name && !strcmp(name, "radix_threshold")) return (long long)options().radix_threshold;
     if (name && !strcmp(name, "scalar_hbm_table")) return options().scalar_hbm_table;
+    if (name && !strcmp(name, "persistent_min_items")) return options().persistent_min_items;
     set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
     return -1;
 }

@@ -81,7 +81,8 @@ struct FjLdsJoinArgs {
     u32 dbg_flags;               // diagnostic ablations: 1 = skip lookups, 2 = skip inserts (results wrong on purpose)
 };
 // next_item: device word for the persistent counting kernel's work counter (nullptr: one workgroup per item)
-hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item = nullptr);
+hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item = nullptr,
+                              u32 persistent_min_items = 8192);
 
 struct FjGtArgs {                // global (non-partitioned) table
     u64* tkeys; u64* tvals; u32* bloom;    // bloom == nullptr: no precheck

@@ -1122,7 +1122,7 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 
 }  // namespace
 
-hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item) {
+hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item, u32 persistent_min_items) {
     const u32 nb = a.nparts * a.nsplit;
     if (materialize) {
         const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
@@ -1135,7 +1135,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         const bool lists = a.build.list && a.probe.list;
         // many items: resident workgroups that prefetch the next item's lists and build keys (join -3 % at c3, -3.5 % at
         // 262144 items); few items (c2: 2048): one workgroup per item balances better
-        if (lists && next_item && nb >= 8192 && !a.dbg && !a.dbg_flags && !getenv("FJ_JOIN_PER_ITEM")) {
+        if (lists && next_item && nb >= persistent_min_items && !a.dbg && !a.dbg_flags) {
             const u32 ldsp = sizeof(CkHdr) + S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
             auto pk = fj_count_join_persistent<512>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);

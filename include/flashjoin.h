@@ -61,6 +61,8 @@ const char* fj_version(void);
  *                        ONE table for the whole build side in HBM, as the reference does in DRAM; 0 (default): they
  *                        run the same partitioned plan as the radix functions (identical results, 2-4x faster here)
  *                        and the HBM table is only the overflow fallback (env FJ_SCALAR_HBM_TABLE).
+ *   "persistent_min_items" - counting joins whose plan has at least this many (partition, probe slice) work items use
+ *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
  * fj_get_option returns -1 for an unknown name. */
 int fj_set_option(const char* name, long long value);
 long long fj_get_option(const char* name);

@@ -28,13 +28,16 @@ def fj():
     return flash_join
 
 
-@pytest.fixture(params=[0, 1], ids=["scalar=planned", "scalar=hbm_table"])
+@pytest.fixture(params=[0, 1, 2], ids=["scalar=planned", "scalar=hbm_table", "persistent_join"])
 def scalar_mode(request, fj):
-    """Run a test under both settings of the "scalar_hbm_table" option: the hash_join* functions served by the
-    partitioned plan (default) and by the literal one-table-in-HBM algorithm (linear probing, bloom word per group)."""
-    fj.set_option("scalar_hbm_table", request.param)
+    """Run a test under the dispatch variants of the native library: the hash_join* functions served by the partitioned
+    plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); and every
+    partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it)."""
+    fj.set_option("scalar_hbm_table", int(request.param == 1))
+    fj.set_option("persistent_min_items", 0 if request.param == 2 else 8192)
     yield request.param
     fj.set_option("scalar_hbm_table", 0)
+    fj.set_option("persistent_min_items", 8192)
 
 
 def _digest(oracle, k, v):
