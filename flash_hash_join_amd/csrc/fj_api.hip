@@ -164,7 +164,7 @@ Plan make_plan(size_t nb, int top_bits) {
     }
     if (p.bits > 0 && p.bits < 5) p.bits = 5;              // a pass with a tiny fan-out serialises on its per-bucket threads
     if (p.bits > top_bits - 32) p.bits = top_bits - 32;      // radix digits come from hash word 1 (32 bits)
-    plan_passes(p, getenv("FJ_SPLIT_FIRST") != nullptr);     // extra bits go to the later passes
+    plan_passes(p, false);                                   // extra bits go to the later passes
     return p;
 }
 
@@ -176,7 +176,7 @@ void pass_init(PassIter& it, int side, bool has_vals, size_t n, const Plan& plan
     it = PassIter();
     it.side = side; it.has_vals = has_vals; it.n = n; it.plan = plan; it.used = top_bits;
     it.lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
-    it.tile_chunks = (!has_vals && getenv("FJ_K_NT1024")) ? 32 : 16;        // chunks per tile of the pass kernel that will read this level
+    it.tile_chunks = 16;                                    // chunks per tile of the pass kernel that will read this level
 }
 
 // workgroups for a launch over n rows: enough to fill the chip, but every (workgroup, bucket) pair ends in a
@@ -238,7 +238,6 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
     a.err = &c->d_sc->err;
     a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.F); a.side = (u32)it.side;
-    a.interleave = getenv("FJ_INTERLEAVE") ? (u32)atoi(getenv("FJ_INTERLEAVE")) : 0u;
     // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter); only a 512-bucket pass that
     // also carries values has to fall back to them (LDS)
     const int line_log = (it.has_vals && it.F > 256) ? 3 : 4;

@@ -35,7 +35,6 @@ struct FjPartArgs {
     u32 fan_log;
     u32 side;                // 0 = build relation, 1 = probe relation (selects the kernel's name only)
     u32 slab;                // chunks a workgroup takes per allocator hit: >= tile chunks + fan-out (fj_slab_for)
-    u32 interleave;          // flat input: workgroup g takes tiles g, g+G, g+2G, ... (the chip sweeps HBM front to back)
 };
 
 // a chunk pool plus its per-bucket chunk lists (output of one pass, input of the next)

@@ -80,11 +80,9 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     const u32 Lc = FLAT ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : 0u;
     const u32 ntiles = FLAT ? (Lc + TC - 1) / TC : *a.in_ntiles;
     const u32 G = gridDim.x, g = blockIdx.x;
-    // tile index space of this workgroup: j = 0..nmine-1 -> tile t0 + j * tstep
-    const bool il = FLAT && a.interleave;
-    const u32 t0 = il ? g : (u32)(((u64)g * ntiles) / G);
-    const u32 tstep = il ? G : 1u;
-    const u32 nmine = il ? (g < ntiles ? (ntiles - g + G - 1) / G : 0u) : (u32)(((u64)(g + 1) * ntiles) / G) - t0;
+    // this workgroup's contiguous run of tiles: t0 .. t0 + nmine - 1
+    const u32 t0 = (u32)(((u64)g * ntiles) / G);
+    const u32 nmine = (u32)(((u64)(g + 1) * ntiles) / G) - t0;
     u32 t = 0;
     const u32 thi = nmine;
     const u32 cap = a.cap_chunks;
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         for (int i = 0; i < KPT / 2; ++i) {
             u64 base; u32 nv;                               // nv = valid keys of this pair (0..2)
             if (FLAT) {
-                base = (u64)(t0 + tt * tstep) * T + ((u32)i * NT + tid) * 2;
+                base = (u64)(t0 + tt) * T + ((u32)i * NT + tid) * 2;
                 nv = base + 1 < a.n_flat ? 2u : (base < a.n_flat ? 1u : 0u);
                 if (base > last_pair) base = last_pair;     // stay inside the array (tail tile only)
             } else {
@@ -135,7 +133,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         if (FLAT && !tiny && (a.n_flat & 1ull)) {            // odd length: the very last key has no pair partner
 #pragma unroll
             for (int i = 0; i < KPT / 2; ++i) {
-                const u64 base = (u64)(t0 + tt * tstep) * T + ((u32)i * NT + tid) * 2;
+                const u64 base = (u64)(t0 + tt) * T + ((u32)i * NT + tid) * 2;
                 if (base + 1 == a.n_flat) { kk[2 * i] = a.in_keys[base]; if (HAS_VALS) vv[2 * i] = a.in_vals[base]; }
             }
         }
@@ -559,10 +557,8 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
     }
     if (vals) {
         // 1024 threads x 4 rows: one workgroup per CU (LDS), but 16 waves of it: 1.63 -> 1.42 ms build phase at c3
-        if (getenv("FJ_KV_NT512")) return launch_part2<512, 8, true>(a, line_log, grid, s);
         return launch_part2<1024, 4, true>(a, line_log, grid, s);
     }
-    if (getenv("FJ_K_NT1024")) return launch_part2<1024, 8, false>(a, line_log, grid, s);
     return launch_part2<512, 8, false>(a, line_log, grid, s);
 }
 
