@@ -139,6 +139,7 @@ def main() -> None:
     engine = HipEngine(device) if (world > 1 or force_dist) else None
 
     units_per_launch = [float(np_gpu)]
+    strategy_seen = ["single GPU"]
     part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": []}
     dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
 
@@ -156,9 +157,14 @@ def main() -> None:
             lt = api.last_timings()
             if world == 1 and not force_dist:
                 npart = lt["passes"]                       # one launch per pass over all probe rows
+            elif t.get("strategy") == "replicate":
+                npart = 1                                  # probe rows never move: one first-pass launch over all of them
+                units_per_launch[0] = t.get("local_probe_rows", np_gpu)
+                strategy_seen[0] = "replicate-build"
             else:
                 npart = min(4, int(t.get("pieces", 0)))    # pipelined exchange: first-pass launches, one per received piece
                 units_per_launch[0] = t.get("local_probe_rows", np_gpu) / max(1, int(t.get("pieces", 1)))
+                strategy_seen[0] = "owner-shuffle"
             for i in range(npart):
                 part_ms.append(lt["probe_part_kernel_ms"][i]); part_launches += 1
             phase["build_ms"].append(lt["build_phase_ms"]); phase["probe_ms"].append(lt["probe_phase_ms"])
@@ -245,7 +251,7 @@ def main() -> None:
         "config": {"workload": f"{fn_name}: {nb_gpu} build x {np_gpu} probe int64 rows per GPU, {hit_bp / 100:.0f}% hit rate"
                                + (" (BASELINE configs[2])" if args.workload == "c3" and args.scale == 1.0 else ""),
                    "function": fn_name, "build_rows_total": nb_total, "probe_rows_total": np_total,
-                   "matches": exp_total, "parallelism": f"radix-owner x{world}" if world > 1 else "single GPU"},
+                   "matches": exp_total, "parallelism": f"{strategy_seen[0]} x{world}" if (world > 1 or force_dist) else "single GPU"},
         "build_time_ms": round(build_ms, 3),
         "phases": phases,
         "roofline": roof,
