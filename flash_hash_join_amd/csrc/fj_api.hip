@@ -176,7 +176,6 @@ void pass_init(PassIter& it, int side, bool has_vals, size_t n, const Plan& plan
     it = PassIter();
     it.side = side; it.has_vals = has_vals; it.n = n; it.plan = plan; it.used = top_bits;
     it.lbound = (n + FJ_CHUNK - 1) / FJ_CHUNK;
-    it.tile_chunks = 16;                                    // chunks per tile of the pass kernel that will read this level
 }
 
 // workgroups for a launch over n rows: enough to fill the chip, but every (workgroup, bucket) pair ends in a
@@ -192,6 +191,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     it.F = 1u << it.plan.fan_log[i];
     it.used -= it.plan.fan_log[i];
     it.appends = appends ? appends : 1;
+    it.tile_chunks = fj_partition_tile_chunks((u32)it.plan.fan_log[i], it.has_vals);
     it.Gmax = pass_groups(it.lbound, it.n, it.tile_chunks, it.F);
     const u32 F = it.F, G = it.Gmax, parents = it.parents;
     const u64 nb_out = (u64)parents * F;
@@ -253,11 +253,12 @@ int pass_complete(fj_ctx* c, PassIter& it, hipStream_t s) {
     it.lbound = it.n / FJ_CHUNK + 1 + (u64)(it.Gmax + it.parents) * it.F * it.appends;
     if (it.i + 1 < it.plan.npass) {           // tile table for the next pass over this level
         const int base = it.side * W_SIDE_STRIDE + (it.i & 1) * W_KINDS;
-        const u64 max_tiles = it.lbound / it.tile_chunks + cs.nb + 1;
+        const u32 tc = fj_partition_tile_chunks((u32)it.plan.fan_log[it.i + 1], it.has_vals);   // tiles of the kernel that will read this level
+        const u64 max_tiles = it.lbound / tc + cs.nb + 1;
         void* p;
         if (get_buf(c, base + W_TOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
         if (get_buf(c, base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1;
-        HIPCHK(fj_launch_tile_table(cs, it.tile_chunks, toff, (uint4*)p, (u32)max_tiles, s));
+        HIPCHK(fj_launch_tile_table(cs, tc, toff, (uint4*)p, (u32)max_tiles, s));
         it.tiles = (const uint4*)p; it.ntiles = toff + cs.nb;
     }
     it.prev = cs; it.have_prev = true;

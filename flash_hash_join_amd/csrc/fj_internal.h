@@ -56,6 +56,8 @@ struct FjChunkSet {
 };
 
 u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log);
+// chunks (of 256 rows) per input tile of the pass kernel chosen for this fan-out and payload
+u32 fj_partition_tile_chunks(u32 fan_log, bool vals);
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s);
 hipError_t fj_launch_group(const FjChunkSet& cs, hipStream_t s);
 hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, hipStream_t s);

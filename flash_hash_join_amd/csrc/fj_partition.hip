@@ -545,7 +545,10 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
     return part_lds_layout(512 * 8, F, 1u << line_log, false, 8).total;
 }
 
-// One partition pass.  Keys-only tiles are 4096 keys (512 threads x 8), key+value tiles 2048.
+u32 fj_partition_tile_chunks(u32 fan_log, bool vals) { return (fan_log == 9 && !vals) ? 32u : 16u; }
+
+// One partition pass.  Tiles are 4096 rows (512 threads x 8 keys, or 1024 threads x 4 rows with values); the
+// keys-only 512-bucket pass takes 8192-key tiles (it is alone on its CU: half as many barriers per key).
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
     if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
     if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < 48 + (1u << a.fan_log)) return hipErrorInvalidValue;
@@ -553,7 +556,7 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
         // 512 buckets: one bucket per thread needs >= 512 threads and the open lines take 64 KiB (keys) -- one
         // 1024-thread workgroup per CU; with values the lines shrink to 64 B so that both payloads still fit
         if (vals) return line_log == 3 ? launch_part2<1024, 4, true>(a, 3, grid, s) : hipErrorInvalidValue;
-        return launch_part2<1024, 4, false>(a, line_log, grid, s);
+        return launch_part2<1024, 8, false>(a, line_log, grid, s);
     }
     if (vals) {
         // 1024 threads x 4 rows: one workgroup per CU (LDS), but 16 waves of it: 1.63 -> 1.42 ms build phase at c3
