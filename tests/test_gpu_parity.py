@@ -277,6 +277,8 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
     (1_000_000, 10_000_000, 5000, "adaptive_join_count", 0),               # BASELINE config 1 sizes on the device
     (300_000_000, 300_000_000, 5000, "hash_join_count_radix", 0),          # 17 radix bits: an 8-bit and a 9-bit pass
     (800_000_000, 200_000_000, 5000, "hash_join_count_radix", 0),          # 18 bits (9 + 9): the replicated build side of 8 GPUs
+    (50_000_000, 3_900_000_000, 2500, "hash_join_count_radix", 0),         # probe side close to the 2^24-chunk directory limit (~4.0e9 rows)
+    (3_000, 2_500_000_000, 7000, "hash_join_count", 0),                    # zero-pass plan over > 2^31 probe rows
 ])
 def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn, hbm):
     """BASELINE.json's full sizes, checked through the size-independent property of the generator:
@@ -295,6 +297,20 @@ def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn, hbm):
     fj.set_option("scalar_hbm_table", 0)
     del dbk, dbv, dpk
     torch.cuda.empty_cache()
+
+
+def test_relation_beyond_the_chunk_directory_is_refused(fj):
+    """A relation of more than ~4.2e9 rows does not fit one GPU's 24-bit chunk directory: the call must fail loudly
+    (RuntimeError), not wrap around."""
+    import torch
+    from flash_hash_join_amd import datagen
+    dbk, dbv = datagen.build_device(10_000_000, "cuda:0")
+    dpk = torch.empty(4_400_000_000, dtype=torch.int64, device="cuda:0")         # contents irrelevant: refused before any kernel
+    with pytest.raises(RuntimeError, match="too large"):
+        fj.hash_join_count_radix(dbk, dbv, dpk)
+    del dpk
+    torch.cuda.empty_cache()
+    assert fj.hash_join_count_radix(dbk, dbv, dbk)[0] == 10_000_000             # the context is still usable
 
 
 @pytest.mark.parametrize("nb,npk", [(10_000_000, 100_000_000), (300_000_000, 50_000_000)])
