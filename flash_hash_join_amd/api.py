@@ -12,7 +12,8 @@ Differences from the reference, all deliberate:
     are reported separately in `last_timings()`;
   * opt-in `return_arrays=True` returns the materialised pairs the reference computes and drops
     (hash_join.cpp:365-380): `(count, seconds, keys, values)`;
-  * torch tensors that already live on a ROCm device are joined in place (no PCIe);
+  * torch tensors that already live on a ROCm device are joined in place (no PCIe); so is any device array that
+    speaks DLPack (`__dlpack__` / `__dlpack_device__`); pandas / Arrow / list inputs go through `np.asarray`;
   * the "scalar" functions (`hash_join*`: ONE table for the whole build side) run the partitioned plan by default:
     a table that does not fit LDS costs a cache-missing 64-B access per probe in HBM, more traffic than two
     streaming partition passes, so on MI355X it is the slower way to the same result at every size.
@@ -157,7 +158,25 @@ def join_device(algo: int, bloom: int, materialize: int, bk, bv, pk, return_arra
     return n, t.total_ms * 1e-3
 
 
+_DL_DEVICE_GPU = (2, 10)         # DLPack device types kDLCUDA (what torch-ROCm reports) and kDLROCM
+
+
+def _from_dlpack_if_device(x: Any):
+    """Device arrays of other libraries (CuPy-ROCm, JAX, Arrow-on-GPU, ...) enter through DLPack, zero-copy."""
+    if _is_torch_tensor(x) or isinstance(x, np.ndarray) or not hasattr(x, "__dlpack_device__"):
+        return x
+    try:
+        dev_type = int(x.__dlpack_device__()[0])
+    except Exception:
+        return x
+    if dev_type not in _DL_DEVICE_GPU:
+        return x
+    import torch
+    return torch.from_dlpack(x)
+
+
 def _join(algo: int, bloom: int, materialize: int, build_keys, build_values, probe_keys, return_arrays: bool):
+    build_keys, build_values, probe_keys = (_from_dlpack_if_device(x) for x in (build_keys, build_values, probe_keys))
     if _is_torch_tensor(build_keys) and build_keys.is_cuda:
         return join_device(algo, bloom, materialize, build_keys, build_values, probe_keys, return_arrays)
     if _is_torch_tensor(build_keys):

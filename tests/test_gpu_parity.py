@@ -161,6 +161,20 @@ def test_device_tensor_inputs_and_device_generators(fj, oracle):
     a, b = oracle.canon_pairs(kk, vv), oracle.canon_pairs(ek, ev)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
+    class Foreign:                       # a device array of "another library": only the DLPack protocol is visible
+        def __init__(self, t): self._t = t
+        def __dlpack__(self, stream=None): return self._t.__dlpack__() if stream is None else self._t.__dlpack__(stream=stream)
+        def __dlpack_device__(self): return self._t.__dlpack_device__()
+    assert fj.hash_join_count_radix(Foreign(dbk), Foreign(dbv), Foreign(dpk))[0] == exp
+    # host containers that are not ndarrays: pandas, Arrow, lists
+    import pandas as pd
+    import pyarrow as pa
+    small_k, small_v, small_p = hbk[:5000], hbv[:5000], hpk[:20000]
+    e2 = oracle.np_join(small_k, small_v, small_p)
+    assert fj.hash_join_count(pd.Series(small_k), pd.Series(small_v), pd.Series(small_p))[0] == e2
+    assert fj.hash_join_count(pa.array(small_k), pa.array(small_v), pa.array(small_p))[0] == e2
+    assert fj.adaptive_join_count(small_k.tolist(), small_v.tolist(), small_p.tolist())[0] == e2
+
 
 @pytest.mark.parametrize("n,bits,with_vals", [(1000, 3, True), (100_000, 8, False), (300_000, 7, True),
                                                 (2_000_000, 13, False), (1_500_000, 10, True), (700_001, 16, False),
