@@ -50,7 +50,7 @@ enum Slot {
     // [side][pingpong][kind]
     W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_REL, W_BOFF, W_SEGOFF, W_TOFF, W_TILES, W_KINDS,
     W_SIDE_STRIDE = 2 * W_KINDS,
-    W_PART_COUNT = 2 * W_SIDE_STRIDE, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
+    W_PART_COUNT = 2 * W_SIDE_STRIDE, W_JOIN_TOFF, W_JOIN_ITEMS, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
     W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_NSLOTS
 };
 
@@ -371,20 +371,43 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
 }
 
 // launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
-int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, hipStream_t s, fj_timings* t,
-                    int evc, u64* out_count, bool* lds_full) {
+int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, u64 pchunk_bound, hipStream_t s,
+                    fj_timings* t, int evc, u64* out_count, bool* lds_full) {
     ja.nparts = 1u << plan.bits;
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
-    u64 nsplit = 1;
-    if (ja.nparts < 2048) {
-        nsplit = (2048 + ja.nparts - 1) / ja.nparts;
-        const u64 per_part = pchunks / ja.nparts;
-        nsplit = std::min<u64>(nsplit, std::max<u64>(1, per_part / 32));
-    }
-    ja.nsplit = (u32)nsplit;
-    const u32 nitems = ja.nparts * ja.nsplit;
     void* p;
+    u32 nitems;
+    if (ja.probe.list) {
+        // work items = tiles of the probe chunk lists.  Few partitions (< 2048): several slices per partition, each
+        // rebuilding the partition's table, so that small builds still fill the chip (a slice keeps >= 32 full chunks
+        // of probe rows per table build).  Many partitions: one item per partition, except that a partition swollen
+        // by a hot key is cut into slices of 4x the average (>= 512 chunks).  `bound` over-estimates the chunk count
+        // (partial chunks), which only makes slices a little longer than planned.
+        const u64 bound = std::max<u64>(pchunk_bound, pchunks);
+        const u64 avg = std::max<u64>(1, bound / ja.nparts);
+        u64 want = 1;
+        if (ja.nparts < 2048) want = std::min<u64>((2048 + ja.nparts - 1) / ja.nparts, std::max<u64>(1, (pchunks / ja.nparts) / 32));
+        const u32 tc = (u32)(want > 1 ? std::max<u64>(8, (avg * 9 / 8 + want - 1) / want) : std::max<u64>(512, 4 * avg));
+        const u64 max_items = bound / tc + ja.nparts + 1;
+        if (max_items >= (1ull << 31)) return set_err("internal error: join item table too large");
+        if (get_buf(c, W_JOIN_TOFF, ((size_t)ja.nparts + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
+        if (get_buf(c, W_JOIN_ITEMS, max_items * sizeof(uint4), &p)) return 1;
+        HIPCHK(fj_launch_tile_table(ja.probe, tc, toff, (uint4*)p, (u32)max_items, s));
+        ja.items = (const uint4*)p; ja.nitems_dev = toff + ja.nparts; ja.items_cap = (u32)max_items;
+        ja.nsplit = 1;
+        nitems = (u32)max_items;
+    } else {
+        u64 nsplit = 1;
+        if (ja.nparts < 2048) {
+            nsplit = (2048 + ja.nparts - 1) / ja.nparts;
+            const u64 per_part = pchunks / ja.nparts;
+            nsplit = std::min<u64>(nsplit, std::max<u64>(1, per_part / 32));
+        }
+        ja.nsplit = (u32)nsplit; ja.items = nullptr; ja.nitems_dev = nullptr; ja.items_cap = 0;
+        nitems = ja.nparts * ja.nsplit;
+    }
     if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
+    if (ja.items) HIPCHK(hipMemsetAsync(ja.part_count, 0, (size_t)nitems * 4, s));     // entries past the device-side item count stay 0
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
     ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr;
     ja.dbg = nullptr;
@@ -451,7 +474,7 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
     if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
     HIPCHK(hipEventRecord(c->ev[E_PPART], s));
 
-    if (radix_join_tail(c, materialize, ja, plan, np, s, t, evc, out_count, lds_full)) return 1;
+    if (radix_join_tail(c, materialize, ja, plan, np, pit.lbound, s, t, evc, out_count, lds_full)) return 1;
     if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
     return 0;
 }
@@ -741,7 +764,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         }
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
-        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, s, &t, st.evc, &count, &lds_full)) return 1;
+        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit.lbound, s, &t, st.evc, &count, &lds_full)) return 1;
         if (lds_full) return set_err("fj_stream_finish: a partition does not fit its LDS table; use fj_join_device on the whole relation");
     } else {
         if (st.plan.npass == 0 && st.nb_seen > 0)

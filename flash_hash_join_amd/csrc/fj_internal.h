@@ -67,12 +67,17 @@ hipError_t fj_launch_scan_u32_to_u64(const u32* in, u64* out, u32 n, hipStream_t
 struct FjLdsJoinArgs {
     FjChunkSet build, probe;     // final-level chunk sets (same nb), or flat arrays (list == nullptr)
     u32 nparts;                  // number of final partitions
-    u32 nsplit;                  // work items per partition (slices of the probe side)
-    u32* part_count;             // [nparts*nsplit] matches per work item
+    u32 nsplit;                  // flat probe side only: work items per partition (equal slices of the probe side)
+    // chunk-list probe side: work items = tiles of the probe chunk lists, {first list index, chunks, partition, -}; a
+    // partition with many probe chunks (skew) becomes many items, each rebuilding the partition's small table
+    const uint4* items;          // nullptr for a flat probe side
+    const u32* nitems_dev;       // device scalar: number of valid entries of items[]
+    u32 items_cap;               // allocated entries (grid of the one-workgroup-per-item kernels)
+    u32* part_count;             // [items] matches per work item
     unsigned long long* total;   // device scalar
     u32* err;
     // materialise
-    const u64* out_off;          // [nparts*nsplit+1] exclusive scan of part_count
+    const u64* out_off;          // [items+1] exclusive scan of part_count
     u64* out_keys;
     u64* out_vals;
     u32 want_dups;               // counting pass of a materialising join: report duplicate build keys (FJ_STAT_DUPS)

@@ -207,16 +207,23 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     u32* pm = gcnt + NGRP / 2;
     u32* bm = pm + JP_META;
     const u32 tid = threadIdx.x, lane = tid & 63;
-    const u32 item = blockIdx.x, p = item / a.nsplit, slice = item % a.nsplit;
-#define FJ_STAMP(i) do { if (a.dbg && tid == 0 && item < 4096) a.dbg[item * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FJ_STAMP(i) do { if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     FJ_STAMP(0);
-
-    u32 b0 = 0, nbc, p0 = 0, npc;
+    // work item -> (partition p, probe chunk-list range [p0 + s_lo, p0 + s_hi))
+    const u32 item = blockIdx.x;
+    u32 p, b0 = 0, nbc, p0 = 0, s_lo, s_hi;
+    if (a.items) {                                   // chunk-list probe side: the item table (skew-proof slices)
+        if (item >= *a.nitems_dev) return;
+        const uint4 it = a.items[item];
+        p = it.z; s_lo = it.x; s_hi = it.x + it.y;
+    } else {                                         // flat probe side: equal slices
+        const u32 slice = item % a.nsplit;
+        p = item / a.nsplit;
+        const u32 npc = (u32)((a.probe.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
+        s_lo = (u32)(((u64)slice * npc) / a.nsplit); s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
+    }
     if (a.build.list) { b0 = a.build.boff[p]; nbc = a.build.boff[p + 1] - b0; }
     else nbc = (u32)((a.build.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
-    if (a.probe.list) { p0 = a.probe.boff[p]; npc = a.probe.boff[p + 1] - p0; }
-    else npc = (u32)((a.probe.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
-    const u32 s_lo = (u32)(((u64)slice * npc) / a.nsplit), s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
     if (nbc == 0 || s_lo >= s_hi) {      // an empty side is skipped (hash_join.cpp:343, :518)
         if (!MAT && tid == 0) a.part_count[item] = 0;
         return;
@@ -467,15 +474,22 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     u32* pm = reinterpret_cast<u32*>(tkeys + S);
     u32* bm = pm + JP_META;
     const u32 tid = threadIdx.x, lane = tid & 63;
-    const u32 item = blockIdx.x, p = item / a.nsplit, slice = item % a.nsplit;
     FJ_STAMP(0);
-
-    u32 b0 = 0, nbc, p0 = 0, npc;
+    // work item -> (partition p, probe chunk-list range [p0 + s_lo, p0 + s_hi))
+    const u32 item = blockIdx.x;
+    u32 p, b0 = 0, nbc, p0 = 0, s_lo, s_hi;
+    if (a.items) {                                   // chunk-list probe side: the item table (skew-proof slices)
+        if (item >= *a.nitems_dev) return;
+        const uint4 it = a.items[item];
+        p = it.z; s_lo = it.x; s_hi = it.x + it.y;
+    } else {                                         // flat probe side: equal slices
+        const u32 slice = item % a.nsplit;
+        p = item / a.nsplit;
+        const u32 npc = (u32)((a.probe.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
+        s_lo = (u32)(((u64)slice * npc) / a.nsplit); s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
+    }
     if (a.build.list) { b0 = a.build.boff[p]; nbc = a.build.boff[p + 1] - b0; }
     else nbc = (u32)((a.build.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
-    if (a.probe.list) { p0 = a.probe.boff[p]; npc = a.probe.boff[p + 1] - p0; }
-    else npc = (u32)((a.probe.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG);
-    const u32 s_lo = (u32)(((u64)slice * npc) / a.nsplit), s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
     if (nbc == 0 || s_lo >= s_hi) {      // an empty side is skipped (hash_join.cpp:343, :518)
         if (tid == 0) a.part_count[item] = 0;
         return;
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
     u32* bm0 = pm0 + 2 * JP_META;                            // [2][JB_META] build-side list entries
     u32* s_next = bm0 + 2 * JB_META;                         // [2] item ids handed out by the global counter
     const u32 tid = threadIdx.x, lane = tid & 63;
-    const u32 nitems = a.nparts * a.nsplit;
+    const u32 nitems = *a.nitems_dev;                       // chunk-list inputs only: items come from the item table
     constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
     static_assert(JP_META <= NT && JB_META <= NT, "one staged list entry per thread");
 
@@ -667,11 +681,9 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
     auto describe = [&](u32 item) -> Desc {                  // wave-uniform scalar loads
         Desc d; d.item = item; d.b0 = 0; d.nbc = 0; d.p0 = 0; d.s_lo = 0; d.s_hi = 0;
         if (item >= nitems) return d;
-        const u32 p = item / a.nsplit, slice = item % a.nsplit;
-        d.b0 = a.build.boff[p]; d.nbc = a.build.boff[p + 1] - d.b0;
-        d.p0 = a.probe.boff[p];
-        const u32 npc = a.probe.boff[p + 1] - d.p0;
-        d.s_lo = (u32)(((u64)slice * npc) / a.nsplit); d.s_hi = (u32)(((u64)(slice + 1) * npc) / a.nsplit);
+        const uint4 it = a.items[item];
+        d.b0 = a.build.boff[it.z]; d.nbc = a.build.boff[it.z + 1] - d.b0;
+        d.p0 = 0; d.s_lo = it.x; d.s_hi = it.x + it.y;
         return d;
     };
     auto live = [&](const Desc& d) { return d.item < nitems && d.nbc > 0 && d.s_lo < d.s_hi; };
@@ -1123,7 +1135,7 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 }  // namespace
 
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item, u32 persistent_min_items) {
-    const u32 nb = a.nparts * a.nsplit;
+    const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;       // grid of the one-workgroup-per-item kernels
     if (materialize) {
         const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
         auto kern = (a.build.list && a.probe.list) ? fj_lds_join_kernel<true, 1024, true> : fj_lds_join_kernel<true, 1024, false>;

@@ -313,6 +313,35 @@ def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn, hbm):
     torch.cuda.empty_cache()
 
 
+def test_hot_probe_key_is_sliced_across_workgroups(fj):
+    """Skew: half of 400M probe rows carry ONE key.  Its partition's probe chunk list is cut into many work items (the
+    item table), so the join stays within a small factor of the uniform case instead of serialising on one workgroup."""
+    import torch
+    from flash_hash_join_amd import datagen
+    nb, npk = 20_000_000, 400_000_000
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=5, hit_bp=5000)
+    n, _ = fj.hash_join_count_radix(dbk, dbv, dpk)
+    n, _ = fj.hash_join_count_radix(dbk, dbv, dpk)
+    uniform_ms = fj.last_timings()["total_ms"]
+    assert n == exp
+    hot = dbk[12345].clone()
+    uniform_hits_in_first_half = int(torch.isin(dpk[: npk // 2: 1000], dbk).sum())     # just to keep the generator honest
+    assert uniform_hits_in_first_half > 0
+    sel = torch.arange(0, npk, 2, device="cuda:0")
+    replaced_hits = fj.hash_join_count_radix(dbk, dbv, dpk[sel].contiguous())[0]        # hits among the rows about to be replaced
+    dpk[sel] = hot
+    n, _ = fj.hash_join_count_radix(dbk, dbv, dpk)
+    n2, _ = fj.hash_join_count_radix(dbk, dbv, dpk)
+    skew_ms = fj.last_timings()["total_ms"]
+    assert n == n2 == exp - replaced_hits + sel.numel()
+    assert skew_ms < 8 * uniform_ms, (skew_ms, uniform_ms)      # (one workgroup streaming 200M rows alone would take ~100x)
+    nm, _, k, v = fj.hash_join_radix(dbk, dbv, dpk, return_arrays=True)               # the materialising pass uses the same items
+    assert nm == n and int((k == hot).sum()) >= sel.numel()
+    del dpk, k, v
+    torch.cuda.empty_cache()
+
+
 def test_relation_beyond_the_chunk_directory_is_refused(fj):
     """A relation of more than ~4.2e9 rows does not fit one GPU's 24-bit chunk directory: the call must fail loudly
     (RuntimeError), not wrap around."""
