@@ -235,6 +235,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     __syncthreads();
 
     u32 cur_parent = 0xFFFFFFFFu;
+    u32 hotb = 0xFFFFFFFFu;                          // see the ranking step
     for (; t < thi; ++t) {
         u64 k[KPT], v[KPT];
 #pragma unroll
@@ -263,12 +264,45 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         for (u32 b = tid; b <= F; b += NT) hist[b] = 0;     // bucket F = dummy bucket for invalid lanes
         __syncthreads();
 
-        // ---- hash, rank inside the tile with LDS atomics (branch-free) --------------------------
+        // ---- hash, rank inside the tile with LDS atomics ------------------------------------------
+        // Lanes of one instruction that hit the same counter are served one after the other, so a hot key (many equal
+        // digits per wave) would make this the slowest step of the tile.  Once per tile a wave tests whether lane 0's
+        // last digit is shared by >= 8 lanes; such a bucket is remembered (hotb, wave-uniform, survives across tiles
+        // until it cools down) and its lanes are then ranked with ONE atomic + a ballot prefix per instruction.  With
+        // uniform keys the test never fires and the loop below is the plain one.
         u32 br[KPT];
+        if (hotb == 0xFFFFFFFFu) {
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const u32 b = (valid & (1u << i)) ? ((fj_hash_w1(k[i]) >> sh32) & FM) : F;
-            br[i] = (b << 16) | atomicAdd(&hist[b], 1u);
+            for (int i = 0; i < KPT; ++i) {
+                const u32 b = (valid & (1u << i)) ? ((fj_hash_w1(k[i]) >> sh32) & FM) : F;
+                br[i] = (b << 16) | atomicAdd(&hist[b], 1u);
+            }
+            // detection, for the tiles that follow: is lane 0's last digit shared by >= 8 lanes of this wave?
+            const u32 bl = br[KPT - 1] >> 16;
+            const u32 cand = (u32)__builtin_amdgcn_readfirstlane((int)bl);
+            if (__popcll(__ballot(bl == cand)) >= 8) hotb = cand;
+        } else {
+            u32 seen = 0;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const u32 b = (valid & (1u << i)) ? ((fj_hash_w1(k[i]) >> sh32) & FM) : F;
+                const u64 m = __ballot(b == hotb);
+                const u32 n = (u32)__popcll(m);
+                seen += n;
+                u32 r;
+                if (n >= 2) {
+                    const int leader = __builtin_ctzll(m);
+                    u32 base = 0;
+                    if ((int)lane == leader) base = atomicAdd(&hist[hotb], n);
+                    base = (u32)__builtin_amdgcn_readlane((int)base, leader);
+                    if (b == hotb) r = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                    else r = atomicAdd(&hist[b], 1u);
+                } else {
+                    r = atomicAdd(&hist[b], 1u);
+                }
+                br[i] = (b << 16) | r;
+            }
+            if (seen < 8) hotb = 0xFFFFFFFFu;                // cooled down
         }
         __syncthreads();
 
@@ -326,18 +360,38 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             tile_k[d] = k[i];
             if (HAS_VALS) tile_v[d] = v[i];
         }
-        if (tid < F) {
+        if (wave * 64 < F) {
             // line descriptors: dst element (32) | bucket (10) | keys of this line that still sit in lo_* (5)
             //                   | tile index of the line's virtual key 0, biased by 32 (17)
-            const u32 b = tid, f0 = st_fill, c0 = st_cur, n0 = st_nch, tb = toff[b];
-            for (u32 q = 0; q < nf; q += LINE) {
-                const u32 pq = f0 + q, kk = pq >> FJ_CHUNK_LOG, off = pq & (FJ_CHUNK - 1);
-                const u32 id = kk == 0 ? c0 : alloc_id(kb + kk - 1);
+            // Thread b writes the descriptors of bucket b -- up to `own_lines` of them (twice the average); a bucket
+            // with more (a hot key: up to T/LINE lines) is finished by its whole wave, 64 descriptors per step.
+            const bool own = tid < F;
+            const u32 f0 = st_fill, c0 = st_cur, tb = own ? toff[tid] : 0u;
+            const u32 nl = own ? (nf >> LINE_LOG) : 0u;
+            auto put = [&](u32 pb, u32 pf0, u32 pc0, u32 pkb, u32 ptb, u32 pleft, u32 pl0, u32 j) {
+                const u32 q = j << LINE_LOG, pq = pf0 + q, kk = pq >> FJ_CHUNK_LOG, off = pq & (FJ_CHUNK - 1);
+                const u32 id = kk == 0 ? pc0 : alloc_id(pkb + kk - 1);
                 const u32 dst = id < cap ? id * FJ_CHUNK + off : FJ_DIR_INVALID;
-                const u32 lc = q == 0 ? st_left : 0u;
-                const u32 sidx = tb + q + 32u - st_left;            // tile index of virtual key q (may precede the run for line 0)
-                line_desc[l0 + (q >> LINE_LOG)] = ((u64)dst << 32) | ((u64)b << 22) | ((u64)lc << 17) | sidx;
+                const u32 lc = j == 0 ? pleft : 0u;
+                const u32 sidx = ptb + q + 32u - pleft;             // tile index of virtual key q (may precede the run for line 0)
+                line_desc[pl0 + j] = ((u64)dst << 32) | ((u64)pb << 22) | ((u64)lc << 17) | sidx;
+            };
+            const u32 avg2 = (2u * T / LINE) >> a.fan_log;          // twice the average number of lines per bucket and tile
+            const u32 own_lines = avg2 > 4u ? avg2 : 4u;
+            for (u32 j = 0; j < nl && j < own_lines; ++j) put(tid, f0, c0, kb, tb, st_left, l0, j);
+            u64 big = __ballot(nl > own_lines);
+            while (big) {                                           // wave-uniform
+                const int src = __builtin_ctzll(big);
+                big &= big - 1;
+                const u32 pf0 = (u32)__builtin_amdgcn_readlane((int)f0, src), pc0 = (u32)__builtin_amdgcn_readlane((int)c0, src);
+                const u32 pkb = (u32)__builtin_amdgcn_readlane((int)kb, src), ptb = (u32)__builtin_amdgcn_readlane((int)tb, src);
+                const u32 pleft = (u32)__builtin_amdgcn_readlane((int)st_left, src), pl0 = (u32)__builtin_amdgcn_readlane((int)l0, src);
+                const u32 pnl = (u32)__builtin_amdgcn_readlane((int)nl, src);
+                for (u32 j = own_lines + lane; j < pnl; j += 64) put(wave * 64 + (u32)src, pf0, pc0, pkb, ptb, pleft, pl0, j);
             }
+        }
+        if (tid < F) {
+            const u32 b = tid, f0 = st_fill, c0 = st_cur, n0 = st_nch, tb = toff[b];
             const u32 outb = (parent * F + b) << FJ_DIR_CNT_BITS;
             const u64 segw = (u64)misc[M_SEG] << 32;
             for (u32 kk = 1; kk <= km; ++kk) {
