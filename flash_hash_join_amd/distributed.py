@@ -92,7 +92,15 @@ class HipEngine:
         self._lib.check(self.L.fj_stream_open(self.ctx, nb_bound, build_appends, np_bound, probe_appends,
                                               self.torch.cuda.current_stream(self.index).cuda_stream, hash_top_bits))
 
+    @staticmethod
+    def _aligned(t):
+        """The C ABI wants contiguous, 16-byte aligned pieces (a view into a larger tensor may be neither)."""
+        if not t.is_contiguous() or t.data_ptr() % 16:
+            t = t.contiguous().clone() if t.data_ptr() % 16 else t.contiguous()
+        return t
+
     def stream_append_build(self, piece):
+        piece = self._aligned(piece)
         self._keep.append(piece)
         self._lib.check(self.L.fj_stream_append_build(self.ctx, piece.data_ptr(), piece.numel(),
                                                       self.torch.cuda.current_stream(self.index).cuda_stream))
@@ -101,6 +109,7 @@ class HipEngine:
         self._lib.check(self.L.fj_stream_advance_probe(self.ctx, self.torch.cuda.current_stream(self.index).cuda_stream))
 
     def stream_append(self, piece):
+        piece = self._aligned(piece)
         self._keep.append(piece)
         self._lib.check(self.L.fj_stream_append_probe(self.ctx, piece.data_ptr(), piece.numel(),
                                                       self.torch.cuda.current_stream(self.index).cuda_stream))

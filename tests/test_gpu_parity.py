@@ -391,7 +391,7 @@ def test_streamed_probe_equals_one_shot(fj, nb, npk, pieces):
 
 
 @pytest.mark.parametrize("nb,npk,bpieces,ppieces", [(2000, 300_000, 1, 3), (50_000, 1_000_000, 4, 2), (1_500_000, 6_000_000, 5, 1),
-                                                    (3_000_000, 20_000_000, 3, 4), (10, 1000, 1, 2), (20_000_000, 30_000_000, 8, 1)])
+                                                    (3_000_000, 20_000_000, 3, 4), (10, 1000, 1, 2), (20_000_000, 30_000_000, 8, 1), (1_000_003, 5_000_011, 7, 3)])
 def test_stream_join_with_both_sides_in_pieces(fj, nb, npk, bpieces, ppieces):
     """fj_stream_open / append_build / append_probe / advance_probe / finish == the one-shot radix count, with the
     probe side closed BEFORE the build side arrives (the replicate-build exchange order) and after it."""
@@ -406,13 +406,13 @@ def test_stream_join_with_both_sides_in_pieces(fj, nb, npk, bpieces, ppieces):
         eng.stream_open(nb, bpieces, npk, ppieces, 64)
         if probe_first:
             for i in range(ppieces):
-                eng.stream_append(pk[pcuts[i]: pcuts[i + 1]].clone())
+                eng.stream_append(pk[pcuts[i]: pcuts[i + 1]])                 # views: the engine aligns them
             eng.stream_advance_probe()
         for i in range(bpieces):
-            eng.stream_append_build(bk[bcuts[i]: bcuts[i + 1]].clone())
+            eng.stream_append_build(bk[bcuts[i]: bcuts[i + 1]])                 # views: the engine aligns them
         if not probe_first:
             for i in range(ppieces):
-                eng.stream_append(pk[pcuts[i]: pcuts[i + 1]].clone())
+                eng.stream_append(pk[pcuts[i]: pcuts[i + 1]])                 # views: the engine aligns them
         assert eng.stream_finish() == exp
 
 
