@@ -280,6 +280,20 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_join_with_ranks_sharing_this_gpu(fj, world):
+    """The multi-GPU step under genuine multi-rank control flow with the real HipEngine: `world` processes share this
+    GPU and talk over gloo (RCCL refuses two ranks on one device; the collectives are staged through the host, nothing
+    else differs from the production path).  Both strategies, counting and materialising, uneven shards at world 3."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_ranks_one_gpu.py"), str(world)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert f"OK: {world} ranks on one GPU" in out.stdout
+
+
 @pytest.mark.parametrize("nb,npk,hit_bp,fn,hbm", [
     (1_000_000, 100_000_000, 5000, "hash_join_count", 0),            # BASELINE config 2
     (1_000_000, 100_000_000, 5000, "hash_join_count", 1),            # ... with the literal one-table algorithm

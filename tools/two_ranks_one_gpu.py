@@ -1,0 +1,81 @@
+"""Two ranks sharing ONE GPU over the gloo backend: runs distributed_join with the real HipEngine under genuine
+multi-rank control flow (RCCL refuses two ranks on one device, and only 1-GPU boxes were available to the builder).
+Collectives that gloo cannot run on device tensors are staged through the host by a thin wrapper - only the transport
+differs from the production path.  usage: python tools/two_ranks_one_gpu.py [world]"""
+import os, sys, socket
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class HostStagedDist:
+    """torch.distributed look-alike that moves device tensors through pinned host copies for gloo."""
+    ReduceOp = dist.ReduceOp
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __getattr__(self, name):
+        return getattr(dist, name)
+
+    def _h(self, t):
+        return t.cpu()
+
+    def all_reduce(self, t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        h = self._h(t); dist.all_reduce(h, op=op, group=group); t.copy_(h); return self._Done()
+
+    def all_gather_into_tensor(self, out, t, group=None, async_op=False):
+        ho, hi = self._h(out), self._h(t); dist.all_gather_into_tensor(ho, hi, group=group); out.copy_(ho); return self._Done()
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        ho, hi = self._h(out), self._h(inp)
+        dist.all_to_all_single(ho, hi, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+        out.copy_(ho); return self._Done()
+
+
+def worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import flash_hash_join_amd.distributed as D
+        from flash_hash_join_amd import datagen, api
+        api.initialize()
+        shim = HostStagedDist()
+        sys.modules["torch.distributed"] = shim            # distributed_join does `import torch.distributed as dist`
+        torch.distributed = shim
+        nb, npk = 6_000_000, 40_000_000                    # global rows; block-distributed
+        b0, b1 = rank * nb // world, (rank + 1) * nb // world
+        p0, p1 = rank * npk // world, (rank + 1) * npk // world
+        bk, bv = datagen.build_device(b1 - b0, "cuda:0", first=b0)
+        pk, exp_local = datagen.probe_device(p1 - p0, nb, "cuda:0", seed=1, hit_bp=5000, first=p0)
+        e = torch.tensor([exp_local]); dist.all_reduce(e); exp = int(e.item())
+        res = {}
+        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1")):
+            os.environ["FJ_DIST_STRATEGY"] = strategy; os.environ["FJ_REPLICATE_PIECES"] = pieces
+            t = {}
+            n, sec = D.distributed_join(bk, bv, pk, timings=t)
+            assert n == exp, (strategy, n, exp)
+            n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
+            M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+            assert n2 == exp and bool(torch.all((v + 1) * M == k)), strategy
+            tot = torch.tensor([k.numel()]); dist.all_reduce(tot)
+            assert int(tot.item()) == exp                   # the ranks' pair sets add up to the global result
+            res[strategy + pieces] = (t["strategy"], t["pieces"], t["local_build_rows"], t["local_probe_rows"])
+        q.put((rank, exp, res))
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn"); q = ctx.Queue()
+    ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps: p.start()
+    rows = [q.get(timeout=600) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60); assert p.exitcode == 0
+    for r in sorted(rows): print(r)
+    print("OK: %d ranks on one GPU, all strategies, counts and pairs exact" % world)
