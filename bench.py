@@ -107,6 +107,11 @@ def main() -> None:
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...` "
                              f"(WORLD_SIZE={world})")
+    # FJ_BENCH_SHARE_GPU=1 (self-test on a 1-GPU box): every rank uses cuda:0 and the collectives travel over gloo through
+    # the host (RCCL refuses two ranks on one device) - exercises this file's N>1 logic, says nothing about speed
+    share_gpu = bool(os.environ.get("FJ_BENCH_SHARE_GPU")) and world > 1
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # FJ_BENCH_FORCE_DIST=1 drives the multi-GPU code path (owner split -> RCCL all-to-all -> join -> all-reduce)
@@ -115,7 +120,15 @@ def main() -> None:
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from two_ranks_one_gpu import HostStagedDist
+            dist = HostStagedDist()
+            sys.modules["torch.distributed"] = dist
+            torch.distributed = dist
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         _flush_c_stdio()
         if force_dist:
             os.environ["FJ_FORCE_EXCHANGE"] = "1"
@@ -128,6 +141,7 @@ def main() -> None:
     materialize = int(fn_name in ("hash_join_radix", "hash_join"))
 
     api.initialize() if local_rank == 0 else api.context(local_rank)
+
     api.set_option("scalar_hbm_table", int("hbm_table" in args.workload))
     bk, bv = datagen.build_device(nb_gpu, device, first=rank * nb_gpu)
     pk, exp_local = datagen.probe_device(np_gpu, nb_total, device, seed=1, hit_bp=hit_bp, first=rank * np_gpu)
@@ -268,6 +282,8 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
         except Exception as ex:      # the baseline never blocks the GPU measurement
             out["cpu_baseline"] = {"error": repr(ex)}
+    if share_gpu:
+        out["note"] = "FJ_BENCH_SHARE_GPU: ranks share cuda:0, gloo + host-staged collectives - a functional self-test, not a measurement"
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

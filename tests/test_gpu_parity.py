@@ -294,6 +294,26 @@ def test_multi_rank_join_with_ranks_sharing_this_gpu(fj, world):
     assert f"OK: {world} ranks on one GPU" in out.stdout
 
 
+def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
+    """bench.py's N>1 branch (per-rank generation, barrier, max over ranks, one JSON line from rank 0) launched the way
+    the driver launches it, with two ranks on this one GPU (FJ_BENCH_SHARE_GPU: gloo, host-staged collectives)."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ, FJ_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["probe_rows_total"] == 2 * 20_000_000
+    assert d["config"]["parallelism"].endswith("x2") and "cpu_baseline" not in d and d["value"] > 0
+
+
 @pytest.mark.parametrize("nb,npk,hit_bp,fn,hbm", [
     (1_000_000, 100_000_000, 5000, "hash_join_count", 0),            # BASELINE config 2
     (1_000_000, 100_000_000, 5000, "hash_join_count", 1),            # ... with the literal one-table algorithm
