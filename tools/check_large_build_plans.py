@@ -1,9 +1,10 @@
-"""Three-pass plans (build sides > 268M rows): count and materialised pairs against the generator's closed form."""
+"""Plans beyond 16 radix bits (build sides > 268M rows: 512-bucket passes; > 1.07G rows: three passes): count and
+materialised pairs against the generator's closed form."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flash_hash_join_amd import api, datagen
 api.initialize()
-for nb, npk in [(300_000_000, 400_000_000), (600_000_000, 200_000_000)]:
+for nb, npk in [(300_000_000, 400_000_000), (600_000_000, 200_000_000), (1_300_000_000, 100_000_000)]:
     bk, bv = datagen.build_device(nb, "cuda:0")
     pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=2, hit_bp=5000)
     n, s = api.join_device(api.ALGO_RADIX, 0, 0, bk, bv, pk)
