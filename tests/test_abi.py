@@ -104,3 +104,45 @@ def test_missing_library_is_an_import_error(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_dispatch_options_round_trip(lib):
+    """fj_set_option / fj_get_option are host-only: defaults, round trip, unknown names and bad values are errors."""
+    from flash_hash_join_amd import api
+    assert api.get_option("radix_threshold") == 0 and api.get_option("scalar_hbm_table") == 0
+    assert api.get_option("persistent_min_items") == 8192
+    try:
+        api.set_option("radix_threshold", 123456); assert api.get_option("radix_threshold") == 123456
+        api.set_option("scalar_hbm_table", 7); assert api.get_option("scalar_hbm_table") == 1
+        api.set_option("persistent_min_items", 0); assert api.get_option("persistent_min_items") == 0
+        with pytest.raises(RuntimeError, match="unknown option"):
+            api.set_option("no_such_option", 1)
+        with pytest.raises(RuntimeError, match=">= 0"):
+            api.set_option("radix_threshold", -1)
+        with pytest.raises(KeyError):
+            api.get_option("no_such_option")
+    finally:
+        api.set_option("radix_threshold", 0); api.set_option("scalar_hbm_table", 0); api.set_option("persistent_min_items", 8192)
+
+
+def test_multi_gpu_strategy_model():
+    """The exchange-strategy choice is pure host arithmetic: probe-heavy joins replicate the build side on small meshes,
+    balanced joins and large meshes shuffle; the environment override wins; the plan mirror matches the native planner's
+    documented break points."""
+    from flash_hash_join_amd import distributed as D
+    os.environ.pop("FJ_DIST_STRATEGY", None)
+    for world in (2, 4, 8):
+        assert D.choose_strategy(world, 100_000_000, 1_000_000_000, False) == "replicate"
+    assert D.choose_strategy(16, 100_000_000, 1_000_000_000, False) == "shuffle"
+    assert D.choose_strategy(8, 100_000_000, 100_000_000, False) == "shuffle"
+    assert D.choose_strategy(8, 400_000_000, 4_000_000_000, False) == "shuffle"        # 3.2e9 replicated rows: past one GPU's directory
+    c = D.strategy_costs(2, 100_000_000, 1_000_000_000, False)
+    assert c["shuffle"] > 3 * c["replicate"]                                           # one xGMI link between two GPUs
+    os.environ["FJ_DIST_STRATEGY"] = "shuffle"
+    try:
+        assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == "shuffle"
+    finally:
+        os.environ.pop("FJ_DIST_STRATEGY")
+    # passes: none up to 4096 rows, one up to 2^8 partitions, two up to 18 bits (512-bucket passes above 16), then three
+    assert [D._plan_passes(n) for n in (1, 4096, 4097, 1 << 20, (1 << 20) + 1, 100_000_000, 268_435_456, 268_435_457,
+                                        800_000_000, 1 << 30, (1 << 30) + 1)] == [0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 3]

@@ -450,6 +450,40 @@ def test_stream_join_with_both_sides_in_pieces(fj, nb, npk, bpieces, ppieces):
         assert eng.stream_finish() == exp
 
 
+def test_c_abi_rejects_bad_arguments(fj):
+    """Error behaviour at the C boundary: status 1 + fj_last_error text, translated to RuntimeError; the context stays usable."""
+    import ctypes
+    import torch
+    from flash_hash_join_amd import _lib, api, datagen
+    L = _lib.load()
+    ctx = api.context(0)
+    bk, bv = datagen.build_device(100_000, "cuda:0")
+    pk, exp = datagen.probe_device(300_000, 100_000, "cuda:0", seed=2, hit_bp=5000)
+    st = torch.cuda.current_stream(0).cuda_stream
+    cnt = ctypes.c_uint64(0)
+    t = _lib.FjTimings()
+
+    def call(algo=2, bkp=None, pkp=None, top=64):
+        return L.fj_join_device(ctx, algo, 0, 0, bk.data_ptr() if bkp is None else bkp, bv.data_ptr(), bk.numel(),
+                                pk.data_ptr() if pkp is None else pkp, pk.numel(), st, top, ctypes.byref(cnt), None, None, 0, ctypes.byref(t))
+    assert call(algo=9) == 1 and "unknown algo" in _lib.last_error()
+    assert call(top=50) == 1 and "hash_top_bits" in _lib.last_error()
+    assert call(bkp=bk.data_ptr() + 8) == 1 and "16-byte aligned" in _lib.last_error()
+    assert call(pkp=0) == 1 and "null input pointer" in _lib.last_error()
+    assert L.fj_join_device(None, 2, 0, 0, bk.data_ptr(), bv.data_ptr(), 1, pk.data_ptr(), 1, st, 64, ctypes.byref(cnt), None, None, 0, None) == 1
+    assert call() == 0 and cnt.value == exp                                      # still works
+    # materialise: emitting into too small a buffer is refused, the pending result survives for a second attempt
+    assert L.fj_join_device(ctx, 2, 0, 1, bk.data_ptr(), bv.data_ptr(), bk.numel(), pk.data_ptr(), pk.numel(), st, 64,
+                            ctypes.byref(cnt), None, None, 0, ctypes.byref(t)) == 0 and cnt.value == exp
+    small_k = torch.empty(exp - 1, dtype=torch.int64, device="cuda:0"); small_v = torch.empty_like(small_k)
+    assert L.fj_emit_pairs(ctx, small_k.data_ptr(), small_v.data_ptr(), exp - 1, st, ctypes.byref(t)) == 1 and "capacity" in _lib.last_error()
+    ok_k = torch.empty(exp, dtype=torch.int64, device="cuda:0"); ok_v = torch.empty_like(ok_k)
+    assert L.fj_emit_pairs(ctx, ok_k.data_ptr(), ok_v.data_ptr(), exp, st, ctypes.byref(t)) == 0
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+    assert bool(torch.all((ok_v + 1) * M == ok_k))
+    assert L.fj_emit_pairs(ctx, ok_k.data_ptr(), ok_v.data_ptr(), exp, st, ctypes.byref(t)) == 1 and "no counted" in _lib.last_error()
+
+
 def test_stream_join_rejects_misuse(fj):
     import torch
     from flash_hash_join_amd import datagen
