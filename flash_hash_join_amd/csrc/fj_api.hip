@@ -290,6 +290,34 @@ int read_scalars(fj_ctx* c, hipStream_t s) {
 
 float ev_ms(fj_ctx* c, int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; }
 
+// diagnostic: per-item phase stamps (s_memrealtime, 100 MHz) written by thread 0 of the first 4096 workgroups of a join kernel
+int stamps_begin(unsigned long long** dbg, hipStream_t s) {
+    static unsigned long long* dbg_buf = nullptr;
+    if (!dbg_buf) HIPCHK(hipMalloc((void**)&dbg_buf, 4096 * 8 * 8));
+    HIPCHK(hipMemsetAsync(dbg_buf, 0, 4096 * 8 * 8, s));
+    *dbg = dbg_buf;
+    return 0;
+}
+int stamps_report(const char* label, const unsigned long long* dbg, u32 nitems, hipStream_t s) {
+    std::vector<unsigned long long> h(4096 * 8);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int i = 0; i < 4096 && i < (int)nitems; ++i) {
+        const unsigned long long* r = &h[i * 8];
+        if (!r[0] || !r[5]) continue;
+        for (int j = 1; j <= 5; ++j) acc[j] += (double)(r[j] - r[j - 1]) * 0.01;      // 100 MHz -> us
+        if (r[0] < tmin) tmin = r[0];
+        if (r[5] > tmax) tmax = r[5];
+        ++n;
+    }
+    if (n == 0) n = 1;
+    fprintf(stderr, "[%s] items=%d  meta+init=%.2f  build=%.2f  buildsync=%.2f  probe=%.2f  fin=%.2f us (means); first 4096 items span %.1f us\n",
+            label, n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, (double)(tmax - tmin) * 0.01);
+    return 0;
+}
+
 int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_timings* t) {
     Pending& pd = c->pend;
     if (!pd.valid) return set_err("fj_emit_pairs: no counted materialising join is pending on this context");
@@ -314,7 +342,10 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
             HIPCHK(fj_launch_scan_u32_to_u64(pd.lds.part_count, (u64*)p, pd.nitems, s));
             pd.lds.out_off = (const u64*)p; pd.lds.out_keys = d_ok; pd.lds.out_vals = d_ov;
+            pd.lds.dbg = nullptr;
+            if (getenv("FJ_EMIT_STAMPS") && stamps_begin(&pd.lds.dbg, s)) return 1;
             HIPCHK(fj_launch_lds_join(pd.lds, true, s));
+            if (pd.lds.dbg) { if (stamps_report("FJ_EMIT_STAMPS", pd.lds.dbg, pd.nitems, s)) return 1; pd.lds.dbg = nullptr; }
         } else {
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.gt_grid + 1) * 8, &p)) return 1;
             HIPCHK(fj_launch_scan_u32_to_u64(pd.gt.wg_count, (u64*)p, pd.gt_grid, s));
@@ -412,31 +443,9 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr;
     ja.dbg = nullptr;
     ja.dbg_flags = getenv("FJ_JOIN_ABLATE") ? (u32)atoi(getenv("FJ_JOIN_ABLATE")) : 0u;
-    static unsigned long long* dbg_buf = nullptr;
-    if (getenv("FJ_JOIN_STAMPS")) {
-        if (!dbg_buf) HIPCHK(hipMalloc((void**)&dbg_buf, 4096 * 8 * 8));
-        HIPCHK(hipMemsetAsync(dbg_buf, 0, 4096 * 8 * 8, s));
-        ja.dbg = dbg_buf;
-    }
+    if (getenv("FJ_JOIN_STAMPS") && stamps_begin(&ja.dbg, s)) return 1;
     HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item, options().persistent_min_items));
-    if (ja.dbg) {
-        std::vector<unsigned long long> h(4096 * 8);
-        HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
-        double acc[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
-        unsigned long long tmin = ~0ull, tmax = 0;
-        for (int i = 0; i < 4096 && i < (int)nitems; ++i) {
-            const unsigned long long* r = &h[i * 8];
-            if (!r[0] || !r[5]) continue;
-            for (int j = 1; j <= 5; ++j) acc[j] += (double)(r[j] - r[j - 1]) * 0.01;      // 100 MHz -> us
-            if (r[0] < tmin) tmin = r[0];
-            if (r[5] > tmax) tmax = r[5];
-            ++n;
-        }
-        fprintf(stderr, "[FJ_JOIN_STAMPS] items=%d  meta+init=%.2f  issue0=%.2f  build=%.2f  buildsync=%.2f  probe=%.2f  fin=%.2f us (means); first 4096 items span %.1f us\n",
-                n, acc[1] / n, 0.0, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, (double)(tmax - tmin) * 0.01);
-        ja.dbg = nullptr;
-    }
+    if (ja.dbg) { if (stamps_report("FJ_JOIN_STAMPS", ja.dbg, nitems, s)) return 1; ja.dbg = nullptr; }
     HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
     if (read_scalars(c, s)) return 1;
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");

@@ -434,6 +434,9 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
             a.part_count[item] = hdr->cnt;
             if (hdr->cnt) atomicAdd(a.total, (unsigned long long)hdr->cnt);
         }
+    } else if (a.dbg) {
+        __syncthreads();                                 // diagnostic only: stamp 5 = the slowest wave is done
+        FJ_STAMP(5);
     }
 }
 
