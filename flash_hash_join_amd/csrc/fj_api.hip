@@ -164,7 +164,10 @@ Plan make_plan(size_t nb, int top_bits) {
     }
     if (p.bits > 0 && p.bits < 5) p.bits = 5;              // a pass with a tiny fan-out serialises on its per-bucket threads
     if (p.bits > top_bits - 32) p.bits = top_bits - 32;      // radix digits come from hash word 1 (32 bits)
-    plan_passes(p, false);                                   // extra bits go to the later passes
+    // extra bits go to the EARLIER passes: a pass over a flat array absorbs a wider fan-out better than one over chunk
+    // lists (per-bucket carry work grows with the fan-out), and fewer children per parent leave fewer partial chunks:
+    // 8+7 instead of 7+8 bits at c3 is 1.3 % faster end to end (A/B on one box)
+    plan_passes(p, true);
     return p;
 }
 
