@@ -52,12 +52,12 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG 
 // The kernel is instruction-issue bound (not HBM bound) on gfx950, so the inner phases are written
 // to minimise issued instructions per key: 32-bit-multiply hash, invalid lanes routed to a dummy
 // bucket instead of branches, per-bucket state in the registers of thread b, the bucket scan done
-// only by the waves that own buckets, 32 B per lane in the write-out.
+// only by the waves that own buckets, whole contiguous lines per store instruction in the write-out.
 // PROBE_SIDE only names the instantiation (identical code): a counting join runs the keys-only kernel over both
 // relations, and per-kernel profiler statistics should not average 100M-row and 1B-row launches together.
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE>
 __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
-    constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LPL = LINE / 4;
+    constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
     const u32 F = 1u << a.fan_log, FM = F - 1;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,31 +409,29 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         // metadata of tile t+2 (fetched at the top of this iteration) -> LDS, BEFORE this tile's stores are
         // issued: the wait for those loads must not also wait for the stores
         if (!FLAT && tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }
-        // ---- write whole lines: 32 B (4 keys) per lane, LINE/4 lanes per line -----------------
+        // ---- write whole lines --------------------------------------------------------------------
         const u32 nl = misc[M_NLINES];
-        for (u32 e = tid; e < nl * LPL; e += NT) {
-            const u32 l = e / LPL, q = (e % LPL) * 4;
+        // 16 B (2 keys) per lane, LINE/2 consecutive lanes per line: one store instruction covers whole, contiguous lines
+        // (1 % faster end to end than 32 B per lane in two instructions, A/B on one box)
+        constexpr u32 WK = 2, WLPL = LINE / WK;
+        for (u32 e = tid; e < nl * WLPL; e += NT) {
+            const u32 l = e / WLPL, q = (e % WLPL) * WK;
             const u64 d = line_desc[l];
             const u32 dst = (u32)(d >> 32);
             if (dst != FJ_DIR_INVALID) {
                 const u32 w = (u32)d, b = w >> 22, lc = (w >> 17) & 31u, sidx = (w & 0x1FFFFu) - 32u;
-                u64 r[4], rv[4];
+                u64 r[WK], rv[WK];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < (int)WK; ++i) {
                     const u32 vi = q + i;
                     const bool in_lo = vi < lc;
                     const u64* sk = in_lo ? (lo_k + b * LINE + vi) : (tile_k + (sidx + vi));
                     r[i] = *sk;
                     if (HAS_VALS) { const u64* sv = in_lo ? (lo_v + b * LINE + vi) : (tile_v + (sidx + vi)); rv[i] = *sv; }
                 }
-                u64x2* o = reinterpret_cast<u64x2*>(a.out_keys + (u64)dst + q);
-                u64x2 r0, r1; r0.x = r[0]; r0.y = r[1]; r1.x = r[2]; r1.y = r[3];
-                o[0] = r0; o[1] = r1;
-                if (HAS_VALS) {
-                    u64x2* ov = reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + q);
-                    u64x2 w0, w1; w0.x = rv[0]; w0.y = rv[1]; w1.x = rv[2]; w1.y = rv[3];
-                    ov[0] = w0; ov[1] = w1;
-                }
+                u64x2 r0; r0.x = r[0]; r0.y = r[1];
+                *reinterpret_cast<u64x2*>(a.out_keys + (u64)dst + q) = r0;
+                if (HAS_VALS) { u64x2 w0; w0.x = rv[0]; w0.y = rv[1]; *reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + q) = w0; }
             }
         }
         if (tid == 0) {
