@@ -445,54 +445,43 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     flush(cur_parent);
 }
 
-// single-workgroup exclusive scan of u32 counts -> u32 offsets[n+1]
-__global__ __launch_bounds__(1024) void fj_scan_u32(const u32* in, u32* __restrict__ out, u32 n) {
-    __shared__ u32 wtot[16];
-    __shared__ u32 carry;
+// Single-workgroup exclusive scans (bucket counts -> offsets): sweeps of 4096 elements, four consecutive elements per
+// thread (coalesced), wave shuffles + 16 LDS words, two barriers per sweep.
+template <typename T, typename In>
+__device__ __forceinline__ void fj_block_scan(In value_at, T* __restrict__ out, u32 n) {
+    __shared__ T wtot[16];
+    __shared__ T carry_s;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (u32 base = 0; base < n; base += 1024) {
-        const u32 i = base + tid;
-        const u32 x = i < n ? in[i] : 0;
-        u32 inc = x;
+    T carry = 0;
+    for (u32 base = 0; base < n; base += 4096) {
+        const u32 i0 = base + tid * 4;
+        T x[4];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
+        for (int j = 0; j < 4; ++j) x[j] = i0 + j < n ? (T)value_at(i0 + j) : (T)0;
+        const T sum = x[0] + x[1] + x[2] + x[3];
+        T inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const T y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
         if (lane == 63) wtot[wave] = inc;
         __syncthreads();
-        u32 woff = carry;
-        for (u32 w = 0; w < wave; ++w) woff += wtot[w];
-        if (i < n) out[i] = inc - x + woff;
+        T run = carry + inc - sum;
+        for (u32 w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { if (i0 + j < n) out[i0 + j] = run; run += x[j]; }
+        if (tid == 1023) carry_s = run;
         __syncthreads();
-        if (tid == 1023) carry = woff + inc;
-        __syncthreads();
+        carry = carry_s;
     }
     if (tid == 0) out[n] = carry;
 }
 
+__global__ __launch_bounds__(1024) void fj_scan_u32(const u32* in, u32* __restrict__ out, u32 n) {
+    fj_block_scan<u32>([&](u32 i) { return in[i]; }, out, n);
+}
+
 // number of tiles of `tc` chunks per bucket (tiles never span buckets), exclusive-scanned
 __global__ __launch_bounds__(1024) void fj_tile_scan(const u32* __restrict__ boff, u32* __restrict__ toff, u32 n, u32 tc) {
-    __shared__ u32 wtot[16];
-    __shared__ u32 carry;
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (u32 base = 0; base < n; base += 1024) {
-        const u32 i = base + tid;
-        const u32 x = i < n ? (boff[i + 1] - boff[i] + tc - 1) / tc : 0;
-        u32 inc = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        u32 woff = carry;
-        for (u32 w = 0; w < wave; ++w) woff += wtot[w];
-        if (i < n) toff[i] = inc - x + woff;
-        __syncthreads();
-        if (tid == 1023) carry = woff + inc;
-        __syncthreads();
-    }
-    if (tid == 0) toff[n] = carry;
+    fj_block_scan<u32>([&](u32 i) { return (boff[i + 1] - boff[i] + tc - 1) / tc; }, toff, n);
 }
 
 // tile t -> (first list index, chunks, bucket)
@@ -511,27 +500,7 @@ __global__ void fj_tile_expand(const u32* __restrict__ boff, const u32* __restri
 
 // same for u64 outputs (result offsets can exceed 2^32)
 __global__ __launch_bounds__(1024) void fj_scan_u32_to_u64(const u32* __restrict__ in, u64* __restrict__ out, u32 n) {
-    __shared__ u64 wtot[16];
-    __shared__ u64 carry;
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (u32 base = 0; base < n; base += 1024) {
-        const u32 i = base + tid;
-        const u64 x = i < n ? in[i] : 0;
-        u64 inc = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u64 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        u64 woff = carry;
-        for (u32 w = 0; w < wave; ++w) woff += wtot[w];
-        if (i < n) out[i] = inc - x + woff;
-        __syncthreads();
-        if (tid == 1023) carry = woff + inc;
-        __syncthreads();
-    }
-    if (tid == 0) out[n] = carry;
+    fj_block_scan<u64>([&](u32 i) { return in[i]; }, out, n);
 }
 
 // chunk lists without atomics: list[boff[bucket] + span offset of the producing segment + rank] = chunk
