@@ -45,6 +45,10 @@ typedef struct fj_timings {
     int radix_bits;              /* total partition bits                                       */
     int fell_back;               /* 1 if the radix path overflowed an LDS table and the global path re-ran */
     uint64_t partitions;
+    int overlapped;              /* 1: the build relation's partition passes ran beside the probe relation's (two streams):
+                                    build_phase_ms is then the wall interval of the build passes INSIDE probe_phase_ms, and
+                                    probe_phase_ms spans from the first probe-side pass to the end of the join            */
+    int reserved;
 } fj_timings;
 
 /* replaces: flash_join.initialize() / initialize_memory_system (hash_join.cpp:596, :639).
@@ -61,6 +65,9 @@ const char* fj_version(void);
  *                        ONE table for the whole build side in HBM, as the reference does in DRAM; 0 (default): they
  *                        run the same partitioned plan as the radix functions (identical results, 2-4x faster here)
  *                        and the HBM table is only the overflow fallback (env FJ_SCALAR_HBM_TABLE).
+ *   "overlap_relations" - 1 (default): one-shot partitioned joins run the two relations' partition passes on two streams
+ *                        (the join waits for both); 0: build relation first, then probe relation, one stream - the
+ *                        schedule under which build_phase_ms / probe_phase_ms are disjoint (env FJ_OVERLAP_RELATIONS).
  *   "persistent_min_items" - counting joins whose plan has at least this many (partition, probe slice) work items use
  *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
  * fj_get_option returns -1 for an unknown name. */

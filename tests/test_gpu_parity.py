@@ -28,16 +28,19 @@ def fj():
     return flash_join
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["scalar=planned", "scalar=hbm_table", "persistent_join"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "serial_relations"])
 def scalar_mode(request, fj):
     """Run a test under the dispatch variants of the native library: the hash_join* functions served by the partitioned
     plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); and every
-    partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it)."""
+    partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it); and the
+    two relations partitioned one after the other on one stream instead of beside each other on two (the default)."""
     fj.set_option("scalar_hbm_table", int(request.param == 1))
     fj.set_option("persistent_min_items", 0 if request.param == 2 else 8192)
+    fj.set_option("overlap_relations", 0 if request.param == 3 else 1)
     yield request.param
     fj.set_option("scalar_hbm_table", 0)
     fj.set_option("persistent_min_items", 8192)
+    fj.set_option("overlap_relations", 1)
 
 
 def _digest(oracle, k, v):
