@@ -404,23 +404,26 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                 for (int i = 0; i < 4; ++i) ok2[i] = __ballot((okm >> (4 * hgrp + i)) & 1u);
                 if (a.dbg_flags & 1u) { hitm[0] = __ballot((k2[0] ^ k2[1]) & 1ull); hitm[1] = hitm[2] = hitm[3] = 0; where[0] = where[1] = where[2] = where[3] = 0; }
                 else lds_probe<MAT, 4>(tkeys, ttags, k2, ok2, he, ovf, lane, hitm, where);
+                if (MAT) {      // ONE LDS cursor bump per wave for the four key slots; lanes ranked inside the ballots
+                    const u32 n0 = (u32)__popcll(hitm[0]), n1 = (u32)__popcll(hitm[1]), n2 = (u32)__popcll(hitm[2]), n3 = (u32)__popcll(hitm[3]);
+                    if (n0 + n1 + n2 + n3) {
+                        u32 wb = 0;
+                        if (lane == 0) wb = atomicAdd(&hdr->cursor, n0 + n1 + n2 + n3);
+                        wb = (u32)__builtin_amdgcn_readfirstlane((int)wb);
+                        const u32 off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u64 m = hitm[i];
-                    if (MAT) {  // one LDS cursor bump per wave and key slot, lanes ranked inside the ballot
-                        if (m) {
-                            u32 wb = 0;
-                            if (lane == 0) wb = atomicAdd(&hdr->cursor, (u32)__popcll(m));
-                            wb = __shfl(wb, 0, 64);
+                        for (int i = 0; i < 4; ++i) {
+                            const u64 m = hitm[i];
                             if ((m >> lane) & 1ull) {
-                                const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                                const u64 o = obase + wb + off[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
                                 a.out_keys[o] = k2[i];
                                 a.out_vals[o] = k2[i] == FJ_EMPTY_KEY ? hdr->empty_val : tvals[where[i]];
                             }
                         }
-                    } else {
-                        wave_hits += (u32)__popcll(m);       // scalar: the count never touches the VALU
                     }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wave_hits += (u32)__popcll(hitm[i]);   // scalar: the count never touches the VALU
                 }
             }
         }
