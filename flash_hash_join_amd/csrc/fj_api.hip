@@ -222,8 +222,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     cs.alloc = &c->d_sc->alloc[it.side * 4 + i];
     HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
     HIPCHK(hipMemsetAsync(cs.bchunks, 0, nb_out * 4, s));
-    HIPCHK(hipMemsetAsync(cs.alloc, 0, 4, s));
-    HIPCHK(hipMemsetAsync(&c->d_sc->seg_counter[it.side * 4 + i], 0, 4, s));
+    // (cs.alloc and this pass's segment counter are zero: clear_plan_scalars at the start of the join)
     it.cs = cs;
     return 0;
 }
@@ -290,6 +289,12 @@ int run_passes(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, hipStr
     return 0;
 }
 
+// result words + every pass's chunk allocator and segment counter, in one fill (each small memset is a ~5 us launch)
+int clear_plan_scalars(fj_ctx* c, hipStream_t s) {
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, owner_counts), s));
+    return 0;
+}
+
 int read_scalars(fj_ctx* c, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -342,6 +347,7 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
                 if (get_buf(c, W_ROWIDX, pd.nb * 8, &p)) return 1;
                 u64* rowidx = (u64*)p;
                 HIPCHK(fj_launch_iota(rowidx, pd.nb, s));
+                HIPCHK(hipMemsetAsync(&c->d_sc->alloc[0], 0, sizeof(c->d_sc->alloc) + sizeof(c->d_sc->seg_counter), s));   // the build side's passes run again
                 PassIter bit;
                 pass_init(bit, 0, true, pd.nb, make_plan(pd.nb, pd.top_bits), pd.top_bits);
                 if (run_passes(c, bit, pd.bk, rowidx, s, &pd.lds.build, nullptr)) return 1;
@@ -483,7 +489,7 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
     const Plan plan = make_plan(nb, top_bits);
     *lds_full = false;
     HIPCHK(hipEventRecord(c->ev[E_START], s));
-    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    if (clear_plan_scalars(c, s)) return 1;
     FjLdsJoinArgs ja{};
     PassIter bit, pit;
     // a counting join never looks at a value: its build side moves keys only (half the build-phase bytes)
@@ -698,7 +704,7 @@ int stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_bound, 
     st.top_bits = top_bits; st.np_bound = np_bound; st.nb_bound = nb_bound;
     st.p_appends_left = (u32)probe_appends; st.b_appends_left = (u32)build_appends;
     HIPCHK(hipEventRecord(c->ev[E_START], s));
-    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    if (clear_plan_scalars(c, s)) return 1;
     if (st.plan.npass > 0) {
         pass_init(st.bit, 0, false, std::max<size_t>(nb_bound, 1), st.plan, top_bits);     // count only: keys
         if (pass_prepare(c, st.bit, (u32)build_appends, s)) return 1;
@@ -890,7 +896,7 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
     hipStream_t s = (hipStream_t)stream;
     Plan plan; plan.bits = total_bits;
     plan_passes(plan, true);
-    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    if (clear_plan_scalars(c, s)) return 1;
     FjChunkSet cs{};
     PassIter dit;
     pass_init(dit, d_vals ? 0 : 1, d_vals != nullptr, n, plan, hash_top_bits);
