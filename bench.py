@@ -190,7 +190,10 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # N>1 with --warmup 0: one untimed priming step anyway, so that RCCL's communicator / channel set-up (seconds) is not
+    # what the first timed step measures
+    priming = 1 if (args.warmup == 0 and (world > 1 or force_dist)) else 0
+    for _ in range(args.warmup + priming):
         got = step(False)
         assert got == exp_total or os.environ.get("FJ_JOIN_ABLATE"), f"warmup count {got} != expected {exp_total}"
     sync()
@@ -300,6 +303,8 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
         except Exception as ex:      # the baseline never blocks the GPU measurement
             out["cpu_baseline"] = {"error": repr(ex)}
+    if priming:
+        out["priming_steps"] = priming
     if share_gpu:
         out["note"] = "FJ_BENCH_SHARE_GPU: ranks share cuda:0, gloo + host-staged collectives - a functional self-test, not a measurement"
     if world > 1 or force_dist:
