@@ -190,9 +190,9 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # N>1 with --warmup 0: one untimed priming step anyway, so that RCCL's communicator / channel set-up (seconds) is not
-    # what the first timed step measures
-    priming = 1 if (args.warmup == 0 and (world > 1 or force_dist)) else 0
+    # --warmup 0: one untimed priming step anyway, so that the workspace allocation (hipMalloc of ~20 GB of pools, ~0.5 s) and
+    # at N>1 RCCL's communicator / channel set-up (seconds) are not what the first timed step measures
+    priming = 1 if args.warmup == 0 else 0
     for _ in range(args.warmup + priming):
         got = step(False)
         assert got == exp_total or os.environ.get("FJ_JOIN_ABLATE"), f"warmup count {got} != expected {exp_total}"
