@@ -279,6 +279,17 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
             n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
             assert n == exp and k.numel() == exp
             assert bool(torch.all((v + 1) * M == k))
+        # messages capped at 1M rows: the shuffle moves every segment in several rounds (list all_to_all on views: the
+        # workaround for RCCL's > 4 GiB-per-peer defect), the replicate path gathers in bounded pieces
+        import flash_hash_join_amd.distributed as D
+        monkeypatch.setattr(D, "_MAX_ELEMS_PER_MESSAGE", 1 << 20)
+        for strategy in ("shuffle", "replicate"):
+            monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
+            t = {}
+            n, sec = distributed_join(bk, bv, pk, timings=t)
+            assert n == exp and (t["exchange_rounds"] > 1 or t["pieces"] >= 3)
+            n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
+            assert n == exp and k.numel() == exp and bool(torch.all((v + 1) * M == k))
     finally:
         dist.destroy_process_group()
 
