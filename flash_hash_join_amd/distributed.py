@@ -207,7 +207,13 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
         works[-1].wait()
     engine.stream_append(recvs[-1])
     t2 = time.perf_counter()
-    local_count = engine.stream_finish()
+    try:
+        local_count = engine.stream_finish()
+    except RuntimeError as ex:                   # a skewed partition overflows its LDS table: one-shot join with its HBM fallback
+        if "does not fit" not in str(ex):
+            raise
+        import torch
+        local_count = int(engine.local_join(bk_r, bv_r, torch.cat(recvs), False, False, 48, False)[0])
     tot = engine.counts_tensor([local_count])
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     engine.synchronize()
@@ -334,7 +340,16 @@ def _replicated_join(dist, group, engine, world, build_keys, build_values, probe
             keep.append(out)
             engine.stream_append_build(out)
         t1 = time.perf_counter()
-        local_count = engine.stream_finish()
+        try:
+            local_count = engine.stream_finish()
+        except RuntimeError as ex:
+            # a partition of the (skewed) build side does not fit its LDS table: the streamed join has no fallback of its
+            # own, the one-shot join does (HBM table); a counting join never reads the values, the keys stand in for them
+            if "does not fit" not in str(ex):
+                raise
+            import torch
+            bk_all = keep[0] if len(keep) == 1 else torch.cat(keep)
+            local_count = int(engine.local_join(bk_all, bk_all, probe_keys, False, bloom, 64, False)[0])
         res = None
         del keep
     tot = engine.counts_tensor([local_count])

@@ -279,6 +279,27 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
             n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
             assert n == exp and k.numel() == exp
             assert bool(torch.all((v + 1) * M == k))
+        # a build side whose keys all land in ONE partition: the streamed (replicate) join reports the overflow and the
+        # one-shot join's HBM-table fallback produces the count
+        def hash_w1(kk):
+            lo = (kk & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (kk >> np.uint64(32)).astype(np.uint32)
+            with np.errstate(over="ignore"):
+                x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+                x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+                x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+                x ^= x >> np.uint32(16)
+            return x
+        cand = np.arange(1, 400000, dtype=np.uint64)
+        skew = cand[(hash_w1(cand) >> np.uint32(27)) == 0][:9000]
+        sbk = torch.from_numpy(skew.view(np.int64)).cuda(); sbv = sbk + 1
+        spk = torch.from_numpy(np.concatenate([skew, cand[:50000]]).view(np.int64)).cuda()
+        sexp = int(np.isin(np.concatenate([skew, cand[:50000]]), skew).sum())
+        for strategy in ("replicate", "shuffle"):
+            monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
+            n, sec = distributed_join(sbk, sbv, spk)
+            assert n == sexp
+            if strategy == "replicate":                                  # (the shuffle consumes the top 16 hash bits for the
+                assert fj.last_timings()["path"] == 1                    #  owner: these keys spread over its partitions)
         # messages capped at 1M rows: the shuffle moves every segment in several rounds (list all_to_all on views: the
         # workaround for RCCL's > 4 GiB-per-peer defect), the replicate path gathers in bounded pieces
         import flash_hash_join_amd.distributed as D
