@@ -187,10 +187,12 @@ void pass_init(PassIter& it, int side, bool has_vals, size_t n, const Plan& plan
 }
 
 // workgroups for a launch over n rows: enough to fill the chip, but every (workgroup, bucket) pair ends in a
-// partial chunk, so keep >= ~64 rows per pair or the consumers drown in tiny chunks (measured: 186 us per join
-// item at B = 1M with 488 workgroups x 256 buckets)
+// partial chunk, so keep >= ~128 rows per pair or the consumers drown in tiny chunks (a join item fetches its build rows
+// 16 chunks at a time: at B = 1M, 61 workgroups x 256 buckets left 64-row chunks and four fetch rounds per table).
+// Swept on c2 (1M x 100M) and 1M x 10M: 64 rows per pair 0.858 / 0.349 ms, 128: 0.789 / 0.304, 256: 0.808 / 0.329,
+// 512: 0.872 / 0.427 (the pass itself slows down with fewer workgroups); c3 is not affected.
 u32 pass_groups(u64 chunks, u64 rows, u32 tile_chunks, u32 F) {
-    const u64 g64 = std::min<u64>(chunks / tile_chunks, rows / ((u64)F * 64));
+    const u64 g64 = std::min<u64>(chunks / tile_chunks, rows / ((u64)F * 128));
     return (u32)std::min<u64>(512, std::max<u64>(1, g64));
 }
 
