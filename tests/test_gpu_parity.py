@@ -573,7 +573,8 @@ def test_fuzz_against_oracle(fj, oracle, seed, scalar_mode):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (fn, seed, nb, npk, kind)
 
 
-@pytest.mark.parametrize("nb,dom,npk", [(3000, 700, 20000), (60000, 9000, 200000), (500000, 120000, 900000), (3000000, 1000000, 4000000)])
+@pytest.mark.parametrize("nb,dom,npk", [(3000, 700, 20000), (60000, 9000, 200000), (500000, 120000, 900000), (3000000, 1000000, 4000000),
+                                        (20_000_000, 6_000_000, 12_000_000)])      # 8192 partitions: the persistent counting kernel reports the duplicates
 def test_duplicate_build_keys_first_occurrence_wins(fj, oracle, nb, dom, npk, scalar_mode):
     """Duplicate build keys with DIFFERENT values: the radix/adaptive joins must emit the value of the FIRST occurrence
     (the reference's radix path: stable partition + insert_local, hash_join.cpp:125 / SURVEY App. B); the scalar path is
