@@ -1,10 +1,13 @@
 // fj_join.hip -- build + probe kernels for MI355X (gfx950).
 //
-// Per final radix partition (one workgroup per (partition, probe slice) work item), mirroring insert_local +
+// Per final radix partition -- work item = a tile of the partition's probe chunk list (several slices for few partitions
+// or a partition swollen by a hot key, each slice rebuilding the small table) --, mirroring insert_local +
 // probe_vectorized of the reference (hash_join.cpp:112-128, :153-182) inside _hash_join_radix_{count,materialize}
 // (:315-381, :498-534):
 //  * fj_count_join_kernel      : counting joins.  Cuckoo table of bare keys in LDS: a lookup is two independent 8-byte
-//    reads and two v_cmp_eq_u64, hit masks and the count live in SGPRs.
+//    reads and two v_cmp_eq_u64, hit masks and the count live in SGPRs.  One workgroup per item.
+//  * fj_count_join_persistent  : the same table and lookups for plans with many items: two resident workgroups per CU
+//    take items from a global counter and prefetch the next item's chunk lists and build keys.
 //  * fj_lds_join_kernel<MAT>   : materialising joins (a value must be fetched).  Open addressing with two candidate
 //    4-slot groups per key, one-byte tags, slot claims by a 32-bit LDS atomic, linear probing as the overflow path.
 //    Duplicate build keys: optional row-index dedup so the FIRST occurrence's value is emitted (hash_join.cpp:125).
