@@ -539,7 +539,12 @@ def test_stream_join_rejects_misuse(fj):
         eng.stream_append(pk)
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+# FJ_FUZZ_SEEDS="a-b" adds seeds for a longer campaign (the committed default stays at 24 seeds x 4 dispatch modes)
+_FUZZ_EXTRA = os.environ.get("FJ_FUZZ_SEEDS", "")
+_FUZZ_SEEDS = list(range(24)) + (list(range(int(_FUZZ_EXTRA.split("-")[0]), int(_FUZZ_EXTRA.split("-")[1]))) if "-" in _FUZZ_EXTRA else [])
+
+
+@pytest.mark.parametrize("seed", _FUZZ_SEEDS)
 def test_fuzz_against_oracle(fj, oracle, seed, scalar_mode):
     """Random sizes and key distributions (uniform, tiny domains with heavy duplication, sequential, skewed),
     duplicate build keys carrying equal values; every count function and the radix/scalar pair sets vs the oracle."""
