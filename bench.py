@@ -288,7 +288,9 @@ def main() -> None:
         "config": {"workload": f"{fn_name}: {nb_gpu} build x {np_gpu} probe int64 rows per GPU, {hit_bp / 100:.0f}% hit rate"
                                + (" (BASELINE configs[2])" if args.workload == "c3" and args.scale == 1.0 else ""),
                    "function": fn_name, "build_rows_total": nb_total, "probe_rows_total": np_total,
-                   "matches": exp_total, "parallelism": f"{strategy_seen[0]} x{world}" if (world > 1 or force_dist) else "single GPU"},
+                   "matches": exp_total, "bench_workload": args.workload,
+                   "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "overlap_relations", "persistent_min_items", "radix_threshold")},
+                   "parallelism": f"{strategy_seen[0]} x{world}" if (world > 1 or force_dist) else "single GPU"},
         "build_time_ms": round(build_ms, 3),
         "phases": phases,
         "roofline": roof,
