@@ -8,8 +8,12 @@ uniform-random int64 keys that are already resident in HBM when the timed region
 
   N = 1 : BASELINE.json configs[2], the configuration the metric's target is quoted on:
           hash_join_count_radix, 100M build x 1B probe rows, 50 % hit rate, one MI355X.
-  N > 1 : the same 100M x 1B rows PER GPU (weak scaling), block-distributed, joined with one RCCL
-          all-to-all per relation over xGMI (flash_hash_join_amd/distributed.py).
+  N > 1 : workload "c5" = BASELINE.json configs[4] cut into its per-GPU shards: 125M build x 1.25B probe rows
+          PER GPU (1B x 10B at N = 8; the same shard size at N = 2 and 4: weak scaling), block-distributed,
+          joined with the owner shuffle - an RCCL all-to-all per relation over xGMI
+          (flash_hash_join_amd/distributed.py).  `python bench.py --gpus N` without a torchrun environment
+          starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process (before
+          anything touches the GPU) and relays its output and exit code.
 
 value = probes processed by all ranks / wall time of the K timed steps (max over ranks), in
 G probes/s, end to end (build side included).  The probe-phase-only rate, the build time, the
@@ -43,6 +47,8 @@ WORKLOADS = {
     "c4_hbm_table_bloom": (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),   # literal one-table algorithm + bloom precheck
     "c3_mat": (100_000_000, 1_000_000_000, 5000, "hash_join_radix"),
     "small": (1_000_000, 10_000_000, 5000, "hash_join_count_radix"),
+    # BASELINE configs[4] (1B x 10B over 8 GPUs) as its per-GPU shard; the default for --gpus > 1
+    "c5": (125_000_000, 1_250_000_000, 5000, "hash_join_count_radix"),
     # what ONE rank joins locally under the replicate-build multi-GPU strategy at N = 2, 4, 8 (c3 rows per GPU)
     "rep2": (200_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
     "rep4": (400_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
@@ -57,6 +63,47 @@ def _flush_c_stdio() -> None:
     except Exception:
         pass
     sys.stdout.flush()
+
+
+def _self_launch(ngpus: int) -> int:
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    return proc.wait()
+
+
+def _host_cpu_facts() -> dict:
+    """CPU model and the affinity mask of this process (BASELINE.md section 4 asks for both beside the core count)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = []
+    ranges, i = [], 0
+    while i < len(aff):                                  # compact "0-63,128-191" form
+        j = i
+        while j + 1 < len(aff) and aff[j + 1] == aff[j] + 1:
+            j += 1
+        ranges.append(str(aff[i]) if i == j else f"{aff[i]}-{aff[j]}")
+        i = j + 1
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cpus": len(aff), "affinity_mask": ",".join(ranges)}
 
 
 def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int) -> dict:
@@ -82,7 +129,7 @@ def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int) -> dict:
     return {"value": round(sample_p / best / 1e9, 5), "unit": "Gprobes/s", "cores": int(cores), "kind": "port",
             "sample": f"adaptive_join_count (radix path) restatement, {sample_b} build x {sample_p} probe rows, "
                       f"{hit_bp / 100:.0f}% hits, best of <=3, core_duration_sec={best:.3f}s",
-            "hw_crc32c": bool(O.lib().fjo_uses_hw_crc())}
+            "hw_crc32c": bool(O.lib().fjo_uses_hw_crc()), **_host_cpu_facts()}
 
 
 def main() -> None:
@@ -90,10 +137,19 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c3 (BASELINE configs[2]) at --gpus 1, c5 (configs[4], 125M x 1.25B rows per GPU) at --gpus > 1")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c3" if args.gpus == 1 else "c5"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched the way the driver launches the 1-GPU bench (`python bench.py --gpus N ...`): become the launcher.
+        # Nothing in this process has touched the GPU (torch is not even imported yet); the ranks run in a child
+        # process tree, their output and exit code are relayed.
+        sys.exit(_self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -286,7 +342,9 @@ def main() -> None:
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int64", "data": "synthetic",
         "config": {"workload": f"{fn_name}: {nb_gpu} build x {np_gpu} probe int64 rows per GPU, {hit_bp / 100:.0f}% hit rate"
-                               + (" (BASELINE configs[2])" if args.workload == "c3" and args.scale == 1.0 else ""),
+                               + (" (BASELINE configs[2])" if args.workload == "c3" and args.scale == 1.0 else "")
+                               + (f" (BASELINE configs[4] cut into per-GPU shards: {nb_total} x {np_total} rows over {world} GPUs"
+                                  + (" = the full 1B x 10B)" if world == 8 else ")") if args.workload == "c5" and args.scale == 1.0 else ""),
                    "function": fn_name, "build_rows_total": nb_total, "probe_rows_total": np_total,
                    "matches": exp_total, "bench_workload": args.workload,
                    "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "overlap_relations", "persistent_min_items", "radix_threshold")},

@@ -147,3 +147,31 @@ def test_multi_gpu_strategy_model():
     # passes: none up to 4096 rows, one up to 2^8 partitions, two up to 18 bits (512-bucket passes above 16), then three
     assert [D._plan_passes(n) for n in (1, 4096, 4097, 1 << 20, (1 << 20) + 1, 100_000_000, 268_435_456, 268_435_457,
                                         800_000_000, 1 << 30, (1 << 30) + 1)] == [0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 3]
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_several_gpus(monkeypatch):
+    """`python bench.py --gpus N` (the driver's command line) outside a torchrun environment must start
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before touching the GPU and
+    relay its exit code; the default multi-GPU workload is c5 (BASELINE configs[4]: 125M x 1.25B rows per GPU)."""
+    import subprocess
+    import bench
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, cwd=None):
+            seen["cmd"], seen["env"] = cmd, env
+
+        def wait(self):
+            return 7
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert "127.0.0.1" in cmd and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert bench.WORKLOADS["c5"][:2] == (125_000_000, 1_250_000_000)
