@@ -40,8 +40,9 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     u64 empty_val;
     u32 err;
     u32 flags;
-    u32 alloc[8];                      // [side*4 + pass] chunk allocators
+    u32 alloc[8];                      // [side*4 + pass] chunk allocators ([side*4 + 3]: the bloom stage's output pool)
     u32 seg_counter[8];                // [side*4 + pass] segment ids
+    unsigned long long bloom_survivors;   // probe keys that passed the bloom precheck
     unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
     u32 next_item;                     // work counter of the persistent join kernel
 };
@@ -56,7 +57,7 @@ enum Slot {
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
 
-enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_SB0, E_SB1, E_FORK, E_PK0, E_NEV = E_PK0 + 8 };
+enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_SB0, E_SB1, E_FORK, E_BF0, E_BF1, E_PK0, E_NEV = E_PK0 + 8 };
 
 struct Pending {
     bool valid = false;
@@ -70,14 +71,21 @@ struct Pending {
     const u64* bk = nullptr; const u64* bv = nullptr; size_t nb = 0; int top_bits = 64;
 };
 
-struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; };
+// bloom_level: 0 = no bloom precheck; L >= 1 = the probe side's level-L chunk set (output of its L-th pass) is filtered
+// against per-bucket Bloom filters of the build side's level L before pass L+1 (csrc/fj_bloom.hip)
+struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; int bloom_level = 0; };
 
 // iteration state over the plan's passes for one relation (see pass_prepare / pass_launch / pass_complete)
 struct PassIter {
     int side = 0; bool has_vals = false; size_t n = 0; Plan plan; int used = 64; u32 parents = 1; u64 lbound = 0;
     u32 tile_chunks = 16; int i = 0;
-    FjChunkSet prev{}; bool have_prev = false; const uint4* tiles = nullptr; const u32* ntiles = nullptr;
+    FjChunkSet prev{}; bool have_prev = false; const uint4* tiles = nullptr; const u32* ntiles = nullptr; const u32* toff = nullptr;
     FjChunkSet cs{}; u32 Gmax = 1, F = 1, appends = 1;
+    int slot = 0, cs_base = 0;           // ping-pong workspace slot of the next output level / base index of cs's buffers
+    // bloom precheck (probe side): run the filter stage once `bloom_level` passes are complete, against bloom_build
+    bool bloom_done = false; const FjChunkSet* bloom_build = nullptr; bool bloom_wait_build = false;
+    // build side: keep a copy of the level the probe side's filter will read
+    int save_level = 0; FjChunkSet saved{};
 };
 
 }  // namespace
@@ -104,6 +112,7 @@ struct fj_ctx {
     Pending pend;
     StreamState st;
     size_t ws_bytes = 0;
+    u32 num_cus = 256;
 };
 
 namespace {
@@ -122,8 +131,11 @@ namespace {
 //                      per probe in HBM -- more traffic than the 40 B per probe the two streaming passes + LDS join
 //                      move -- so on this machine "scalar" is the slower way to the same result at every size.
 struct Options {
-    size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; int overlap_relations;
+    size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; int overlap_relations; u32 plan_target_keys;
     Options() {
+        const char* pt = getenv("FJ_PLAN_TARGET_KEYS");
+        plan_target_keys = pt ? (u32)strtoul(pt, nullptr, 10) : FJ_PART_TARGET_KEYS;
+        if (plan_target_keys < 16 || plan_target_keys > FJ_PART_TARGET_KEYS) plan_target_keys = FJ_PART_TARGET_KEYS;
         const char* th = getenv("FJ_RADIX_THRESHOLD");
         radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)0;
         const char* sg = getenv("FJ_SCALAR_HBM_TABLE");
@@ -161,10 +173,11 @@ void plan_passes(Plan& p, bool extra_first) {
     }
 }
 
-Plan make_plan(size_t nb, int top_bits) {
+Plan make_plan(size_t nb, int top_bits, bool want_bloom = false) {
     Plan p;
-    if (nb > FJ_PART_TARGET_KEYS) {
-        u64 parts = (nb + FJ_PART_TARGET_KEYS - 1) / FJ_PART_TARGET_KEYS;
+    const u64 target = options().plan_target_keys;            // 4096 in production; smaller values make small inputs take deep plans (tests)
+    if (nb > target) {
+        u64 parts = (nb + target - 1) / target;
         while ((1ull << p.bits) < parts) ++p.bits;
     }
     if (p.bits > 0 && p.bits < 5) p.bits = 5;              // a pass with a tiny fan-out serialises on its per-bucket threads
@@ -173,6 +186,17 @@ Plan make_plan(size_t nb, int top_bits) {
     // lists (per-bucket carry work grows with the fan-out), and fewer children per parent leave fewer partial chunks:
     // 8+7 instead of 7+8 bits at c3 is 1.3 % faster end to end (A/B on one box)
     plan_passes(p, true);
+    if (want_bloom && p.npass >= 2) {
+        // The precheck filters the input of the LAST pass (level npass-1) with an LDS-resident filter per bucket of that
+        // level: it needs <= FJ_BLOOM_MAX_KEYS build keys per bucket, and is strong below FJ_BLOOM_GOOD_KEYS.  A two-pass
+        // plan moves bits into its first pass (up to 9: the 512-bucket kernel) to get there; the final partitions are the
+        // same either way (digits are consecutive bits of hash word 1).
+        if (p.npass == 2)
+            while (p.fan_log[0] < FJ_MAX_FAN_LOG && p.fan_log[1] > 4 && (nb >> p.fan_log[0]) > FJ_BLOOM_GOOD_KEYS) { ++p.fan_log[0]; --p.fan_log[1]; }
+        int lvl_bits = 0;
+        for (int i = 0; i + 1 < p.npass; ++i) lvl_bits += p.fan_log[i];
+        if ((nb >> lvl_bits) <= FJ_BLOOM_MAX_KEYS) p.bloom_level = p.npass - 1;
+    }
     return p;
 }
 
@@ -210,7 +234,8 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
         return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
     FjChunkSet cs{};
     cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0; cs.fan_mask = F - 1; cs.max_segs = (G + parents + 2) * it.appends;
-    const int base = it.side * W_SIDE_STRIDE + (i & 1) * W_KINDS;
+    const int base = it.side * W_SIDE_STRIDE + (it.slot & 1) * W_KINDS;
+    it.cs_base = base;
     void* p;
     if (get_buf(c, base + W_POOL_K, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.keys = (u64*)p;
     cs.vals = nullptr;
@@ -256,29 +281,83 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     return 0;
 }
 
+// tile table of it.cs (whose buffers live at it.cs_base) for a consumer that reads `tc` chunks per tile
+int level_tile_table(fj_ctx* c, PassIter& it, u32 tc, hipStream_t s) {
+    const FjChunkSet& cs = it.cs;
+    const u64 max_tiles = it.lbound / tc + cs.nb + 1;
+    void* p;
+    if (get_buf(c, it.cs_base + W_TOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
+    if (get_buf(c, it.cs_base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1;
+    HIPCHK(fj_launch_tile_table(cs, tc, toff, (uint4*)p, (u32)max_tiles, s));
+    it.tiles = (const uint4*)p; it.ntiles = toff + cs.nb; it.toff = toff;
+    return 0;
+}
+
+bool bloom_stage_follows(const PassIter& it, int level) { return it.plan.bloom_level == level && it.bloom_build && !it.bloom_done; }
+
 int pass_complete(fj_ctx* c, PassIter& it, hipStream_t s) {
     const FjChunkSet& cs = it.cs;
     HIPCHK(fj_launch_group(cs, s));
     it.lbound = it.n / FJ_CHUNK + 1 + (u64)(it.Gmax + it.parents) * it.F * it.appends;
-    if (it.i + 1 < it.plan.npass) {           // tile table for the next pass over this level
-        const int base = it.side * W_SIDE_STRIDE + (it.i & 1) * W_KINDS;
-        const u32 tc = fj_partition_tile_chunks((u32)it.plan.fan_log[it.i + 1], it.has_vals);   // tiles of the kernel that will read this level
-        const u64 max_tiles = it.lbound / tc + cs.nb + 1;
-        void* p;
-        if (get_buf(c, base + W_TOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
-        if (get_buf(c, base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1;
-        HIPCHK(fj_launch_tile_table(cs, tc, toff, (uint4*)p, (u32)max_tiles, s));
-        it.tiles = (const uint4*)p; it.ntiles = toff + cs.nb;
+    if (bloom_stage_follows(it, it.i + 1)) {  // the bloom stage reads this level next
+        if (level_tile_table(c, it, fj_bloom_tile_chunks(), s)) return 1;
+    } else if (it.i + 1 < it.plan.npass) {    // tile table for the next pass over this level
+        if (level_tile_table(c, it, fj_partition_tile_chunks((u32)it.plan.fan_log[it.i + 1], it.has_vals), s)) return 1;
     }
     it.prev = cs; it.have_prev = true;
     it.parents = cs.nb;
-    ++it.i;
+    ++it.i; ++it.slot;
+    if (it.save_level == it.i) it.saved = cs;
+    return 0;
+}
+
+// Bloom precheck between two probe-side passes: it.prev (level bloom_level, tile table built for the filter kernel) ->
+// a chunk set with the same buckets that holds only the keys that may be in the build side (csrc/fj_bloom.hip).
+int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
+    const FjChunkSet in = it.prev;
+    const u32 G = c->num_cus;
+    const u32 nw = fj_bloom_waves_per_group();
+    const u64 max_segs = (u64)nw * ((u64)in.nb + G) + 16;
+    const u64 cap64 = it.n / FJ_CHUNK + 1 + max_segs + (u64)16 * nw * G;
+    if (cap64 >= (1ull << 24)) return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
+    FjChunkSet cs{};
+    cs.cap = (u32)cap64; cs.nb = in.nb; cs.n_flat = 0; cs.fan_mask = 0; cs.max_segs = (u32)max_segs;
+    const int base = it.side * W_SIDE_STRIDE + (it.slot & 1) * W_KINDS;
+    void* p;
+    if (get_buf(c, base + W_POOL_K, cap64 * FJ_CHUNK * 8, &p)) return 1; cs.keys = (u64*)p;
+    cs.vals = nullptr;
+    if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
+    if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
+    if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
+    if (get_buf(c, base + W_BCHUNKS, (size_t)cs.nb * 4, &p)) return 1; cs.bchunks = (u32*)p;
+    if (get_buf(c, base + W_BOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
+    if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * 4, &p)) return 1; cs.seg_off = (u32*)p;
+    cs.alloc = &c->d_sc->alloc[it.side * 4 + 3];
+    HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
+    HIPCHK(hipMemsetAsync(cs.bchunks, 0, (size_t)cs.nb * 4, s));
+    FjBloomArgs a{};
+    a.build = *it.bloom_build; a.probe = in; a.tiles = it.tiles; a.toff = it.toff; a.ntiles = it.ntiles;
+    a.out_keys = cs.keys; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off; a.bchunks = cs.bchunks;
+    a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + 3];
+    a.cap_chunks = cs.cap; a.max_segs = cs.max_segs; a.err = &c->d_sc->err; a.survivors = &c->d_sc->bloom_survivors;
+    if (it.bloom_wait_build) HIPCHK(hipStreamWaitEvent(s, c->ev[E_BUILD], 0));      // the build relation is partitioned on the side stream
+    HIPCHK(hipEventRecord(c->ev[E_BF0], s));
+    HIPCHK(fj_launch_bloom_filter(a, G, s));
+    HIPCHK(hipEventRecord(c->ev[E_BF1], s));
+    it.cs = cs; it.cs_base = base;
+    HIPCHK(fj_launch_group(cs, s));
+    it.lbound = it.n / FJ_CHUNK + 1 + max_segs;
+    if (level_tile_table(c, it, fj_partition_tile_chunks((u32)it.plan.fan_log[it.i], it.has_vals), s)) return 1;
+    it.prev = cs;
+    ++it.slot;
+    it.bloom_done = true;
     return 0;
 }
 
 // run every remaining pass of `it` (input of pass 0: the flat arrays); `out` describes the final level
 int run_passes(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, hipStream_t s, FjChunkSet* out, int* ev_cursor) {
     while (it.i < it.plan.npass) {
+        if (bloom_stage_follows(it, it.i) && bloom_stage(c, it, s)) return 1;
         if (pass_prepare(c, it, 1, s)) return 1;
         if (pass_launch(c, it, keys, vals, it.n, s, ev_cursor)) return 1;
         if (pass_complete(c, it, s)) return 1;
@@ -475,6 +554,8 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     t->total_ms = ev_ms(c, E_START, E_JOIN);
     t->overlapped = overlapped ? 1 : 0;
     for (int i = 0; i < evc && i < 4; ++i) t->probe_part_kernel_ms[i] = ev_ms(c, E_PK0 + 2 * i, E_PK0 + 2 * i + 1);
+    t->bloom_level = plan.bloom_level;
+    if (plan.bloom_level > 0) { t->filter_ms = ev_ms(c, E_BF0, E_BF1); t->filter_survivors = c->h_sc->bloom_survivors; }
     if (c->h_sc->err & FJ_ERR_LDS_FULL) { *lds_full = true; return 0; }
     *out_count = c->h_sc->total;
     c->pend.valid = false;
@@ -486,9 +567,9 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
 }
 
 // radix path: partition both relations, then one LDS-table join per final partition
-int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
+int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
                hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
-    const Plan plan = make_plan(nb, top_bits);
+    const Plan plan = make_plan(nb, top_bits, bloom != 0);
     *lds_full = false;
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     if (clear_plan_scalars(c, s)) return 1;
@@ -499,7 +580,20 @@ int join_radix(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t 
     int evc = 0;
     pass_init(pit, 1, false, np, plan, top_bits);
     const bool overlap = options().overlap_relations != 0;
-    if (overlap) {
+    if (plan.bloom_level > 0) {
+        // bloom precheck: the probe side's level `bloom_level` is filtered against the build side's same level
+        bit.save_level = plan.bloom_level; pit.bloom_build = &bit.saved; pit.bloom_wait_build = overlap;
+    }
+    if (overlap && plan.bloom_level > 0) {
+        // as below, but the build relation is enqueued first: the filter stage needs its level descriptor on the host
+        HIPCHK(hipEventRecord(c->ev[E_FORK], s));
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev[E_FORK], 0));
+        if (run_passes(c, bit, bk, materialize ? bv : nullptr, c->side, &ja.build, nullptr)) return 1;
+        HIPCHK(hipEventRecord(c->ev[E_BUILD], c->side));
+        if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
+        HIPCHK(hipStreamWaitEvent(s, c->ev[E_BUILD], 0));
+        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+    } else if (overlap) {
         // The two relations are partitioned on two streams: their passes do not depend on each other, and the small
         // bookkeeping kernels between the passes of one relation (scans, list build, tile table: ~0.25 ms during which
         // HBM idles) run while the other relation's pass streams (c3: 9.42 -> 9.20 ms).  The join waits for both.
@@ -537,6 +631,7 @@ int fj_set_option(const char* name, long long value) {
     if (!strcmp(name, "radix_threshold")) { if (value < 0) return set_err("fj_set_option: radix_threshold must be >= 0"); options().radix_threshold = (size_t)value; return 0; }
     if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
     if (!strcmp(name, "overlap_relations")) { options().overlap_relations = value != 0; return 0; }
+    if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); options().plan_target_keys = (u32)value; return 0; }
     if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
     return set_err("fj_set_option: unknown option '%s'", name);
 }
@@ -546,6 +641,7 @@ long long fj_get_option(const char* name) {
     if (name && !strcmp(name, "scalar_hbm_table")) return options().scalar_hbm_table;
     if (name && !strcmp(name, "persistent_min_items")) return options().persistent_min_items;
     if (name && !strcmp(name, "overlap_relations")) return options().overlap_relations;
+    if (name && !strcmp(name, "plan_target_keys")) return options().plan_target_keys;
     set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
     return -1;
 }
@@ -570,6 +666,7 @@ fj_ctx* fj_ctx_create(int device) {
     if (hipSetDevice(device) != hipSuccess) { set_err("fj_ctx_create: hipSetDevice(%d) failed", device); return nullptr; }
     fj_ctx* c = new fj_ctx();
     c->device = device;
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->num_cus = (u32)ncu; }
     bool ok = hipMalloc((void**)&c->d_sc, sizeof(Scalars)) == hipSuccess &&
               hipHostMalloc((void**)&c->h_sc, sizeof(Scalars), hipHostMallocDefault) == hipSuccess &&
               hipMemset(c->d_sc, 0, sizeof(Scalars)) == hipSuccess;
@@ -613,7 +710,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
         count = 0;
     } else if (use_radix) {
         bool lds_full = false;
-        if (join_radix(c, materialize, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count, &lds_full)) return 1;
+        if (join_radix(c, materialize, bloom, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count, &lds_full)) return 1;
         if (lds_full) {
             fj_timings t2; memset(&t2, 0, sizeof t2);
             if (join_global(c, bloom, materialize, d_bk, d_bv, nb, d_pk, np, s, &t2, &count)) return 1;

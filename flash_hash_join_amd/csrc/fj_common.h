@@ -35,6 +35,13 @@ static inline unsigned fj_slab_for(unsigned fan) { return fan > 256u ? 2u * FJ_S
 #define FJ_LDS_GROUP 4u
 #define FJ_PART_TARGET_KEYS 4096u               // average build keys per final partition (load <= 0.5)
 
+// Bloom precheck of the partitioned join (csrc/fj_bloom.hip): an LDS-resident blocked Bloom filter over one bucket of an
+// intermediate partition level, 64-bit blocks, 4 bits per key.  144 KiB of the CU's 160 KiB.
+#define FJ_BLOOM_BLOCKS 18432u
+#define FJ_BLOOM_BITS (FJ_BLOOM_BLOCKS * 64u)
+#define FJ_BLOOM_MAX_KEYS 400000u                // build keys per filtered bucket above which the filter is not worth running (< 3 bits per key)
+#define FJ_BLOOM_GOOD_KEYS 215000u               // ... below which it is strong (>= 5.5 bits per key): the plan widens its first pass to get here
+
 // Global (HBM / Infinity-Cache resident) table for the non-partitioned path: groups of 8 keys
 // = one 64-B sector.
 #define FJ_GT_GROUP 8u

@@ -63,6 +63,26 @@ hipError_t fj_launch_group(const FjChunkSet& cs, hipStream_t s);
 hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, hipStream_t s);
 hipError_t fj_launch_scan_u32_to_u64(const u32* in, u64* out, u32 n, hipStream_t s);
 
+// ---- bloom precheck between two probe-side passes (csrc/fj_bloom.hip) ----------------------------
+struct FjBloomArgs {
+    FjChunkSet build;            // build relation at the filtered level: keys, list, boff
+    FjChunkSet probe;            // probe relation at the same level: keys, list, nb
+    const uint4* tiles;          // tile table over the probe chunk lists (tiles of fj_bloom_tile_chunks() chunks)
+    const u32* toff;             // [nb+1] first tile of every bucket; toff[nb] = number of tiles
+    const u32* ntiles;           // == toff + nb
+    // output chunk pool: same bucket structure, survivors only (a level with fan-out 1: seg_off[segment])
+    u64* out_keys; u32* out_dir; u64* out_rel; u32* seg_off; u32* bchunks; u32* alloc; u32* seg_counter;
+    u32 cap_chunks, max_segs;
+    u32* err;
+    unsigned long long* survivors;   // device scalar: probe keys that passed
+};
+u32 fj_bloom_tile_chunks();
+u32 fj_bloom_waves_per_group();
+hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, hipStream_t s);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
+hipError_t fj_set_max_lds_once(const void* fn, u32 bytes);
+
 // ---- joins ------------------------------------------------------------------------------------
 struct FjLdsJoinArgs {
     FjChunkSet build, probe;     // final-level chunk sets (same nb), or flat arrays (list == nullptr)

@@ -1148,7 +1148,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
     if (materialize) {
         const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
         auto kern = (a.build.list && a.probe.list) ? fj_lds_join_kernel<true, 1024, true> : fj_lds_join_kernel<true, 1024, false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     } else {
@@ -1159,7 +1159,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         if (lists && next_item && nb >= persistent_min_items && !a.dbg && !a.dbg_flags) {
             const u32 ldsp = sizeof(CkHdr) + S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
             auto pk = fj_count_join_persistent<512>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+            hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
             if (e != hipSuccess) return e;
             e = hipMemsetAsync(next_item, 0, 4, s);
             if (e != hipSuccess) return e;
@@ -1168,7 +1168,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
             return hipGetLastError();
         }
         auto kern = lists ? fj_count_join_kernel<512, true> : fj_count_join_kernel<512, false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a);
     }

@@ -20,6 +20,8 @@
 // Algorithmic HBM bytes per key and pass: 8 read + 8 written (keys only), 16 + 16 with values.
 #include "fj_internal.h"
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -537,7 +539,7 @@ hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
     const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64);
     auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, s, a);
     return hipGetLastError();
@@ -559,6 +561,26 @@ hipError_t launch_part2(const FjPartArgs& a, int line_log, u32 grid, hipStream_t
 }
 
 }  // namespace
+
+hipError_t fj_set_max_lds_once(const void* fn, u32 bytes) {
+    struct Seen { const void* fn; int dev; u32 bytes; };
+    static std::mutex mu;
+    static std::vector<Seen> seen;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    for (Seen& x : seen)
+        if (x.fn == fn && x.dev == dev) {
+            if (x.bytes >= bytes) return hipSuccess;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) x.bytes = bytes;
+            return e;
+        }
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) seen.push_back({fn, dev, bytes});
+    return e;
+}
 
 u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
     const u32 F = 1u << fan_log;

@@ -49,6 +49,11 @@ typedef struct fj_timings {
                                     build_phase_ms is then the wall interval of the build passes INSIDE probe_phase_ms, and
                                     probe_phase_ms spans from the first probe-side pass to the end of the join            */
     int reserved;
+    /* bloom precheck of the partitioned plan (the *_bloom functions): */
+    double filter_ms;            /* the filter kernel between the probe side's passes (part of probe_phase_ms)              */
+    uint64_t filter_survivors;   /* probe keys that passed it (hits + false positives); 0 when bloom_level == 0             */
+    int bloom_level;             /* 0: no precheck ran; L: the probe side was filtered after its L-th partition pass         */
+    int reserved2;
 } fj_timings;
 
 /* replaces: flash_join.initialize() / initialize_memory_system (hash_join.cpp:596, :639).
@@ -70,6 +75,9 @@ const char* fj_version(void);
  *                        schedule under which build_phase_ms / probe_phase_ms are disjoint (env FJ_OVERLAP_RELATIONS).
  *   "persistent_min_items" - counting joins whose plan has at least this many (partition, probe slice) work items use
  *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
+ *   "plan_target_keys" - average build keys per final partition the plan aims for (default and maximum 4096 = half an LDS
+ *                        table; env FJ_PLAN_TARGET_KEYS).  A testing knob: small values make small inputs take the deep
+ *                        (two- and three-pass, bloom-filtered) plans that production only uses for >1M-row build sides.
  * fj_get_option returns -1 for an unknown name. */
 int fj_set_option(const char* name, long long value);
 long long fj_get_option(const char* name);

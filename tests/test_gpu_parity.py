@@ -28,12 +28,16 @@ def fj():
     return flash_join
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "serial_relations"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "serial_relations", "deep_plans"])
 def scalar_mode(request, fj):
     """Run a test under the dispatch variants of the native library: the hash_join* functions served by the partitioned
     plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); and every
     partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it); and the
-    two relations partitioned one after the other on one stream instead of beside each other on two (the default)."""
+    two relations partitioned one after the other on one stream instead of beside each other on two (the default); and
+    "deep_plans": 32 build keys per final partition instead of 4096, so that the small inputs of these tests run the two-
+    and three-pass plans -- and, in the *_bloom functions, the bloom precheck between the probe side's passes -- that
+    production only takes for build sides above a million rows."""
+    fj.set_option("plan_target_keys", 32 if request.param == 4 else 4096)
     fj.set_option("scalar_hbm_table", int(request.param == 1))
     fj.set_option("persistent_min_items", 0 if request.param == 2 else 8192)
     fj.set_option("overlap_relations", 0 if request.param == 3 else 1)
@@ -41,6 +45,7 @@ def scalar_mode(request, fj):
     fj.set_option("scalar_hbm_table", 0)
     fj.set_option("persistent_min_items", 8192)
     fj.set_option("overlap_relations", 1)
+    fj.set_option("plan_target_keys", 4096)
 
 
 def _digest(oracle, k, v):
@@ -377,8 +382,38 @@ def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn, hbm):
     n2, _ = getattr(fj, fn)(dbk, dbv, dpk)                                         # idempotent, workspace reuse
     assert n2 == exp
     assert fj.last_timings()["path"] == (1 if hbm else 0)
+    if "bloom" in fn and not hbm and nb >= 100_000_000:                           # config 4: the precheck ran and pruned the misses
+        t = fj.last_timings()
+        assert t["bloom_level"] == 1 and exp <= t["filter_survivors"] <= exp + 0.2 * (npk - exp), t
     fj.set_option("scalar_hbm_table", 0)
     del dbk, dbv, dpk
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("hit_bp", [0, 500, 5000, 10000])
+@pytest.mark.parametrize("nb,npk", [(5_000_000, 40_000_000), (30_000_000, 60_000_000)])
+def test_bloom_precheck_prunes_misses_and_keeps_every_hit(fj, nb, npk, hit_bp):
+    """The *_bloom functions run a bloom precheck between the probe side's two partition passes (an LDS-resident filter per
+    level-1 bucket, built from the build side's same bucket): counts stay exact at 0 / 5 / 50 / 100 % hits (no false
+    negatives), the keys that pass are the hits plus a bounded share of the misses, and the non-bloom functions do not
+    run it (role of hash_join.cpp:165, :183-189)."""
+    import torch
+    from flash_hash_join_amd import datagen
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=21, hit_bp=hit_bp)
+    assert fj.hash_join_count_radix(dbk, dbv, dpk)[0] == exp
+    assert fj.last_timings()["bloom_level"] == 0
+    for fn in ("hash_join_count_radix_bloom", "hash_join_count_bloom", "adaptive_join_count_bloom"):
+        n, _ = getattr(fj, fn)(dbk, dbv, dpk)
+        t = fj.last_timings()
+        assert n == exp, (fn, hit_bp)
+        assert t["bloom_level"] == 1 and t["passes"] == 2 and t["fell_back"] == 0, (fn, t)
+        assert exp <= t["filter_survivors"] <= exp + 0.25 * (npk - exp) + 1000, (fn, hit_bp, t["filter_survivors"], exp)
+    n, _, k, v = fj.hash_join_radix_bloom(dbk, dbv, dpk, return_arrays=True)
+    assert n == exp and k.numel() == exp and fj.last_timings()["bloom_level"] == 1
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+    assert bool(torch.all((v + 1) * M == k))
+    del dbk, dbv, dpk, k, v
     torch.cuda.empty_cache()
 
 
