@@ -210,7 +210,7 @@ def main() -> None:
 
     units_per_launch = [float(np_gpu)]
     strategy_seen = ["single GPU"]
-    part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": []}
+    part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": [], "filter_ms": []}
     dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
 
     def step(record: bool) -> int:
@@ -239,6 +239,7 @@ def main() -> None:
                 part_ms.append(lt["probe_part_kernel_ms"][i]); part_launches += 1
             phase["build_ms"].append(lt["build_phase_ms"]); phase["probe_ms"].append(lt["probe_phase_ms"])
             phase["join_ms"].append(lt["join_ms"]); phase["total_ms"].append(lt["total_ms"]); phase["emit_ms"].append(lt["emit_ms"])
+            phase["filter_ms"].append(lt["filter_ms"])
         return int(res[0])
 
     def sync():
@@ -326,6 +327,8 @@ def main() -> None:
         "k_radix_passes": k, "radix_bits": lt["radix_bits"], "partitions": lt["partitions"], "path": lt["path"],
         "build_phase_ms": round(build_ms, 3), "probe_phase_ms": round(probe_ms, 3), "join_kernel_ms": round(mean(phase["join_ms"]), 3),
         "device_total_ms": round(mean(phase["total_ms"]), 3),
+        "bloom_level": lt["bloom_level"], "bloom_filter_kernel_ms": round(mean(phase["filter_ms"]), 3) if lt["bloom_level"] else None,
+        "bloom_survivors": lt["filter_survivors"] if lt["bloom_level"] else None,
         "phase_schedule": phase_schedule, "device_total_serial_ms": round(serial_total_ms, 3) if serial_total_ms else None,
         "probe_phase_gprobes_per_s": round(np_gpu / (probe_ms * 1e-3) / 1e9, 2) if probe_ms else None,
         "probe_phase_algorithmic_bytes": (24 * k + 8) * np_gpu,

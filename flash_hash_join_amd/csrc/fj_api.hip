@@ -132,7 +132,11 @@ namespace {
 //                      move -- so on this machine "scalar" is the slower way to the same result at every size.
 struct Options {
     size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; int overlap_relations; u32 plan_target_keys;
+    int bloom_variant, bloom_overlap;
     Options() {
+        bloom_overlap = getenv("FJ_BLOOM_OVERLAP") ? atoi(getenv("FJ_BLOOM_OVERLAP")) : 0;
+        const char* bvr = getenv("FJ_BLOOM_VARIANT");
+        bloom_variant = bvr ? atoi(bvr) : 0;
         const char* pt = getenv("FJ_PLAN_TARGET_KEYS");
         plan_target_keys = pt ? (u32)strtoul(pt, nullptr, 10) : FJ_PART_TARGET_KEYS;
         if (plan_target_keys < 16 || plan_target_keys > FJ_PART_TARGET_KEYS) plan_target_keys = FJ_PART_TARGET_KEYS;
@@ -318,7 +322,7 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     const u32 G = c->num_cus;
     const u32 nw = fj_bloom_waves_per_group();
     const u64 max_segs = (u64)nw * ((u64)in.nb + G) + 16;
-    const u64 cap64 = it.n / FJ_CHUNK + 1 + max_segs + (u64)16 * nw * G;
+    const u64 cap64 = it.n / FJ_CHUNK + 1 + max_segs + (u64)fj_bloom_slab_chunks() * nw * G;
     if (cap64 >= (1ull << 24)) return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
     FjChunkSet cs{};
     cs.cap = (u32)cap64; cs.nb = in.nb; cs.n_flat = 0; cs.fan_mask = 0; cs.max_segs = (u32)max_segs;
@@ -340,9 +344,10 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     a.out_keys = cs.keys; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off; a.bchunks = cs.bchunks;
     a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + 3];
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs; a.err = &c->d_sc->err; a.survivors = &c->d_sc->bloom_survivors;
+    a.dbg_flags = getenv("FJ_BLOOM_ABLATE") ? (u32)atoi(getenv("FJ_BLOOM_ABLATE")) : 0u;
     if (it.bloom_wait_build) HIPCHK(hipStreamWaitEvent(s, c->ev[E_BUILD], 0));      // the build relation is partitioned on the side stream
     HIPCHK(hipEventRecord(c->ev[E_BF0], s));
-    HIPCHK(fj_launch_bloom_filter(a, G, s));
+    HIPCHK(fj_launch_bloom_filter(a, G, options().bloom_variant, s));
     HIPCHK(hipEventRecord(c->ev[E_BF1], s));
     it.cs = cs; it.cs_base = base;
     HIPCHK(fj_launch_group(cs, s));
@@ -579,12 +584,15 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     pass_init(bit, 0, materialize != 0, nb, plan, top_bits);
     int evc = 0;
     pass_init(pit, 1, false, np, plan, top_bits);
-    const bool overlap = options().overlap_relations != 0;
+    bool overlap = options().overlap_relations != 0;
+    // bloom plans: the filter stage needs the whole build side, and a build relation squeezed in beside the 1024-thread
+    // first probe pass finishes late (measured: 9.5 ms overlapped against 8.4 ms one after the other at c4): build first
+    if (plan.bloom_level > 0 && !options().bloom_overlap) overlap = false;
     if (plan.bloom_level > 0) {
         // bloom precheck: the probe side's level `bloom_level` is filtered against the build side's same level
         bit.save_level = plan.bloom_level; pit.bloom_build = &bit.saved; pit.bloom_wait_build = overlap;
     }
-    if (overlap && plan.bloom_level > 0) {
+    if (overlap && plan.bloom_level > 0 && options().bloom_overlap) {
         // as below, but the build relation is enqueued first: the filter stage needs its level descriptor on the host
         HIPCHK(hipEventRecord(c->ev[E_FORK], s));
         HIPCHK(hipStreamWaitEvent(c->side, c->ev[E_FORK], 0));
@@ -632,6 +640,7 @@ int fj_set_option(const char* name, long long value) {
     if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
     if (!strcmp(name, "overlap_relations")) { options().overlap_relations = value != 0; return 0; }
     if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); options().plan_target_keys = (u32)value; return 0; }
+    if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); options().bloom_variant = (int)value; return 0; }
     if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
     return set_err("fj_set_option: unknown option '%s'", name);
 }
@@ -642,6 +651,7 @@ long long fj_get_option(const char* name) {
     if (name && !strcmp(name, "persistent_min_items")) return options().persistent_min_items;
     if (name && !strcmp(name, "overlap_relations")) return options().overlap_relations;
     if (name && !strcmp(name, "plan_target_keys")) return options().plan_target_keys;
+    if (name && !strcmp(name, "bloom_variant")) return options().bloom_variant;
     set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
     return -1;
 }

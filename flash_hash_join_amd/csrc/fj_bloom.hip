@@ -11,14 +11,23 @@
 // 205-270 G keys/s (one divergent L1/L2 access per key), in the Infinity Cache / HBM at 51 G keys/s.  So the filter is
 // an LDS-resident blocked Bloom filter over ONE bucket of an intermediate partition level, built on the fly:
 //
-//   * one 1024-thread workgroup per CU owns ~144 KiB of LDS = 18432 blocks of 64 bits;
+//   * one 1024-thread workgroup per CU owns 140 KiB of LDS = 35840 words of filter (+ 16 KiB of per-wave staging);
 //   * work = tiles of the probe side's level-L chunk lists (tile table, bucket by bucket); a workgroup takes a
 //     contiguous run of tiles (snapped to bucket boundaries when they are close);
 //   * when its bucket changes the workgroup rebuilds the filter from the BUILD side's chunks of that bucket
 //     (<= ~400K keys, read once more from HBM/L2: 8 B per build key per workgroup that visits the bucket);
-//   * probe keys stream through registers two tiles ahead (no barrier in the steady state), each key tests 4 bits of
-//     one 64-bit block; survivors are compacted per wave (ballot + mbcnt) straight into wave-private 2-KiB chunks of
-//     an output chunk pool with the same bucket structure, so the next partition pass reads it like any other level.
+//   * probe keys stream through registers two tiles ahead (no barrier in the steady state), each key tests 2 bits of
+//     one 32-bit word; survivors are compacted per wave (ballot + mbcnt) into an LDS staging row and leave in whole
+//     512-B pieces for wave-private 2-KiB chunks of an output chunk pool with the same bucket structure, so the next
+//     partition pass reads it like any other level.
+//
+// Measured at config 4 (1B probe keys, 5 % hits, 512 level-1 buckets of ~195K build keys; FJ_BLOOM_ABLATE): reading the
+// chunk lists and counting only 1.75 ms (4.6 TB/s, the rate the join kernel also reads chunk lists at; includes the ~770
+// filter builds), + hashing and the LDS lookup 1.86 ms, + staging survivors in LDS 2.14 ms, + writing them 2.3-2.4 ms.
+// A wave's four loads of a tile each cover half of ONE chunk, so chunk ids and counts live in SGPRs (scalar address
+// arithmetic); survivors go through LDS so that the global store is one 512-B instruction per 64 survivors.  The hash
+// is not what bounds it (two-multiply mixer + 2 bits per key: 2.29 ms, 13.8 % pass; hash word 2 + 4 bits: 2.33 ms,
+// 12.0 % pass), so the stronger one is the default.
 //
 // No false negatives by construction (insert and test use the same bits); false positives only cost the work the
 // filter would have saved.  Algorithmic HBM bytes: 8 B per probe key read + 8 B per survivor written (+ the build
@@ -28,23 +37,51 @@
 namespace {
 
 constexpr u32 BF_NT = 1024;                 // threads per workgroup (one workgroup per CU)
+constexpr u32 BF_NW = BF_NT / 64;
 constexpr u32 BF_KPT = 8;                   // probe keys per thread and tile
 constexpr u32 BF_T = BF_NT * BF_KPT;        // 8192 keys = 32 chunks per tile
-constexpr u32 BF_SLAB = 16;                 // output chunks a wave takes per allocator hit
+constexpr u32 BF_STG = 128;                 // staging row of a wave: keys
+// output chunks a wave takes per allocator hit.  The hit is a returning global atomic: its wait drains the wave's whole load
+// pipeline, so it must be rare - 128 chunks = 32768 survivors cover a wave's share of a 1B-row probe side at 13 % survivors
+constexpr u32 BF_SLAB = 128;
 
-// block index + the two 32-bit halves of the key's 4-bit mask.  Hash word 2 is independent of the radix digits (word 1).
-__device__ __forceinline__ void bf_bits(u64 key, u32& idx, u32& mlo, u32& mhi) {
-    const u32 w = fj_hash_w2(key);
-    const u32 h = w * 0x9E3779B1u;
-    idx = __umulhi(w, FJ_BLOOM_BLOCKS);
-    mlo = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
-    mhi = (1u << ((h >> 10) & 31u)) | (1u << ((h >> 15) & 31u));
+__device__ __forceinline__ u32 bf_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Filter position of a key: byte offset of its LDS word / block and the mask to test or set.
+//   VAR 1: two-multiply mixer over a fold of the key, 2 bits in one 32-bit word.  (A mixer from 24-bit
+//   multiplies - full rate - spread (i+1)*M keys so badly that 32 % of the probe keys passed at 5 % hits.)
+//   VAR 0 (default): the join's hash word 2 (five 32-bit multiplies), 4 bits in one 64-bit block.
+// Either is independent of the radix digits (hash word 1); a weak spot costs false positives, never a wrong result.
+template <int VAR>
+__device__ __forceinline__ void bf_bits(u64 key, u32& byte_off, u32& mlo, u32& mhi) {
+    if (VAR == 0) {
+        const u32 w = fj_hash_w2(key), h = w * 0x9E3779B1u;
+        byte_off = __umulhi(w, FJ_BLOOM_WORDS / 2u) * 8u;
+        mlo = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+        mhi = (1u << ((h >> 10) & 31u)) | (1u << ((h >> 15) & 31u));
+        return;
+    }
+    u32 x = (u32)key ^ __builtin_rotateleft32((u32)(key >> 32), 15);
+    x *= 0x9E3779B1u; x ^= x >> 15;
+    x *= 0x85EBCA77u; x ^= x >> 13;
+    byte_off = __umulhi(x, FJ_BLOOM_WORDS) * 4u;
+    mlo = (1u << (x & 31u)) | (1u << ((x >> 5) & 31u));
+    mhi = 0;
+}
+template <int VAR>
+__device__ __forceinline__ void bf_insert(unsigned char* filt, u64 key) {
+    u32 o, mlo, mhi;
+    bf_bits<VAR>(key, o, mlo, mhi);
+    if (VAR == 0) atomicOr(reinterpret_cast<unsigned long long*>(filt + o), ((unsigned long long)mhi << 32) | mlo);
+    else atomicOr(reinterpret_cast<u32*>(filt + o), mlo);
 }
 
+template <int VAR>
 __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* filt = reinterpret_cast<u64*>(smem);                // [FJ_BLOOM_BLOCKS]
-    const u32 tid = threadIdx.x, lane = tid & 63;
+    unsigned char* filt = smem;                                          // FJ_BLOOM_WORDS * 4 bytes
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = bf_uni(tid >> 6);
+    u64* stg = reinterpret_cast<u64*>(smem + FJ_BLOOM_WORDS * 4) + wave * BF_STG;   // this wave's staging row
     const u32 ntiles = *a.ntiles;
     const u32 G = gridDim.x, g = blockIdx.x;
     const u32 nb = a.probe.nb;
@@ -64,147 +101,184 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
     if (t0 >= t1) return;
     const u32 nmine = t1 - t0;
 
-    // ---- input side: descriptors -> chunk-list entries -> keys, each a tile earlier than its consumer ------------
-    // thread tid reads key pairs (i*NT + tid)*2, i = 0..3: chunk j = i*8 + tid/128 of the tile, offset (tid%128)*2
-    const u32 jbase = tid >> 7, off = (tid & 127u) * 2u;
+    // ---- input side: descriptors -> chunk-list entries -> keys, each a step earlier than its consumer ------------
+    // thread tid reads key pairs (i*NT + tid)*2, i = 0..3: chunk j = i*8 + tid/128 of the tile, byte offset (tid%128)*16.
+    // j is the same for all lanes of a wave: entries, ids and counts are wave-uniform.
+    const u32 jb = bf_uni(tid >> 7), off = (tid & 127u) * 2u, off16 = (tid & 127u) * 16u;
     struct Desc { u32 pos, len, bucket; };
-    auto get_desc = [&](u32 tt) -> Desc {
+    auto get_desc = [&](u32 tt) -> Desc {                    // (vector load of a uniform address; made uniform at use)
         const uint4 d = a.tiles[t0 + (tt < nmine ? tt : nmine - 1)];
         Desc r; r.pos = d.x; r.len = tt < nmine ? d.y : 0u; r.bucket = d.z; return r;
     };
-    auto get_entries = [&](const Desc& d, u32 (&e)[4], u32& vm) {      // unconditional loads (clamped), validity in vm
-        vm = 0;
+    auto get_entries = [&](const Desc& d, u32 (&e)[4]) {     // unconditional loads (index clamped): straight-line code
+        const u32 pos = bf_uni(d.pos), len = bf_uni(d.len);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const u32 j = (u32)i * 8u + jbase;
-            const u32 jj = j < d.len ? j : (d.len ? d.len - 1 : 0u);
-            e[i] = a.probe.list[d.pos + jj];
-            vm |= (j < d.len ? 1u : 0u) << i;
+            const u32 j = (u32)i * 8u + jb;
+            e[i] = a.probe.list[pos + (j < len ? j : (len ? len - 1 : 0u))];
         }
     };
-    auto get_keys = [&](const u32 (&e)[4], u32 vm, u64 (&kk)[BF_KPT], u32& okm) {
-        okm = 0;
+    // request the keys of a tile: scalar base per chunk + constant lane offset; the chunks' key counts stay in SGPRs
+    // (validity of a lane's keys is one compare against them at test time)
+    auto get_keys = [&](const u32 (&e)[4], u32 len, u64 (&kk)[BF_KPT], u32 (&cn)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const u32 cnt = (vm >> i) & 1u ? FJ_LIST_CNT(e[i]) : 0u;
-            const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + (u64)FJ_LIST_ID(e[i]) * FJ_CHUNK + off);
+            const u32 eu = bf_uni(e[i]);
+            const u32 cnt = ((u32)i * 8u + jb) < len ? FJ_LIST_CNT(eu) : 0u;
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(a.probe.keys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
+            const u64x2 q = *reinterpret_cast<const u64x2*>(base + off16);
             kk[2 * i] = q.x; kk[2 * i + 1] = q.y;
-            okm |= ((off < cnt ? 1u : 0u) | (off + 1 < cnt ? 2u : 0u)) << (2 * i);
+            cn[i] = cnt;
         }
     };
 
-    // ---- output side: wave-private chunks ------------------------------------------------------------------------
-    u32 cur = FJ_DIR_INVALID, fill = FJ_CHUNK;      // current chunk and its fill (wave-uniform)
+    // ---- output side: wave-private chunks, filled 64 keys at a time from the wave's staging row --------------------
+    u32 cur = FJ_DIR_INVALID, fill = FJ_CHUNK;      // current chunk and its fill (wave-uniform; a multiple of 64 until the segment ends)
+    u32 ns = 0;                                     // staged survivors of this wave (< 64 between key slots)
     u32 nch = 0, seg = 0;                           // chunks of this (wave, bucket run) = one segment of the bucket's chunk list
     u32 slab_cur = 0, slab_rem = 0;
     unsigned long long survivors = 0;
     const u32 cap = a.cap_chunks;
-    auto new_chunk = [&](u32 bucket) -> u32 {       // wave-uniform
+    auto next_chunk = [&](u32 bucket) {             // wave-uniform: close `cur` (full), open a fresh chunk
+        if (cur != FJ_DIR_INVALID && lane == 0 && cur < cap) a.out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | FJ_CHUNK;
         if (slab_rem == 0) {
             u32 base = 0;
             if (lane == 0) { base = atomicAdd(a.alloc, BF_SLAB); if (base + BF_SLAB > cap) atomicOr(a.err, FJ_ERR_POOL); }
-            slab_cur = (u32)__builtin_amdgcn_readfirstlane((int)base); slab_rem = BF_SLAB;
+            slab_cur = bf_uni(base); slab_rem = BF_SLAB;
         }
-        const u32 c = slab_cur; ++slab_cur; --slab_rem;
-        if (lane == 0 && c < cap) a.out_rel[c] = ((u64)seg << 32) | nch;
-        ++nch;
-        return c;
+        cur = slab_cur; ++slab_cur; --slab_rem;
+        if (lane == 0 && cur < cap) a.out_rel[cur] = ((u64)seg << 32) | nch;
+        ++nch; fill = 0;
+    };
+    auto flush = [&](u32 bucket, u32 n) {           // write staged keys [0, n), n <= 64, behind the chunk's fill
+        if (fill == FJ_CHUNK) next_chunk(bucket);
+        if (lane < n && cur < cap && !(a.dbg_flags & 4u)) {     // (4: diagnostic, everything but the store itself)
+            unsigned char* base = reinterpret_cast<unsigned char*>(a.out_keys + (u64)((a.dbg_flags & 8u) ? (cur & 1023u) : cur) * FJ_CHUNK + fill);   // (8: diagnostic, stores stay in L2)
+            *reinterpret_cast<u64*>(base + lane * 8u) = stg[lane];
+        }
+        fill += n;
     };
     auto end_segment = [&](u32 bucket) {            // close this wave's run inside `bucket`
+        if (ns) { flush(bucket, ns); ns = 0; }
         if (nch > 0 && lane == 0) {
-            if (cur < cap && fill > 0) a.out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | fill;
+            if (cur < cap) a.out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | fill;
             const u32 o = atomicAdd(&a.bchunks[bucket], nch);
             if (seg < a.max_segs) a.seg_off[seg] = o;
         }
         cur = FJ_DIR_INVALID; fill = FJ_CHUNK; nch = 0;
     };
 
-    // ---- prologue ----------------------------------------------------------------------------------------------------
-    Desc dC = get_desc(2), dD = get_desc(3);
-    u64 kA[BF_KPT], kB[BF_KPT];
-    u32 okA, okB, eC[4], vmC;
-    u32 bktA, bktB;
+    // ---- prologue: keys of tiles 0-1, entries of tiles 2-3, descriptors of tiles 4-5 in flight ----------------------
+    // Every buffer rotates by NAME (the loop body is written three times): a register copy of a buffer whose load is
+    // still in flight would make the wave wait for that load.  And every dependent request is issued TWO steps before
+    // its consumer and BEFORE the keys of its step: vector memory operations retire in issue order, so by the time a
+    // step's keys (requested two steps ago) are there, the entries and the descriptor it needs are there too - a step
+    // has one wait, for its keys.  (With a one-step distance the wait for the entries sat right behind the previous
+    // step's survivor stores, which count in the same vmcnt: 2.29 ms per 1B keys against 1.88 ms with the stores
+    // ablated.)
+    u64 K0[BF_KPT], K1[BF_KPT], K2[BF_KPT];
+    u32 C0[4], C1[4], C2[4];                           // key counts of the four chunks a wave reads per tile (wave-uniform)
+    u32 E0[4], E1[4], E2[4];                           // chunk-list entries
+    Desc D0, D1, D2;
+    u32 bq0, bq1, bq2, bq3, lq0, lq1;                  // buckets of tiles t..t+3, lengths of tiles t+2, t+3 (SGPRs)
     {
-        const Desc d0 = get_desc(0), d1 = get_desc(1);
-        u32 e0[4], e1[4], v0, v1;
-        get_entries(d0, e0, v0); get_entries(d1, e1, v1);
-        get_entries(dC, eC, vmC);
-        get_keys(e0, v0, kA, okA); get_keys(e1, v1, kB, okB);
-        bktA = d0.bucket; bktB = d1.bucket;
+        const Desc d0 = get_desc(0), d1 = get_desc(1), d2 = get_desc(2), d3 = get_desc(3);
+        D1 = get_desc(4); D2 = get_desc(5);
+        u32 e0[4], e1[4];
+        get_entries(d0, e0); get_entries(d1, e1);
+        get_entries(d2, E2); get_entries(d3, E0);
+        get_keys(e0, bf_uni(d0.len), K0, C0); get_keys(e1, bf_uni(d1.len), K1, C1);
+        bq0 = bf_uni(d0.bucket); bq1 = bf_uni(d1.bucket); bq2 = bf_uni(d2.bucket); bq3 = bf_uni(d3.bucket);
+        lq0 = bf_uni(d2.len); lq1 = bf_uni(d3.len);
     }
-    u32 bktC = dC.bucket;
 
     u32 cur_bucket = 0xFFFFFFFFu;
-    for (u32 t = 0; t < nmine; ++t) {
-        // tile t's keys are in kA; request tile t+2's keys, tile t+3's entries, tile t+4's descriptor
-        u64 kC[BF_KPT]; u32 okC;
-        get_keys(eC, vmC, kC, okC);
-        u32 eD[4], vmD;
-        get_entries(dD, eD, vmD);
-        const Desc dE = get_desc(t + 4);
+    u32 t = 0;
+    // one tile: kCur holds tile t; requests go out for tile t+2's keys (entries eUse), tile t+4's entries (descriptor
+    // dUse) and tile t+6's descriptor
+    auto step = [&](const u64 (&kCur)[BF_KPT], const u32 (&cnCur)[4], u64 (&kNew)[BF_KPT], u32 (&cnNew)[4],
+                    const u32 (&eUse)[4], u32 (&eNew)[4], const Desc& dUse, Desc& dNew) {
+        const u32 bucket = bq0;
+        const Desc du = dUse;                          // tile t+4 (read before dNew, which may alias another name's register, is written)
+        dNew = get_desc(t + 6);
+        get_entries(du, eNew);
+        get_keys(eUse, lq0, kNew, cnNew);
+        bq0 = bq1; bq1 = bq2; bq2 = bq3; bq3 = bf_uni(du.bucket);
+        lq0 = lq1; lq1 = bf_uni(du.len);
 
-        const u32 bucket = bktA;
         if (bucket != cur_bucket) {                 // workgroup-uniform: rebuild the filter for this bucket
             if (cur_bucket != 0xFFFFFFFFu) end_segment(cur_bucket);
             __syncthreads();                        // every wave is done testing against the old filter
-            for (u32 i = tid; i < FJ_BLOOM_BLOCKS; i += BF_NT) filt[i] = 0;
+            for (u32 i = tid; i < FJ_BLOOM_WORDS / 2; i += BF_NT) reinterpret_cast<u64*>(filt)[i] = 0;
             __syncthreads();
             const u32 b0 = a.build.boff[bucket], nbc = a.build.boff[bucket + 1] - b0;
-            for (u32 c0 = 0; c0 < nbc; c0 += 32) {  // 32 chunks = 8192 build keys per step, four 16-B loads per thread in flight
+            // 32 chunks = 8192 build keys per step: the step's four list entries per thread, then its four 16-B key loads; the
+            // entries of the NEXT step are requested before this step's keys are used
+            auto bentries = [&](u32 c0, u32 (&e)[4]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 j = c0 + (u32)i * 8u + jb;
+                    e[i] = a.build.list[b0 + (j < nbc ? j : (nbc ? nbc - 1 : 0u))];
+                }
+            };
+            u32 be[4];
+            if (nbc) bentries(0, be);
+            for (u32 c0 = 0; c0 < nbc; c0 += 32) {
                 u64x2 q[4]; u32 cn[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const u32 j = c0 + (u32)i * 8u + jbase;
-                    const u32 e = a.build.list[b0 + (j < nbc ? j : nbc - 1)];
-                    cn[i] = j < nbc ? FJ_LIST_CNT(e) : 0u;
-                    q[i] = *reinterpret_cast<const u64x2*>(a.build.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + off);
+                    const u32 eu = bf_uni(be[i]);
+                    cn[i] = (c0 + (u32)i * 8u + jb) < nbc ? FJ_LIST_CNT(eu) : 0u;
+                    const unsigned char* base = reinterpret_cast<const unsigned char*>(a.build.keys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
+                    q[i] = *reinterpret_cast<const u64x2*>(base + off16);
                 }
+                u32 bn[4];
+                bentries(c0 + 32 < nbc ? c0 + 32 : c0, bn);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    u32 idx, mlo, mhi;
-                    if (off < cn[i]) { bf_bits(q[i].x, idx, mlo, mhi); atomicOr((unsigned long long*)&filt[idx], ((unsigned long long)mhi << 32) | mlo); }
-                    if (off + 1 < cn[i]) { bf_bits(q[i].y, idx, mlo, mhi); atomicOr((unsigned long long*)&filt[idx], ((unsigned long long)mhi << 32) | mlo); }
+                    if (off < cn[i]) bf_insert<VAR>(filt, q[i].x);
+                    if (off + 1 < cn[i]) bf_insert<VAR>(filt, q[i].y);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) be[i] = bn[i];
             }
             __syncthreads();
             if (lane == 0) { seg = atomicAdd(a.seg_counter, 1u); if (seg >= a.max_segs) atomicOr(a.err, FJ_ERR_POOL); }
-            seg = (u32)__builtin_amdgcn_readfirstlane((int)seg);
+            seg = bf_uni(seg);
             cur_bucket = bucket;
         }
 
-        // ---- test the 8 keys of this lane, compact the survivors of the wave into its chunk ----------------------
-        u64 w[BF_KPT]; u32 mlo[BF_KPT], mhi[BF_KPT];
-#pragma unroll
-        for (int i = 0; i < (int)BF_KPT; ++i) { u32 idx; bf_bits(kA[i], idx, mlo[i], mhi[i]); w[i] = filt[idx]; }
+        // ---- test the 8 keys of this lane, compact the survivors of the wave into its staging row -------------------
+        u32 wlo[BF_KPT], whi[BF_KPT], mlo[BF_KPT], mhi[BF_KPT];
 #pragma unroll
         for (int i = 0; i < (int)BF_KPT; ++i) {
-            const bool pass = ((okA >> i) & 1u) && ((u32)w[i] & mlo[i]) == mlo[i] && ((u32)(w[i] >> 32) & mhi[i]) == mhi[i];
-            const u64 m = __ballot(pass);
+            u32 o; bf_bits<VAR>(kCur[i], o, mlo[i], mhi[i]);
+            if (a.dbg_flags & 2u) { wlo[i] = (u32)kCur[i]; whi[i] = 0; mlo[i] = 1; mhi[i] = 0; continue; }   // diagnostic: no hash use, no LDS read
+            if (VAR == 0) { const u64 w = *reinterpret_cast<const u64*>(filt + o); wlo[i] = (u32)w; whi[i] = (u32)(w >> 32); }
+            else { wlo[i] = *reinterpret_cast<const u32*>(filt + o); whi[i] = 0; }
+        }
+#pragma unroll
+        for (int i = 0; i < (int)BF_KPT; ++i) {
+            const bool hit = (wlo[i] & mlo[i]) == mlo[i] && (VAR != 0 || (whi[i] & mhi[i]) == mhi[i]);
+            u64 m = __ballot(hit && (off + (u32)(i & 1)) < cnCur[i >> 1]);
+            if (a.dbg_flags & 1u) { survivors += (u32)__popcll(m); m = 0; }      // diagnostic: count, do not compact
             if (m) {
                 const u32 n = (u32)__popcll(m);
-                const u32 dst = fill + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                u32 nxt = cur;
-                if (fill + n > FJ_CHUNK) nxt = new_chunk(bucket);
-                if (pass) {
-                    const u32 c = dst < FJ_CHUNK ? cur : nxt;
-                    if (c < cap) a.out_keys[(u64)c * FJ_CHUNK + (dst & (FJ_CHUNK - 1))] = kA[i];
-                }
-                fill += n;
-                if (fill >= FJ_CHUNK) {             // the current chunk is complete (fill == 256 exactly, or it overflowed into nxt)
-                    if (cur != FJ_DIR_INVALID && lane == 0 && cur < cap) a.out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | FJ_CHUNK;
-                    if (nxt != cur) { cur = nxt; fill -= FJ_CHUNK; }
-                }
+                if ((m >> lane) & 1ull) stg[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = kCur[i];
+                ns += n;
                 survivors += n;
+                if (ns >= 64) {                     // a whole 512-B piece leaves; the rest moves to the front of the row
+                    flush(bucket, 64);
+                    ns -= 64;
+                    if (lane < ns) { const u64 v = stg[64 + lane]; stg[lane] = v; }
+                }
             }
         }
-
-        // rotate the pipeline
-#pragma unroll
-        for (int i = 0; i < (int)BF_KPT; ++i) { kA[i] = kB[i]; kB[i] = kC[i]; }
-        okA = okB; okB = okC; bktA = bktB; bktB = bktC; bktC = dD.bucket;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) eC[i] = eD[i];
-        vmC = vmD; dD = dE;
+    };
+    for (;;) {
+        step(K0, C0, K2, C2, E2, E1, D1, D0); if (++t >= nmine) break;
+        step(K1, C1, K0, C0, E0, E2, D2, D1); if (++t >= nmine) break;
+        step(K2, C2, K1, C1, E1, E0, D0, D2); if (++t >= nmine) break;
     }
     if (cur_bucket != 0xFFFFFFFFu) end_segment(cur_bucket);
     if (lane == 0 && survivors) atomicAdd(a.survivors, survivors);
@@ -213,12 +287,14 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
 }  // namespace
 
 u32 fj_bloom_tile_chunks() { return BF_T / FJ_CHUNK; }
-u32 fj_bloom_waves_per_group() { return BF_NT / 64; }
+u32 fj_bloom_waves_per_group() { return BF_NW; }
+u32 fj_bloom_slab_chunks() { return BF_SLAB; }
 
-hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, hipStream_t s) {
-    const u32 lds = FJ_BLOOM_BLOCKS * 8;
-    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(fj_bloom_filter_kernel), lds);
+hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, int variant, hipStream_t s) {
+    const u32 lds = FJ_BLOOM_WORDS * 4 + BF_NW * BF_STG * 8;
+    auto kern = variant == 0 ? fj_bloom_filter_kernel<0> : fj_bloom_filter_kernel<1>;
+    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fj_bloom_filter_kernel, dim3(grid), dim3(BF_NT), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BF_NT), lds, s, a);
     return hipGetLastError();
 }

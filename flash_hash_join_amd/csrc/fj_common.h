@@ -36,9 +36,9 @@ static inline unsigned fj_slab_for(unsigned fan) { return fan > 256u ? 2u * FJ_S
 #define FJ_PART_TARGET_KEYS 4096u               // average build keys per final partition (load <= 0.5)
 
 // Bloom precheck of the partitioned join (csrc/fj_bloom.hip): an LDS-resident blocked Bloom filter over one bucket of an
-// intermediate partition level, 64-bit blocks, 4 bits per key.  144 KiB of the CU's 160 KiB.
-#define FJ_BLOOM_BLOCKS 18432u
-#define FJ_BLOOM_BITS (FJ_BLOOM_BLOCKS * 64u)
+// intermediate partition level: 35840 32-bit words = 140 KiB of the CU's 160 KiB (the rest stages survivors).
+#define FJ_BLOOM_WORDS 35840u
+#define FJ_BLOOM_BITS (FJ_BLOOM_WORDS * 32u)
 #define FJ_BLOOM_MAX_KEYS 400000u                // build keys per filtered bucket above which the filter is not worth running (< 3 bits per key)
 #define FJ_BLOOM_GOOD_KEYS 215000u               // ... below which it is strong (>= 5.5 bits per key): the plan widens its first pass to get here
 

@@ -75,10 +75,12 @@ struct FjBloomArgs {
     u32 cap_chunks, max_segs;
     u32* err;
     unsigned long long* survivors;   // device scalar: probe keys that passed
+    u32 dbg_flags;                   // diagnostic ablations (FJ_BLOOM_ABLATE): 1 = count survivors but do not write them, 2 = no filter lookup (results wrong on purpose)
 };
 u32 fj_bloom_tile_chunks();
 u32 fj_bloom_waves_per_group();
-hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, hipStream_t s);
+u32 fj_bloom_slab_chunks();
+hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, int variant, hipStream_t s);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
 hipError_t fj_set_max_lds_once(const void* fn, u32 bytes);
