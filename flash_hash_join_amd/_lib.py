@@ -33,7 +33,7 @@ class FjTimings(ctypes.Structure):
         ("join_ms", ctypes.c_double), ("emit_ms", ctypes.c_double), ("probe_part_kernel_ms", ctypes.c_double * 4),
         ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
         ("path", ctypes.c_int), ("passes", ctypes.c_int), ("radix_bits", ctypes.c_int), ("fell_back", ctypes.c_int),
-        ("partitions", ctypes.c_uint64), ("overlapped", ctypes.c_int), ("reserved", ctypes.c_int),
+        ("partitions", ctypes.c_uint64), ("overlapped", ctypes.c_int), ("lds_retries", ctypes.c_int),
         ("filter_ms", ctypes.c_double), ("filter_survivors", ctypes.c_uint64), ("bloom_level", ctypes.c_int), ("reserved2", ctypes.c_int),
     ]
 

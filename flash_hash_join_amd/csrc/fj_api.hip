@@ -167,10 +167,13 @@ int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
 }
 
 
-// passes for `bits` radix bits: 8-bit passes (256 buckets, 128-B lines, two workgroups per CU) while two of them
-// reach, 9-bit passes (512 buckets) beyond 16 bits -- a wider pass is slower per row but cheaper than a third pass
+// passes for `bits` radix bits: one pass up to 9 bits (256 buckets, 128-B lines, two workgroups per CU; 512 buckets for
+// exactly 9 bits: slower per row than an 8-bit pass, far cheaper than two passes), two passes up to 18 bits (8-bit passes
+// while they reach, a 9-bit pass beyond 16 bits), three beyond
+int plan_npass(int bits) { return bits <= FJ_MAX_FAN_LOG ? (bits > 0 ? 1 : 0) : (bits <= 2 * FJ_MAX_FAN_LOG ? 2 : (bits + FJ_MAX_FAN_LOG - 1) / FJ_MAX_FAN_LOG); }
+
 void plan_passes(Plan& p, bool extra_first) {
-    p.npass = p.bits <= 16 ? (p.bits + 7) / 8 : (p.bits + FJ_MAX_FAN_LOG - 1) / FJ_MAX_FAN_LOG;
+    p.npass = plan_npass(p.bits);
     for (int i = 0; i < p.npass; ++i) {
         const int rem = p.bits % p.npass;
         p.fan_log[i] = p.bits / p.npass + ((extra_first ? i < rem : i >= p.npass - rem) ? 1 : 0);
@@ -183,6 +186,15 @@ Plan make_plan(size_t nb, int top_bits, bool want_bloom = false) {
     if (nb > target) {
         u64 parts = (nb + target - 1) / target;
         while ((1ull << p.bits) < parts) ++p.bits;
+    }
+    // Counting joins keep a partition in a 2-location cuckoo table of 8192 slots, reliable to a load of ~0.42 and useless
+    // above 0.5 (stash used by < 1 % of the tables at 0.40, by 39 % at 0.48).  Where one more radix bit costs no
+    // extra pass the plan takes it once the average partition exceeds FJ_PLAN_BUMP_KEYS (nb at 4096 * 2^k would otherwise
+    // put half of the partitions over the table's limit); partitions that still overflow are redone one by one on the
+    // tagged table (fj_launch_lds_join_retry), not by re-running the whole join.
+    if (target == FJ_PART_TARGET_KEYS && (nb >> p.bits) > FJ_PLAN_BUMP_KEYS && p.bits < top_bits - 32) {
+        const int nb1 = p.bits == 0 ? 5 : p.bits + 1;
+        if (p.bits == 0 || plan_npass(nb1) == plan_npass(p.bits)) p.bits = nb1;
     }
     if (p.bits > 0 && p.bits < 5) p.bits = 5;              // a pass with a tiny fan-out serialises on its per-bucket threads
     if (p.bits > top_bits - 32) p.bits = top_bits - 32;      // radix digits come from hash word 1 (32 bits)
@@ -540,7 +552,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
     if (ja.items) HIPCHK(hipMemsetAsync(ja.part_count, 0, (size_t)nitems * 4, s));     // entries past the device-side item count stay 0
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
-    ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr;
+    ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr; ja.retry_only = 0;
     ja.dbg = nullptr;
     ja.dbg_flags = getenv("FJ_JOIN_ABLATE") ? (u32)atoi(getenv("FJ_JOIN_ABLATE")) : 0u;
     if (getenv("FJ_JOIN_STAMPS") && stamps_begin(&ja.dbg, s)) return 1;
@@ -548,6 +560,16 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     if (ja.dbg) { if (stamps_report("FJ_JOIN_STAMPS", ja.dbg, nitems, s)) return 1; ja.dbg = nullptr; }
     HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
     if (read_scalars(c, s)) return 1;
+    t->lds_retries = 0;
+    if ((c->h_sc->err & FJ_STAT_RETRY) && !(c->h_sc->err & (FJ_ERR_POOL | FJ_ERR_LDS_FULL))) {
+        // some partitions overflowed the cuckoo table (load above ~0.45): those items run again on the tagged table
+        ja.retry_only = 1;
+        HIPCHK(fj_launch_lds_join_retry(ja, s));
+        ja.retry_only = 0;
+        HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+        if (read_scalars(c, s)) return 1;
+        t->lds_retries = 1;
+    }
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
     t->path = 0; t->passes = plan.npass; t->radix_bits = plan.bits; t->partitions = ja.nparts;
     // one-shot joins: build_phase_ms = wall interval of the build relation's passes, which run BESIDE the probe relation's
@@ -781,7 +803,7 @@ int stream_flat_join(fj_ctx* c, StreamState& st, const u64* d_pk, size_t n, hipS
     void* p;
     if (get_buf(c, W_PART_COUNT, (size_t)ja.nsplit * 4, &p)) return 1; ja.part_count = (u32*)p;
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err; ja.dbg = nullptr; ja.dbg_flags = 0;
-    ja.want_dups = 0; ja.dedup = 0; ja.orig_vals = nullptr;
+    ja.want_dups = 0; ja.dedup = 0; ja.orig_vals = nullptr; ja.retry_only = 0;
     HIPCHK(fj_launch_lds_join(ja, false, s));
     return 0;
 }
@@ -926,7 +948,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
         if (read_scalars(c, s)) return 1;
-        if (c->h_sc->err & FJ_ERR_LDS_FULL) return set_err("fj_stream_finish: the build side does not fit one LDS table");
+        if (c->h_sc->err & (FJ_ERR_LDS_FULL | FJ_STAT_RETRY)) return set_err("fj_stream_finish: the build side does not fit one LDS table");
         count = c->h_sc->total;
         t.path = 0; t.passes = 0; t.partitions = 1;
         t.total_ms = ev_ms(c, E_START, E_JOIN);

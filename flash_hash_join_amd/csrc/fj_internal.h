@@ -6,6 +6,8 @@
 #define FJ_ERR_POOL 1u       // chunk pool exhausted (sizing bug) -> call fails
 #define FJ_ERR_LDS_FULL 2u   // a final partition does not fit its LDS table -> global-table fallback
 #define FJ_STAT_DUPS 4u      // (status, not an error) the build side holds duplicate keys
+#define FJ_STAT_RETRY 8u     // (status) some counting-join items overflowed the cuckoo table: part_count[item] == FJ_ITEM_RETRY marks them
+#define FJ_ITEM_RETRY 0xFFFFFFFFu
 
 // ---- partition pass ---------------------------------------------------------------------------
 struct FjPartArgs {
@@ -102,6 +104,7 @@ struct FjLdsJoinArgs {
     const u64* out_off;          // [items+1] exclusive scan of part_count
     u64* out_keys;
     u64* out_vals;
+    u32 retry_only;              // tagged-table counting kernel: process only the items the cuckoo kernel marked FJ_ITEM_RETRY
     u32 want_dups;               // counting pass of a materialising join: report duplicate build keys (FJ_STAT_DUPS)
     u32 dedup;                   // materialising pass: build 'values' are row indices, the smallest wins, then orig_vals[idx]
     const u64* orig_vals;        // the caller's build_values (dedup only)
@@ -111,6 +114,9 @@ struct FjLdsJoinArgs {
 // next_item: device word for the persistent counting kernel's work counter (nullptr: one workgroup per item)
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item = nullptr,
                               u32 persistent_min_items = 8192);
+// second chance for the items whose partition overflowed the cuckoo table (load > ~0.45): the tagged 2x4-slot table
+// with linear-probing overflow holds up to 8128 keys; only a partition beyond that raises FJ_ERR_LDS_FULL
+hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a, hipStream_t s);
 
 struct FjGtArgs {                // global (non-partitioned) table
     u64* tkeys; u64* tvals; u32* bloom;    // bloom == nullptr: no precheck

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
         return;
     }
     if (MAT && a.part_count[item] == 0) return;
+    if (!MAT && a.retry_only && a.part_count[item] != FJ_ITEM_RETRY) return;   // second chance for the cuckoo kernel's overflows only
 
     constexpr u32 CPL = NT / (FJ_CHUNK / 2);          // chunks covered by one 16-B load per lane
     constexpr u32 CPR = 4 * CPL;                      // chunks per round (4 loads per lane = 8 keys)
@@ -344,6 +345,10 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
         if (tid == 0) { atomicOr(a.err, FJ_ERR_LDS_FULL); if (!MAT) a.part_count[item] = 0; }
         return;
     }
+    // counting pass of a materialising join, second-chance table: racing copies of a duplicated key can sit in the table
+    // unnoticed, and this table has no sweep for them - report "duplicates possible", which only selects the (always
+    // correct) first-occurrence emit path
+    if (!MAT && a.want_dups && tid == 0) atomicOr(a.err, FJ_STAT_DUPS);
     if (dedup) {
         // Two racing copies of one key may both have been stored, each with the smallest row index IT saw: give every
         // copy the minimum over all copies (every copy lives in g1, g2 or, for overflow keys, the walk from g1), then
@@ -590,8 +595,8 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     FJ_STAMP(2);
     __syncthreads();
     FJ_STAMP(3);
-    if (hdr->full) {                                 // stash overflow: host falls back to the global-table path
-        if (tid == 0) { atomicOr(a.err, FJ_ERR_LDS_FULL); a.part_count[item] = 0; }
+    if (hdr->full) {                                 // stash overflow: the item is redone with the tagged table (fj_launch_lds_join_retry)
+        if (tid == 0) { atomicOr(a.err, FJ_STAT_RETRY); a.part_count[item] = FJ_ITEM_RETRY; }
         return;
     }
     const u64 he = hdr->has_empty ? ~0ull : 0ull;
@@ -864,8 +869,8 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
         if (lvn) load_build(bmn, 0, nbbn); else bok = 0;
         if (tid == 0) {
             const u32 cnt = (lv && !full) ? hdr->cnt : 0u;
-            if (full) atomicOr(a.err, FJ_ERR_LDS_FULL);     // stash overflow: host falls back to the global-table path
-            a.part_count[d.item] = cnt;
+            if (full) atomicOr(a.err, FJ_STAT_RETRY);       // stash overflow: the item is redone with the tagged table
+            a.part_count[d.item] = full ? FJ_ITEM_RETRY : cnt;
             if (cnt) atomicAdd(a.total, (unsigned long long)cnt);
         }
         if (dn.item >= nitems) break;
@@ -1172,6 +1177,18 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a0, hipStream_t s) {
+    FjLdsJoinArgs a = a0;
+    a.retry_only = 1;
+    const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;
+    const u32 lds = sizeof(JoinHdr) + S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
+    auto kern = (a.build.list && a.probe.list) ? fj_lds_join_kernel<false, 1024, true> : fj_lds_join_kernel<false, 1024, false>;
+    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     return hipGetLastError();
 }
 

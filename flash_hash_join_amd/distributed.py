@@ -239,12 +239,22 @@ _SPLIT_S_PER_ROW = 2.7e-12         # shuffle: owner histogram + the un-overlappe
 _JOIN_S_PER_ROW = 2.0e-12          # per-partition join, per probe row
 
 
+def _npass(bits: int) -> int:
+    return (1 if bits > 0 else 0) if bits <= 9 else (2 if bits <= 18 else -(-bits // 9))
+
+
 def _plan_passes(nb: int) -> int:
     """Partition passes of the single-GPU plan for a build side of nb rows (csrc/fj_api.hip make_plan)."""
-    if nb <= 4096:
-        return 0
-    bits = max(5, (-(-nb // 4096) - 1).bit_length())
-    return -(-bits // 8) if bits <= 16 else -(-bits // 9)
+    bits = 0
+    if nb > 4096:
+        bits = (-(-nb // 4096) - 1).bit_length()
+    if (nb >> bits) > 3950:                       # one more radix bit where it costs no extra pass (FJ_PLAN_BUMP_KEYS)
+        nb1 = 5 if bits == 0 else bits + 1
+        if bits == 0 or _npass(nb1) == _npass(bits):
+            bits = nb1
+    if 0 < bits < 5:
+        bits = 5
+    return _npass(bits)
 
 
 def strategy_costs(world: int, nb: int, np_: int, materialize: bool) -> dict:

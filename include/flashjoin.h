@@ -48,7 +48,7 @@ typedef struct fj_timings {
     int overlapped;              /* 1: the build relation's partition passes ran beside the probe relation's (two streams):
                                     build_phase_ms is then the wall interval of the build passes INSIDE probe_phase_ms, and
                                     probe_phase_ms spans from the first probe-side pass to the end of the join            */
-    int reserved;
+    int lds_retries;             /* 1 if some partitions overflowed the counting join's cuckoo table and were redone on the tagged table */
     /* bloom precheck of the partitioned plan (the *_bloom functions): */
     double filter_ms;            /* the filter kernel between the probe side's passes (part of probe_phase_ms)              */
     uint64_t filter_survivors;   /* probe keys that passed it (hits + false positives); 0 when bloom_level == 0             */

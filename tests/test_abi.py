@@ -144,9 +144,11 @@ def test_multi_gpu_strategy_model():
         assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == "shuffle"
     finally:
         os.environ.pop("FJ_DIST_STRATEGY")
-    # passes: none up to 4096 rows, one up to 2^8 partitions, two up to 18 bits (512-bucket passes above 16), then three
-    assert [D._plan_passes(n) for n in (1, 4096, 4097, 1 << 20, (1 << 20) + 1, 100_000_000, 268_435_456, 268_435_457,
-                                        800_000_000, 1 << 30, (1 << 30) + 1)] == [0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 3]
+    # passes: none up to 3950 rows (one cuckoo table), one up to 9 radix bits (512 buckets), two up to 18 bits,
+    # then three; a build side just under 4096 * 2^k takes one more bit where that costs no extra pass
+    assert [D._plan_passes(n) for n in (1, 3950, 3951, 4096, 4097, 1 << 20, (1 << 20) + 1, 2_000_000, 2_100_000, 100_000_000,
+                                        268_435_456, 268_435_457, 800_000_000, 1 << 30, (1 << 30) + 1)] == \
+        [0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3]
 
 
 def test_bench_launches_its_own_ranks_when_asked_for_several_gpus(monkeypatch):

@@ -147,6 +147,55 @@ def test_lds_overflow_falls_back_to_global_table(fj, oracle):
     assert n == exp and np.array_equal(np.sort(v), np.sort(k) + np.uint64(1))
 
 
+@pytest.mark.parametrize("nb", [3_800, 4_096, 1 << 20, 1 << 27])
+def test_build_sizes_at_the_edge_of_the_lds_table_do_not_fall_back(fj, nb):
+    """nb = 4096 * 2^k is the worst case for a plan that aims at 4096 keys per 8192-slot table: the counting join's cuckoo
+    table is reliable only to a load of ~0.42.  The plan takes one more radix bit where that is free, and partitions that
+    still overflow are redone one by one on the tagged table - never the whole join on the HBM table."""
+    import torch
+    from flash_hash_join_amd import datagen
+    npk = min(4 * nb, 200_000_000)
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=31, hit_bp=5000)
+    n, _ = fj.hash_join_count_radix(dbk, dbv, dpk)
+    t = fj.last_timings()
+    assert n == exp and t["fell_back"] == 0 and t["path"] == 0, t
+    n, _, k, v = fj.hash_join_radix(dbk, dbv, dpk, return_arrays=True)
+    assert n == exp and fj.last_timings()["fell_back"] == 0
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+    assert bool(torch.all((v + 1) * M == k))
+    del dbk, dbv, dpk, k, v
+    torch.cuda.empty_cache()
+
+
+def test_partition_over_the_cuckoo_limit_is_redone_on_the_tagged_table(fj, oracle):
+    """6000 build keys in ONE partition: too many for the counting join's cuckoo table (4096 at best), fine for the tagged
+    table (8128): only that partition's items are redone (lds_retries), no HBM-table fallback; duplicates among them keep
+    first-occurrence semantics in the materialising join."""
+    def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
+        lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+            x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+            x ^= x >> np.uint32(16)
+        return x
+    cand = np.arange(1, 400000, dtype=np.uint64)
+    one = cand[(hash_w1(cand) >> np.uint32(27)) == 0][:6000]     # top 5 hash bits equal -> one of the plan's 32 partitions
+    rest = cand[(hash_w1(cand) >> np.uint32(27)) != 0][:3000]
+    bk = np.concatenate([one, rest, one[:500]])                    # 500 duplicated keys with different values
+    bv = np.arange(bk.size, dtype=np.uint64) + np.uint64(7)
+    pk = np.concatenate([bk, cand[:50000]])
+    exp, ek, ev = oracle.np_join(bk, bv, pk, return_arrays=True)
+    n, _ = fj.hash_join_count_radix(bk, bv, pk)
+    t = fj.last_timings()
+    assert n == exp and t["fell_back"] == 0 and t["lds_retries"] == 1, t
+    n, _, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+    assert n == exp and fj.last_timings()["fell_back"] == 0
+    a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_device_tensor_inputs_and_device_generators(fj, oracle):
     import torch
     from flash_hash_join_amd import datagen
@@ -187,7 +236,7 @@ def test_device_tensor_inputs_and_device_generators(fj, oracle):
 @pytest.mark.parametrize("n,bits,with_vals", [(1000, 3, True), (100_000, 8, False), (300_000, 7, True),
                                                 (2_000_000, 13, False), (1_500_000, 10, True), (700_001, 16, False),
                                                 (2_000_000, 17, False), (1_200_000, 17, True), (3_000_000, 18, False),
-                                                (2_500_000, 18, True), (1_000_000, 20, False)])
+                                                (2_500_000, 18, True), (1_000_000, 20, False), (1_500_000, 9, False), (800_000, 9, True)])
 def test_partition_pass_in_isolation(fj, n, bits, with_vals):
     """fj_debug_partition: the chunk lists are a permutation of the input and every row sits in the
     bucket named by the top `bits` bits of its hash (1 pass for bits <= 8, 2 passes up to 18 bits -- 512-bucket passes
@@ -415,6 +464,59 @@ def test_bloom_precheck_prunes_misses_and_keeps_every_hit(fj, nb, npk, hit_bp):
     assert bool(torch.all((v + 1) * M == k))
     del dbk, dbv, dpk, k, v
     torch.cuda.empty_cache()
+
+
+def test_config5_every_owner_shard_at_full_size_on_one_gpu(fj):
+    """BASELINE configs[4] (flash_join_radix, 1B build x 10B probe rows over 8 GPUs) at FULL size on this one GPU: for each
+    of the 8 owners in turn, the 8 ranks' blocks (125M x 1.25B rows each, generated like bench.py generates them) are split
+    by owner (fj_owner_hist / fj_owner_scatter, nranks = 8), the owner's 8 build segments and 8 probe segments - what the
+    all-to-all would deliver - are joined with fj_stream_begin / fj_stream_append_probe / fj_stream_finish at
+    hash_top_bits = 48, and the 8 owners' counts add up to the closed-form count of the whole 1B x 10B join."""
+    import torch
+    from flash_hash_join_amd import datagen, api
+    from flash_hash_join_amd.distributed import HipEngine
+    world, nb_rank, np_rank = 8, 125_000_000, 1_250_000_000
+    nb_total = nb_rank * world
+    eng = HipEngine("cuda:0")
+    expected = None
+    owner_counts, owner_build_rows, owner_probe_rows = [], [], []
+    for o in range(world):
+        bks, bvs, pks, exp_sum = [], [], [], 0
+        for r in range(world):
+            bk, bv = datagen.build_device(nb_rank, "cuda:0", first=r * nb_rank)
+            ks, vs, bc = eng.owner_split(bk, bv, world)
+            lo = sum(bc[:o])
+            bks.append(ks[lo: lo + bc[o]].clone()); bvs.append(vs[lo: lo + bc[o]].clone())
+            del bk, bv, ks, vs
+            pk, e = datagen.probe_device(np_rank, nb_total, "cuda:0", seed=1, hit_bp=5000, first=r * np_rank)
+            exp_sum += e
+            pc = eng.owner_hist(pk, world)
+            ps = eng.owner_scatter(pk, world, pc)
+            lo = sum(pc[:o])
+            pks.append(ps[lo: lo + pc[o]].clone())
+            del pk, ps
+        if expected is None:
+            expected = exp_sum
+            assert abs(expected - 0.5 * np_rank * world) < 6 * (np_rank * world) ** 0.5
+        assert exp_sum == expected
+        bk_o, bv_o = torch.cat(bks), torch.cat(bvs)
+        del bks, bvs
+        np_o = sum(p.numel() for p in pks)
+        assert abs(bk_o.numel() - nb_rank) < 0.01 * nb_rank and abs(np_o - np_rank) < 0.01 * np_rank      # uniform keys: balanced owners
+        eng.stream_begin(bk_o, bv_o, np_o, world, 48)
+        for p in pks:
+            eng.stream_append(p)
+        n = eng.stream_finish()
+        t = fj.last_timings()
+        assert t["path"] == 0 and t["fell_back"] == 0 and t["passes"] == 2
+        if o == 0:                                   # the one-shot join of the same shard agrees with the streamed one
+            n1, _ = api.join_device(api.ALGO_RADIX, 0, 0, bk_o, bv_o, torch.cat(pks), hash_top_bits=48)
+            assert n1 == n
+        owner_counts.append(n); owner_build_rows.append(bk_o.numel()); owner_probe_rows.append(np_o)
+        del bk_o, bv_o, pks
+        torch.cuda.empty_cache()
+    assert sum(owner_build_rows) == nb_total and sum(owner_probe_rows) == np_rank * world
+    assert sum(owner_counts) == expected, (owner_counts, expected)
 
 
 def test_hot_probe_key_is_sliced_across_workgroups(fj):
