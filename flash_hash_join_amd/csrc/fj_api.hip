@@ -43,8 +43,9 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     u32 alloc[8];                      // [side*4 + pass] chunk allocators ([side*4 + 3]: the bloom stage's output pool)
     u32 seg_counter[8];                // [side*4 + pass] segment ids
     unsigned long long bloom_survivors;   // probe keys that passed the bloom precheck
-    unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
     u32 next_item;                     // work counter of the persistent join kernel
+    u32 pad_;
+    unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
 };
 
 enum Slot {
@@ -82,6 +83,9 @@ struct PassIter {
     FjChunkSet prev{}; bool have_prev = false; const uint4* tiles = nullptr; const u32* ntiles = nullptr; const u32* toff = nullptr;
     FjChunkSet cs{}; u32 Gmax = 1, F = 1, appends = 1;
     int slot = 0, cs_base = 0;           // ping-pong workspace slot of the next output level / base index of cs's buffers
+    // probe side of a join: the final level's consumer is the join kernel; its item table (tiles of the final probe chunk
+    // lists) and per-item count array are produced by the final level's bookkeeping launches
+    bool want_items = false; u32 items_cap = 0; u32* part_count = nullptr;
     // bloom precheck (probe side): run the filter stage once `bloom_level` passes are complete, against bloom_build
     bool bloom_done = false; const FjChunkSet* bloom_build = nullptr; bool bloom_wait_build = false;
     // build side: keep a copy of the level the probe side's filter will read
@@ -113,6 +117,8 @@ struct fj_ctx {
     StreamState st;
     size_t ws_bytes = 0;
     u32 num_cus = 256;
+    bool plan_in_flight = false;       // a plan was begun and has not completed (an error in between leaves chunk counts behind)
+    bool zeros_dirty = false;          // ... in which case the next plan re-zeroes the self-cleaning buffers it uses
 };
 
 namespace {
@@ -166,6 +172,17 @@ int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
     return 0;
 }
 
+
+// A buffer that is zero whenever nobody is using it: its consumer clears what it read (bucket chunk counts: fj_level_scan),
+// so a join needs no memset for it.  Zeroed here when it is (re)allocated, and when the previous join on this context did
+// not run to completion (c->zeros_dirty).
+int get_zeroed_buf(fj_ctx* c, int slot, size_t bytes, void** out, hipStream_t s) {
+    const size_t before = c->bufs[slot].bytes;          // (a re-allocation may well return the old address: compare sizes)
+    if (get_buf(c, slot, bytes, out)) return 1;
+    if (c->bufs[slot].bytes != before) HIPCHK(hipMemsetAsync(*out, 0, c->bufs[slot].bytes, s));
+    else if (c->zeros_dirty) HIPCHK(hipMemsetAsync(*out, 0, bytes ? bytes : 16, s));
+    return 0;
+}
 
 // passes for `bits` radix bits: one pass up to 9 bits (256 buckets, 128-B lines, two workgroups per CU; 512 buckets for
 // exactly 9 bits: slower per row than an 8-bit pass, far cheaper than two passes), two passes up to 18 bits (8-bit passes
@@ -259,13 +276,13 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
     if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
     if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
-    if (get_buf(c, base + W_BCHUNKS, nb_out * 4, &p)) return 1; cs.bchunks = (u32*)p;
+    if (get_zeroed_buf(c, base + W_BCHUNKS, nb_out * 4, &p, s)) return 1; cs.bchunks = (u32*)p;
     if (get_buf(c, base + W_BOFF, (nb_out + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
     if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * F * 4, &p)) return 1; cs.seg_off = (u32*)p;
     cs.alloc = &c->d_sc->alloc[it.side * 4 + i];
-    HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
-    HIPCHK(hipMemsetAsync(cs.bchunks, 0, nb_out * 4, s));
-    // (cs.alloc and this pass's segment counter are zero: clear_plan_scalars at the start of the join)
+    // No memsets: the directory word of every chunk id below the allocator's high-water mark is written by the workgroup
+    // that took the id (unused ids are marked at its exit); bchunks is cleared by its reader; cs.alloc and this pass's
+    // segment counter are zero (clear_plan_scalars at the start of the join).
     it.cs = cs;
     return 0;
 }
@@ -297,32 +314,57 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     return 0;
 }
 
-// tile table of it.cs (whose buffers live at it.cs_base) for a consumer that reads `tc` chunks per tile
-int level_tile_table(fj_ctx* c, PassIter& it, u32 tc, hipStream_t s) {
+bool bloom_stage_follows(const PassIter& it, int level) { return it.plan.bloom_level == level && it.bloom_build && !it.bloom_done; }
+
+// Work items of the join over the final probe level: tiles of `tc` chunks of the probe chunk lists.  Few partitions
+// (< 2048): several slices per partition, each rebuilding the partition's table, so that small builds still fill the chip
+// (a slice keeps >= 32 full chunks of probe rows per table build).  Many partitions: one item per partition, except that
+// a partition swollen by a hot key is cut into slices of 4x the average (>= 512 chunks).  `bound` over-estimates the
+// chunk count (partial chunks), which only makes slices a little longer than planned.
+void join_item_geometry(u64 nparts, size_t np, u64 chunk_bound, u32* tc, u64* max_items) {
+    const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
+    const u64 bound = std::max<u64>(chunk_bound, pchunks);
+    const u64 avg = std::max<u64>(1, bound / nparts);
+    u64 want = 1;
+    if (nparts < 2048) want = std::min<u64>((2048 + nparts - 1) / nparts, std::max<u64>(1, (pchunks / nparts) / 32));
+    *tc = (u32)(want > 1 ? std::max<u64>(8, (avg * 9 / 8 + want - 1) / want) : std::max<u64>(512, 4 * avg));
+    *max_items = bound / *tc + nparts + 1;
+}
+
+// Bookkeeping of the level in it.cs (buffers at it.cs_base), two launches: chunk-list offsets + lists, and the tile table
+// of whatever reads the level next - the bloom stage, the next pass, or (probe side, final level) the join's item table
+// together with its per-item count array.
+int level_finish(fj_ctx* c, PassIter& it, bool final_level, hipStream_t s) {
     const FjChunkSet& cs = it.cs;
-    const u64 max_tiles = it.lbound / tc + cs.nb + 1;
+    u32 tc = 0; u64 max_tiles = 0; u32* zero_tail = nullptr;
+    if (bloom_stage_follows(it, it.i)) tc = fj_bloom_tile_chunks();
+    else if (!final_level) tc = fj_partition_tile_chunks((u32)it.plan.fan_log[it.i], it.has_vals);
+    else if (it.want_items) join_item_geometry(cs.nb, it.n, it.lbound, &tc, &max_tiles);
+    if (tc && !max_tiles) max_tiles = it.lbound / tc + cs.nb + 1;
+    if (max_tiles >= (1ull << 31)) return set_err("internal error: tile table too large");
+    u32* toff = nullptr; uint4* tiles = nullptr;
     void* p;
-    if (get_buf(c, it.cs_base + W_TOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
-    if (get_buf(c, it.cs_base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1;
-    HIPCHK(fj_launch_tile_table(cs, tc, toff, (uint4*)p, (u32)max_tiles, s));
-    it.tiles = (const uint4*)p; it.ntiles = toff + cs.nb; it.toff = toff;
+    if (tc) {
+        if (get_buf(c, it.cs_base + W_TOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; toff = (u32*)p;
+        if (get_buf(c, it.cs_base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1; tiles = (uint4*)p;
+        if (final_level) {
+            if (get_buf(c, W_PART_COUNT, (size_t)max_tiles * 4, &p)) return 1;
+            it.part_count = zero_tail = (u32*)p; it.items_cap = (u32)max_tiles;
+        }
+    }
+    HIPCHK(fj_launch_group(cs, tc, toff, tiles, (u32)max_tiles, zero_tail, s));
+    it.tiles = tiles; it.ntiles = toff ? toff + cs.nb : nullptr; it.toff = toff;
     return 0;
 }
 
-bool bloom_stage_follows(const PassIter& it, int level) { return it.plan.bloom_level == level && it.bloom_build && !it.bloom_done; }
-
 int pass_complete(fj_ctx* c, PassIter& it, hipStream_t s) {
     const FjChunkSet& cs = it.cs;
-    HIPCHK(fj_launch_group(cs, s));
     it.lbound = it.n / FJ_CHUNK + 1 + (u64)(it.Gmax + it.parents) * it.F * it.appends;
-    if (bloom_stage_follows(it, it.i + 1)) {  // the bloom stage reads this level next
-        if (level_tile_table(c, it, fj_bloom_tile_chunks(), s)) return 1;
-    } else if (it.i + 1 < it.plan.npass) {    // tile table for the next pass over this level
-        if (level_tile_table(c, it, fj_partition_tile_chunks((u32)it.plan.fan_log[it.i + 1], it.has_vals), s)) return 1;
-    }
+    ++it.i;                                   // (level_finish looks at the stage that follows the level just completed)
+    if (level_finish(c, it, it.i == it.plan.npass, s)) return 1;
     it.prev = cs; it.have_prev = true;
     it.parents = cs.nb;
-    ++it.i; ++it.slot;
+    ++it.slot;
     if (it.save_level == it.i) it.saved = cs;
     return 0;
 }
@@ -345,12 +387,10 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
     if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
     if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
-    if (get_buf(c, base + W_BCHUNKS, (size_t)cs.nb * 4, &p)) return 1; cs.bchunks = (u32*)p;
+    if (get_zeroed_buf(c, base + W_BCHUNKS, (size_t)cs.nb * 4, &p, s)) return 1; cs.bchunks = (u32*)p;
     if (get_buf(c, base + W_BOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
     if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * 4, &p)) return 1; cs.seg_off = (u32*)p;
     cs.alloc = &c->d_sc->alloc[it.side * 4 + 3];
-    HIPCHK(hipMemsetAsync(cs.dir, 0xFF, cap64 * 4, s));
-    HIPCHK(hipMemsetAsync(cs.bchunks, 0, (size_t)cs.nb * 4, s));
     FjBloomArgs a{};
     a.build = *it.bloom_build; a.probe = in; a.tiles = it.tiles; a.toff = it.toff; a.ntiles = it.ntiles;
     a.out_keys = cs.keys; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off; a.bchunks = cs.bchunks;
@@ -362,12 +402,11 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     HIPCHK(fj_launch_bloom_filter(a, G, options().bloom_variant, s));
     HIPCHK(hipEventRecord(c->ev[E_BF1], s));
     it.cs = cs; it.cs_base = base;
-    HIPCHK(fj_launch_group(cs, s));
     it.lbound = it.n / FJ_CHUNK + 1 + max_segs;
-    if (level_tile_table(c, it, fj_partition_tile_chunks((u32)it.plan.fan_log[it.i], it.has_vals), s)) return 1;
+    it.bloom_done = true;
+    if (level_finish(c, it, false, s)) return 1;          // the next pass reads the survivors
     it.prev = cs;
     ++it.slot;
-    it.bloom_done = true;
     return 0;
 }
 
@@ -392,6 +431,11 @@ int clear_plan_scalars(fj_ctx* c, hipStream_t s) {
     HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, owner_counts), s));
     return 0;
 }
+
+// Bracket of a partitioned plan: the self-cleaning buffers (get_zeroed_buf) are trusted only if the previous plan on this
+// context ran all its bookkeeping.  begin_plan before the first pass_prepare, end_plan once the result was read back.
+void begin_plan(fj_ctx* c) { c->zeros_dirty = c->plan_in_flight; c->plan_in_flight = true; }
+void end_plan(fj_ctx* c) { c->plan_in_flight = false; }
 
 int read_scalars(fj_ctx* c, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
@@ -448,7 +492,9 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
                 HIPCHK(hipMemsetAsync(&c->d_sc->alloc[0], 0, sizeof(c->d_sc->alloc) + sizeof(c->d_sc->seg_counter), s));   // the build side's passes run again
                 PassIter bit;
                 pass_init(bit, 0, true, pd.nb, make_plan(pd.nb, pd.top_bits), pd.top_bits);
+                begin_plan(c);
                 if (run_passes(c, bit, pd.bk, rowidx, s, &pd.lds.build, nullptr)) return 1;
+                end_plan(c);                  // (a pool error of these passes surfaces through the emit kernel's missing rows: same sizes as the counted join)
                 pd.lds.dedup = 1; pd.lds.orig_vals = pd.bv;
             }
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
@@ -514,31 +560,17 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
 }
 
 // launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
-int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, u64 pchunk_bound, hipStream_t s,
+int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, const PassIter& pit, hipStream_t s,
                     fj_timings* t, int evc, u64* out_count, bool* lds_full, bool overlapped = false) {
     ja.nparts = 1u << plan.bits;
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
     void* p;
     u32 nitems;
     if (ja.probe.list) {
-        // work items = tiles of the probe chunk lists.  Few partitions (< 2048): several slices per partition, each
-        // rebuilding the partition's table, so that small builds still fill the chip (a slice keeps >= 32 full chunks
-        // of probe rows per table build).  Many partitions: one item per partition, except that a partition swollen
-        // by a hot key is cut into slices of 4x the average (>= 512 chunks).  `bound` over-estimates the chunk count
-        // (partial chunks), which only makes slices a little longer than planned.
-        const u64 bound = std::max<u64>(pchunk_bound, pchunks);
-        const u64 avg = std::max<u64>(1, bound / ja.nparts);
-        u64 want = 1;
-        if (ja.nparts < 2048) want = std::min<u64>((2048 + ja.nparts - 1) / ja.nparts, std::max<u64>(1, (pchunks / ja.nparts) / 32));
-        const u32 tc = (u32)(want > 1 ? std::max<u64>(8, (avg * 9 / 8 + want - 1) / want) : std::max<u64>(512, 4 * avg));
-        const u64 max_items = bound / tc + ja.nparts + 1;
-        if (max_items >= (1ull << 31)) return set_err("internal error: join item table too large");
-        if (get_buf(c, W_JOIN_TOFF, ((size_t)ja.nparts + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
-        if (get_buf(c, W_JOIN_ITEMS, max_items * sizeof(uint4), &p)) return 1;
-        HIPCHK(fj_launch_tile_table(ja.probe, tc, toff, (uint4*)p, (u32)max_items, s));
-        ja.items = (const uint4*)p; ja.nitems_dev = toff + ja.nparts; ja.items_cap = (u32)max_items;
+        // work items = tiles of the probe chunk lists, built with the final level's bookkeeping (level_finish)
+        ja.items = pit.tiles; ja.nitems_dev = pit.ntiles; ja.items_cap = pit.items_cap; ja.part_count = pit.part_count;
         ja.nsplit = 1;
-        nitems = (u32)max_items;
+        nitems = pit.items_cap;
     } else {
         u64 nsplit = 1;
         if (ja.nparts < 2048) {
@@ -548,9 +580,8 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
         }
         ja.nsplit = (u32)nsplit; ja.items = nullptr; ja.nitems_dev = nullptr; ja.items_cap = 0;
         nitems = ja.nparts * ja.nsplit;
+        if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
     }
-    if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
-    if (ja.items) HIPCHK(hipMemsetAsync(ja.part_count, 0, (size_t)nitems * 4, s));     // entries past the device-side item count stay 0
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
     ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr; ja.retry_only = 0;
     ja.dbg = nullptr;
@@ -571,6 +602,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
         t->lds_retries = 1;
     }
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
+    end_plan(c);                              // every prepared pass ran its bookkeeping: the self-cleaning buffers are clean
     t->path = 0; t->passes = plan.npass; t->radix_bits = plan.bits; t->partitions = ja.nparts;
     // one-shot joins: build_phase_ms = wall interval of the build relation's passes, which run BESIDE the probe relation's
     // passes; probe_phase_ms = wall interval from the first probe-side pass to the end of the join (it contains the
@@ -598,6 +630,7 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
                hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
     const Plan plan = make_plan(nb, top_bits, bloom != 0);
     *lds_full = false;
+    begin_plan(c);
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     if (clear_plan_scalars(c, s)) return 1;
     FjLdsJoinArgs ja{};
@@ -606,6 +639,7 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     pass_init(bit, 0, materialize != 0, nb, plan, top_bits);
     int evc = 0;
     pass_init(pit, 1, false, np, plan, top_bits);
+    pit.want_items = true;
     bool overlap = options().overlap_relations != 0;
     // bloom plans: the filter stage needs the whole build side, and a build relation squeezed in beside the 1024-thread
     // first probe pass finishes late (measured: 9.5 ms overlapped against 8.4 ms one after the other at c4): build first
@@ -641,7 +675,7 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
     }
 
-    if (radix_join_tail(c, materialize, ja, plan, np, pit.lbound, s, t, evc, out_count, lds_full, overlap)) return 1;
+    if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, overlap)) return 1;
     if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
     return 0;
 }
@@ -834,12 +868,14 @@ int stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_bound, 
     st.plan = make_plan(nb_bound, top_bits);
     st.top_bits = top_bits; st.np_bound = np_bound; st.nb_bound = nb_bound;
     st.p_appends_left = (u32)probe_appends; st.b_appends_left = (u32)build_appends;
+    begin_plan(c);
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     if (clear_plan_scalars(c, s)) return 1;
     if (st.plan.npass > 0) {
         pass_init(st.bit, 0, false, std::max<size_t>(nb_bound, 1), st.plan, top_bits);     // count only: keys
         if (pass_prepare(c, st.bit, (u32)build_appends, s)) return 1;
         pass_init(st.pit, 1, false, std::max<size_t>(np_bound, 1), st.plan, top_bits);
+        st.pit.want_items = true;
         if (pass_prepare(c, st.pit, (u32)probe_appends, s)) return 1;
     }
     st.active = true;
@@ -940,7 +976,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         }
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
-        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit.lbound, s, &t, st.evc, &count, &lds_full)) return 1;
+        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full)) return 1;
         if (lds_full) return set_err("fj_stream_finish: a partition does not fit its LDS table; use fj_join_device on the whole relation");
     } else {
         if (st.plan.npass == 0 && st.nb_seen > 0)
@@ -948,6 +984,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
         if (read_scalars(c, s)) return 1;
+        if (st.plan.npass == 0) end_plan(c);          // (a partitioned plan with an empty side never ran its bookkeeping: stays "in flight")
         if (c->h_sc->err & (FJ_ERR_LDS_FULL | FJ_STAT_RETRY)) return set_err("fj_stream_finish: the build side does not fit one LDS table");
         count = c->h_sc->total;
         t.path = 0; t.passes = 0; t.partitions = 1;
@@ -1022,11 +1059,12 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
                        int hash_top_bits, void* stream, uint64_t* h_out_keys, uint64_t* h_out_vals,
                        uint32_t* h_bucket_of, uint64_t* h_nvalid) {
     if (!c) return set_err("fj_debug_partition: null context");
-    if (total_bits < 1 || total_bits > 24) return set_err("fj_debug_partition: total_bits must be 1..24");
+    if (total_bits < 2 || total_bits > 24) return set_err("fj_debug_partition: total_bits must be 2..24");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     Plan plan; plan.bits = total_bits;
     plan_passes(plan, true);
+    begin_plan(c);
     if (clear_plan_scalars(c, s)) return 1;
     FjChunkSet cs{};
     PassIter dit;
@@ -1034,6 +1072,7 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
     if (run_passes(c, dit, d_keys, d_vals, s, &cs, nullptr)) return 1;
     if (read_scalars(c, s)) return 1;
     if (c->h_sc->err) return set_err("fj_debug_partition: device error word 0x%x", c->h_sc->err);
+    end_plan(c);
     std::vector<u32> dir(cs.cap), list(cs.cap), boff(cs.nb + 1);
     HIPCHK(hipMemcpy(dir.data(), cs.dir, (size_t)cs.cap * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(list.data(), cs.list, (size_t)cs.cap * 4, hipMemcpyDeviceToHost));

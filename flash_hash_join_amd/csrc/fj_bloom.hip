@@ -281,6 +281,8 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
         step(K2, C2, K1, C1, E1, E0, D0, D2); if (++t >= nmine) break;
     }
     if (cur_bucket != 0xFFFFFFFFu) end_segment(cur_bucket);
+    // unused chunk ids of this wave's slab stay unlisted (the directory needs no memset: every id is defined by its owner)
+    for (u32 j = lane; j < slab_rem; j += 64) { const u32 id = slab_cur + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
     if (lane == 0 && survivors) atomicAdd(a.survivors, survivors);
 }
 

@@ -1166,8 +1166,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
             auto pk = fj_count_join_persistent<512>;
             hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
             if (e != hipSuccess) return e;
-            e = hipMemsetAsync(next_item, 0, 4, s);
-            if (e != hipSuccess) return e;
+            // (*next_item is zero: cleared with the plan's scalars at the start of the join)
             const u32 grid = nb < 512 ? nb : 512;            // two resident workgroups per CU
             hipLaunchKernelGGL(pk, dim3(grid), dim3(512), ldsp, s, a, next_item);
             return hipGetLastError();

@@ -177,6 +177,11 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     // end of a segment (= this workgroup's share of one parent bucket): write the carried
     // remainders, fix the last chunk's count, reserve the chunk-list spans, reset the state
     auto flush = [&](u32 parent) {
+        {   // a slab remainder too small for the flush is abandoned below: its ids stay unlisted (the directory has no memset)
+            const u32 rem0 = misc[M_SLAB_REM], cur0 = misc[M_SLAB_CUR];
+            if (rem0 < F && tid < rem0 && cur0 + tid < cap) a.out_dir[cur0 + tid] = FJ_DIR_INVALID;
+            __syncthreads();
+        }
         if (tid == 0) {
             if (misc[M_SLAB_REM] < F) {
                 const u32 nb = atomicAdd(a.alloc, a.slab);
@@ -445,75 +450,146 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     }
     carry();
     flush(cur_parent);
+    // The chunk ids this workgroup took from the allocator but never used stay unlisted: their directory words say so.
+    // (Every id below the allocator's high-water mark is thus defined by its owner - the directory needs no memset.)
+    for (u32 j = tid; j < misc[M_SLAB_REM]; j += NT) { const u32 id = misc[M_SLAB_CUR] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
 }
 
-// Single-workgroup exclusive scans (bucket counts -> offsets): sweeps of 4096 elements, four consecutive elements per
-// thread (coalesced), wave shuffles + 16 LDS words, two barriers per sweep.
-template <typename T, typename In>
-__device__ __forceinline__ void fj_block_scan(In value_at, T* __restrict__ out, u32 n) {
-    __shared__ T wtot[16];
-    __shared__ T carry_s;
+// Single-workgroup exclusive scan (bucket counts -> offsets): sweeps of 16384 elements.  A thread takes four groups of four
+// consecutive elements, 4096 elements apart (every load and store instruction covers 1 KiB of consecutive addresses: the
+// scan runs on ONE CU, whose address unit handles one cache line per clock - 64-B-strided accesses were 5x slower);
+// wave shuffles + 64 LDS words, two barriers per sweep.  Returns the total.
+template <typename T, typename In, typename Out>
+__device__ __forceinline__ T fj_block_scan(In value_at, Out put, u32 n) {
+    __shared__ T wtot[4][16];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T carry = 0;
-    for (u32 base = 0; base < n; base += 4096) {
-        const u32 i0 = base + tid * 4;
-        T x[4];
+    for (u32 base = 0; base < n; base += 16384) {
+        T x[4][4], sum[4], inc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = i0 + j < n ? (T)value_at(i0 + j) : (T)0;
-        const T sum = x[0] + x[1] + x[2] + x[3];
-        T inc = sum;
+        for (int j = 0; j < 4; ++j) {
+            const u32 e0 = base + 4u * ((u32)j * 1024u + tid);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const T y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
-        if (lane == 63) wtot[wave] = inc;
+            for (int k = 0; k < 4; ++k) x[j][k] = e0 + k < n ? (T)value_at(e0 + k) : (T)0;
+            sum[j] = x[j][0] + x[j][1] + x[j][2] + x[j][3];
+            T v = sum[j];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const T y = __shfl_up(v, d, 64); if ((int)lane >= d) v += y; }
+            inc[j] = v;
+            if (lane == 63) wtot[j][wave] = v;
+        }
         __syncthreads();
-        T run = carry + inc - sum;
-        for (u32 w = 0; w < wave; ++w) run += wtot[w];
+        T before = carry, total = carry;               // sum of the (group, wave) cells in front of this thread's / of the whole sweep
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { if (i0 + j < n) out[i0 + j] = run; run += x[j]; }
-        if (tid == 1023) carry_s = run;
-        __syncthreads();
-        carry = carry_s;
+        for (int j = 0; j < 4; ++j) {
+            T mine = 0, all = 0;
+            for (u32 w = 0; w < 16; ++w) { const T c = wtot[j][w]; all += c; if (w < wave) mine += c; }
+            T run = total + mine + inc[j] - sum[j];
+            const u32 e0 = base + 4u * ((u32)j * 1024u + tid);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (e0 + k < n) put(e0 + k, run); run += x[j][k]; }
+            total += all;
+        }
+        (void)before;
+        carry = total;
+        __syncthreads();                               // wtot is rewritten by the next sweep / a following scan
     }
-    if (tid == 0) out[n] = carry;
+    return carry;
 }
 
-__global__ __launch_bounds__(1024) void fj_scan_u32(const u32* in, u32* __restrict__ out, u32 n) {
-    fj_block_scan<u32>([&](u32 i) { return in[i]; }, out, n);
-}
-
-// number of tiles of `tc` chunks per bucket (tiles never span buckets), exclusive-scanned
-__global__ __launch_bounds__(1024) void fj_tile_scan(const u32* __restrict__ boff, u32* __restrict__ toff, u32 n, u32 tc) {
-    fj_block_scan<u32>([&](u32 i) { return (boff[i + 1] - boff[i] + tc - 1) / tc; }, toff, n);
+// After a pass, one workgroup: per-bucket chunk counts -> chunk-list offsets boff[0..n] and - for a consumer that reads
+// `tc` chunks per tile - the tile offsets toff[0..n], both from one read of the counts (a packed 64-bit scan: chunks in the
+// low word, tiles in the high word); the counts are cleared for the next join (nobody else reads them).
+// n % 4 == 0 (every level has a power-of-two bucket count >= 32): 16-B loads and stores throughout.
+__global__ __launch_bounds__(1024) void fj_level_scan(u32* __restrict__ bchunks, u32* __restrict__ boff, u32 n, u32 tc,
+                                                      u32* __restrict__ toff) {
+    __shared__ u64 wtot[4][16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float rtc = tc ? 1.0f / (float)tc : 0.f;
+    auto tiles_of = [&](u32 c) -> u32 {          // ceil(c / tc) without an integer division (c < 2^24: exact after one correction)
+        if (!tc) return 0u;
+        u32 q = (u32)((float)c * rtc);
+        while (q * tc < c) ++q;
+        while (q && (q - 1) * tc >= c) --q;
+        return q;
+    };
+    u64 carry = 0;
+    for (u32 base = 0; base < n; base += 16384) {
+        uint4 x[4]; u64 sum[4], inc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 e0 = base + 4u * ((u32)j * 1024u + tid);
+            x[j] = make_uint4(0, 0, 0, 0);
+            if (e0 < n) { x[j] = *reinterpret_cast<const uint4*>(bchunks + e0); *reinterpret_cast<uint4*>(bchunks + e0) = make_uint4(0, 0, 0, 0); }
+            sum[j] = ((u64)x[j].x + x[j].y + x[j].z + x[j].w) | ((u64)(tiles_of(x[j].x) + tiles_of(x[j].y) + tiles_of(x[j].z) + tiles_of(x[j].w)) << 32);
+            u64 v = sum[j];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u64 y = __shfl_up(v, d, 64); if ((int)lane >= d) v += y; }
+            inc[j] = v;
+            if (lane == 63) wtot[j][wave] = v;
+        }
+        __syncthreads();
+        u64 total = carry;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u64 mine = 0, all = 0;
+            for (u32 w = 0; w < 16; ++w) { const u64 c = wtot[j][w]; all += c; if (w < wave) mine += c; }
+            u64 run = total + mine + inc[j] - sum[j];
+            const u32 e0 = base + 4u * ((u32)j * 1024u + tid);
+            if (e0 < n) {
+                uint4 ob, ot;
+                ob.x = (u32)run; ot.x = (u32)(run >> 32); run += (u64)x[j].x | ((u64)tiles_of(x[j].x) << 32);
+                ob.y = (u32)run; ot.y = (u32)(run >> 32); run += (u64)x[j].y | ((u64)tiles_of(x[j].y) << 32);
+                ob.z = (u32)run; ot.z = (u32)(run >> 32); run += (u64)x[j].z | ((u64)tiles_of(x[j].z) << 32);
+                ob.w = (u32)run; ot.w = (u32)(run >> 32);
+                *reinterpret_cast<uint4*>(boff + e0) = ob;
+                if (tc) *reinterpret_cast<uint4*>(toff + e0) = ot;
+            }
+            total += all;
+        }
+        carry = total;
+        __syncthreads();
+    }
+    if (tid == 0) { boff[n] = (u32)carry; if (tc) toff[n] = (u32)(carry >> 32); }
 }
 
 // tile t -> (first list index, chunks, bucket)
-__global__ void fj_tile_expand(const u32* __restrict__ boff, const u32* __restrict__ toff, u32 n, u32 tc,
-                               uint4* __restrict__ tiles, u32 max_tiles) {
-    u32 total = toff[n];
-    if (total > max_tiles) total = max_tiles;
-    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        u32 lo = 0, hi = n;                       // last p with toff[p] <= t
-        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
-        const u32 pos = boff[lo] + (t - toff[lo]) * tc;
-        const u32 rem = boff[lo + 1] - pos;
-        tiles[t] = make_uint4(pos, rem < tc ? rem : tc, lo, 0);
-    }
+__device__ __forceinline__ void fj_tile_expand_one(const u32* __restrict__ boff, const u32* __restrict__ toff, u32 n, u32 tc,
+                                                   uint4* __restrict__ tiles, u32 t) {
+    u32 lo = 0, hi = n;                       // last p with toff[p] <= t
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
+    const u32 pos = boff[lo] + (t - toff[lo]) * tc;
+    const u32 rem = boff[lo + 1] - pos;
+    tiles[t] = make_uint4(pos, rem < tc ? rem : tc, lo, 0);
 }
 
 // same for u64 outputs (result offsets can exceed 2^32)
 __global__ __launch_bounds__(1024) void fj_scan_u32_to_u64(const u32* __restrict__ in, u64* __restrict__ out, u32 n) {
-    fj_block_scan<u64>([&](u32 i) { return in[i]; }, out, n);
+    const u64 total = fj_block_scan<u64>([&](u32 i) { return in[i]; }, [&](u32 i, u64 v) { out[i] = v; }, n);
+    if (threadIdx.x == 0) out[n] = total;
 }
 
-// chunk lists without atomics: list[boff[bucket] + span offset of the producing segment + rank] = chunk
-__global__ void fj_list_build(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
-                              u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
-                              u32 max_segs, u32* __restrict__ list) {
+// chunk lists without atomics: list[boff[bucket] + span offset of the producing segment + rank] = chunk.  The same launch
+// expands the consumer's tile table (independent work on the scan's outputs) and clears the tail of an optional per-tile
+// array (the join's per-item counts: entries past the device-side item count must read 0).
+__global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
+                               u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
+                               u32 max_segs, u32* __restrict__ list,
+                               u32 nb, u32 tc, const u32* __restrict__ toff, uint4* __restrict__ tiles, u32 max_tiles,
+                               u32* __restrict__ zero_tail) {
     // a chain of dependent loads per chunk (dir/rel -> boff/seg_off -> store): four chunks per thread and step keep
-    // four chains in flight (the kernel is latency-bound: ~4M chunks at c3)
+    // four chains in flight (the kernel is latency-bound: ~4M chunks at c3), and the grid fills the chip's thread slots
     u32 n = *nalloc; if (n > cap) n = cap;
-    const u32 stride = gridDim.x * blockDim.x;
-    for (u32 i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    const u32 stride = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tc) {
+        u32 total = toff[nb];
+        if (total > max_tiles) total = max_tiles;
+        for (u32 t = gtid; t < max_tiles; t += stride) {
+            if (t < total) fj_tile_expand_one(boff, toff, nb, tc, tiles, t);
+            else if (zero_tail) zero_tail[t] = 0;
+        }
+    }
+    for (u32 i0 = gtid; i0 < n; i0 += 4 * stride) {
         u32 e[4]; u64 r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -531,6 +607,21 @@ __global__ void fj_list_build(const u32* __restrict__ dir, const u64* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (ok[u]) list[pos[u]] = (((e[u] & FJ_DIR_CNT_MASK) - 1u) << 24) | (i0 + u * stride);
+    }
+}
+
+// a tile table alone (a second consumer of a level whose lists exist already)
+__global__ __launch_bounds__(1024) void fj_tile_scan(const u32* __restrict__ boff, u32* __restrict__ toff, u32 n, u32 tc) {
+    const u32 tt = fj_block_scan<u32>([&](u32 i) { return (boff[i + 1] - boff[i] + tc - 1) / tc; }, [&](u32 i, u32 v) { toff[i] = v; }, n);
+    if (threadIdx.x == 0) toff[n] = tt;
+}
+__global__ void fj_tile_expand(const u32* __restrict__ boff, const u32* __restrict__ toff, u32 n, u32 tc,
+                               uint4* __restrict__ tiles, u32 max_tiles, u32* __restrict__ zero_tail) {
+    u32 total = toff[n];
+    if (total > max_tiles) total = max_tiles;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < max_tiles; t += gridDim.x * blockDim.x) {
+        if (t < total) fj_tile_expand_one(boff, toff, n, tc, tiles, t);
+        else if (zero_tail) zero_tail[t] = 0;
     }
 }
 
@@ -608,18 +699,20 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
     return launch_part2<512, 8, false>(a, line_log, grid, s);
 }
 
-// After a pass: per-bucket chunk counts -> offsets -> chunk lists (no atomics).
-hipError_t fj_launch_group(const FjChunkSet& cs, hipStream_t s) {
-    hipLaunchKernelGGL(fj_scan_u32, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb);
-    hipLaunchKernelGGL(fj_list_build, dim3(512), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
-                       cs.fan_mask, cs.max_segs, cs.list);
+// After a pass, two launches: per-bucket chunk counts -> offsets (+ the consumer's tile offsets), then chunk lists
+// (no atomics) + the consumer's tile table.  tc == 0: no consumer tile table.
+hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s) {
+    if (cs.nb & 3u) return hipErrorInvalidValue;           // fj_level_scan works in 16-B pieces
+    hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
+    hipLaunchKernelGGL(fj_level_lists, dim3(2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
+                       cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
     return hipGetLastError();
 }
 
-// Tile table of a chunk set for a consumer pass with `tc` chunks per tile.
-hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, hipStream_t s) {
+// Tile table of a chunk set (lists already built) for a consumer with `tc` chunks per tile.
+hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s) {
     hipLaunchKernelGGL(fj_tile_scan, dim3(1), dim3(1024), 0, s, cs.boff, toff, cs.nb, tc);
-    hipLaunchKernelGGL(fj_tile_expand, dim3(256), dim3(256), 0, s, cs.boff, toff, cs.nb, tc, tiles, max_tiles);
+    hipLaunchKernelGGL(fj_tile_expand, dim3(256), dim3(256), 0, s, cs.boff, toff, cs.nb, tc, tiles, max_tiles, zero_tail);
     return hipGetLastError();
 }
 

@@ -174,7 +174,7 @@ int fj_generate_probe(fj_ctx* ctx, uint64_t* d_keys, uint64_t first, size_t n, u
                       uint64_t seed, uint32_t hit_bp, uint64_t* h_expected_hits, void* stream);
 
 /*
- * Diagnostic for the test-suite: runs total_bits (1..24) of radix partitioning over a flat
+ * Diagnostic for the test-suite: runs total_bits (2..24) of radix partitioning over a flat
  * device relation and writes the final per-bucket chunk lists, linearised bucket by bucket, into
  * host arrays of n rows (h_out_vals may be NULL when d_vals is NULL).  *h_nvalid = rows written.
  */

@@ -399,7 +399,8 @@ def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["probe_rows_total"] == 2 * 20_000_000
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["probe_rows_total"] == 2 * 25_000_000     # default at N > 1: c5 (x 0.02)
+    assert d["config"]["bench_workload"] == "c5" and d["config"]["build_rows_total"] == 2 * 2_500_000
     assert d["config"]["parallelism"].endswith("x2") and "cpu_baseline" not in d and d["value"] > 0
 
 
