@@ -44,6 +44,8 @@ WORKLOADS = {
     "c3": (100_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
     "c4": (100_000_000, 1_000_000_000, 500, "hash_join_count_radix_bloom"),
     "c4_scalar_bloom": (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),
+    "c4_adaptive": (100_000_000, 1_000_000_000, 500, "adaptive_join_count"),             # the sampled hit rate turns the precheck on
+    "c3_adaptive": (100_000_000, 1_000_000_000, 5000, "adaptive_join_count"),            # ... and leaves it off at 50 % hits
     "c4_hbm_table_bloom": (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom"),   # literal one-table algorithm + bloom precheck
     "c3_mat": (100_000_000, 1_000_000_000, 5000, "hash_join_radix"),
     "small": (1_000_000, 10_000_000, 5000, "hash_join_count_radix"),
@@ -192,7 +194,8 @@ def main() -> None:
     nb_gpu, np_gpu, hit_bp, fn_name = WORKLOADS[args.workload]
     nb_gpu, np_gpu = max(1, int(nb_gpu * args.scale)), max(1, int(np_gpu * args.scale))
     nb_total, np_total = nb_gpu * world, np_gpu * world
-    algo = {"hash_join_count": api.ALGO_SCALAR, "hash_join_count_bloom": api.ALGO_SCALAR}.get(fn_name, api.ALGO_RADIX)
+    algo = {"hash_join_count": api.ALGO_SCALAR, "hash_join_count_bloom": api.ALGO_SCALAR, "adaptive_join_count": api.ALGO_ADAPTIVE,
+            "adaptive_join_count_bloom": api.ALGO_ADAPTIVE}.get(fn_name, api.ALGO_RADIX)
     bloom = int("bloom" in fn_name)
     materialize = int(fn_name in ("hash_join_radix", "hash_join"))
 
@@ -328,7 +331,7 @@ def main() -> None:
         "build_phase_ms": round(build_ms, 3), "probe_phase_ms": round(probe_ms, 3), "join_kernel_ms": round(mean(phase["join_ms"]), 3),
         "device_total_ms": round(mean(phase["total_ms"]), 3),
         "bloom_level": lt["bloom_level"], "bloom_filter_kernel_ms": round(mean(phase["filter_ms"]), 3) if lt["bloom_level"] else None,
-        "bloom_survivors": lt["filter_survivors"] if lt["bloom_level"] else None,
+        "bloom_survivors": lt["filter_survivors"] if lt["bloom_level"] else None, "sampled_hit_bp": lt["sampled_hit_bp"],
         "phase_schedule": phase_schedule, "device_total_serial_ms": round(serial_total_ms, 3) if serial_total_ms else None,
         "probe_phase_gprobes_per_s": round(np_gpu / (probe_ms * 1e-3) / 1e9, 2) if probe_ms else None,
         "probe_phase_algorithmic_bytes": (24 * k + 8) * np_gpu,

@@ -43,6 +43,7 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     u32 alloc[8];                      // [side*4 + pass] chunk allocators ([side*4 + 3]: the bloom stage's output pool)
     u32 seg_counter[8];                // [side*4 + pass] segment ids
     unsigned long long bloom_survivors;   // probe keys that passed the bloom precheck
+    unsigned long long sample_hits;       // sampled probe rows found in the build side (adaptive bloom decision)
     u32 next_item;                     // work counter of the persistent join kernel
     u32 pad_;
     unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
@@ -138,8 +139,10 @@ namespace {
 //                      move -- so on this machine "scalar" is the slower way to the same result at every size.
 struct Options {
     size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; int overlap_relations; u32 plan_target_keys;
-    int bloom_variant, bloom_overlap;
+    int bloom_variant, bloom_overlap, bloom_auto, bloom_auto_max_hit_bp;
     Options() {
+        bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
+        bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 3000;
         bloom_overlap = getenv("FJ_BLOOM_OVERLAP") ? atoi(getenv("FJ_BLOOM_OVERLAP")) : 0;
         const char* bvr = getenv("FJ_BLOOM_VARIANT");
         bloom_variant = bvr ? atoi(bvr) : 0;
@@ -626,10 +629,17 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
 }
 
 // radix path: partition both relations, then one LDS-table join per final partition
+// bloom: 0 = no precheck, 1 = precheck whenever the plan allows one (the *_bloom functions), 2 = decide from a sample
+// of the probe side (the adaptive_* functions): SURVEY 8(f) "bloom auto-enable by sampled hit rate"
 int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
                hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
-    const Plan plan = make_plan(nb, top_bits, bloom != 0);
+    Plan plan = make_plan(nb, top_bits, bloom != 0);
     *lds_full = false;
+    t->sampled_hit_bp = -1;
+    // a sample only pays where the precheck could: a filterable plan and a probe side that dominates the work
+    if (bloom == 2 && (plan.bloom_level == 0 || np < 4 * nb || np < (1u << 24) || !options().bloom_auto)) {
+        bloom = 0; plan = make_plan(nb, top_bits, false);
+    }
     begin_plan(c);
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     if (clear_plan_scalars(c, s)) return 1;
@@ -638,15 +648,42 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     // a counting join never looks at a value: its build side moves keys only (half the build-phase bytes)
     pass_init(bit, 0, materialize != 0, nb, plan, top_bits);
     int evc = 0;
-    pass_init(pit, 1, false, np, plan, top_bits);
-    pit.want_items = true;
     bool overlap = options().overlap_relations != 0;
     // bloom plans: the filter stage needs the whole build side, and a build relation squeezed in beside the 1024-thread
     // first probe pass finishes late (measured: 9.5 ms overlapped against 8.4 ms one after the other at c4): build first
     if (plan.bloom_level > 0 && !options().bloom_overlap) overlap = false;
+    if (plan.bloom_level > 0) bit.save_level = plan.bloom_level;
+    if (bloom == 2) {
+        // Decide from a sample.  The build relation is partitioned first, with the filterable plan (its final partitions
+        // are the same under either plan: digits are consecutive hash bits); FJ_SAMPLE_KEYS probe rows, evenly spaced, are
+        // looked up in their final build partitions (a wave scans the partition's ~3000 keys: 25 MB of reads in all); the
+        // host reads the hit count and picks the probe side's plan.  Costs the overlap of the two relations and ~50 us.
+        if (run_passes(c, bit, bk, materialize ? bv : nullptr, s, &ja.build, nullptr)) return 1;
+        HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+        const u32 nsamp = FJ_SAMPLE_KEYS;
+        HIPCHK(fj_launch_sample_hits(ja.build, pk, np, nsamp, (u32)(top_bits - 32 - plan.bits), (1u << plan.bits) - 1u, &c->d_sc->sample_hits, s));
+        HIPCHK(hipMemcpyAsync(&c->h_sc->sample_hits, &c->d_sc->sample_hits, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const u32 hit_bp = (u32)(c->h_sc->sample_hits * 10000ull / nsamp);
+        t->sampled_hit_bp = (int)hit_bp;
+        Plan pplan = plan;
+        const bool on = hit_bp <= (u32)options().bloom_auto_max_hit_bp;
+        if (!on) { pplan = make_plan(nb, top_bits, false); plan.bloom_level = 0; }
+        pass_init(pit, 1, false, np, pplan, top_bits);
+        pit.want_items = true;
+        if (on) { pit.bloom_build = &bit.saved; pit.bloom_wait_build = false; }
+        if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
+        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+        plan.npass = pplan.npass;
+        if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, false)) return 1;
+        if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
+        return 0;
+    }
+    pass_init(pit, 1, false, np, plan, top_bits);
+    pit.want_items = true;
     if (plan.bloom_level > 0) {
         // bloom precheck: the probe side's level `bloom_level` is filtered against the build side's same level
-        bit.save_level = plan.bloom_level; pit.bloom_build = &bit.saved; pit.bloom_wait_build = overlap;
+        pit.bloom_build = &bit.saved; pit.bloom_wait_build = overlap;
     }
     if (overlap && plan.bloom_level > 0 && options().bloom_overlap) {
         // as below, but the build relation is enqueued first: the filter stage needs its level descriptor on the host
@@ -696,6 +733,8 @@ int fj_set_option(const char* name, long long value) {
     if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
     if (!strcmp(name, "overlap_relations")) { options().overlap_relations = value != 0; return 0; }
     if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); options().plan_target_keys = (u32)value; return 0; }
+    if (!strcmp(name, "bloom_auto")) { options().bloom_auto = value != 0; return 0; }
+    if (!strcmp(name, "bloom_auto_max_hit_bp")) { if (value < 0 || value > 10000) return set_err("fj_set_option: bloom_auto_max_hit_bp must be 0..10000"); options().bloom_auto_max_hit_bp = (int)value; return 0; }
     if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); options().bloom_variant = (int)value; return 0; }
     if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
     return set_err("fj_set_option: unknown option '%s'", name);
@@ -708,6 +747,8 @@ long long fj_get_option(const char* name) {
     if (name && !strcmp(name, "overlap_relations")) return options().overlap_relations;
     if (name && !strcmp(name, "plan_target_keys")) return options().plan_target_keys;
     if (name && !strcmp(name, "bloom_variant")) return options().bloom_variant;
+    if (name && !strcmp(name, "bloom_auto")) return options().bloom_auto;
+    if (name && !strcmp(name, "bloom_auto_max_hit_bp")) return options().bloom_auto_max_hit_bp;
     set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
     return -1;
 }
@@ -767,6 +808,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     fj_timings t; memset(&t, 0, sizeof t);
+    t.sampled_hit_bp = -1;
     u64 count = 0;
     c->pend.valid = false;
     const Options& opt = options();
@@ -776,11 +818,13 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
         count = 0;
     } else if (use_radix) {
         bool lds_full = false;
-        if (join_radix(c, materialize, bloom, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count, &lds_full)) return 1;
+        // adaptive_*: the precheck is decided from a sample of the probe side; *_bloom by name: always on; otherwise off
+        const int bloom_mode = algo == FJ_ALGO_ADAPTIVE ? (options().bloom_auto ? 2 : (bloom ? 1 : 0)) : (bloom ? 1 : 0);
+        if (join_radix(c, materialize, bloom_mode, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count, &lds_full)) return 1;
         if (lds_full) {
             fj_timings t2; memset(&t2, 0, sizeof t2);
             if (join_global(c, bloom, materialize, d_bk, d_bv, nb, d_pk, np, s, &t2, &count)) return 1;
-            t2.total_ms += t.total_ms; t2.fell_back = 1; t = t2;
+            t2.total_ms += t.total_ms; t2.fell_back = 1; t2.sampled_hit_bp = t.sampled_hit_bp; t = t2;
         }
     } else {
         if (join_global(c, bloom, materialize, d_bk, d_bv, nb, d_pk, np, s, &t, &count)) return 1;

@@ -121,6 +121,11 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
 // with linear-probing overflow holds up to 8128 keys; only a partition beyond that raises FJ_ERR_LDS_FULL
 hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a, hipStream_t s);
 
+// how many of `nsamples` evenly spaced probe rows have their key in the build side (final chunk set `build`, partition id =
+// (hash word 1 >> shift32) & pmask): one wave per sample scans the sample's build partition
+hipError_t fj_launch_sample_hits(const FjChunkSet& build, const u64* pk, u64 np, u32 nsamples, u32 shift32, u32 pmask,
+                                 unsigned long long* hits, hipStream_t s);
+
 struct FjGtArgs {                // global (non-partitioned) table
     u64* tkeys; u64* tvals; u32* bloom;    // bloom == nullptr: no precheck
     u64 cap_mask;                           // capacity - 1 (capacity = power of two, multiple of 8)

@@ -881,6 +881,23 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
     }
 }
 
+// ---- hit-rate sample for the adaptive joins' bloom decision ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void fj_sample_hits_kernel(FjChunkSet build, const u64* __restrict__ pk, u64 np, u32 nsamples,
+                                                             u32 shift32, u32 pmask, unsigned long long* __restrict__ hits) {
+    const u32 lane = threadIdx.x & 63, widx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (widx >= nsamples) return;
+    const u64 key = pk[(u64)widx * (np / nsamples)];            // wave-uniform
+    const u32 p = (fj_hash_w1(key) >> shift32) & pmask;
+    const u32 b0 = build.boff[p], nbc = build.boff[p + 1] - b0;
+    bool found = false;
+    for (u32 c = 0; c < nbc; ++c) {
+        const u32 e = build.list[b0 + c], cnt = FJ_LIST_CNT(e);
+        const u64* ck = build.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK;
+        for (u32 o = lane; o < cnt; o += 64) found |= ck[o] == key;
+    }
+    if (__ballot(found) && lane == 0) atomicAdd(hits, 1ull);
+}
+
 // =============================== global (non-partitioned) table ===============================
 __device__ __forceinline__ u32 gt_bloom_mask(u64 h) {      // 3 bits of a 32-bit word per 8-slot group
     return (1u << ((h >> 40) & 31)) | (1u << ((h >> 45) & 31)) | (1u << ((h >> 50) & 31));
@@ -1188,6 +1205,13 @@ hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a0, hipStream_t s) {
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_sample_hits(const FjChunkSet& build, const u64* pk, u64 np, u32 nsamples, u32 shift32, u32 pmask,
+                                 unsigned long long* hits, hipStream_t s) {
+    if (!build.list || np < nsamples) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fj_sample_hits_kernel, dim3((nsamples * 64 + 255) / 256), dim3(256), 0, s, build, pk, np, nsamples, shift32, pmask, hits);
     return hipGetLastError();
 }
 

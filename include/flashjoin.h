@@ -53,7 +53,7 @@ typedef struct fj_timings {
     double filter_ms;            /* the filter kernel between the probe side's passes (part of probe_phase_ms)              */
     uint64_t filter_survivors;   /* probe keys that passed it (hits + false positives); 0 when bloom_level == 0             */
     int bloom_level;             /* 0: no precheck ran; L: the probe side was filtered after its L-th partition pass         */
-    int reserved2;
+    int sampled_hit_bp;          /* adaptive_* joins: hit rate (basis points) of the probe-side sample that decided on the precheck; -1: no sample taken */
 } fj_timings;
 
 /* replaces: flash_join.initialize() / initialize_memory_system (hash_join.cpp:596, :639).
@@ -75,6 +75,11 @@ const char* fj_version(void);
  *                        schedule under which build_phase_ms / probe_phase_ms are disjoint (env FJ_OVERLAP_RELATIONS).
  *   "persistent_min_items" - counting joins whose plan has at least this many (partition, probe slice) work items use
  *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
+ *   "bloom_auto"       - 1 (default): the adaptive_* functions decide on the bloom precheck of the partitioned plan from a
+ *                        sample of the probe side (4096 rows looked up in the partitioned build side): on when at most
+ *                        "bloom_auto_max_hit_bp" (default 3000 = 30 %) of them hit; 0: adaptive_*_bloom filter, adaptive_* do
+ *                        not, as named (env FJ_BLOOM_AUTO, FJ_BLOOM_AUTO_MAX_HIT_BP).  The explicit hash_join*_bloom
+ *                        functions always run the precheck when the plan has two or more passes; hash_join* never do.
  *   "plan_target_keys" - average build keys per final partition the plan aims for (default and maximum 4096 = half an LDS
  *                        table; env FJ_PLAN_TARGET_KEYS).  A testing knob: small values make small inputs take the deep
  *                        (two- and three-pass, bloom-filtered) plans that production only uses for >1M-row build sides.
