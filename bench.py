@@ -314,6 +314,7 @@ def main() -> None:
     phase_schedule = "as timed"
     serial_total_ms = None
     if lt.get("overlapped") and world == 1 and not force_dist:
+        was = api.get_option("overlap_relations")
         api.set_option("overlap_relations", 0)
         try:
             sb, sp, stot = [], [], []
@@ -325,7 +326,7 @@ def main() -> None:
             build_ms, probe_ms, serial_total_ms = mean(sb), mean(sp), mean(stot)
             phase_schedule = "serial schedule (overlap_relations=0), 3 extra steps after the timed region"
         finally:
-            api.set_option("overlap_relations", 1)
+            api.set_option("overlap_relations", was)
     phases = {
         "k_radix_passes": k, "radix_bits": lt["radix_bits"], "partitions": lt["partitions"], "path": lt["path"],
         "build_phase_ms": round(build_ms, 3), "probe_phase_ms": round(probe_ms, 3), "join_kernel_ms": round(mean(phase["join_ms"]), 3),

@@ -128,8 +128,12 @@ namespace {
 //   radix_threshold  : adaptive joins take the non-partitioned HBM table below this many build rows.  MI355X: the
 //                      partitioned driver wins at every build size (<= 4096 rows it runs zero passes: one LDS table per
 //                      workgroup over the flat inputs), so the switch point is 0 (tools/sweep_adaptive.py).
-//   overlap_relations : one-shot partitioned joins partition the two relations on two streams (default) or one after the
-//                      other on the caller's stream (disjoint build / probe phase timings).
+//   overlap_relations : one-shot partitioned joins partition the two relations one after the other on the caller's stream
+//                      (default: disjoint build / probe phase timings) or beside each other on two streams.  Round 1's
+//                      default was the two-stream schedule (it hid ~0.25 ms of bookkeeping launches: 9.42 -> 9.27 ms at c3);
+//                      with the bookkeeping fused into two launches per level there is little left to hide and the
+//                      contention costs more: 9.43 ms serial against 9.70 ms overlapped (3 alternating runs of 30 steps on
+//                      each of two boxes).
 //   persistent_min_items : counting joins with at least this many (partition, slice) items run the persistent join
 //                      kernel (resident workgroups that prefetch the next item); below it one workgroup per item.
 //   scalar_hbm_table : 1 = the reference's "scalar" functions (hash_join*, one table for the whole build side) use the
@@ -156,7 +160,7 @@ struct Options {
         const char* pm = getenv("FJ_PERSISTENT_MIN_ITEMS");
         persistent_min_items = pm ? (u32)strtoul(pm, nullptr, 10) : 8192u;
         const char* ov = getenv("FJ_OVERLAP_RELATIONS");
-        overlap_relations = ov ? atoi(ov) : 1;
+        overlap_relations = ov ? atoi(ov) : 0;
     }
 };
 Options& options() { static Options o; return o; }

@@ -70,9 +70,10 @@ const char* fj_version(void);
  *                        ONE table for the whole build side in HBM, as the reference does in DRAM; 0 (default): they
  *                        run the same partitioned plan as the radix functions (identical results, 2-4x faster here)
  *                        and the HBM table is only the overflow fallback (env FJ_SCALAR_HBM_TABLE).
- *   "overlap_relations" - 1 (default): one-shot partitioned joins run the two relations' partition passes on two streams
- *                        (the join waits for both); 0: build relation first, then probe relation, one stream - the
- *                        schedule under which build_phase_ms / probe_phase_ms are disjoint (env FJ_OVERLAP_RELATIONS).
+ *   "overlap_relations" - 0 (default): build relation first, then probe relation, one stream - build_phase_ms and
+ *                        probe_phase_ms are disjoint; 1: one-shot partitioned joins run the two relations' partition passes
+ *                        on two streams (the join waits for both) - measured slower since the per-level bookkeeping was
+ *                        fused into two launches (env FJ_OVERLAP_RELATIONS).
  *   "persistent_min_items" - counting joins whose plan has at least this many (partition, probe slice) work items use
  *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
  *   "bloom_auto"       - 1 (default): the adaptive_* functions decide on the bloom precheck of the partitioned plan from a

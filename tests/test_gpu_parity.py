@@ -28,23 +28,23 @@ def fj():
     return flash_join
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "serial_relations", "deep_plans"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "overlapped_relations", "deep_plans"])
 def scalar_mode(request, fj):
     """Run a test under the dispatch variants of the native library: the hash_join* functions served by the partitioned
     plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); and every
     partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it); and the
-    two relations partitioned one after the other on one stream instead of beside each other on two (the default); and
+    two relations partitioned beside each other on two streams instead of one after the other on one (the default); and
     "deep_plans": 32 build keys per final partition instead of 4096, so that the small inputs of these tests run the two-
     and three-pass plans -- and, in the *_bloom functions, the bloom precheck between the probe side's passes -- that
     production only takes for build sides above a million rows."""
     fj.set_option("plan_target_keys", 32 if request.param == 4 else 4096)
     fj.set_option("scalar_hbm_table", int(request.param == 1))
     fj.set_option("persistent_min_items", 0 if request.param == 2 else 8192)
-    fj.set_option("overlap_relations", 0 if request.param == 3 else 1)
+    fj.set_option("overlap_relations", 1 if request.param == 3 else 0)
     yield request.param
     fj.set_option("scalar_hbm_table", 0)
     fj.set_option("persistent_min_items", 8192)
-    fj.set_option("overlap_relations", 1)
+    fj.set_option("overlap_relations", 0)
     fj.set_option("plan_target_keys", 4096)
 
 
