@@ -134,6 +134,43 @@ def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int) -> dict:
             "hw_crc32c": bool(O.lib().fjo_uses_hw_crc()), **_host_cpu_facts()}
 
 
+def host_entry(device) -> dict:
+    """The drop-in NumPy entry (fj_join_host) at BASELINE configs[1] sizes (1M x 100M rows, 816 MB in): wall time of
+    flash_join.hash_join_count on pageable NumPy arrays - copy through the pinned ring with the join's first pass running
+    under it - next to the time a plain pinned-memory H2D copy of the same bytes takes on this box.  Never `value`."""
+    import numpy as np
+    import torch
+    import flash_join
+    from flash_hash_join_amd import api, datagen
+    nb, npk = 1_000_000, 100_000_000
+    bk, bv = datagen.build_device(nb, device)
+    pk, exp = datagen.probe_device(npk, nb, device, seed=1, hit_bp=5000)
+    hbk, hbv, hpk = (x.cpu().numpy().view(np.uint64) for x in (bk, bv, pk))
+    del bk, bv, pk
+    walls = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        n, sec = flash_join.hash_join_count(hbk, hbv, hpk)
+        walls.append((time.perf_counter() - t0) * 1e3)
+        assert n == exp, (n, exp)
+    lt = api.last_timings()
+    nbytes = (2 * nb + npk) * 8
+    pin = torch.empty(nbytes // 8, dtype=torch.int64).pin_memory()
+    dst = torch.empty(nbytes // 8, dtype=torch.int64, device=device)
+    h2d = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dst.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d.append((time.perf_counter() - t0) * 1e3)
+    w, h = min(walls[1:]), min(h2d[1:])
+    return {"workload": "hash_join_count on NumPy arrays, 1000000 build x 100000000 probe rows (BASELINE configs[1] sizes)",
+            "bytes_in": nbytes, "wall_incl_pcie_ms": round(w, 3), "pinned_h2d_only_ms": round(h, 3), "wall_over_h2d": round(w / h, 3),
+            "h2d_GBps": round(nbytes / h / 1e6, 1), "gprobes_per_s_incl_pcie": round(npk / w / 1e6, 3),
+            "device_resident_ms": round(lt["total_ms"], 3), "streamed_under_copy": bool(lt["host_streamed"])}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +180,7 @@ def main() -> None:
                     help="default: c3 (BASELINE configs[2]) at --gpus 1, c5 (configs[4], 125M x 1.25B rows per GPU) at --gpus > 1")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-entry", action="store_true", help="skip the PCIe-inclusive measurement of the NumPy entry")
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "c3" if args.gpus == 1 else "c5"
@@ -360,6 +398,16 @@ def main() -> None:
         "phases": phases,
         "roofline": roof,
     }
+    if rank == 0 and world == 1 and not args.no_host_entry and not force_dist:
+        try:
+            del bk, bv, pk
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        try:
+            out["host_entry"] = host_entry(device)
+        except Exception as ex:
+            out["host_entry"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             # full workload on the host when it fits (the oracle needs ~2.5x the input bytes), else a 1/10 sample
@@ -367,7 +415,10 @@ def main() -> None:
             need = (nb_gpu * 16 + np_gpu * 8) * 2.5
             full = psutil.virtual_memory().available > need + (8 << 30)
             sb, sp = (nb_gpu, np_gpu) if full else (max(1, nb_gpu // 10), max(1, np_gpu // 10))
-            del bk, bv, pk
+            try:
+                del bk, bv, pk
+            except NameError:
+                pass
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
         except Exception as ex:      # the baseline never blocks the GPU measurement

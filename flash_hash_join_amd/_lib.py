@@ -34,7 +34,7 @@ class FjTimings(ctypes.Structure):
         ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
         ("path", ctypes.c_int), ("passes", ctypes.c_int), ("radix_bits", ctypes.c_int), ("fell_back", ctypes.c_int),
         ("partitions", ctypes.c_uint64), ("overlapped", ctypes.c_int), ("lds_retries", ctypes.c_int),
-        ("filter_ms", ctypes.c_double), ("filter_survivors", ctypes.c_uint64), ("bloom_level", ctypes.c_int), ("sampled_hit_bp", ctypes.c_int),
+        ("filter_ms", ctypes.c_double), ("filter_survivors", ctypes.c_uint64), ("bloom_level", ctypes.c_int), ("sampled_hit_bp", ctypes.c_int), ("host_streamed", ctypes.c_int), ("reserved3", ctypes.c_int),
     ]
 
     def as_dict(self):

@@ -14,7 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -59,7 +63,7 @@ enum Slot {
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
 
-enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_SB0, E_SB1, E_FORK, E_BF0, E_BF1, E_PK0, E_NEV = E_PK0 + 8 };
+enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_SB0, E_SB1, E_FORK, E_BF0, E_BF1, E_H0, E_H1, E_H2, E_PK0, E_NEV = E_PK0 + 8 };
 
 struct Pending {
     bool valid = false;
@@ -83,6 +87,7 @@ struct PassIter {
     u32 tile_chunks = 16; int i = 0;
     FjChunkSet prev{}; bool have_prev = false; const uint4* tiles = nullptr; const u32* ntiles = nullptr; const u32* toff = nullptr;
     FjChunkSet cs{}; u32 Gmax = 1, F = 1, appends = 1;
+    size_t piece_rows = 0;               // > 0: no single append of the first pass brings more rows than this (sizes the per-append slack)
     int slot = 0, cs_base = 0;           // ping-pong workspace slot of the next output level / base index of cs's buffers
     // probe side of a join: the final level's consumer is the join kernel; its item table (tiles of the final probe chunk
     // lists) and per-item count array are produced by the final level's bookkeeping launches
@@ -118,6 +123,8 @@ struct fj_ctx {
     StreamState st;
     size_t ws_bytes = 0;
     u32 num_cus = 256;
+    void* stage[3] = {nullptr, nullptr, nullptr};     // pinned staging ring of the host-buffer entry (fj_join_host)
+    size_t stage_bytes = 0;
     bool plan_in_flight = false;       // a plan was begun and has not completed (an error in between leaves chunk counts behind)
     bool zeros_dirty = false;          // ... in which case the next plan re-zeroes the self-cleaning buffers it uses
 };
@@ -267,6 +274,8 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     it.appends = appends ? appends : 1;
     it.tile_chunks = fj_partition_tile_chunks((u32)it.plan.fan_log[i], it.has_vals);
     it.Gmax = pass_groups(it.lbound, it.n, it.tile_chunks, it.F);
+    if (it.piece_rows && it.appends > 1 && !it.have_prev)      // many small appends: each launch has few workgroups, so little slack per append
+        it.Gmax = std::min(it.Gmax, pass_groups((it.piece_rows + FJ_CHUNK - 1) / FJ_CHUNK, it.piece_rows, it.tile_chunks, it.F));
     const u32 F = it.F, G = it.Gmax, parents = it.parents;
     const u64 nb_out = (u64)parents * F;
     const u64 cap64 = it.n / FJ_CHUNK + 1 + (2ull * (G + parents) * F + (u64)(G + 1) * fj_slab_for(F)) * it.appends;
@@ -793,6 +802,7 @@ void fj_ctx_destroy(fj_ctx* c) {
     for (auto& b : c->bufs) if (b.p) (void)hipFree(b.p);
     for (int i = 0; i < E_NEV; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->side) (void)hipStreamDestroy(c->side);
+    for (void* p : c->stage) if (p) (void)hipHostFree(p);
     if (c->d_sc) (void)hipFree(c->d_sc);
     if (c->h_sc) (void)hipHostFree(c->h_sc);
     delete c;
@@ -909,7 +919,8 @@ int stream_flush_build(fj_ctx* c, StreamState& st, hipStream_t s) {
     return 0;
 }
 
-int stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends, hipStream_t s, int top_bits) {
+int stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends, hipStream_t s, int top_bits,
+                size_t probe_piece_rows = 0) {
     StreamState& st = c->st;
     st = StreamState();
     c->pend.valid = false;
@@ -924,6 +935,7 @@ int stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_bound, 
         if (pass_prepare(c, st.bit, (u32)build_appends, s)) return 1;
         pass_init(st.pit, 1, false, std::max<size_t>(np_bound, 1), st.plan, top_bits);
         st.pit.want_items = true;
+        st.pit.piece_rows = probe_piece_rows;
         if (pass_prepare(c, st.pit, (u32)probe_appends, s)) return 1;
     }
     st.active = true;
@@ -1157,11 +1169,86 @@ int fj_memcpy_d2h(void* h, const void* d, size_t bytes) { if (bytes) HIPCHK(hipM
 void fj_free_host(void* p) { free(p); }
 int fj_last_timings(fj_timings* out) { if (!out) return set_err("fj_last_timings: null"); *out = g_last; return 0; }
 
+// ---- host-buffer entry: pageable NumPy memory -> pinned staging ring -> HBM, pipelined with the join's first pass ----
+}  // extern "C"
+namespace {
+
+// memcpy by a few persistent threads: one core copies pageable -> pinned memory at 10-15 GB/s, PCIe Gen5 x16 moves ~55
+class CopyPool {
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable work_, done_;
+    const char* src_ = nullptr; char* dst_ = nullptr; size_t n_ = 0;
+    unsigned gen_ = 0, remaining_ = 0;
+    bool stop_ = false;
+    void slice(unsigned id, unsigned parts, size_t* off, size_t* len) const {
+        const size_t per = ((n_ / parts) + 4095) & ~(size_t)4095;
+        *off = std::min(n_, per * id);
+        *len = id + 1 == parts ? n_ - *off : std::min(per, n_ - *off);
+    }
+    void worker(unsigned id) {
+        unsigned seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(m_);
+            work_.wait(l, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            size_t off, len; slice(id + 1, (unsigned)th_.size() + 1, &off, &len);
+            const char* s = src_; char* d = dst_;
+            l.unlock();
+            if (len) memcpy(d + off, s + off, len);
+            l.lock();
+            if (--remaining_ == 0) done_.notify_one();
+        }
+    }
+public:
+    explicit CopyPool(unsigned nthreads) { for (unsigned i = 0; i + 1 < nthreads; ++i) th_.emplace_back([this, i] { worker(i); }); }
+    ~CopyPool() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } work_.notify_all(); for (auto& t : th_) t.join(); }
+    void copy(void* dst, const void* src, size_t n) {
+        if (n < (4u << 20) || th_.empty()) { memcpy(dst, src, n); return; }
+        { std::lock_guard<std::mutex> l(m_); src_ = (const char*)src; dst_ = (char*)dst; n_ = n; remaining_ = (unsigned)th_.size(); ++gen_; }
+        work_.notify_all();
+        size_t off, len; slice(0, (unsigned)th_.size() + 1, &off, &len);
+        if (len) memcpy((char*)dst + off, (const char*)src + off, len);
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&] { return remaining_ == 0; });
+    }
+};
+CopyPool& copy_pool() {
+    static CopyPool pool([] {
+        if (const char* e = getenv("FJ_HOST_COPY_THREADS")) return (unsigned)std::max(1, atoi(e));
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        return std::min(12u, std::max(2u, hw / 4));
+    }());
+    return pool;
+}
+
+// src (pageable host memory) -> dst (device), `piece` bytes at a time through the context's pinned ring; the copy of piece
+// i+1 into the ring overlaps the DMA of piece i.  on_piece(offset, bytes, event) is called once a piece's DMA is enqueued on
+// the context's copy stream (the event fires when it has landed).
+int h2d_pipelined(fj_ctx* c, void* dst, const void* src, size_t bytes, size_t piece, unsigned* cursor,
+                  const std::function<int(size_t, size_t, hipEvent_t)>& on_piece) {
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t n = std::min(piece, bytes - off);
+        const unsigned k = (*cursor)++ % 3u;
+        HIPCHK(hipEventSynchronize(c->ev[E_H0 + k]));                         // the ring slot's previous DMA has left it
+        copy_pool().copy(c->stage[k], (const char*)src + off, n);
+        HIPCHK(hipMemcpyAsync((char*)dst + off, c->stage[k], n, hipMemcpyHostToDevice, c->side));
+        HIPCHK(hipEventRecord(c->ev[E_H0 + k], c->side));
+        if (on_piece && on_piece(off, n, c->ev[E_H0 + k])) return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+extern "C" {
+
 int fj_join_host(int algo, int bloom, int materialize,
                  const uint64_t* bk, const uint64_t* bv, size_t nb, const uint64_t* pk, size_t np,
                  uint64_t* out_count, double* out_seconds, uint64_t** out_keys, uint64_t** out_vals) {
     if (out_keys) *out_keys = nullptr;
     if (out_vals) *out_vals = nullptr;
+    if (algo < 0 || algo > 2) return set_err("fj_join_host: unknown algo %d", algo);
     if (!g_host_ctx) {
         int dev = 0;
         if (const char* d = getenv("FJ_DEVICE")) dev = atoi(d);
@@ -1169,21 +1256,64 @@ int fj_join_host(int algo, int bloom, int materialize,
         if (!g_host_ctx) return 1;
     }
     fj_ctx* c = g_host_ctx;
+    HIPCHK(hipSetDevice(c->device));
     void *dbk, *dbv, *dpk;
     if (get_buf(c, W_H_BK, nb * 8, &dbk) || get_buf(c, W_H_BV, nb * 8, &dbv) || get_buf(c, W_H_PK, np * 8, &dpk)) return 1;
+    // pieces: >= 16 MiB (the ring's DMA and memcpy run at full rate), at most 48 of them for the probe side (the streamed
+    // join takes <= 64 appends), a multiple of 4 KiB
+    size_t piece = std::max<size_t>(16u << 20, (np * 8 + 47) / 48);
+    piece = (piece + 4095) & ~(size_t)4095;
+    if (c->stage_bytes < piece) {
+        for (void*& p : c->stage) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+        c->stage_bytes = 0;
+        for (void*& p : c->stage) HIPCHK(hipHostMalloc(&p, piece, hipHostMallocDefault));
+        c->stage_bytes = piece;
+    }
+    const Options& opt = options();
+    const bool use_radix = algo == FJ_ALGO_RADIX || (algo == FJ_ALGO_ADAPTIVE && nb >= opt.radix_threshold) ||
+                           (algo == FJ_ALGO_SCALAR && !opt.scalar_hbm_table);
+    // A counting join of the partitioned plan starts on the first piece: the build side is copied and partitioned, then every
+    // probe piece gets its first partition pass while the next one crosses PCIe (the join hides under the copy; the bloom
+    // precheck is skipped here - it saves device time the copy does not leave on the critical path).
+    const bool streamed = use_radix && !materialize && nb > 0 && np > 0;
+    hipStream_t js = nullptr;
     auto t0 = std::chrono::steady_clock::now();
-    if (nb) { HIPCHK(hipMemcpy(dbk, bk, nb * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dbv, bv, nb * 8, hipMemcpyHostToDevice)); }
-    if (np) HIPCHK(hipMemcpy(dpk, pk, np * 8, hipMemcpyHostToDevice));
-    const double h2d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    fj_timings t;
+    unsigned cursor = 0;
+    fj_timings t; memset(&t, 0, sizeof t); t.sampled_hit_bp = -1;
     u64 count = 0;
-    if (fj_join_device(c, algo, bloom, materialize, (const u64*)dbk, (const u64*)dbv, nb, (const u64*)dpk, np, nullptr, 64,
-                       &count, nullptr, nullptr, 0, &t)) return 1;
+    bool joined = false;
+    if (h2d_pipelined(c, dbk, bk, nb * 8, piece, &cursor, nullptr)) return 1;
+    if (!streamed) {
+        if (h2d_pipelined(c, dbv, bv, nb * 8, piece, &cursor, nullptr)) return 1;
+        if (h2d_pipelined(c, dpk, pk, np * 8, piece, &cursor, nullptr)) return 1;
+        HIPCHK(hipStreamSynchronize(c->side));
+    } else {
+        HIPCHK(hipStreamSynchronize(c->side));                                  // build keys are in HBM
+        const int appends = (int)((np * 8 + piece - 1) / piece);
+        if (stream_open(c, nb, 1, np, appends, js, 64, piece / 8)) return 1;
+        if (stream_append_build(c, (const u64*)dbk, nb, js)) return 1;
+        if (stream_flush_build(c, c->st, js)) return 1;
+        auto on_piece = [&](size_t off, size_t n, hipEvent_t landed) -> int {
+            HIPCHK(hipStreamWaitEvent(js, landed, 0));
+            return fj_stream_append_probe(c, (const u64*)((const char*)dpk + off), n / 8, js);
+        };
+        if (h2d_pipelined(c, dpk, pk, np * 8, piece, &cursor, on_piece)) return 1;
+        uint64_t cnt = 0;
+        if (fj_stream_finish(c, js, &cnt, &t) == 0) { count = cnt; joined = true; }
+        else if (g_err.find("does not fit") == std::string::npos) return 1;
+        // (a partition beyond the LDS tables: the whole relation is in HBM by now, the one-shot join below has the HBM-table fallback)
+        if (!joined) { if (h2d_pipelined(c, dbv, bv, nb * 8, piece, &cursor, nullptr)) return 1; HIPCHK(hipStreamSynchronize(c->side)); }
+    }
+    const double h2d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!joined) {
+        if (fj_join_device(c, algo, bloom, materialize, (const u64*)dbk, (const u64*)dbv, nb, (const u64*)dpk, np, js, 64,
+                           &count, nullptr, nullptr, 0, &t)) return 1;
+    }
     double d2h = 0;
     if (materialize && c->pend.valid) {
         void *dok, *dov;
         if (get_buf(c, W_H_OK, count * 8, &dok) || get_buf(c, W_H_OV, count * 8, &dov)) return 1;
-        if (emit_pending(c, (u64*)dok, (u64*)dov, count, nullptr, &t)) return 1;
+        if (emit_pending(c, (u64*)dok, (u64*)dov, count, js, &t)) return 1;
         if (out_keys && out_vals) {
             u64* hk = (u64*)malloc(std::max<size_t>(count, 1) * 8);
             u64* hv = (u64*)malloc(std::max<size_t>(count, 1) * 8);
@@ -1194,7 +1324,10 @@ int fj_join_host(int algo, int bloom, int materialize,
             *out_keys = hk; *out_vals = hv;
         }
     }
+    // h2d_ms: wall time from the first byte copied to the last piece enqueued + joined when the join was streamed under the
+    // copy (then total_ms, the device-resident time, lies INSIDE it), else the copies alone
     t.h2d_ms = h2d; t.d2h_ms = d2h;
+    t.host_streamed = joined ? 1 : 0;
     g_last = t;
     if (out_count) *out_count = count;
     if (out_seconds) *out_seconds = t.total_ms * 1e-3;

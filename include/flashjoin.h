@@ -54,6 +54,8 @@ typedef struct fj_timings {
     uint64_t filter_survivors;   /* probe keys that passed it (hits + false positives); 0 when bloom_level == 0             */
     int bloom_level;             /* 0: no precheck ran; L: the probe side was filtered after its L-th partition pass         */
     int sampled_hit_bp;          /* adaptive_* joins: hit rate (basis points) of the probe-side sample that decided on the precheck; -1: no sample taken */
+    int host_streamed;           /* fj_join_host: 1 if the join ran piece by piece under the PCIe copy (h2d_ms then contains it) */
+    int reserved3;
 } fj_timings;
 
 /* replaces: flash_join.initialize() / initialize_memory_system (hash_join.cpp:596, :639).

@@ -196,6 +196,28 @@ def test_partition_over_the_cuckoo_limit_is_redone_on_the_tagged_table(fj, oracl
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_numpy_entry_streams_the_join_under_the_copy(fj, oracle):
+    """fj_join_host: pageable NumPy arrays go through a pinned ring in pieces of >= 16 MiB; a counting join of the partitioned
+    plan gets its first pass per piece while the next piece crosses PCIe (host_streamed), materialising joins copy first.
+    Results equal the oracle's either way, including a probe side of several pieces with a ragged tail."""
+    from flash_hash_join_amd import datagen
+    nb, npk = 700_000, 9_000_001                                   # 72 MB of probe keys: five pieces, odd tail
+    bk, bv = datagen.build_numpy(nb)
+    pk, exp = datagen.probe_numpy(npk, nb, seed=13, hit_bp=4000)
+    for fn in COUNT_FUNCS:
+        n, sec = getattr(fj, fn)(bk, bv, pk)
+        t = fj.last_timings()
+        assert n == exp and t["host_streamed"] == 1 and t["h2d_ms"] > 0, (fn, t)
+    n, sec, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+    assert n == exp and fj.last_timings()["host_streamed"] == 0
+    assert np.array_equal(k, (v + np.uint64(1)) * datagen.M)
+    fj.set_option("scalar_hbm_table", 1)
+    try:
+        assert fj.hash_join_count(bk, bv, pk)[0] == exp and fj.last_timings()["host_streamed"] == 0 and fj.last_timings()["path"] == 1
+    finally:
+        fj.set_option("scalar_hbm_table", 0)
+
+
 def test_device_tensor_inputs_and_device_generators(fj, oracle):
     import torch
     from flash_hash_join_amd import datagen
