@@ -248,6 +248,17 @@ def main() -> None:
         dist.all_reduce(e)
         exp_total = int(e.item())
     engine = HipEngine(device) if (world > 1 or force_dist) else None
+    link = None
+    if world > 1 and not share_gpu:
+        # one all-to-all of 128 MiB per peer: the per-link rate this node delivers (recorded; also what FJ_DIST_STRATEGY=auto prices with)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import xgmi_probe
+            from flash_hash_join_amd import distributed as _D
+            link = xgmi_probe.measure(dist, device, 128)
+            _D.set_link_rate(link["link_GBps"] * 1e9)
+        except Exception as ex:
+            link = {"error": repr(ex)}
 
     units_per_launch = [float(np_gpu)]
     strategy_seen = ["single GPU"]
@@ -423,6 +434,8 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
         except Exception as ex:      # the baseline never blocks the GPU measurement
             out["cpu_baseline"] = {"error": repr(ex)}
+    if link is not None:
+        out["xgmi_all_to_all"] = link
     if priming:
         out["priming_steps"] = priming
     if share_gpu:

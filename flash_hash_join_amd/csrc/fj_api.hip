@@ -38,6 +38,22 @@ int set_err(const char* fmt, ...) {
         if (e_ != hipSuccess) return set_err("%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
     } while (0)
 
+// The C ABI runs on the context's device and leaves the caller's current device as it found it (torch reads the
+// runtime's current device: a join on cuda:1 must not move later torch allocations there).
+struct DeviceGuard {
+    int prev = -1; bool changed = false; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); changed = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define FJ_ON_DEVICE(dev)                                                                                   \
+    DeviceGuard dev_guard_(dev);                                                                            \
+    if (dev_guard_.err != hipSuccess) return set_err("selecting HIP device %d failed: %s", (int)(dev), hipGetErrorString(dev_guard_.err))
+
 struct Scalars {                       // device scratch words, mirrored in pinned host memory
     unsigned long long total;
     unsigned long long expected;
@@ -528,6 +544,12 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
         }
     }
     HIPCHK(hipEventRecord(c->ev[E_EMIT1], s));
+    if (pd.count > 0) {
+        // the emitting kernel can still refuse an item (a table that the counting pass's stricter cuckoo table accepted should
+        // never do so, but nothing else enforces that): unwritten output rows must not be handed back with status 0
+        if (read_scalars(c, s)) return 1;
+        if (c->h_sc->err & (FJ_ERR_LDS_FULL | FJ_ERR_POOL)) { pd.valid = false; return set_err("fj_emit_pairs: the emitting pass could not place every partition in LDS (device error word 0x%x)", c->h_sc->err); }
+    }
     HIPCHK(hipStreamSynchronize(s));
     if (t) { t->emit_ms = ev_ms(c, E_EMIT0, E_EMIT1); t->total_ms += t->emit_ms; t->probe_phase_ms += t->emit_ms; }
     pd.valid = false;
@@ -783,7 +805,8 @@ fj_ctx* fj_ctx_create(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || device < 0 || device >= n) { set_err("fj_ctx_create: HIP device %d not available (%d devices)", device, n); return nullptr; }
-    if (hipSetDevice(device) != hipSuccess) { set_err("fj_ctx_create: hipSetDevice(%d) failed", device); return nullptr; }
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) { set_err("fj_ctx_create: hipSetDevice(%d) failed", device); return nullptr; }
     fj_ctx* c = new fj_ctx();
     c->device = device;
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->num_cus = (u32)ncu; }
@@ -798,7 +821,7 @@ fj_ctx* fj_ctx_create(int device) {
 
 void fj_ctx_destroy(fj_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     for (auto& b : c->bufs) if (b.p) (void)hipFree(b.p);
     for (int i = 0; i < E_NEV; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -819,7 +842,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
     if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_join_device: hash_top_bits must be 64 or 48");
     if ((nb && (!d_bk || !d_bv)) || (np && !d_pk)) return set_err("fj_join_device: null input pointer");
     if (((uintptr_t)d_bk | (uintptr_t)d_bv | (uintptr_t)d_pk) & 15) return set_err("fj_join_device: input pointers must be 16-byte aligned");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     fj_timings t; memset(&t, 0, sizeof t);
     t.sampled_hit_bp = -1;
@@ -854,7 +877,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
 
 int fj_emit_pairs(fj_ctx* c, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, void* stream, fj_timings* timings) {
     if (!c) return set_err("fj_emit_pairs: null context");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     fj_timings t = g_last;
     if (emit_pending(c, d_out_keys, d_out_vals, out_capacity, (hipStream_t)stream, &t)) return 1;
     if (timings) *timings = t;
@@ -866,7 +889,7 @@ int fj_owner_split(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, si
                    uint64_t* d_out_keys, uint64_t* d_out_vals, uint64_t* h_counts, void* stream) {
     if (!c) return set_err("fj_owner_split: null context");
     if (nranks < 1 || nranks > 64) return set_err("fj_owner_split: nranks must be 1..64");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(c->d_sc->owner_counts, 0, sizeof(unsigned long long) * 128, s));   // counts + cursors
     HIPCHK(fj_launch_owner_hist(d_keys, n, (u32)nranks, c->d_sc->owner_counts, s));
@@ -963,13 +986,13 @@ int fj_stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_boun
     if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_stream_open: hash_top_bits must be 64 or 48");
     if (build_appends < 1 || build_appends > 64 || probe_appends < 1 || probe_appends > 64)
         return set_err("fj_stream_open: build_appends and probe_appends must be 1..64");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     return stream_open(c, nb_bound, build_appends, np_bound, probe_appends, (hipStream_t)stream, hash_top_bits);
 }
 
 int fj_stream_append_build(fj_ctx* c, const uint64_t* d_bk, size_t n, void* stream) {
     if (!c || !c->st.active) return set_err("fj_stream_append_build: no stream join is open on this context");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     return stream_append_build(c, (const u64*)d_bk, n, (hipStream_t)stream);
 }
 
@@ -980,7 +1003,7 @@ int fj_stream_begin(fj_ctx* c, const uint64_t* d_bk, const uint64_t* d_bv, size_
     if (max_appends < 1 || max_appends > 64) return set_err("fj_stream_begin: max_appends must be 1..64");
     if (nb && (!d_bk || !d_bv)) return set_err("fj_stream_begin: null input pointer");
     if (((uintptr_t)d_bk | (uintptr_t)d_bv) & 15) return set_err("fj_stream_begin: input pointers must be 16-byte aligned");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     if (stream_open(c, nb, 1, np_bound, max_appends, s, hash_top_bits)) return 1;
     if (stream_append_build(c, (const u64*)d_bk, nb, s)) return 1;
@@ -995,7 +1018,7 @@ int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stre
     if (!d_pk || ((uintptr_t)d_pk & 15)) return set_err("fj_stream_append_probe: probe piece must be a 16-byte aligned device pointer");
     if (st.p_appends_left == 0) return set_err("fj_stream_append_probe: more pieces than probe_appends");
     if (st.np_seen + n > st.np_bound) return set_err("fj_stream_append_probe: more probe rows than np_bound");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     --st.p_appends_left; st.np_seen += n;
     if (st.plan.npass > 0) return pass_launch(c, st.pit, d_pk, nullptr, n, s, st.evc < 4 ? &st.evc : nullptr);
@@ -1009,7 +1032,7 @@ int fj_stream_advance_probe(fj_ctx* c, void* stream) {
     if (!c || !c->st.active) return set_err("fj_stream_advance_probe: no stream join is open on this context");
     StreamState& st = c->st;
     if (st.probe_done) return 0;
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     st.probe_done = true;
     if (st.plan.npass > 0 && st.np_seen > 0) {
@@ -1023,7 +1046,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
     if (!c || !c->st.active) return set_err("fj_stream_finish: no stream join is open on this context");
     StreamState& st = c->st;
     st.active = false;
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     fj_timings t; memset(&t, 0, sizeof t);
     u64 count = 0;
@@ -1062,7 +1085,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
 int fj_owner_hist(fj_ctx* c, const uint64_t* d_keys, size_t n, int nranks, uint64_t* h_counts, void* stream) {
     if (!c) return set_err("fj_owner_hist: null context");
     if (nranks < 1 || nranks > 64) return set_err("fj_owner_hist: nranks must be 1..64");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(c->d_sc->owner_counts, 0, sizeof(unsigned long long) * 64, s));
     HIPCHK(fj_launch_owner_hist(d_keys, n, (u32)nranks, c->d_sc->owner_counts, s));
@@ -1078,7 +1101,7 @@ int fj_owner_scatter(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, 
                      uint64_t* d_out_keys, uint64_t* d_out_vals, void* stream) {
     if (!c) return set_err("fj_owner_scatter: null context");
     if (nranks < 1 || nranks > 64) return set_err("fj_owner_scatter: nranks must be 1..64");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     // the offsets travel in a pinned slot that a previous asynchronous scatter may still be reading: drain first
     HIPCHK(hipStreamSynchronize(s));
@@ -1093,7 +1116,7 @@ int fj_owner_scatter(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, 
 
 int fj_generate_build(fj_ctx* c, uint64_t* d_keys, uint64_t* d_vals, uint64_t first, size_t n, void* stream) {
     if (!c) return set_err("fj_generate_build: null context");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     HIPCHK(fj_launch_gen_build(d_keys, d_vals, first, n, (hipStream_t)stream));
     return 0;
 }
@@ -1102,7 +1125,7 @@ int fj_generate_probe(fj_ctx* c, uint64_t* d_keys, uint64_t first, size_t n, uin
                       uint32_t hit_bp, uint64_t* h_expected_hits, void* stream) {
     if (!c) return set_err("fj_generate_probe: null context");
     if (build_total == 0) return set_err("fj_generate_probe: build_total must be > 0");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(&c->d_sc->expected, 0, sizeof(unsigned long long), s));
     HIPCHK(fj_launch_gen_probe(d_keys, first, n, build_total, seed, hit_bp, &c->d_sc->expected, s));
@@ -1120,7 +1143,7 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
                        uint32_t* h_bucket_of, uint64_t* h_nvalid) {
     if (!c) return set_err("fj_debug_partition: null context");
     if (total_bits < 2 || total_bits > 24) return set_err("fj_debug_partition: total_bits must be 2..24");
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     Plan plan; plan.bits = total_bits;
     plan_passes(plan, true);
@@ -1256,7 +1279,7 @@ int fj_join_host(int algo, int bloom, int materialize,
         if (!g_host_ctx) return 1;
     }
     fj_ctx* c = g_host_ctx;
-    HIPCHK(hipSetDevice(c->device));
+    FJ_ON_DEVICE(c->device);
     void *dbk, *dbv, *dpk;
     if (get_buf(c, W_H_BK, nb * 8, &dbk) || get_buf(c, W_H_BV, nb * 8, &dbv) || get_buf(c, W_H_PK, np * 8, &dpk)) return 1;
     // pieces: >= 16 MiB (the ring's DMA and memcpy run at full rate), at most 48 of them for the probe side (the streamed

@@ -1,7 +1,8 @@
 """Multi-GPU radix join: one process per GPU over RCCL/xGMI.
 
 The reference is single-process; this is new design.  Two exchange strategies, chosen per call
-by a per-link byte + local-work cost model (choose_strategy; FJ_DIST_STRATEGY=shuffle|replicate overrides):
+by FJ_DIST_STRATEGY = shuffle (default: the exchange north_star names) | replicate | auto (a per-link byte + local-work
+cost model, choose_strategy):
 
 replicate -- every rank all-gathers the build KEYS (and values when materialising) and joins its own probe rows
   against all of them; probe rows never move, their partition passes run while the build keys are on the wire
@@ -52,6 +53,13 @@ class HipEngine:
 
     def empty(self, n: int):
         return self.torch.empty(n, dtype=self.torch.int64, device=self.device)
+
+    def normalize(self, bk, bv, pk):
+        """The dtype / contiguity / alignment normalisation of api.join_device, for callers that hand raw data_ptr()s on."""
+        bk, bv, pk = self.api._dev_tensor(bk, "build_keys"), self.api._dev_tensor(bv, "build_values"), self.api._dev_tensor(pk, "probe_keys")
+        if bv.numel() < bk.numel():
+            raise ValueError(f"build_values has {bv.numel()} elements, build_keys has {bk.numel()}")
+        return bk, bv, pk
 
     def counts_tensor(self, counts: List[int]):
         return self.torch.tensor(counts, dtype=self.torch.int64, device=self.device)
@@ -168,7 +176,7 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
     # build side: split, exchange, start the build-side passes
     bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)
     n = probe_keys.numel()
-    bounds = [n * c // pieces for c in range(pieces + 1)]
+    bounds = [(n * c // pieces) & ~1 for c in range(pieces)] + [n]      # even row offsets: every piece stays 16-byte aligned
     views = [probe_keys[bounds[c]: bounds[c + 1]] for c in range(pieces)]
     p_counts = [engine.owner_hist(v, world) for v in views]                  # [piece][owner]
     t1 = time.perf_counter()
@@ -271,9 +279,20 @@ def strategy_costs(world: int, nb: int, np_: int, materialize: bool) -> dict:
     return {"shuffle": t_shuffle, "replicate": t_replicate}
 
 
+def set_link_rate(bytes_per_s: float) -> None:
+    """Replace the built-in per-link rate of the strategy model by a measured one (tools/xgmi_probe.py; bench.py does this
+    once at N > 1)."""
+    global _LINK_BYTES_PER_S
+    if bytes_per_s > 0:
+        _LINK_BYTES_PER_S = float(bytes_per_s)
+
+
 def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
-    """'replicate' or 'shuffle' for per-rank relation sizes nb x np_ (the maxima over the ranks)."""
-    forced = os.environ.get("FJ_DIST_STRATEGY", "auto")
+    """'shuffle' (the owner exchange north_star names: the default) or 'replicate', for per-rank relation sizes nb x np_
+    (the maxima over the ranks).  FJ_DIST_STRATEGY=replicate|shuffle forces one; FJ_DIST_STRATEGY=auto lets the cost model
+    decide - it is only as good as its link rate (set_link_rate with a measured value) and was never checked against a
+    multi-GPU run, which is why it is not the default."""
+    forced = os.environ.get("FJ_DIST_STRATEGY", "shuffle")
     if forced in ("replicate", "shuffle"):
         return forced
     if world * nb >= (1 << 31):               # replicated build side must stay inside one GPU's chunk directory
@@ -386,6 +405,8 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     import torch.distributed as dist
     if engine is None:
         engine = HipEngine()
+    if hasattr(engine, "normalize"):             # int64/uint64, contiguous, 16-byte aligned: what the C ABI's pointers must be
+        build_keys, build_values, probe_keys = engine.normalize(build_keys, build_values, probe_keys)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1 and os.environ.get("FJ_FORCE_EXCHANGE") and not dist.is_initialized():
         raise RuntimeError("FJ_FORCE_EXCHANGE needs an initialised process group")

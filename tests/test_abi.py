@@ -138,6 +138,9 @@ def test_multi_gpu_strategy_model():
     documented break points."""
     from flash_hash_join_amd import distributed as D
     os.environ.pop("FJ_DIST_STRATEGY", None)
+    for world in (2, 4, 8, 16):
+        assert D.choose_strategy(world, 100_000_000, 1_000_000_000, False) == "shuffle"      # the default is the owner shuffle
+    os.environ["FJ_DIST_STRATEGY"] = "auto"                                                  # the model decides
     for world in (2, 4, 8):
         assert D.choose_strategy(world, 100_000_000, 1_000_000_000, False) == "replicate"
     assert D.choose_strategy(16, 100_000_000, 1_000_000_000, False) == "shuffle"
@@ -145,9 +148,15 @@ def test_multi_gpu_strategy_model():
     assert D.choose_strategy(8, 400_000_000, 4_000_000_000, False) == "shuffle"        # 3.2e9 replicated rows: past one GPU's directory
     c = D.strategy_costs(2, 100_000_000, 1_000_000_000, False)
     assert c["shuffle"] > 3 * c["replicate"]                                           # one xGMI link between two GPUs
-    os.environ["FJ_DIST_STRATEGY"] = "shuffle"
+    old = D._LINK_BYTES_PER_S
+    D.set_link_rate(400e9)                                                                   # a measured, much faster link: shuffle wins at N = 8
     try:
-        assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == "shuffle"
+        assert D.choose_strategy(8, 100_000_000, 1_000_000_000, False) == "shuffle"
+    finally:
+        D.set_link_rate(old)
+    os.environ["FJ_DIST_STRATEGY"] = "replicate"
+    try:
+        assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == "replicate"
     finally:
         os.environ.pop("FJ_DIST_STRATEGY")
     # passes: none up to 3950 rows (one cuckoo table), one up to 9 radix bits (512 buckets), two up to 18 bits,

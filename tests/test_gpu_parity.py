@@ -196,6 +196,32 @@ def test_partition_over_the_cuckoo_limit_is_redone_on_the_tagged_table(fj, oracl
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_j1_harness_prints_parsable_result_lines(fj):
+    """tools/benchmark_j1.py (the reference's benchmark.py cases, benchmark.py:83, :240-274): every RESULT line parses, the
+    six implementations x two tasks are there for the three J1 cases, the CPU column (oracle port) rides along, and all
+    columns of a case agree on the result."""
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "benchmark_j1.py"), "--sizes", "1e6", "--reps", "1", "--cpu", "--duckdb"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    pat = re.compile(r"^RESULT,Library=([\w]+),Task=(join_count|join_materialize),Case=([\w\.\-+]+),Threads=([\w+]+),Time=([\d.]+)(?:,Core=([\d.]+))?,Result=(\d+)$")
+    rows = [pat.match(l.strip()) for l in out.stdout.splitlines() if l.strip().startswith("RESULT,")]
+    assert rows and all(rows), [l for l in out.stdout.splitlines() if l.startswith("RESULT,") and not pat.match(l.strip())]
+    by_case = {}
+    for m in rows:
+        by_case.setdefault(m.group(3), []).append(m)
+    assert sorted(by_case) == ["1e6-Q1", "1e6-Q2", "1e6-Q5"]
+    for case, ms in by_case.items():
+        libs = {(m.group(1), m.group(2)) for m in ms}
+        for lib in ("adaptive_join", "adaptive_bloom", "flash_join", "flash_join_bloom", "flash_join_radix", "flash_join_radix_bloom", "cpu_reference_port"):
+            assert (lib, "join_count") in libs and (lib, "join_materialize") in libs, (case, lib)
+        assert len({m.group(7) for m in ms}) == 1, (case, "implementations disagree")
+        assert all(float(m.group(5)) > 0 for m in ms)
+
+
 def test_numpy_entry_streams_the_join_under_the_copy(fj, oracle):
     """fj_join_host: pageable NumPy arrays go through a pinned ring in pieces of >= 16 MiB; a counting join of the partitioned
     plan gets its first pass per piece while the next piece crosses PCIe (host_streamed), materialising joins copy first.

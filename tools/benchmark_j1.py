@@ -3,10 +3,18 @@
 
 benchmark.py joins db-benchmark "J1" tables (`benchmark.py:166-171, 202-207`): probe table x with N rows against
 build tables small / medium / big with N/1e6, N/1e3 and N rows, N in {1e7, 2e7, 4e7}, six implementations x
-{join_count, join_materialize}, and prints `RESULT,Library=..,Task=..,Threads=..,Time=..,Result=..` lines
-(`benchmark.py:83`).  The R data generator is not available, so keys are synthetic with the same shapes:
-build keys are unique ids, ~90 % of the probe rows hit (db-benchmark joins are mostly-matching).
-Inputs live in HBM (torch tensors); Time is wall time of the call, Core is the device time it returns.
+{join_count, join_materialize} (`benchmark.py:240-247`), then DuckDB (`benchmark.py:264-274`), and prints
+`RESULT,Library=..,Task=..,Threads=..,Time=..,Result=..` lines (`benchmark.py:83`).  The R data generator is not
+available, so keys are synthetic with the same shapes: build keys are unique ids, ~90 % of the probe rows hit
+(db-benchmark joins are mostly-matching).
+
+Columns (the `Library=` field):
+  * the six flash_join implementations on the GPU - inputs in HBM (`--inputs device`, default) or as NumPy arrays
+    crossing PCIe inside the timed call (`--inputs numpy`: what benchmark.py itself would time);
+  * `cpu_reference_port` (`--cpu`): the oracle's C restatement of the reference algorithm on this host's cores -
+    the column benchmark.py's own flash_join numbers correspond to (test infrastructure, never the product path);
+  * `duckdb` (`--duckdb`): the reference's comparison column, only when the duckdb module is installed.
+Time = wall time of the call, Core = the core_duration_sec the call returns, best of --reps.
 """
 import argparse
 import os
@@ -16,6 +24,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flash_join                              # imported first, like benchmark.py:13-18
 flash_join.initialize()
+import numpy as np                             # noqa: E402
 import torch                                   # noqa: E402
 from flash_hash_join_amd import datagen        # noqa: E402
 
@@ -25,30 +34,83 @@ IMPLS = [("adaptive_join", "adaptive_join_count", "adaptive_join"), ("adaptive_b
          ("flash_join_radix_bloom", "hash_join_count_radix_bloom", "hash_join_radix_bloom")]     # benchmark.py:240-247
 
 
+def result_line(label, task, case, threads, wall, core, res):
+    core_s = "" if core is None else f",Core={core:.5f}"
+    print(f"RESULT,Library={label},Task={task},Case={case},Threads={threads},Time={wall:.4f}{core_s},Result={res}", flush=True)
+
+
+def best_of(reps, call, sync):
+    best_wall, best_core, res = None, None, None
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        out = call()
+        sync()
+        wall = time.perf_counter() - t0
+        res, core = out if isinstance(out, tuple) else (out, None)
+        if best_wall is None or wall < best_wall:
+            best_wall, best_core = wall, core
+    return best_wall, best_core, int(res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="1e7,2e7,4e7")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--inputs", choices=("device", "numpy"), default="device")
+    ap.add_argument("--cpu", action="store_true", help="add the cpu_reference_port column (oracle restatement, all host cores)")
+    ap.add_argument("--duckdb", action="store_true", help="add the duckdb column when the module is installed")
     args = ap.parse_args()
+    O = None
+    if args.cpu:
+        from oracle import oracle as O
+        O.build()
+    duck = None
+    if args.duckdb:
+        try:
+            import duckdb as duck
+        except ImportError:
+            print("duckdb is not installed: column skipped", flush=True)
+    gpu_sync = torch.cuda.synchronize
     for n_s in args.sizes.split(","):
         n = int(float(n_s))
         for q, nb in (("Q1", max(1, n // 1_000_000)), ("Q2", max(1, n // 1000)), ("Q5", n)):
+            case = f"{n_s}-{q}"
             bk, bv = datagen.build_device(nb, "cuda:0")
             pk, exp = datagen.probe_device(n, nb, "cuda:0", seed=7, hit_bp=9000)
+            hbk = hbv = hpk = None
+            if args.inputs == "numpy" or O is not None or duck is not None:
+                hbk, hbv, hpk = (x.cpu().numpy().view(np.uint64) for x in (bk, bv, pk))
+            a, b, p = (hbk, hbv, hpk) if args.inputs == "numpy" else (bk, bv, pk)
             for label, fcount, fmat in IMPLS:
                 for task, fn in (("join_count", fcount), ("join_materialize", fmat)):
-                    best_wall, best_core, res = None, None, None
-                    for _ in range(args.reps):
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        res, core = getattr(flash_join, fn)(bk, bv, pk)
-                        torch.cuda.synchronize()
-                        wall = time.perf_counter() - t0
-                        if best_wall is None or wall < best_wall:
-                            best_wall, best_core = wall, core
+                    wall, core, res = best_of(args.reps, lambda: getattr(flash_join, fn)(a, b, p), gpu_sync)
                     assert res == exp, (label, task, res, exp)
-                    print(f"RESULT,Library={label},Task={task},Case={n_s}-{q},Threads=gpu,Time={best_wall:.4f},Core={best_core:.5f},Result={res}")
-            del bk, bv, pk
+                    result_line(label, task, case, "gpu" if args.inputs == "device" else "gpu+pcie", wall, core, res)
+            if O is not None:
+                cores = int(O.lib().fjo_default_threads())
+                for task, mat in (("join_count", False), ("join_materialize", True)):
+                    wall, core, res = best_of(1, lambda: O.c_join(hbk, hbv, hpk, algo="adaptive", bloom=False, materialize=mat, threads=0)[:2],
+                                              lambda: None)
+                    assert res == exp, ("cpu_reference_port", task, res, exp)
+                    result_line("cpu_reference_port", task, case, cores, wall, core, res)
+            if duck is not None:
+                import pandas as pd
+                con = duck.connect(database=":memory:")
+                build_df = pd.DataFrame({"key": hbk, "value": hbv})       # noqa: F841  (duckdb reads the frames by name)
+                probe_df = pd.DataFrame({"key": hpk})                     # noqa: F841
+                con.execute("CREATE TABLE build_native AS SELECT * FROM build_df")
+                con.execute("CREATE TABLE probe_native AS SELECT * FROM probe_df")
+                wall, _, res = best_of(1, lambda: con.execute("SELECT count(*) FROM build_native b JOIN probe_native p ON b.key = p.key").fetchone()[0], lambda: None)
+                result_line("duckdb", "join_count", case, os.cpu_count(), wall, None, res)
+
+                def mat():
+                    con.execute("CREATE OR REPLACE TEMPORARY TABLE temp AS SELECT p.key, b.value FROM build_native b JOIN probe_native p ON b.key = p.key")
+                    return con.execute("SELECT count(*) FROM temp").fetchone()[0]
+                wall, _, res = best_of(1, mat, lambda: None)
+                result_line("duckdb", "join_materialize", case, os.cpu_count(), wall, None, res)
+                con.close()
+            del bk, bv, pk, a, b, p
             torch.cuda.empty_cache()
 
 

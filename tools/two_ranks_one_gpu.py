@@ -34,6 +34,14 @@ class HostStagedDist:
         dist.all_to_all_single(ho, hi, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
         out.copy_(ho); return self._Done()
 
+    def all_to_all(self, outs, ins, group=None, async_op=False):
+        """List form (the bounded-message rounds of distributed._exchange): views of device tensors on both sides."""
+        hos, his = [self._h(o) for o in outs], [self._h(i) for i in ins]
+        dist.all_to_all(hos, his, group=group)
+        for o, h in zip(outs, hos):
+            o.copy_(h)
+        return self._Done()
+
 
 def worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
