@@ -336,8 +336,12 @@ def main() -> None:
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp) and world == 1 and not force_dist and args.workload == "c3" and args.scale == 1.0:
-            try:      # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc.sh + tools/traffic_json.py), committed
-                traffic = json.load(open(tp)).get("fj_partition_kernel_keys_bytes_per_launch")
+            try:      # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc.sh + tools/traffic_json.py), committed together
+                      # with the hash of the kernel sources they measured: stale numbers (a kernel changed since) are not reported
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from source_hash import kernel_source_hash
+                tj = json.load(open(tp))
+                traffic = tj.get("fj_partition_kernel_keys_bytes_per_launch") if tj.get("source_sha256") == kernel_source_hash() else None
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",

@@ -1,9 +1,27 @@
-set -x
-cd $GRAFT_REPO_ROOT
-./tools/pmc.sh gpurun_out/pmc11 > gpurun_out/pmc11_summary.txt 2>&1
-R=$PWD; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats11 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench11_under_rocprof.log 2>&1
-cd $R
-python bench.py > gpurun_out/bench11.log 2>&1
-grep "^{\"metric" gpurun_out/bench11.log | tail -1
-find gpurun_out/stats11 -name "*kernel_stats.csv" | head
+#!/bin/bash
+# One GPU call that produces what is committed under profiles/ for a kernel version:  tools/collect_profiles.sh <tag>
+#   PMC passes (c3, c4, c3_mat, c2), rocprofv3 --kernel-trace --stats (c3, c4, c3_mat, c2 and the literal HBM-table forms),
+#   the default bench line, the other workloads' bench lines, the J1 harness log, traffic_latest.json.
+TAG=${1:-r02}
+cd ${GRAFT_REPO_ROOT:-$PWD}
+O=gpurun_out/$TAG; mkdir -p $O
+for w in c3 c4 c3_mat c2; do
+  ./tools/pmc.sh $O/pmc_$w --workload $w --no-host-entry > $O/${w}_pmc_summary.txt 2>&1
+done
+for w in c3 c4 c3_mat c2 c2_hbm_table c4_hbm_table_bloom; do
+  ./tools/prof_stats.sh ${TAG}_$w --workload $w --steps 20 --warmup 3 --no-host-entry > $O/${w}_kernel_stats.txt 2>&1
+  cp $(find gpurun_out/stats_${TAG}_$w -name "*kernel_stats.csv" | head -1) $O/${w}_kernel_stats.csv
+  grep "^{\"metric" gpurun_out/stats_${TAG}_$w.log | tail -1 > $O/${w}_bench_under_rocprof.json
+done
+FJ_OVERLAP_RELATIONS=0 python tools/trace_timeline.py gpurun_out/stats_${TAG}_c3 > $O/c3_timeline.txt 2>&1
+python tools/trace_timeline.py gpurun_out/stats_${TAG}_c4 > $O/c4_timeline.txt 2>&1
+python tools/trace_timeline.py gpurun_out/stats_${TAG}_c3_mat > $O/c3_mat_timeline.txt 2>&1
+python tools/traffic_json.py $O/c3_pmc_summary.txt $O/traffic_latest.json > /dev/null 2>&1
+timeout 900 python bench.py 2>&1 | tail -1 > $O/c3_bench.json
+: > $O/other_workloads.jsonl
+for w in c2 c2_hbm_table c4 c4_scalar_bloom c4_adaptive c4_hbm_table_bloom c3_adaptive c3_mat small rep2 rep4 rep8 c5; do
+  timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 >> $O/other_workloads.jsonl
+done
+timeout 900 python tools/benchmark_j1.py --sizes 1e7,4e7 --cpu --duckdb > $O/j1_shaped_benchmark.log 2>&1
+timeout 600 python tools/benchmark_j1.py --sizes 1e7 --inputs numpy --reps 2 > $O/j1_shaped_benchmark_numpy_inputs.log 2>&1
+ls -la $O | head -50

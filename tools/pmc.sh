@@ -9,7 +9,7 @@ for i in 1 2 3 4; do
     3) C="FETCH_SIZE GRBM_GUI_ACTIVE";;
     4) C="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum";;
   esac
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $R/$OUT/run$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-entry "$@" > $R/$OUT/run$i.log 2>&1
 done
 cd $R
 python3 tools/pmc_summary.py $OUT

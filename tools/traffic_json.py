@@ -1,7 +1,9 @@
 """Turn a tools_pmc.sh summary into profiles/traffic_latest.json (HBM bytes per launch of the dominant kernel).
 gfx950: FETCH_SIZE counts 1/2 of wide coalesced read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE exact;
 both are reported in KiB and were collected in separate passes."""
-import json, re, sys
+import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import kernel_source_hash
 summary, out = sys.argv[1], sys.argv[2]
 fetch, write = [], []
 for line in open(summary):
@@ -15,6 +17,6 @@ for line in open(summary):
 f = sum(fetch) / len(fetch) * 1024 * 2
 w = sum(write) / len(write) * 1024
 json.dump({"fj_partition_kernel_keys_bytes_per_launch": round(f + w), "read_bytes": round(f), "write_bytes": round(w),
-           "source": summary, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 half-count of wide reads); mean over the two probe-side passes"},
+           "source": summary, "source_sha256": kernel_source_hash(), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 half-count of wide reads); mean over the two probe-side passes"},
           open(out, "w"), indent=1)
 print(open(out).read())
