@@ -68,7 +68,10 @@ const char* fj_version(void);
 /* Process-wide dispatch options (no reference counterpart; the reference hard-codes 1'000'000 at hash_join.cpp:576):
  *   "radix_threshold"  - adaptive_* joins use the non-partitioned HBM table below this many build rows (default 0:
  *                        the partitioned driver wins at every size on MI355X; env FJ_RADIX_THRESHOLD);
- *   "scalar_hbm_table" - 1: the "scalar" functions (FJ_ALGO_SCALAR: hash_join*, hash_join.cpp:383-496, :536-567) keep
+ *   "scalar_hbm_table" - (the HBM-table path is NOT a fast path: probe 0.05-0.07 of the HBM peak, build by global CAS 20 ms per
+ *                        100M rows, profiles/README.md; it exists as the literal form of the reference's scalar algorithm
+ *                        and as the fallback for a partition of more than 8128 distinct keys)
+ *                        1: the "scalar" functions (FJ_ALGO_SCALAR: hash_join*, hash_join.cpp:383-496, :536-567) keep
  *                        ONE table for the whole build side in HBM, as the reference does in DRAM; 0 (default): they
  *                        run the same partitioned plan as the radix functions (identical results, 2-4x faster here)
  *                        and the HBM table is only the overflow fallback (env FJ_SCALAR_HBM_TABLE).
