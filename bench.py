@@ -364,9 +364,9 @@ def main() -> None:
     # disjoint phases SURVEY defines are measured on a few extra steps with the serial schedule, outside the timed region.
     k = lt["passes"]
     probe_ms, build_ms = mean(phase["probe_ms"]), mean(phase["build_ms"])
-    phase_schedule = "as timed"
+    phase_schedule = "as timed" + (" (interleaved one-stream schedule: build_phase = the build relation's passes, probe_phase = the rest)" if lt.get("overlapped") == 2 else "")
     serial_total_ms = None
-    if lt.get("overlapped") and world == 1 and not force_dist:
+    if lt.get("overlapped") == 1 and world == 1 and not force_dist:
         was = api.get_option("overlap_relations")
         api.set_option("overlap_relations", 0)
         try:
@@ -407,7 +407,7 @@ def main() -> None:
                                   + (" = the full 1B x 10B)" if world == 8 else ")") if args.workload == "c5" and args.scale == 1.0 else ""),
                    "function": fn_name, "build_rows_total": nb_total, "probe_rows_total": np_total,
                    "matches": exp_total, "bench_workload": args.workload,
-                   "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "overlap_relations", "persistent_min_items", "radix_threshold")},
+                   "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "overlap_relations", "interleave_relations", "persistent_min_items", "radix_threshold", "bloom_auto")},
                    "parallelism": f"{strategy_seen[0]} x{world}" if (world > 1 or force_dist) else "single GPU"},
         "build_time_ms": round(build_ms, 3),
         "phases": phases,

@@ -28,7 +28,7 @@ def fj():
     return flash_join
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "overlapped_relations", "deep_plans"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "overlapped_relations", "deep_plans", "interleaved_relations"])
 def scalar_mode(request, fj):
     """Run a test under the dispatch variants of the native library: the hash_join* functions served by the partitioned
     plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); and every
@@ -38,6 +38,7 @@ def scalar_mode(request, fj):
     and three-pass plans -- and, in the *_bloom functions, the bloom precheck between the probe side's passes -- that
     production only takes for build sides above a million rows."""
     fj.set_option("plan_target_keys", 32 if request.param == 4 else 4096)
+    fj.set_option("interleave_relations", 1 if request.param == 5 else 0)       # probe level bookkeeping under the build passes
     fj.set_option("scalar_hbm_table", int(request.param == 1))
     fj.set_option("persistent_min_items", 0 if request.param == 2 else 8192)
     fj.set_option("overlap_relations", 1 if request.param == 3 else 0)
@@ -46,6 +47,7 @@ def scalar_mode(request, fj):
     fj.set_option("persistent_min_items", 8192)
     fj.set_option("overlap_relations", 0)
     fj.set_option("plan_target_keys", 4096)
+    fj.set_option("interleave_relations", 0)
 
 
 def _digest(oracle, k, v):
