@@ -126,6 +126,8 @@ struct StreamState {            // fj_stream_*: a counting join whose relations 
     // zero-pass plans (build side <= one LDS table): the pieces are joined as flat arrays
     const u64* flat_build = nullptr;
     const u64* flat_probe[64]; size_t flat_np[64]; u32 nflat = 0;
+    // every piece appended so far (they stay allocated until fj_stream_finish returns): what the HBM-table fallback reads
+    std::vector<std::pair<const u64*, size_t>> bpieces, ppieces;
 };
 
 struct fj_ctx {
@@ -960,6 +962,41 @@ int stream_flat_join(fj_ctx* c, StreamState& st, const u64* d_pk, size_t n, hipS
     return 0;
 }
 
+// counting join of the appended pieces over one table in HBM (fj_gt_*): the fallback of a streamed join
+int stream_global_count(fj_ctx* c, StreamState& st, hipStream_t s, fj_timings* t, u64* out_count) {
+    u64 cap = 64;
+    while (cap < 2 * (u64)st.nb_seen) cap <<= 1;
+    FjGtArgs a{};
+    void* p;
+    if (get_buf(c, W_GT_KEYS, cap * 8, &p)) return 1; a.tkeys = (u64*)p;
+    if (get_buf(c, W_GT_VALS, cap * 8, &p)) return 1; a.tvals = (u64*)p;
+    a.bloom = nullptr;
+    if (get_buf(c, W_WG_COUNT, (size_t)2048 * 4, &p)) return 1; a.wg_count = (u32*)p;
+    a.cap_mask = cap - 1; a.flags = &c->d_sc->flags; a.empty_val = &c->d_sc->empty_val; a.total = &c->d_sc->total;
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    HIPCHK(hipMemsetAsync(c->d_sc, 0, offsetof(Scalars, alloc), s));
+    HIPCHK(hipMemsetAsync(a.tkeys, 0xFF, cap * 8, s));
+    for (const auto& bp : st.bpieces) {
+        a.bk = bp.first; a.bv = bp.first; a.nb = bp.second;           // a counting join never reads the values
+        HIPCHK(fj_launch_gt_build(a, s));
+    }
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    for (const auto& pp : st.ppieces) {
+        a.pk = pp.first; a.np = pp.second;
+        const u32 grid = (u32)std::min<u64>(2048, std::max<u64>(1, ((pp.second + 1) / 2) / 256));
+        if (pp.second) HIPCHK(fj_launch_gt_probe(a, false, grid, s));
+    }
+    HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+    if (read_scalars(c, s)) return 1;
+    *out_count = c->h_sc->total;
+    t->path = 1; t->passes = 0; t->radix_bits = 0; t->partitions = 1;
+    t->build_phase_ms = ev_ms(c, E_START, E_BUILD);
+    t->join_ms = ev_ms(c, E_BUILD, E_JOIN);
+    t->probe_phase_ms = t->join_ms;
+    t->total_ms = ev_ms(c, E_START, E_JOIN);
+    return 0;
+}
+
 // the build side is complete: run its remaining passes (or fix the flat table input of a zero-pass plan)
 int stream_flush_build(fj_ctx* c, StreamState& st, hipStream_t s) {
     if (st.build_done) return 0;
@@ -1010,6 +1047,7 @@ int stream_append_build(fj_ctx* c, const u64* d_bk, size_t n, hipStream_t s) {
     if (st.b_appends_left == 0) return set_err("fj_stream_append_build: more pieces than build_appends");
     if (st.nb_seen + n > st.nb_bound) return set_err("fj_stream_append_build: more build rows than nb_bound");
     --st.b_appends_left; st.nb_seen += n;
+    st.bpieces.emplace_back(d_bk, n);
     if (st.plan.npass > 0) return pass_launch(c, st.bit, d_bk, nullptr, n, s, nullptr);
     if (st.flat_build) return set_err("fj_stream_append_build: a build side of <= %d rows must arrive in one piece", (int)FJ_PART_TARGET_KEYS);
     st.flat_build = d_bk;
@@ -1058,6 +1096,7 @@ int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stre
     FJ_ON_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
     --st.p_appends_left; st.np_seen += n;
+    st.ppieces.emplace_back((const u64*)d_pk, n);
     if (st.plan.npass > 0) return pass_launch(c, st.pit, d_pk, nullptr, n, s, st.evc < 4 ? &st.evc : nullptr);
     // zero-pass plan (tiny build side): join this piece right away when the build side is known, else at finish
     if (st.build_done) return st.ja.build.n_flat == 0 ? 0 : stream_flat_join(c, st, d_pk, n, s);
@@ -1097,7 +1136,13 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
         if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full)) return 1;
-        if (lds_full) return set_err("fj_stream_finish: a partition does not fit its LDS table; use fj_join_device on the whole relation");
+        if (lds_full) {
+            // a partition of more than 8128 distinct build keys: count over ONE table in HBM, piece by piece (the streamed
+            // join's own fallback; the one-shot join has the same one)
+            fj_timings t2; memset(&t2, 0, sizeof t2); t2.sampled_hit_bp = -1;
+            if (stream_global_count(c, st, s, &t2, &count)) return 1;
+            t2.total_ms += t.total_ms; t2.fell_back = 1; t = t2;
+        }
     } else {
         if (st.plan.npass == 0 && st.nb_seen > 0)
             for (u32 i = 0; i < st.nflat; ++i) if (stream_flat_join(c, st, st.flat_probe[i], st.flat_np[i], s)) return 1;
@@ -1105,13 +1150,24 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
         if (read_scalars(c, s)) return 1;
         if (st.plan.npass == 0) end_plan(c);          // (a partitioned plan with an empty side never ran its bookkeeping: stays "in flight")
-        if (c->h_sc->err & (FJ_ERR_LDS_FULL | FJ_STAT_RETRY)) return set_err("fj_stream_finish: the build side does not fit one LDS table");
+        if (c->h_sc->err & (FJ_ERR_LDS_FULL | FJ_STAT_RETRY)) {
+            // the one table of a zero-pass plan overflowed (a build side of ~3900 rows at a bad moment): HBM-table fallback
+            fj_timings t2; memset(&t2, 0, sizeof t2); t2.sampled_hit_bp = -1;
+            if (stream_global_count(c, st, s, &t2, &count)) return 1;
+            t2.fell_back = 1;
+            if (out_count) *out_count = count;
+            if (timings) *timings = t2;
+            g_last = t2;
+            return 0;
+        }
         count = c->h_sc->total;
         t.path = 0; t.passes = 0; t.partitions = 1;
         t.total_ms = ev_ms(c, E_START, E_JOIN);
     }
-    t.build_phase_ms = ev_ms(c, E_SB0, E_SB1);                  // the two sides may have run in either order
-    t.probe_phase_ms = t.total_ms - t.build_phase_ms;
+    if (!t.fell_back) {
+        t.build_phase_ms = ev_ms(c, E_SB0, E_SB1);              // the two sides may have run in either order
+        t.probe_phase_ms = t.total_ms - t.build_phase_ms;
+    }
     if (out_count) *out_count = count;
     if (timings) *timings = t;
     g_last = t;

@@ -690,6 +690,36 @@ def test_stream_join_with_both_sides_in_pieces(fj, nb, npk, bpieces, ppieces):
         assert eng.stream_finish() == exp
 
 
+def test_streamed_join_falls_back_to_the_hbm_table_by_itself(fj):
+    """A streamed (multi-GPU building block) join whose build side puts 9000 keys into one partition - beyond even the tagged
+    LDS table - counts over one table in HBM inside fj_stream_finish: exact count, fell_back = 1, no exception."""
+    import torch
+    from flash_hash_join_amd.distributed import HipEngine
+    def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
+        lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+            x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+            x ^= x >> np.uint32(16)
+        return x
+    cand = np.arange(1, 400000, dtype=np.uint64)
+    skew = cand[(hash_w1(cand) >> np.uint32(27)) == 0][:9000]
+    probe = np.concatenate([skew, cand[:50000]])
+    exp = int(np.isin(probe, skew).sum())
+    bk = torch.from_numpy(skew.view(np.int64)).cuda()
+    pk = torch.from_numpy(probe.view(np.int64)).cuda()
+    eng = HipEngine("cuda:0")
+    eng.stream_open(bk.numel(), 2, pk.numel(), 3, 64)
+    eng.stream_append(pk[:20000]); eng.stream_append(pk[20000:40000])
+    eng.stream_append_build(bk[:5000]); eng.stream_append_build(bk[5000:])
+    eng.stream_append(pk[40000:])
+    assert eng.stream_finish() == exp
+    t = fj.last_timings()
+    assert t["fell_back"] == 1 and t["path"] == 1, t
+    assert fj.hash_join_count_radix(bk, bk, pk)[0] == exp                      # the context is fine afterwards
+
+
 def test_c_abi_rejects_bad_arguments(fj):
     """Error behaviour at the C boundary: status 1 + fj_last_error text, translated to RuntimeError; the context stays usable."""
     import ctypes
