@@ -31,6 +31,7 @@ from . import _lib
 from ._lib import FjTimings, check
 
 ALGO_ADAPTIVE, ALGO_SCALAR, ALGO_RADIX = 0, 1, 2
+ALGO_MANY_TO_MANY = 0x10          # FJ_ALGO_MANY_TO_MANY: OR'ed into algo (extension, include/flashjoin.h)
 
 _ctxs: Dict[int, int] = {}
 _last: Optional[FjTimings] = None
@@ -245,6 +246,18 @@ def hash_join_count_bloom(build_keys, build_values, probe_keys):
     return _join(ALGO_SCALAR, 1, 0, build_keys, build_values, probe_keys, False)
 
 
+# ---- extension: many-to-many inner join (the reference deduplicates build keys, hash_join.cpp:125) -------------------
+def inner_join_count(build_keys, build_values, probe_keys):
+    """Number of (probe row, build row) pairs with equal keys - every duplicate build row counts (SQL inner join).
+    Not part of the reference's API; same argument and return conventions as the other joins."""
+    return _join(ALGO_RADIX | ALGO_MANY_TO_MANY, 0, 0, build_keys, build_values, probe_keys, False)
+
+
+def inner_join(build_keys, build_values, probe_keys, return_arrays: bool = False):
+    """Materialises every (probe_key, build_value) pair of the many-to-many inner join; `return_arrays=True` returns them."""
+    return _join(ALGO_RADIX | ALGO_MANY_TO_MANY, 0, 1, build_keys, build_values, probe_keys, return_arrays)
+
+
 def initialize() -> None:
     """Replaces initialize_memory_system (hash_join.cpp:596, :639): checks that a HIP device is
     usable and warms up the native context. Returns None like the reference."""
@@ -268,4 +281,5 @@ REFERENCE_EXPORTS = [
     "initialize",
 ]
 ALIASES = ["flash_join", "flash_join_radix", "flash_join_bloom", "flash_join_radix_bloom", "adaptive_bloom"]
-__all__ = REFERENCE_EXPORTS + ALIASES + ["last_timings", "join_device", "context", "set_option", "get_option"]
+EXTENSIONS = ["inner_join", "inner_join_count"]
+__all__ = REFERENCE_EXPORTS + ALIASES + EXTENSIONS + ["last_timings", "join_device", "context", "set_option", "get_option"]

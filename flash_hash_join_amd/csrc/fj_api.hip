@@ -230,9 +230,10 @@ void plan_passes(Plan& p, bool extra_first) {
     }
 }
 
-Plan make_plan(size_t nb, int top_bits, bool want_bloom = false) {
+Plan make_plan(size_t nb, int top_bits, bool want_bloom = false, u64 target_override = 0) {
     Plan p;
-    const u64 target = options().plan_target_keys;            // 4096 in production; smaller values make small inputs take deep plans (tests)
+    const u64 target = target_override ? std::min<u64>(target_override, options().plan_target_keys)
+                                       : options().plan_target_keys;   // 4096 in production; smaller values make small inputs take deep plans (tests)
     if (nb > target) {
         u64 parts = (nb + target - 1) / target;
         while ((1ull << p.bits) < parts) ++p.bits;
@@ -242,7 +243,7 @@ Plan make_plan(size_t nb, int top_bits, bool want_bloom = false) {
     // extra pass the plan takes it once the average partition exceeds FJ_PLAN_BUMP_KEYS (nb at 4096 * 2^k would otherwise
     // put half of the partitions over the table's limit); partitions that still overflow are redone one by one on the
     // tagged table (fj_launch_lds_join_retry), not by re-running the whole join.
-    if (target == FJ_PART_TARGET_KEYS && (nb >> p.bits) > FJ_PLAN_BUMP_KEYS && p.bits < top_bits - 32) {
+    if (!target_override && target == FJ_PART_TARGET_KEYS && (nb >> p.bits) > FJ_PLAN_BUMP_KEYS && p.bits < top_bits - 32) {
         const int nb1 = p.bits == 0 ? 5 : p.bits + 1;
         if (p.bits == 0 || plan_npass(nb1) == plan_npass(p.bits)) p.bits = nb1;
     }
@@ -361,7 +362,8 @@ void join_item_geometry(u64 nparts, size_t np, u64 chunk_bound, u32* tc, u64* ma
     const u64 bound = std::max<u64>(chunk_bound, pchunks);
     const u64 avg = std::max<u64>(1, bound / nparts);
     u64 want = 1;
-    if (nparts < 2048) want = std::min<u64>((2048 + nparts - 1) / nparts, std::max<u64>(1, (pchunks / nparts) / 32));
+    static const u64 target_items = getenv("FJ_JOIN_ITEMS_TARGET") ? strtoull(getenv("FJ_JOIN_ITEMS_TARGET"), nullptr, 10) : 2048;   // (tuning knob)
+    if (nparts < target_items) want = std::min<u64>((target_items + nparts - 1) / nparts, std::max<u64>(1, (pchunks / nparts) / 32));
     *tc = (u32)(want > 1 ? std::max<u64>(8, (avg * 9 / 8 + want - 1) / want) : std::max<u64>(512, 4 * avg));
     *max_items = bound / *tc + nparts + 1;
 }
@@ -539,6 +541,11 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
             if (getenv("FJ_EMIT_STAMPS") && stamps_begin(&pd.lds.dbg, s)) return 1;
             HIPCHK(fj_launch_lds_join(pd.lds, true, s));
             if (pd.lds.dbg) { if (stamps_report("FJ_EMIT_STAMPS", pd.lds.dbg, pd.nitems, s)) return 1; pd.lds.dbg = nullptr; }
+        } else if (pd.path == 2) {           // many-to-many: count per item -> scan -> emit
+            if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
+            HIPCHK(fj_launch_scan_u32_to_u64(pd.lds.part_count, (u64*)p, pd.nitems, s));
+            pd.lds.out_off = (const u64*)p; pd.lds.out_keys = d_ok; pd.lds.out_vals = d_ov;
+            HIPCHK(fj_launch_mm_join(pd.lds, true, s));
         } else {
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.gt_grid + 1) * 8, &p)) return 1;
             HIPCHK(fj_launch_scan_u32_to_u64(pd.gt.wg_count, (u64*)p, pd.gt_grid, s));
@@ -789,6 +796,57 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     return 0;
 }
 
+// EXTENSION: many-to-many inner join on the partitioned plan (csrc/fj_many.hip).  Build relation first (with its values when
+// materialising), then the probe relation, then one workgroup per work item; no bloom stage, no fallback: a partition of
+// more than 4096 build rows is an error.
+int join_many(fj_ctx* c, int materialize, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
+              hipStream_t s, fj_timings* t, u64* out_count) {
+    const Plan plan = make_plan(nb, top_bits, false, 2048);          // aim at half of the kernel's 4096 rows per partition
+    begin_plan(c);
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    if (clear_plan_scalars(c, s)) return 1;
+    FjLdsJoinArgs ja{};
+    PassIter bit, pit;
+    pass_init(bit, 0, materialize != 0, nb, plan, top_bits);
+    pass_init(pit, 1, false, np, plan, top_bits);
+    pit.want_items = true;
+    int evc = 0;
+    if (run_passes(c, bit, bk, materialize ? bv : nullptr, s, &ja.build, nullptr)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+    ja.nparts = 1u << plan.bits;
+    u32 nitems;
+    void* p;
+    if (ja.probe.list) {
+        ja.items = pit.tiles; ja.nitems_dev = pit.ntiles; ja.items_cap = pit.items_cap; ja.part_count = pit.part_count; ja.nsplit = 1;
+        nitems = pit.items_cap;
+    } else {
+        const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
+        ja.nsplit = (u32)std::min<u64>(2048, std::max<u64>(1, pchunks / 32)); ja.items = nullptr; ja.nitems_dev = nullptr; ja.items_cap = 0;
+        nitems = ja.nparts * ja.nsplit;
+        if (get_buf(c, W_PART_COUNT, (size_t)nitems * 4, &p)) return 1; ja.part_count = (u32*)p;
+    }
+    ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
+    HIPCHK(fj_launch_mm_join(ja, false, s));
+    HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+    if (read_scalars(c, s)) return 1;
+    if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
+    end_plan(c);
+    if (c->h_sc->err & FJ_ERR_LDS_FULL)
+        return set_err("many-to-many join: a final partition holds more than 4096 build rows (a build key with thousands of duplicates?); not supported");
+    *out_count = c->h_sc->total;
+    t->path = 0; t->passes = plan.npass; t->radix_bits = plan.bits; t->partitions = ja.nparts;
+    t->build_phase_ms = ev_ms(c, E_START, E_BUILD);
+    t->join_ms = ev_ms(c, E_PPART, E_JOIN);
+    t->probe_phase_ms = ev_ms(c, E_BUILD, E_JOIN);
+    t->total_ms = ev_ms(c, E_START, E_JOIN);
+    for (int i = 0; i < evc && i < 4; ++i) t->probe_part_kernel_ms[i] = ev_ms(c, E_PK0 + 2 * i, E_PK0 + 2 * i + 1);
+    c->pend.valid = false;
+    if (materialize) { c->pend.valid = true; c->pend.path = 2; c->pend.lds = ja; c->pend.nitems = nitems; c->pend.count = *out_count; c->pend.has_dups = false; }
+    return 0;
+}
+
 fj_ctx* g_host_ctx = nullptr;
 
 
@@ -877,6 +935,8 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
                    void* stream, int hash_top_bits, uint64_t* out_count,
                    uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, fj_timings* timings) {
     if (!c) return set_err("fj_join_device: null context");
+    const bool many = algo >= 0 && (algo & FJ_ALGO_MANY_TO_MANY) != 0;
+    if (many) algo &= ~FJ_ALGO_MANY_TO_MANY;
     if (algo < 0 || algo > 2) return set_err("fj_join_device: unknown algo %d", algo);
     if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_join_device: hash_top_bits must be 64 or 48");
     if ((nb && (!d_bk || !d_bv)) || (np && !d_pk)) return set_err("fj_join_device: null input pointer");
@@ -892,6 +952,8 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
                      (algo == FJ_ALGO_SCALAR && !opt.scalar_hbm_table);
     if (nb == 0 || np == 0) {                   // empty side: (0, t), hash_join.cpp behaviour for empty inputs
         count = 0;
+    } else if (many) {
+        if (join_many(c, materialize, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count)) return 1;
     } else if (use_radix) {
         bool lds_full = false;
         // adaptive_*: the precheck is decided from a sample of the probe side; *_bloom by name: always on; otherwise off
@@ -1364,7 +1426,8 @@ int fj_join_host(int algo, int bloom, int materialize,
                  uint64_t* out_count, double* out_seconds, uint64_t** out_keys, uint64_t** out_vals) {
     if (out_keys) *out_keys = nullptr;
     if (out_vals) *out_vals = nullptr;
-    if (algo < 0 || algo > 2) return set_err("fj_join_host: unknown algo %d", algo);
+    const bool many_host = algo >= 0 && (algo & FJ_ALGO_MANY_TO_MANY) != 0;
+    if (algo < 0 || (algo & ~FJ_ALGO_MANY_TO_MANY) > 2) return set_err("fj_join_host: unknown algo %d", algo);
     if (!g_host_ctx) {
         int dev = 0;
         if (const char* d = getenv("FJ_DEVICE")) dev = atoi(d);
@@ -1391,7 +1454,7 @@ int fj_join_host(int algo, int bloom, int materialize,
     // A counting join of the partitioned plan starts on the first piece: the build side is copied and partitioned, then every
     // probe piece gets its first partition pass while the next one crosses PCIe (the join hides under the copy; the bloom
     // precheck is skipped here - it saves device time the copy does not leave on the critical path).
-    const bool streamed = use_radix && !materialize && nb > 0 && np > 0;
+    const bool streamed = use_radix && !materialize && nb > 0 && np > 0 && !many_host;
     hipStream_t js = nullptr;
     auto t0 = std::chrono::steady_clock::now();
     unsigned cursor = 0;

@@ -126,6 +126,9 @@ hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a, hipStream_t s);
 hipError_t fj_launch_sample_hits(const FjChunkSet& build, const u64* pk, u64 np, u32 nsamples, u32 shift32, u32 pmask,
                                  unsigned long long* hits, hipStream_t s);
 
+// many-to-many join of one work item's partition (csrc/fj_many.hip): counting (part_count / total) or emitting at out_off
+hipError_t fj_launch_mm_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s);
+
 struct FjGtArgs {                // global (non-partitioned) table
     u64* tkeys; u64* tvals; u32* bloom;    // bloom == nullptr: no precheck
     u64 cap_mask;                           // capacity - 1 (capacity = power of two, multiple of 8)

@@ -29,6 +29,12 @@ extern "C" {
 #define FJ_ALGO_SCALAR 1   /* _hash_join_scalar_{count,materialize}     hash_join.cpp:383-496, :536-567 */
 #define FJ_ALGO_RADIX 2    /* _hash_join_radix_{count,materialize}      hash_join.cpp:315-381, :498-534 */
 
+/* EXTENSION (no reference counterpart: the reference deduplicates build keys, hash_join.cpp:125): OR this into `algo` for a
+ * many-to-many inner join - every build row is kept, a probe row yields one pair per build row with its key, the count is the
+ * number of pairs.  Partitioned plan only; fails when a final partition would hold more than 4096 build rows (a key with
+ * thousands of duplicates).  `bloom` is ignored. */
+#define FJ_ALGO_MANY_TO_MANY 0x10
+
 typedef struct fj_ctx fj_ctx;
 
 /* Per-call device timings (milliseconds, HIP events on the caller's stream) and plan facts. */

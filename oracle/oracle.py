@@ -146,6 +146,27 @@ def np_join(build_keys, build_values, probe_keys, return_arrays: bool = False):
     return int(hit.sum()), pk[hit], uv[pos_c[hit]]
 
 
+def np_inner_join(build_keys, build_values, probe_keys, return_arrays: bool = False):
+    """NumPy oracle of the many-to-many extension (no reference counterpart: the reference dedups build keys): every build
+    row with the probe row's key yields a pair.  Sort + searchsorted ranges + repeat."""
+    bk, bv, pk = _as_u64(build_keys), _as_u64(build_values), _as_u64(probe_keys)
+    if bk.size == 0 or pk.size == 0:
+        e = np.empty(0, dtype=np.uint64)
+        return (0, e, e.copy()) if return_arrays else 0
+    order = np.argsort(bk, kind="stable")
+    sk, sv = bk[order], bv[order]
+    lo = np.searchsorted(sk, pk, side="left")
+    hi = np.searchsorted(sk, pk, side="right")
+    mult = (hi - lo).astype(np.int64)
+    total = int(mult.sum())
+    if not return_arrays:
+        return total
+    out_k = np.repeat(pk, mult)
+    starts = np.repeat(lo, mult)
+    within = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(mult) - mult, mult)
+    return total, out_k, sv[starts + within]
+
+
 def canon_pairs(keys, vals) -> Tuple[np.ndarray, np.ndarray]:
     """Sort (key, value) pairs so two outputs can be compared modulo order."""
     k, v = _as_u64(keys), _as_u64(vals)

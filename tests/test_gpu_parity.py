@@ -720,6 +720,48 @@ def test_streamed_join_falls_back_to_the_hbm_table_by_itself(fj):
     assert fj.hash_join_count_radix(bk, bk, pk)[0] == exp                      # the context is fine afterwards
 
 
+@pytest.mark.parametrize("nb,dom,npk", [(1, 1, 1), (300, 40, 2000), (5000, 700, 60000), (60000, 9000, 300000), (1_000_000, 400_000, 3_000_000),
+                                        (6_000_000, 3_000_000, 5_000_000)])
+def test_many_to_many_extension_matches_the_numpy_oracle(fj, oracle, nb, dom, npk):
+    """inner_join / inner_join_count (extension; the reference dedups build keys, hash_join.cpp:125): every duplicate build row
+    yields a pair.  Counts and pair multisets vs the NumPy oracle, zero-, one- and two-pass plans, duplicates on both sides,
+    keys 0 and 2^64-1 included; the reference-semantics functions on the same inputs still dedup."""
+    rng = np.random.default_rng(nb + 7)
+    ids = rng.integers(0, dom, size=nb, dtype=np.uint64)
+    bk = ids * np.uint64(0x9E3779B97F4A7C15)
+    bk[ids == 1] = np.uint64(2**64 - 1)                                       # the table's empty marker as a (duplicated) key
+    bv = np.arange(nb, dtype=np.uint64) + np.uint64(5 * 10**12)               # value = row id: every row distinguishable
+    pids = rng.integers(0, 2 * dom + 1, size=npk, dtype=np.uint64)
+    pk = pids * np.uint64(0x9E3779B97F4A7C15)
+    pk[pids == 1] = np.uint64(2**64 - 1)
+    exp, ek, ev = oracle.np_inner_join(bk, bv, pk, return_arrays=True)
+    n, sec = fj.inner_join_count(bk, bv, pk)
+    assert isinstance(n, int) and isinstance(sec, float) and n == exp
+    n, sec, k, v = fj.inner_join(bk, bv, pk, return_arrays=True)
+    assert n == exp and k.size == exp
+    a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert fj.inner_join(bk, bv, pk)[0] == exp                                # (int, float) form
+    assert fj.hash_join_count_radix(bk, bv, pk)[0] == oracle.np_join(bk, bv, pk)     # the reference's N:1 semantics are untouched
+    import torch
+    dk, dv, dp = (torch.from_numpy(x.view(np.int64)).cuda() for x in (bk, bv, pk))
+    n2, _, k2, v2 = fj.inner_join(dk, dv, dp, return_arrays=True)             # device tensors
+    assert n2 == exp and k2.numel() == exp
+    a2 = oracle.canon_pairs(k2.cpu().numpy().view(np.uint64), v2.cpu().numpy().view(np.uint64))
+    assert np.array_equal(a2[0], b[0]) and np.array_equal(a2[1], b[1])
+
+
+def test_many_to_many_refuses_a_key_with_too_many_duplicates(fj):
+    """More than 4096 build rows in one final partition (here: one key 6000 times) do not fit the kernel's LDS tables: a
+    clear error, not a wrong result; the context stays usable."""
+    bk = np.concatenate([np.full(6000, 12345, dtype=np.uint64), np.arange(100000, 100500, dtype=np.uint64)])
+    bv = np.arange(bk.size, dtype=np.uint64)
+    pk = np.array([12345, 100001, 7], dtype=np.uint64)
+    with pytest.raises(RuntimeError, match="4096 build rows"):
+        fj.inner_join_count(bk, bv, pk)
+    assert fj.hash_join_count_radix(bk, bv, pk)[0] == 2
+
+
 def test_c_abi_rejects_bad_arguments(fj):
     """Error behaviour at the C boundary: status 1 + fj_last_error text, translated to RuntimeError; the context stays usable."""
     import ctypes

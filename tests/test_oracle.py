@@ -138,3 +138,17 @@ def test_baseline_config1_on_cpu(oracle):
     for algo in ("scalar", "radix", "adaptive"):
         for bloom in (False, True):
             assert oracle.c_join(bk.view(np.int64), bv, pk, algo=algo, bloom=bloom)[0] == exp
+
+
+def test_numpy_oracle_of_the_many_to_many_extension():
+    """np_inner_join against a brute-force double loop on small inputs with duplicates on both sides."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    for nb, npk, dom in [(1, 1, 2), (40, 70, 9), (300, 500, 40), (0, 5, 3), (5, 0, 3)]:
+        bk = rng.integers(0, dom, size=nb, dtype=np.uint64)
+        bv = rng.integers(0, 2**64, size=nb, dtype=np.uint64)
+        pk = rng.integers(0, dom + 2, size=npk, dtype=np.uint64)
+        exp = sorted((int(k), int(v)) for k in pk for kb, v in zip(bk, bv) if kb == k)
+        n, ok, ov = O.np_inner_join(bk, bv, pk, return_arrays=True)
+        assert n == len(exp) == O.np_inner_join(bk, bv, pk)
+        assert sorted(zip(ok.tolist(), ov.tolist())) == exp
