@@ -630,18 +630,24 @@ def test_relation_beyond_the_chunk_directory_is_refused(fj):
     assert fj.hash_join_count_radix(dbk, dbv, dbk)[0] == 10_000_000             # the context is still usable
 
 
-@pytest.mark.parametrize("nb,npk", [(10_000_000, 100_000_000), (300_000_000, 50_000_000)])
+@pytest.mark.parametrize("nb,npk", [(10_000_000, 100_000_000), (300_000_000, 50_000_000), (100_000_000, 1_000_000_000)])
 def test_full_size_materialize_pairs_property(fj, nb, npk):
-    """10M x 100M materialise (and 300M x 50M: a 512-bucket pass that carries values): every emitted pair satisfies
-    key == (value+1)*M, count is closed-form."""
+    """10M x 100M materialise, 300M x 50M (a 512-bucket pass that carries values) and BASELINE config 3's full 100M x 1B
+    through hash_join_radix (500M pairs): every emitted pair satisfies key == (value+1)*M, count is closed-form."""
     import torch
     from flash_hash_join_amd import datagen
     dbk, dbv = datagen.build_device(nb, "cuda:0")
     dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=9, hit_bp=5000)
     n, sec, k, v = fj.hash_join_radix(dbk, dbv, dpk, return_arrays=True)
     assert n == exp and k.numel() == exp
+    del dpk
     M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")      # 0x9E3779B97F4A7C15 as int64
-    assert bool(torch.all((v + 1) * M == k))
+    step = 100_000_000                                                              # (in slices: no 4 GB temporaries)
+    for lo in range(0, exp, step):
+        assert bool(torch.all((v[lo: lo + step] + 1) * M == k[lo: lo + step]))
+    assert int(v.min()) >= 0 and int(v.max()) < nb
+    del k, v, dbk, dbv
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("nb,npk,pieces", [(2000, 300_000, 3), (50_000, 1_000_000, 4), (1_500_000, 6_000_000, 5),
