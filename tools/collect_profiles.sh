@@ -5,7 +5,7 @@
 TAG=${1:-r02}
 cd ${GRAFT_REPO_ROOT:-$PWD}
 O=gpurun_out/$TAG; mkdir -p $O
-for w in c3 c4 c3_mat c2; do
+for w in c3 c4 c3_mat c2 c2_hbm_table; do
   ./tools/pmc.sh $O/pmc_$w --workload $w --no-host-entry > $O/${w}_pmc_summary.txt 2>&1
 done
 for w in c3 c4 c3_mat c2 c2_hbm_table c4_hbm_table_bloom; do
