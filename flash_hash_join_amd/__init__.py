@@ -7,4 +7,4 @@ HIP kernels + C ABI (csrc/, include/flashjoin.h), the host-side mirror of the re
 from .api import *  # noqa: F401,F403
 from .api import REFERENCE_EXPORTS, ALIASES, last_timings, join_device, context  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -172,7 +172,7 @@ struct Options {
     Options() {
         interleave_relations = getenv("FJ_INTERLEAVE_RELATIONS") ? atoi(getenv("FJ_INTERLEAVE_RELATIONS")) : 0;
         bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
-        bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 3000;
+        bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2500;     // measured break-even at c4 sizes: 28 % hits (profiles/r02_bloom_threshold.csv)
         bloom_overlap = getenv("FJ_BLOOM_OVERLAP") ? atoi(getenv("FJ_BLOOM_OVERLAP")) : 0;
         const char* bvr = getenv("FJ_BLOOM_VARIANT");
         bloom_variant = bvr ? atoi(bvr) : 0;
@@ -855,7 +855,7 @@ fj_ctx* g_host_ctx = nullptr;
 extern "C" {
 
 const char* fj_last_error(void) { return g_err.c_str(); }
-const char* fj_version(void) { return "flash_hash_join_amd 0.1 (gfx950)"; }
+const char* fj_version(void) { return "flash_hash_join_amd 0.2 (gfx950)"; }
 
 int fj_set_option(const char* name, long long value) {
     if (!name) return set_err("fj_set_option: null name");

@@ -94,7 +94,7 @@ const char* fj_version(void);
  *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
  *   "bloom_auto"       - 1 (default): the adaptive_* functions decide on the bloom precheck of the partitioned plan from a
  *                        sample of the probe side (4096 rows looked up in the partitioned build side): on when at most
- *                        "bloom_auto_max_hit_bp" (default 3000 = 30 %) of them hit; 0: adaptive_*_bloom filter, adaptive_* do
+ *                        "bloom_auto_max_hit_bp" (default 2500 = 25 %; measured break-even 28 %) of them hit; 0: adaptive_*_bloom filter, adaptive_* do
  *                        not, as named (env FJ_BLOOM_AUTO, FJ_BLOOM_AUTO_MAX_HIT_BP).  The explicit hash_join*_bloom
  *                        functions always run the precheck when the plan has two or more passes; hash_join* never do.
  *   "plan_target_keys" - average build keys per final partition the plan aims for (default and maximum 4096 = half an LDS

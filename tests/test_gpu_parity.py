@@ -510,14 +510,14 @@ def test_bloom_precheck_prunes_misses_and_keeps_every_hit(fj, nb, npk, hit_bp):
         assert t["bloom_level"] == 1 and t["passes"] == 2 and t["fell_back"] == 0 and t["sampled_hit_bp"] == -1, (fn, t)
         assert exp <= t["filter_survivors"] <= exp + 0.25 * (npk - exp) + 1000, (fn, hit_bp, t["filter_survivors"], exp)
     # the adaptive functions (either name) decide from a sample of 4096 probe rows where a precheck could pay (a probe side of
-    # >= 4x the build side): on up to 30 % sampled hits
+    # >= 4x the build side): on up to 25 % sampled hits
     for fn in ("adaptive_join_count", "adaptive_join_count_bloom"):
         n, _ = getattr(fj, fn)(dbk, dbv, dpk)
         t = fj.last_timings()
         assert n == exp and t["fell_back"] == 0, (fn, hit_bp)
         if npk >= 4 * nb:
             assert abs(t["sampled_hit_bp"] - hit_bp) <= 350, (fn, t["sampled_hit_bp"], hit_bp)
-            assert t["bloom_level"] == (1 if t["sampled_hit_bp"] <= 3000 else 0), (fn, t)
+            assert t["bloom_level"] == (1 if t["sampled_hit_bp"] <= fj.get_option("bloom_auto_max_hit_bp") else 0), (fn, t)
         else:
             assert t["sampled_hit_bp"] == -1 and t["bloom_level"] == 0, (fn, t)
     fj.set_option("bloom_auto", 0)                      # as named: adaptive_*_bloom filter, adaptive_* do not
