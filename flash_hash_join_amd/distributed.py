@@ -1,8 +1,8 @@
 """Multi-GPU radix join: one process per GPU over RCCL/xGMI.
 
 The reference is single-process; this is new design.  Two exchange strategies, chosen per call
-by FJ_DIST_STRATEGY = shuffle (default: the exchange north_star names) | replicate | auto (a per-link byte + local-work
-cost model, choose_strategy):
+by FJ_DIST_STRATEGY = shuffle | replicate | auto (a per-link byte + local-work cost model, choose_strategy); unset it
+means the shuffle north_star names, or the model's choice once a link rate was measured on the node (set_link_rate):
 
 replicate -- every rank all-gathers the build KEYS (and values when materialising) and joins its own probe rows
   against all of them; probe rows never move, their partition passes run while the build keys are on the wire
@@ -279,20 +279,25 @@ def strategy_costs(world: int, nb: int, np_: int, materialize: bool) -> dict:
     return {"shuffle": t_shuffle, "replicate": t_replicate}
 
 
-def set_link_rate(bytes_per_s: float) -> None:
+_LINK_MEASURED = False
+
+
+def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
     """Replace the built-in per-link rate of the strategy model by a measured one (tools/xgmi_probe.py; bench.py does this
-    once at N > 1)."""
-    global _LINK_BYTES_PER_S
+    once at N > 1).  With a measured rate the default strategy becomes the model's choice."""
+    global _LINK_BYTES_PER_S, _LINK_MEASURED
     if bytes_per_s > 0:
         _LINK_BYTES_PER_S = float(bytes_per_s)
+        _LINK_MEASURED = bool(measured)
 
 
 def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
-    """'shuffle' (the owner exchange north_star names: the default) or 'replicate', for per-rank relation sizes nb x np_
-    (the maxima over the ranks).  FJ_DIST_STRATEGY=replicate|shuffle forces one; FJ_DIST_STRATEGY=auto lets the cost model
-    decide - it is only as good as its link rate (set_link_rate with a measured value) and was never checked against a
-    multi-GPU run, which is why it is not the default."""
-    forced = os.environ.get("FJ_DIST_STRATEGY", "shuffle")
+    """'shuffle' (the owner exchange north_star names) or 'replicate', for per-rank relation sizes nb x np_ (the maxima
+    over the ranks).  FJ_DIST_STRATEGY=replicate|shuffle forces one, =auto lets the cost model decide.  Unset: the shuffle,
+    unless a link rate was MEASURED on this node (set_link_rate; bench.py measures one all-to-all at N > 1) - then the model
+    decides with that rate: on a point-to-point mesh the probe-heavy shuffle puts (P*8 + B*16)/N bytes on every link
+    (6 GB per step at N = 2 for config 5's shards) where replicating the build side puts B*8 (1 GB)."""
+    forced = os.environ.get("FJ_DIST_STRATEGY", "auto" if _LINK_MEASURED else "shuffle")
     if forced in ("replicate", "shuffle"):
         return forced
     if world * nb >= (1 << 31):               # replicated build side must stay inside one GPU's chunk directory

@@ -148,12 +148,16 @@ def test_multi_gpu_strategy_model():
     assert D.choose_strategy(8, 400_000_000, 4_000_000_000, False) == "shuffle"        # 3.2e9 replicated rows: past one GPU's directory
     c = D.strategy_costs(2, 100_000_000, 1_000_000_000, False)
     assert c["shuffle"] > 3 * c["replicate"]                                           # one xGMI link between two GPUs
+    os.environ.pop("FJ_DIST_STRATEGY")
     old = D._LINK_BYTES_PER_S
-    D.set_link_rate(400e9)                                                                   # a measured, much faster link: shuffle wins at N = 8
+    D.set_link_rate(400e9)                                                                   # a MEASURED, much faster link: the model decides by default
     try:
         assert D.choose_strategy(8, 100_000_000, 1_000_000_000, False) == "shuffle"
+        D.set_link_rate(45e9)
+        assert D.choose_strategy(2, 125_000_000, 1_250_000_000, False) == "replicate"        # one link would carry half of everything
     finally:
-        D.set_link_rate(old)
+        D.set_link_rate(old, measured=False)
+    assert D.choose_strategy(2, 125_000_000, 1_250_000_000, False) == "shuffle"              # nothing measured: the named default
     os.environ["FJ_DIST_STRATEGY"] = "replicate"
     try:
         assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == "replicate"
