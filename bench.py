@@ -55,6 +55,10 @@ WORKLOADS = {
     "rep2": (200_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
     "rep4": (400_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
     "rep8": (800_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
+    # ... and at config 5's shard sizes (125M x 1.25B per GPU): N = 2, 4, 8 ranks' build keys against one rank's probe rows
+    "c5_rep2": (250_000_000, 1_250_000_000, 5000, "hash_join_count_radix"),
+    "c5_rep4": (500_000_000, 1_250_000_000, 5000, "hash_join_count_radix"),
+    "c5_rep8": (1_000_000_000, 1_250_000_000, 5000, "hash_join_count_radix"),
 }
 
 
