@@ -73,7 +73,7 @@ enum Slot {
     // [side][pingpong][kind]
     W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_REL, W_BOFF, W_SEGOFF, W_TOFF, W_TILES, W_KINDS,
     W_SIDE_STRIDE = 2 * W_KINDS,
-    W_PART_COUNT = 2 * W_SIDE_STRIDE, W_JOIN_TOFF, W_JOIN_ITEMS, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
+    W_PART_COUNT = 2 * W_SIDE_STRIDE, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
     W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_NSLOTS
 };
 

@@ -65,7 +65,6 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
 // of the level's consumer (tc chunks per tile; 0 = none); zero_tail: optional [max_tiles] array whose entries past the
 // number of tiles are cleared
 hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s);
-hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s);
 hipError_t fj_launch_scan_u32_to_u64(const u32* in, u64* out, u32 n, hipStream_t s);
 
 // ---- bloom precheck between two probe-side passes (csrc/fj_bloom.hip) ----------------------------

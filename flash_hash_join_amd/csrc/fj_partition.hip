@@ -610,21 +610,6 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
     }
 }
 
-// a tile table alone (a second consumer of a level whose lists exist already)
-__global__ __launch_bounds__(1024) void fj_tile_scan(const u32* __restrict__ boff, u32* __restrict__ toff, u32 n, u32 tc) {
-    const u32 tt = fj_block_scan<u32>([&](u32 i) { return (boff[i + 1] - boff[i] + tc - 1) / tc; }, [&](u32 i, u32 v) { toff[i] = v; }, n);
-    if (threadIdx.x == 0) toff[n] = tt;
-}
-__global__ void fj_tile_expand(const u32* __restrict__ boff, const u32* __restrict__ toff, u32 n, u32 tc,
-                               uint4* __restrict__ tiles, u32 max_tiles, u32* __restrict__ zero_tail) {
-    u32 total = toff[n];
-    if (total > max_tiles) total = max_tiles;
-    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < max_tiles; t += gridDim.x * blockDim.x) {
-        if (t < total) fj_tile_expand_one(boff, toff, n, tc, tiles, t);
-        else if (zero_tail) zero_tail[t] = 0;
-    }
-}
-
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE>
 hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
@@ -706,13 +691,6 @@ hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles
     hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
     hipLaunchKernelGGL(fj_level_lists, dim3(2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
                        cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
-    return hipGetLastError();
-}
-
-// Tile table of a chunk set (lists already built) for a consumer with `tc` chunks per tile.
-hipError_t fj_launch_tile_table(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s) {
-    hipLaunchKernelGGL(fj_tile_scan, dim3(1), dim3(1024), 0, s, cs.boff, toff, cs.nb, tc);
-    hipLaunchKernelGGL(fj_tile_expand, dim3(256), dim3(256), 0, s, cs.boff, toff, cs.nb, tc, tiles, max_tiles, zero_tail);
     return hipGetLastError();
 }
 
