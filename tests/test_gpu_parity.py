@@ -650,6 +650,24 @@ def test_full_size_materialize_pairs_property(fj, nb, npk):
     torch.cuda.empty_cache()
 
 
+def test_full_size_adaptive_materialize_with_the_precheck(fj):
+    """BASELINE config 4's sizes (100M x 1B, 5 % hits) through adaptive_join: the sampled hit rate turns the bloom precheck on,
+    the 50M emitted pairs satisfy key == (value+1)*M and the count is the closed form; adaptive_join_bloom agrees."""
+    import torch
+    from flash_hash_join_amd import datagen
+    nb, npk = 100_000_000, 1_000_000_000
+    dbk, dbv = datagen.build_device(nb, "cuda:0")
+    dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=1, hit_bp=500)
+    n, sec, k, v = fj.adaptive_join(dbk, dbv, dpk, return_arrays=True)
+    t = fj.last_timings()
+    assert n == exp and k.numel() == exp and t["bloom_level"] == 1 and 300 <= t["sampled_hit_bp"] <= 700, t
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+    assert bool(torch.all((v + 1) * M == k))
+    assert fj.adaptive_join_bloom(dbk, dbv, dpk)[0] == exp
+    del dbk, dbv, dpk, k, v
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("nb,npk,pieces", [(2000, 300_000, 3), (50_000, 1_000_000, 4), (1_500_000, 6_000_000, 5),
                                            (3_000_000, 20_000_000, 4), (10, 1000, 2)])
 def test_streamed_probe_equals_one_shot(fj, nb, npk, pieces):
