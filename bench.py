@@ -51,6 +51,9 @@ WORKLOADS = {
     "small": (1_000_000, 10_000_000, 5000, "hash_join_count_radix"),
     # BASELINE configs[4] (1B x 10B over 8 GPUs) as its per-GPU shard; the default for --gpus > 1
     "c5": (125_000_000, 1_250_000_000, 5000, "hash_join_count_radix"),
+    # the same shards at config 4's 5 % hit rate through the *_bloom function: at N > 1 the owner shuffle's sender-side
+    # precheck decides from a sample whether to filter the probe exchange (distributed._prefilter_mode)
+    "c5_bloom": (125_000_000, 1_250_000_000, 500, "hash_join_count_radix_bloom"),
     # what ONE rank joins locally under the replicate-build multi-GPU strategy at N = 2, 4, 8 (c3 rows per GPU)
     "rep2": (200_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
     "rep4": (400_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
@@ -268,6 +271,7 @@ def main() -> None:
     strategy_seen = ["single GPU"]
     part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": [], "filter_ms": []}
     dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
+    dlast = {}
 
     def step(record: bool) -> int:
         nonlocal part_launches
@@ -279,6 +283,7 @@ def main() -> None:
             if record:
                 for k in dtimes:
                     dtimes[k].append(t.get(k, 0.0))
+                dlast.update(t)
         if record:
             lt = api.last_timings()
             if world == 1 and not force_dist:
@@ -399,6 +404,9 @@ def main() -> None:
     if world > 1 or force_dist:
         phases.update({kk: round(mean(v) * 1e3, 3) for kk, v in (("split_ms", dtimes["split_s"]), ("exchange_ms", dtimes["exchange_s"]),
                                                                  ("local_join_ms", dtimes["join_s"]))})
+        phases.update({"shuffle_prefilter": dlast.get("prefilter"), "shuffle_prefilter_mode": dlast.get("prefilter_mode"),
+                       "shuffle_prefilter_sampled_survivors": dlast.get("prefilter_sampled_survivors"),
+                       "probe_rows_sent_rank0": dlast.get("probe_rows_sent")})
 
     out = {
         "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",

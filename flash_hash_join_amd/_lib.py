@@ -22,6 +22,7 @@ SYMBOLS = [
     "fj_set_option", "fj_get_option",
     "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe",
     "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
+    "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
     "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h",
 ]
@@ -103,6 +104,9 @@ def load() -> ctypes.CDLL:
     L.fj_stream_begin.restype = i32; L.fj_stream_begin.argtypes = [vp, vp, vp, sz, sz, i32, vp, i32]
     L.fj_stream_append_probe.restype = i32; L.fj_stream_append_probe.argtypes = [vp, vp, sz, vp]
     L.fj_stream_finish.restype = i32; L.fj_stream_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
+    L.fj_bloom_filter_words.restype = sz; L.fj_bloom_filter_words.argtypes = []
+    L.fj_bloom_export.restype = i32; L.fj_bloom_export.argtypes = [vp, vp, sz, i32, vp, vp]
+    L.fj_bloom_prefilter.restype = i32; L.fj_bloom_prefilter.argtypes = [vp, vp, sz, i32, vp, vp, sz, pu64, vp]
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]
     L.fj_generate_probe.restype = i32
     L.fj_generate_probe.argtypes = [vp, vp, u64, sz, u64, u64, ctypes.c_uint32, pu64, vp]

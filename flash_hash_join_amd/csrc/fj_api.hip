@@ -74,7 +74,7 @@ enum Slot {
     W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_REL, W_BOFF, W_SEGOFF, W_TOFF, W_TILES, W_KINDS,
     W_SIDE_STRIDE = 2 * W_KINDS,
     W_PART_COUNT = 2 * W_SIDE_STRIDE, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
-    W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_NSLOTS
+    W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_BKEYS, W_BBASE, W_NSLOTS
 };
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
@@ -110,6 +110,8 @@ struct PassIter {
     bool want_items = false; u32 items_cap = 0; u32* part_count = nullptr;
     // bloom precheck (probe side): run the filter stage once `bloom_level` passes are complete, against bloom_build
     bool bloom_done = false; const FjChunkSet* bloom_build = nullptr; bool bloom_wait_build = false;
+    const u32* bloom_prebuilt = nullptr;            // filters shipped by another GPU (sender-side precheck) instead of bloom_build's keys
+    unsigned long long* bloom_bucket_keys = nullptr; // [buckets] survivors per bucket (for flattening the survivors)
     // build side: keep a copy of the level the probe side's filter will read
     int save_level = 0; FjChunkSet saved{};
 };
@@ -433,6 +435,7 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     a.out_keys = cs.keys; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off; a.bchunks = cs.bchunks;
     a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + 3];
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs; a.err = &c->d_sc->err; a.survivors = &c->d_sc->bloom_survivors;
+    a.prebuilt = it.bloom_prebuilt; a.bucket_keys = it.bloom_bucket_keys;
     a.dbg_flags = getenv("FJ_BLOOM_ABLATE") ? (u32)atoi(getenv("FJ_BLOOM_ABLATE")) : 0u;
     if (it.bloom_wait_build) HIPCHK(hipStreamWaitEvent(s, c->ev[E_BUILD], 0));      // the build relation is partitioned on the side stream
     HIPCHK(hipEventRecord(c->ev[E_BF0], s));
@@ -441,7 +444,7 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     it.cs = cs; it.cs_base = base;
     it.lbound = it.n / FJ_CHUNK + 1 + max_segs;
     it.bloom_done = true;
-    if (level_finish(c, it, false, s)) return 1;          // the next pass reads the survivors
+    if (level_finish(c, it, it.i == it.plan.npass, s)) return 1;   // the next pass reads the survivors (none follows a sender-side precheck)
     it.prev = cs;
     ++it.slot;
     return 0;
@@ -939,6 +942,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
     if (many) algo &= ~FJ_ALGO_MANY_TO_MANY;
     if (algo < 0 || algo > 2) return set_err("fj_join_device: unknown algo %d", algo);
     if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_join_device: hash_top_bits must be 64 or 48");
+    if (c->st.active) return set_err("fj_join_device: a stream join is open on this context (fj_stream_finish it first)");
     if ((nb && (!d_bk || !d_bv)) || (np && !d_pk)) return set_err("fj_join_device: null input pointer");
     if (((uintptr_t)d_bk | (uintptr_t)d_bv | (uintptr_t)d_pk) & 15) return set_err("fj_join_device: input pointers must be 16-byte aligned");
     FJ_ON_DEVICE(c->device);
@@ -1267,6 +1271,76 @@ int fj_owner_scatter(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, 
     HIPCHK(hipMemsetAsync(c->d_sc->owner_cursors, 0, sizeof(unsigned long long) * 64, s));
     HIPCHK(fj_launch_owner_scatter(d_keys, d_vals, n, (u32)nranks, c->d_sc->owner_offsets, c->d_sc->owner_cursors, d_out_keys, d_out_vals, s));
     return 0;                                         // asynchronous: ordered on `stream`
+}
+
+// ---- sender-side bloom precheck of the owner shuffle (no reference counterpart) -----------------------------------------
+// An owner GPU partitions its build keys by FJ_PREFILTER_BITS radix bits (at the hash_top_bits it joins with) and exports one
+// LDS-sized Bloom filter per bucket; a peer partitions the probe rows it is about to send by the same bits, tests them against
+// the owner's filters (the bloom stage of the partitioned plan, csrc/fj_bloom.hip, with the filters read from HBM) and sends
+// only the survivors.
+size_t fj_bloom_filter_words(void) { return ((size_t)1 << FJ_PREFILTER_BITS) * FJ_BLOOM_WORDS; }
+
+int fj_bloom_export(fj_ctx* c, const uint64_t* d_build_keys, size_t nb, int hash_top_bits, uint32_t* d_filters, void* stream) {
+    if (!c) return set_err("fj_bloom_export: null context");
+    if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_bloom_export: hash_top_bits must be 64 or 48");
+    if (c->st.active) return set_err("fj_bloom_export: a stream join is open on this context (fj_stream_finish it first)");
+    if (!d_filters || (nb && !d_build_keys) || ((uintptr_t)d_build_keys & 15) || ((uintptr_t)d_filters & 15)) return set_err("fj_bloom_export: null or misaligned pointer");
+    FJ_ON_DEVICE(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const u32 nbuckets = 1u << FJ_PREFILTER_BITS;
+    if (nb == 0) { HIPCHK(hipMemsetAsync(d_filters, 0, (size_t)nbuckets * FJ_BLOOM_WORDS * 4, s)); return 0; }   // empty filters reject everything
+    Plan plan; plan.bits = FJ_PREFILTER_BITS; plan_passes(plan, true);
+    begin_plan(c);
+    if (clear_plan_scalars(c, s)) return 1;
+    PassIter bit;
+    pass_init(bit, 0, false, nb, plan, hash_top_bits);
+    FjChunkSet cs{};
+    if (run_passes(c, bit, (const u64*)d_build_keys, nullptr, s, &cs, nullptr)) return 1;
+    HIPCHK(fj_launch_bloom_export(cs, d_filters, c->num_cus, options().bloom_variant, s));
+    if (read_scalars(c, s)) return 1;
+    if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
+    end_plan(c);
+    return 0;
+}
+
+int fj_bloom_prefilter(fj_ctx* c, const uint64_t* d_probe_keys, size_t n, int hash_top_bits, const uint32_t* d_filters,
+                       uint64_t* d_out_keys, size_t out_capacity, uint64_t* out_n, void* stream) {
+    if (!c) return set_err("fj_bloom_prefilter: null context");
+    if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_bloom_prefilter: hash_top_bits must be 64 or 48");
+    if (c->st.active) return set_err("fj_bloom_prefilter: a stream join is open on this context (fj_stream_finish it first)");
+    if (!d_filters || !out_n || (n && (!d_probe_keys || !d_out_keys)) || ((uintptr_t)d_probe_keys & 15) || ((uintptr_t)d_filters & 15) || ((uintptr_t)d_out_keys & 7))
+        return set_err("fj_bloom_prefilter: null or misaligned pointer");
+    if (out_capacity < n) return set_err("fj_bloom_prefilter: output capacity %zu < %zu input rows", out_capacity, n);
+    *out_n = 0;
+    if (n == 0) return 0;
+    FJ_ON_DEVICE(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    Plan plan; plan.bits = FJ_PREFILTER_BITS; plan_passes(plan, true);
+    plan.bloom_level = 1;
+    begin_plan(c);
+    if (clear_plan_scalars(c, s)) return 1;
+    const u32 nbuckets = 1u << FJ_PREFILTER_BITS;
+    void* p;
+    if (get_buf(c, W_BKEYS, (size_t)nbuckets * 8, &p)) return 1; unsigned long long* bkeys = (unsigned long long*)p;
+    if (get_buf(c, W_BBASE, ((size_t)nbuckets + 1) * 8, &p)) return 1; unsigned long long* bbase = (unsigned long long*)p;
+    HIPCHK(hipMemsetAsync(bkeys, 0, (size_t)nbuckets * 8, s));
+    static const FjChunkSet no_build{};                     // (the filters are prebuilt: the build side's chunks are not here)
+    PassIter pit;
+    pass_init(pit, 1, false, n, plan, hash_top_bits);
+    pit.bloom_build = &no_build; pit.bloom_prebuilt = (const u32*)d_filters; pit.bloom_bucket_keys = bkeys;
+    FjChunkSet cs{};
+    if (run_passes(c, pit, (const u64*)d_probe_keys, nullptr, s, &cs, nullptr)) return 1;      // the pass; the filter stage follows it:
+    if (bloom_stage(c, pit, s)) return 1;
+    cs = pit.prev;
+    HIPCHK(fj_launch_flatten(cs, bkeys, bbase, (u64*)d_out_keys, s));
+    if (read_scalars(c, s)) return 1;
+    HIPCHK(hipMemcpyAsync(&c->h_sc->expected, &bbase[nbuckets], sizeof(unsigned long long), hipMemcpyDeviceToHost, s));   // (pinned scratch word)
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
+    end_plan(c);
+    if (c->h_sc->expected != c->h_sc->bloom_survivors) return set_err("internal error: prefilter flattened %llu of %llu survivors", c->h_sc->expected, c->h_sc->bloom_survivors);
+    *out_n = c->h_sc->expected;
+    return 0;
 }
 
 int fj_generate_build(fj_ctx* c, uint64_t* d_keys, uint64_t* d_vals, uint64_t first, size_t n, void* stream) {

@@ -76,6 +76,45 @@ __device__ __forceinline__ void bf_insert(unsigned char* filt, u64 key) {
     else atomicOr(reinterpret_cast<u32*>(filt + o), mlo);
 }
 
+// Build the LDS filter of one bucket from the build relation's chunks of that bucket (all threads of the workgroup; ends
+// with a barrier).  32 chunks = 8192 build keys per step: the step's four list entries per thread, then its four 16-B key
+// loads; the entries of the NEXT step are requested before this step's keys are used.
+template <int VAR>
+__device__ __forceinline__ void bf_build_filter(unsigned char* filt, const FjChunkSet& build, u32 bucket, u32 tid, u32 jb, u32 off, u32 off16) {
+    for (u32 i = tid; i < FJ_BLOOM_WORDS / 2; i += BF_NT) reinterpret_cast<u64*>(filt)[i] = 0;
+    __syncthreads();
+    const u32 b0 = build.boff[bucket], nbc = build.boff[bucket + 1] - b0;
+    auto bentries = [&](u32 c0, u32 (&e)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 j = c0 + (u32)i * 8u + jb;
+            e[i] = build.list[b0 + (j < nbc ? j : (nbc ? nbc - 1 : 0u))];
+        }
+    };
+    u32 be[4];
+    if (nbc) bentries(0, be);
+    for (u32 c0 = 0; c0 < nbc; c0 += 32) {
+        u64x2 q[4]; u32 cn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 eu = bf_uni(be[i]);
+            cn[i] = (c0 + (u32)i * 8u + jb) < nbc ? FJ_LIST_CNT(eu) : 0u;
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(build.keys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
+            q[i] = *reinterpret_cast<const u64x2*>(base + off16);
+        }
+        u32 bn[4];
+        bentries(c0 + 32 < nbc ? c0 + 32 : c0, bn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (off < cn[i]) bf_insert<VAR>(filt, q[i].x);
+            if (off + 1 < cn[i]) bf_insert<VAR>(filt, q[i].y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) be[i] = bn[i];
+    }
+    __syncthreads();
+}
+
 template <int VAR>
 __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -136,6 +175,7 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
     u32 cur = FJ_DIR_INVALID, fill = FJ_CHUNK;      // current chunk and its fill (wave-uniform; a multiple of 64 until the segment ends)
     u32 ns = 0;                                     // staged survivors of this wave (< 64 between key slots)
     u32 nch = 0, seg = 0;                           // chunks of this (wave, bucket run) = one segment of the bucket's chunk list
+    u32 seg_keys = 0;                               // survivors of this wave inside the current bucket run
     u32 slab_cur = 0, slab_rem = 0;
     unsigned long long survivors = 0;
     const u32 cap = a.cap_chunks;
@@ -164,8 +204,9 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
             if (cur < cap) a.out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | fill;
             const u32 o = atomicAdd(&a.bchunks[bucket], nch);
             if (seg < a.max_segs) a.seg_off[seg] = o;
+            if (a.bucket_keys && seg_keys) atomicAdd(&a.bucket_keys[bucket], (unsigned long long)seg_keys);
         }
-        cur = FJ_DIR_INVALID; fill = FJ_CHUNK; nch = 0;
+        cur = FJ_DIR_INVALID; fill = FJ_CHUNK; nch = 0; seg_keys = 0;
     };
 
     // ---- prologue: keys of tiles 0-1, entries of tiles 2-3, descriptors of tiles 4-5 in flight ----------------------
@@ -209,40 +250,13 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
         if (bucket != cur_bucket) {                 // workgroup-uniform: rebuild the filter for this bucket
             if (cur_bucket != 0xFFFFFFFFu) end_segment(cur_bucket);
             __syncthreads();                        // every wave is done testing against the old filter
-            for (u32 i = tid; i < FJ_BLOOM_WORDS / 2; i += BF_NT) reinterpret_cast<u64*>(filt)[i] = 0;
-            __syncthreads();
-            const u32 b0 = a.build.boff[bucket], nbc = a.build.boff[bucket + 1] - b0;
-            // 32 chunks = 8192 build keys per step: the step's four list entries per thread, then its four 16-B key loads; the
-            // entries of the NEXT step are requested before this step's keys are used
-            auto bentries = [&](u32 c0, u32 (&e)[4]) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u32 j = c0 + (u32)i * 8u + jb;
-                    e[i] = a.build.list[b0 + (j < nbc ? j : (nbc ? nbc - 1 : 0u))];
-                }
-            };
-            u32 be[4];
-            if (nbc) bentries(0, be);
-            for (u32 c0 = 0; c0 < nbc; c0 += 32) {
-                u64x2 q[4]; u32 cn[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u32 eu = bf_uni(be[i]);
-                    cn[i] = (c0 + (u32)i * 8u + jb) < nbc ? FJ_LIST_CNT(eu) : 0u;
-                    const unsigned char* base = reinterpret_cast<const unsigned char*>(a.build.keys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
-                    q[i] = *reinterpret_cast<const u64x2*>(base + off16);
-                }
-                u32 bn[4];
-                bentries(c0 + 32 < nbc ? c0 + 32 : c0, bn);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (off < cn[i]) bf_insert<VAR>(filt, q[i].x);
-                    if (off + 1 < cn[i]) bf_insert<VAR>(filt, q[i].y);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) be[i] = bn[i];
+            if (a.prebuilt) {                       // filters built elsewhere (another GPU's build keys: the sender-side precheck of the owner shuffle)
+                const uint4* src = reinterpret_cast<const uint4*>(a.prebuilt + (u64)bucket * FJ_BLOOM_WORDS);
+                for (u32 i = tid; i < FJ_BLOOM_WORDS / 4; i += BF_NT) reinterpret_cast<uint4*>(filt)[i] = src[i];
+                __syncthreads();
+            } else {
+                bf_build_filter<VAR>(filt, a.build, bucket, tid, jb, off, off16);
             }
-            __syncthreads();
             if (lane == 0) { seg = atomicAdd(a.seg_counter, 1u); if (seg >= a.max_segs) atomicOr(a.err, FJ_ERR_POOL); }
             seg = bf_uni(seg);
             cur_bucket = bucket;
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
                 if ((m >> lane) & 1ull) stg[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = kCur[i];
                 ns += n;
                 survivors += n;
+                seg_keys += n;
                 if (ns >= 64) {                     // a whole 512-B piece leaves; the rest moves to the front of the row
                     flush(bucket, 64);
                     ns -= 64;
@@ -286,7 +301,90 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
     if (lane == 0 && survivors) atomicAdd(a.survivors, survivors);
 }
 
+// Write the filters of ALL buckets of a build-side level to HBM (FJ_BLOOM_WORDS words each): what an owner GPU ships to its
+// peers so that they can run the precheck before sending it their probe rows.
+template <int VAR>
+__global__ __launch_bounds__(BF_NT, 1) void fj_bloom_export_kernel(FjChunkSet build, u32* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tid = threadIdx.x;
+    const u32 jb = bf_uni(tid >> 7), off = (tid & 127u) * 2u, off16 = (tid & 127u) * 16u;
+    for (u32 b = blockIdx.x; b < build.nb; b += gridDim.x) {
+        bf_build_filter<VAR>(smem, build, b, tid, jb, off, off16);
+        uint4* dst = reinterpret_cast<uint4*>(out + (u64)b * FJ_BLOOM_WORDS);
+        for (u32 i = tid; i < FJ_BLOOM_WORDS / 4; i += BF_NT) dst[i] = reinterpret_cast<const uint4*>(smem)[i];
+        __syncthreads();
+    }
+}
+
+// exclusive scan of per-bucket key counts (nb <= 1024: one workgroup) -> base[0..nb]
+__global__ __launch_bounds__(1024) void fj_bucket_base_kernel(const unsigned long long* __restrict__ bkeys, unsigned long long* __restrict__ base, u32 nb) {
+    __shared__ unsigned long long wtot[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long x = tid < nb ? bkeys[tid] : 0ull;
+    unsigned long long inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    unsigned long long run = inc - x, total = 0;
+    for (u32 w = 0; w < 16; ++w) { if (w < wave) run += wtot[w]; total += wtot[w]; }
+    if (tid < nb) base[tid] = run;
+    if (tid == 0) base[nb] = total;
+}
+
+// chunk set -> dense array: one workgroup per bucket walks the bucket's chunk list in batches of 256 chunks (block scan of the
+// chunks' key counts -> offsets), each wave copies whole chunks (256 keys = 4 per lane)
+__global__ __launch_bounds__(256) void fj_flatten_kernel(FjChunkSet cs, const unsigned long long* __restrict__ base, u64* __restrict__ out) {
+    __shared__ u32 s_off[257];
+    __shared__ u32 s_ent[256];
+    __shared__ u32 wsum[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 b = blockIdx.x; b < cs.nb; b += gridDim.x) {
+        const u32 l0 = cs.boff[b], n = cs.boff[b + 1] - l0;
+        unsigned long long run = base[b];
+        for (u32 c0 = 0; c0 < n; c0 += 256) {
+            const u32 e = c0 + tid < n ? cs.list[l0 + c0 + tid] : 0u;
+            const u32 cnt = c0 + tid < n ? FJ_LIST_CNT(e) : 0u;
+            u32 inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            u32 pre = inc - cnt;
+            for (u32 w = 0; w < wave; ++w) pre += wsum[w];
+            s_off[tid] = pre; s_ent[tid] = e;
+            if (tid == 255) s_off[256] = pre + cnt;
+            __syncthreads();
+            const u32 m = n - c0 < 256 ? n - c0 : 256;
+            for (u32 j = wave; j < m; j += 4) {
+                const u32 ee = s_ent[j], cc = FJ_LIST_CNT(ee);
+                const u64* src = cs.keys + (u64)FJ_LIST_ID(ee) * FJ_CHUNK;
+                u64* dst = out + run + s_off[j];
+                for (u32 k = lane; k < cc; k += 64) dst[k] = src[k];
+            }
+            run += s_off[256];
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t fj_launch_bloom_export(const FjChunkSet& build, u32* out, u32 grid, int variant, hipStream_t s) {
+    const u32 lds = FJ_BLOOM_WORDS * 4;
+    auto kern = variant == 0 ? fj_bloom_export_kernel<0> : fj_bloom_export_kernel<1>;
+    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid < build.nb ? grid : build.nb), dim3(BF_NT), lds, s, build, out);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_flatten(const FjChunkSet& cs, const unsigned long long* bucket_keys, unsigned long long* base, u64* out, hipStream_t s) {
+    if (cs.nb > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fj_bucket_base_kernel, dim3(1), dim3(1024), 0, s, bucket_keys, base, cs.nb);
+    hipLaunchKernelGGL(fj_flatten_kernel, dim3(cs.nb), dim3(256), 0, s, cs, base, out);
+    return hipGetLastError();
+}
 
 u32 fj_bloom_tile_chunks() { return BF_T / FJ_CHUNK; }
 u32 fj_bloom_waves_per_group() { return BF_NW; }

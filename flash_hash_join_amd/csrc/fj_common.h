@@ -43,6 +43,7 @@ static inline unsigned fj_slab_for(unsigned fan) { return fan > 256u ? 2u * FJ_S
 #define FJ_BLOOM_MAX_KEYS 400000u                // build keys per filtered bucket above which the filter is not worth running (< 3 bits per key)
 #define FJ_BLOOM_GOOD_KEYS 215000u               // ... below which it is strong (>= 5.5 bits per key): the plan widens its first pass to get here
 
+#define FJ_PREFILTER_BITS 9                      // sender-side precheck of the owner shuffle: radix bits = 512 filters per owner
 #define FJ_SAMPLE_KEYS 4096u                     // probe rows sampled by the adaptive joins to decide on the precheck
 
 // Global (HBM / Infinity-Cache resident) table for the non-partitioned path: groups of 8 keys

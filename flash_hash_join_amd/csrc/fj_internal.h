@@ -79,12 +79,17 @@ struct FjBloomArgs {
     u32 cap_chunks, max_segs;
     u32* err;
     unsigned long long* survivors;   // device scalar: probe keys that passed
+    const u32* prebuilt;             // non-null: filters come from HBM (FJ_BLOOM_WORDS words per bucket) instead of being built from `build`
+    unsigned long long* bucket_keys; // non-null: [nb] survivors per bucket are accumulated here (zeroed by the caller)
     u32 dbg_flags;                   // diagnostic ablations (FJ_BLOOM_ABLATE): 1 = count survivors but do not write them, 2 = no filter lookup (results wrong on purpose)
 };
 u32 fj_bloom_tile_chunks();
 u32 fj_bloom_waves_per_group();
 u32 fj_bloom_slab_chunks();
 hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, int variant, hipStream_t s);
+// all bucket filters of a build-side level -> HBM; chunk set -> dense array (base[nb+1] receives the buckets' offsets, base[nb] the total)
+hipError_t fj_launch_bloom_export(const FjChunkSet& build, u32* out, u32 grid, int variant, hipStream_t s);
+hipError_t fj_launch_flatten(const FjChunkSet& cs, const unsigned long long* bucket_keys, unsigned long long* base, u64* out, hipStream_t s);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
 hipError_t fj_set_max_lds_once(const void* fn, u32 bytes);

@@ -61,6 +61,12 @@ class HipEngine:
             raise ValueError(f"build_values has {bv.numel()} elements, build_keys has {bk.numel()}")
         return bk, bv, pk
 
+    def empty_like(self, t):
+        return self.torch.empty_like(t)
+
+    def cat(self, parts):
+        return self.torch.cat(list(parts))
+
     def counts_tensor(self, counts: List[int]):
         return self.torch.tensor(counts, dtype=self.torch.int64, device=self.device)
 
@@ -133,6 +139,25 @@ class HipEngine:
         self.api._last = t
         return int(cnt.value)
 
+    def bloom_export(self, build_keys, hash_top_bits: int):
+        """Bloom filters of the build keys this rank owns: 512 radix buckets x fj_bloom_filter_words()/512 words (int32 tensor)."""
+        t = self.torch
+        build_keys = self._aligned(build_keys)
+        out = t.empty(int(self.L.fj_bloom_filter_words()), dtype=t.int32, device=self.device)
+        self._lib.check(self.L.fj_bloom_export(self.ctx, build_keys.data_ptr(), build_keys.numel(), hash_top_bits, out.data_ptr(),
+                                               t.cuda.current_stream(self.index).cuda_stream))
+        return out
+
+    def bloom_prefilter(self, keys, filters, hash_top_bits: int):
+        """The rows of `keys` that may match the owner whose filters these are (no row that matches is dropped; the order changes)."""
+        t = self.torch
+        keys = self._aligned(keys)
+        out = self.empty(keys.numel())
+        n = ctypes.c_uint64(0)
+        self._lib.check(self.L.fj_bloom_prefilter(self.ctx, keys.data_ptr(), keys.numel(), hash_top_bits, filters.data_ptr(),
+                                                  out.data_ptr(), out.numel(), ctypes.byref(n), t.cuda.current_stream(self.index).cuda_stream))
+        return out[: int(n.value)]
+
     def local_join(self, bk, bv, pk, materialize: bool, bloom: bool, hash_top_bits: int, return_arrays: bool):
         return self.api.join_device(self.api.ALGO_RADIX, int(bloom), int(materialize), bk, bv, pk,
                                     return_arrays=return_arrays, hash_top_bits=hash_top_bits)
@@ -169,9 +194,61 @@ def _exchange(dist, group, engine, send, send_counts: List[int], recv_counts: Li
     return recv
 
 
-def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces: int, timings: Optional[dict]):
+def _prefilter_mode(bloom: bool) -> str:
+    """Sender-side bloom precheck of the probe exchange: "on" | "off" | "auto".  FJ_DIST_PREFILTER=1 / 0 / auto decides;
+    unset, the *_bloom meaning (`bloom=True`) asks for "auto": the filters are exported and a sample of the probe rows is
+    tested against them; the precheck runs when few enough rows survive to pay for the extra pass (_prefilter_break_even)."""
+    env = os.environ.get("FJ_DIST_PREFILTER", "")
+    if env in ("0", "1", "auto"):
+        return {"0": "off", "1": "on", "auto": "auto"}[env]
+    return "auto" if bloom else "off"
+
+
+# fj_bloom_prefilter on one MI355X, 156M-row segments against 125M-key owners (profiles/r02_prefilter_probe.txt):
+# 1.33 ms at 13 % survivors ... 2.25 ms at 100 %  =  8.5 ps + 5.9 ps x survivors, per row
+_PREFILTER_S_PER_ROW = 8.5e-12
+_PREFILTER_S_PER_SURVIVOR = 5.9e-12
+_PREFILTER_SAMPLE_ROWS = 1 << 20
+
+
+def _prefilter_break_even(world: int) -> float:
+    """Survivor fraction below which the precheck pays: a sender filters `world` segments one after the other while its
+    links carry one segment each in parallel, so per segment row it spends world * (a + b f) and saves (8 B / link) * (1 - f).
+    A 0.8 margin covers what the model leaves out (the filters' own 73 MB per link, the lost scatter/exchange overlap)."""
+    link = 8.0 / _LINK_BYTES_PER_S
+    f = (link - _PREFILTER_S_PER_ROW * world) / (link + _PREFILTER_S_PER_SURVIVOR * world)
+    return max(0.0, 0.8 * f)
+
+
+def _sampled_survivors(dist, group, engine, world, probe_keys, filters) -> float:
+    """Fraction of a strided sample of every rank's probe rows that passes the owners' filters (identical on all ranks)."""
+    n = probe_keys.numel()
+    kept = m = 0
+    if n:
+        m = min(n, _PREFILTER_SAMPLE_ROWS)
+        sample = probe_keys[:: max(1, n // m)][:m].contiguous()
+        m = sample.numel()
+        s, _, counts = engine.owner_split(sample, None, world)
+        off = 0
+        for d in range(world):
+            kept += int(engine.bloom_prefilter(s[off: off + counts[d]], filters[d], 48).numel())
+            off += counts[d]
+    v = engine.counts_tensor([kept, m])
+    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    kept, m = (int(x) for x in v.tolist())
+    return kept / m if m else 1.0
+
+
+def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces: int, timings: Optional[dict],
+                     prefilter: str = "off"):
     """Counting join with the probe exchange cut into `pieces` rounds: the owner-scatter of piece c+1 and the first
-    partition pass over piece c-1 run while piece c is on the wire (asynchronous all-to-all)."""
+    partition pass over piece c-1 run while piece c is on the wire (asynchronous all-to-all).
+
+    prefilter ("on" / "auto"): every owner exports Bloom filters of the build keys it received (512 radix buckets, one
+    LDS-sized filter each: fj_bloom_export), one all-gather hands them to every rank, and a rank sends an owner only the
+    probe rows that pass that owner's filters (fj_bloom_prefilter).  Costs 73 MB per link for the filters + one more
+    partition pass on the sender; saves (1 - survivors) of the probe exchange, which is what bounds the shuffle
+    (DESIGN.md section 6)."""
     t0 = time.perf_counter()
     # build side: split, exchange, start the build-side passes
     bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)
@@ -180,26 +257,66 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
     views = [probe_keys[bounds[c]: bounds[c + 1]] for c in range(pieces)]
     p_counts = [engine.owner_hist(v, world) for v in views]                  # [piece][owner]
     t1 = time.perf_counter()
-    # one all-to-all tells every rank what it will receive: build counts + per-piece probe counts
-    flat = []
-    for d in range(world):
-        flat += [b_counts[d]] + [p_counts[c][d] for c in range(pieces)]
-    send_c = engine.counts_tensor(flat)
-    recv_c = engine.counts_tensor([0] * len(flat))
-    dist.all_to_all_single(recv_c, send_c, group=group)
-    rc = recv_c.reshape(world, pieces + 1).tolist()
-    b_recv = [int(r[0]) for r in rc]
-    p_recv = [[int(rc[src][c + 1]) for src in range(world)] for c in range(pieces)]      # [piece][source]
-    mx = engine.counts_tensor([max([max(b_counts)] + [max(pc) for pc in p_counts])])
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-    rounds = max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
-    bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
-    bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+
+    def exchange_counts(flat, per_rank):
+        send_c = engine.counts_tensor(flat)
+        recv_c = engine.counts_tensor([0] * len(flat))
+        dist.all_to_all_single(recv_c, send_c, group=group)
+        return recv_c.reshape(world, per_rank).tolist()
+
+    def message_rounds(largest):
+        mx = engine.counts_tensor([largest])
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        return max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
+
+    scattered, filtered, sampled = None, False, None
+    if prefilter == "off":
+        # one all-to-all tells every rank what it will receive: build counts + per-piece probe counts
+        flat = []
+        for d in range(world):
+            flat += [b_counts[d]] + [p_counts[c][d] for c in range(pieces)]
+        rc = exchange_counts(flat, pieces + 1)
+        b_recv = [int(r[0]) for r in rc]
+        p_recv = [[int(rc[src][c + 1]) for src in range(world)] for c in range(pieces)]      # [piece][source]
+        rounds = message_rounds(max([max(b_counts)] + [max(pc) for pc in p_counts]))
+        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
+        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+    else:
+        # the build side travels first: its owners' filters decide what the probe side sends
+        b_recv = [int(r[0]) for r in exchange_counts(list(b_counts), 1)]
+        b_rounds = message_rounds(max(b_counts))
+        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, b_rounds)
+        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, b_rounds)
+        mine = engine.bloom_export(bk_r, 48)
+        filters = [engine.empty_like(mine) for _ in range(world)]
+        dist.all_gather(filters, mine, group=group)
+        filtered = True
+        if prefilter == "auto":
+            sampled = _sampled_survivors(dist, group, engine, world, probe_keys, filters)
+            filtered = sampled < _prefilter_break_even(world)
+        if filtered:
+            scattered = []
+            for c in range(pieces):
+                s_c = engine.owner_scatter(views[c], world, p_counts[c])
+                off, kept = 0, []
+                for d in range(world):
+                    kept.append(engine.bloom_prefilter(s_c[off: off + p_counts[c][d]], filters[d], 48))
+                    off += p_counts[c][d]
+                p_counts[c] = [int(k.numel()) for k in kept]
+                scattered.append(engine.cat(kept))
+        del filters, mine
+        flat = []
+        for d in range(world):
+            flat += [p_counts[c][d] for c in range(pieces)]
+        rc = exchange_counts(flat, pieces)
+        p_recv = [[int(rc[src][c]) for src in range(world)] for c in range(pieces)]
+        rounds = message_rounds(max(max(pc) for pc in p_counts))
+    sent_rows = sum(sum(pc) for pc in p_counts)
     np_total = sum(sum(p) for p in p_recv)
     engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
     keep, works, recvs = [], [], []
     for c in range(pieces):
-        s_c = engine.owner_scatter(views[c], world, p_counts[c])
+        s_c = scattered[c] if scattered is not None else engine.owner_scatter(views[c], world, p_counts[c])
         r_c = engine.empty(sum(p_recv[c]))
         if rounds <= 1:
             w = dist.all_to_all_single(r_c, s_c, output_split_sizes=p_recv[c], input_split_sizes=p_counts[c], group=group, async_op=True)
@@ -220,8 +337,7 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
     except RuntimeError as ex:                   # a skewed partition overflows its LDS table: one-shot join with its HBM fallback
         if "does not fit" not in str(ex):
             raise
-        import torch
-        local_count = int(engine.local_join(bk_r, bv_r, torch.cat(recvs), False, False, 48, False)[0])
+        local_count = int(engine.local_join(bk_r, bv_r, engine.cat(recvs), False, False, 48, False)[0])
     tot = engine.counts_tensor([local_count])
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     engine.synchronize()
@@ -229,7 +345,8 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
     del keep
     if timings is not None:
         timings.update(split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2, exchange_rounds=rounds, pieces=pieces,
-                       local_build_rows=sum(b_recv), local_probe_rows=np_total, local_count=local_count)
+                       local_build_rows=sum(b_recv), local_probe_rows=np_total, local_count=local_count,
+                       prefilter=filtered, prefilter_mode=prefilter, prefilter_sampled_survivors=sampled, probe_rows_sent=sent_rows)
     return int(tot.item()), t3 - t0
 
 
@@ -436,7 +553,8 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     if timings is not None:
         timings["strategy"] = "shuffle"
     if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
-        return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings)
+        return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings,
+                                prefilter=_prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off")
 
     # 1. split by owner
     bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)

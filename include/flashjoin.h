@@ -163,6 +163,19 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
                      uint64_t* d_out_keys, uint64_t* d_out_vals, void* stream);
 
 /*
+ * Sender-side bloom precheck of the owner shuffle (no reference counterpart).  fj_bloom_export: an owner partitions the
+ * nb build keys it owns by 9 radix bits (at the hash_top_bits it will join with) and writes one Bloom filter per bucket,
+ * fj_bloom_filter_words() 32-bit words each, 512 buckets, into d_filters (the caller all-gathers them).  fj_bloom_prefilter:
+ * a peer tests the n probe keys it is about to send to that owner against the owner's filters and writes the keys that may
+ * match, densely, into d_out_keys (capacity >= n); *out_n = how many (synchronous).  No key that is in the owner's build
+ * side is ever dropped.
+ */
+size_t fj_bloom_filter_words(void);        /* words per owner = 512 * words per bucket */
+int fj_bloom_export(fj_ctx* ctx, const uint64_t* d_build_keys, size_t nb, int hash_top_bits, uint32_t* d_filters, void* stream);
+int fj_bloom_prefilter(fj_ctx* ctx, const uint64_t* d_probe_keys, size_t n, int hash_top_bits, const uint32_t* d_filters,
+                       uint64_t* d_out_keys, size_t out_capacity, uint64_t* out_n, void* stream);
+
+/*
  * A counting radix join whose relations arrive in pieces (multi-GPU: the pieces of an exchange).  No reference
  * counterpart; same result as fj_join_device(FJ_ALGO_RADIX, 0, 0, ...) on the concatenations.
  *

@@ -170,6 +170,24 @@ def test_multi_gpu_strategy_model():
         [0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3]
 
 
+def test_shuffle_prefilter_decision_model(monkeypatch):
+    """The sender-side precheck of the owner shuffle: environment / `bloom` -> mode, and the survivor fraction below which
+    the sampled ("auto") decision runs it: generous on small meshes (a sender filters N segments while each link carries
+    one), never on a link too fast to be worth a pass."""
+    from flash_hash_join_amd import distributed as D
+    monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False)
+    assert D._prefilter_mode(False) == "off" and D._prefilter_mode(True) == "auto"
+    for env, mode in (("0", "off"), ("1", "on"), ("auto", "auto")):
+        monkeypatch.setenv("FJ_DIST_PREFILTER", env)
+        assert D._prefilter_mode(False) == D._prefilter_mode(True) == mode
+    monkeypatch.setenv("FJ_DIST_PREFILTER", "bogus")
+    assert D._prefilter_mode(True) == "auto" and D._prefilter_mode(False) == "off"
+    be = [D._prefilter_break_even(w) for w in (2, 4, 8, 16)]
+    assert be == sorted(be, reverse=True) and 0.6 < be[0] < 0.8 and 0.3 < be[2] < 0.45 and be[3] < 0.2
+    monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 1e15)
+    assert D._prefilter_break_even(8) == 0.0
+
+
 def test_bench_launches_its_own_ranks_when_asked_for_several_gpus(monkeypatch):
     """`python bench.py --gpus N` (the driver's command line) outside a torchrun environment must start
     `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before touching the GPU and

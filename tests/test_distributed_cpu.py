@@ -37,6 +37,29 @@ class OracleEngine:
     def counts_tensor(self, counts):
         return torch.tensor(counts, dtype=torch.int64)
 
+    def empty_like(self, t):
+        return torch.empty_like(t)
+
+    def cat(self, parts):
+        return torch.cat(list(parts))
+
+    # stand-in for fj_bloom_export / fj_bloom_prefilter: ONE 2^20-bit filter per owner, one bit per key (what the protocol
+    # needs from them: fixed-size filters that never reject a key of the build side)
+    _FBITS = 1 << 20
+
+    def _fpos(self, keys):
+        return (_fmix64(keys.numpy().view(np.uint64).copy()) % np.uint64(self._FBITS)).astype(np.int64)
+
+    def bloom_export(self, build_keys, hash_top_bits):
+        assert hash_top_bits == 48
+        bits = np.zeros(self._FBITS, dtype=np.int32)
+        bits[self._fpos(build_keys)] = 1
+        return torch.from_numpy(bits)
+
+    def bloom_prefilter(self, keys, filters, hash_top_bits):
+        assert hash_top_bits == 48 and filters.numel() == self._FBITS
+        return keys[torch.from_numpy(filters.numpy()[self._fpos(keys)] != 0)]
+
     def owner_split(self, keys, vals, world):
         k = keys.numpy().view(np.uint64)
         owner = (((_fmix64(k.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)).astype(np.int64)
@@ -99,7 +122,10 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     small_messages = strategy == "replicate_small_messages"
+    variant = strategy.split("_", 1)[1] if "_" in strategy else ""
+    prefilter = variant in ("prefilter", "prefilterauto")
     strategy = strategy.split("_")[0]
+    os.environ["FJ_DIST_PREFILTER"] = {"prefilter": "1", "prefilterauto": "auto", "prefilterdeclined": "auto"}.get(variant, "0")
     os.environ["FJ_DIST_STRATEGY"] = strategy
     if strategy == "replicate":
         os.environ["FJ_REPLICATE_PIECES"] = "3"
@@ -107,6 +133,9 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     try:
         from flash_hash_join_amd import datagen
         from flash_hash_join_amd.distributed import distributed_join
+        if variant == "prefilterdeclined":      # an infinitely fast link: the sampled decision turns the precheck down
+            import flash_hash_join_amd.distributed as D
+            D._LINK_BYTES_PER_S = 1e15
         if small_messages:                      # every collective carries <= 3000 rows per rank: 4 pieces, reordered rank-major
             import flash_hash_join_amd.distributed as D
             D._MAX_ELEMS_PER_MESSAGE = 3000
@@ -122,8 +151,17 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         tc = {}
         cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)        # counting: pipelined exchange
         assert cnt == int(exp.item()) and tc["strategy"] == t["strategy"] == strategy
-        assert tc["local_probe_rows"] == t["local_probe_rows"]
         keys = res[2].numpy().view(np.uint64)
+        assert tc.get("prefilter", False) == prefilter
+        if variant.startswith("prefilter"):
+            assert tc["prefilter_mode"] == ("on" if variant == "prefilter" else "auto")
+            assert (tc["prefilter_sampled_survivors"] is None) == (variant == "prefilter")
+            if variant != "prefilter":
+                assert 0.45 < tc["prefilter_sampled_survivors"] < 0.6          # 50 % hits + a few false positives
+        if prefilter:                           # half the probe rows miss: the filters (load 1/40) keep nearly none of them
+            assert tc["local_probe_rows"] < t["local_probe_rows"] and tc["probe_rows_sent"] < 0.6 * (p1 - p0)
+        else:
+            assert tc["local_probe_rows"] == t["local_probe_rows"]
         if strategy == "shuffle":
             assert tc["pieces"] == 4
             # every pair this rank owns must hash to this rank
@@ -143,7 +181,8 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "replicate", "replicate_small_messages"])
+@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
+                                      "replicate_small_messages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):
     nb, npk = 20000, 90000

@@ -353,6 +353,43 @@ def test_owner_split_then_local_joins_equals_global_join(fj):
     assert total == exp
 
 
+@pytest.mark.parametrize("top_bits", [64, 48])
+@pytest.mark.parametrize("nb,npk,hit_bp", [(1, 1000, 5000), (3000, 200_000, 0), (1_000_000, 5_000_000, 500), (20_000_000, 30_000_000, 2500),
+                                            (150_000_000, 40_000_000, 100)])
+def test_sender_side_prefilter_keeps_every_hit(fj, nb, npk, hit_bp, top_bits):
+    """fj_bloom_export + fj_bloom_prefilter (the owner shuffle's sender-side precheck): the survivors are a sub-multiset
+    of the probe keys that contains every key of the build side, joining them gives the same count, and at low hit rates
+    most misses are gone (filter load: nb / 512 keys in a 1.1 Mbit filter)."""
+    import torch
+    from flash_hash_join_amd import datagen, api
+    from flash_hash_join_amd.distributed import HipEngine
+    bk, bv = datagen.build_device(nb, "cuda:0")
+    pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=13, hit_bp=hit_bp)
+    eng = HipEngine("cuda:0")
+    filt = eng.bloom_export(bk, top_bits)
+    assert filt.numel() == 512 * 35840
+    kept = eng.bloom_prefilter(pk, filt, top_bits)
+    assert exp <= kept.numel() <= npk
+    hit = torch.isin(pk, bk)
+    assert int(hit.sum()) == exp
+    ks, ps = torch.sort(kept)[0], torch.sort(pk)[0]
+    assert torch.equal(torch.sort(pk[hit])[0], ks[torch.isin(ks, bk)])              # every hit survives, with its multiplicity
+    uk, uc = torch.unique_consecutive(ks, return_counts=True)
+    pu, pc = torch.unique_consecutive(ps, return_counts=True)
+    at = torch.searchsorted(pu, uk)
+    assert bool(torch.all(pu[at.clamp(max=pu.numel() - 1)] == uk)) and bool(torch.all(uc <= pc[at.clamp(max=pu.numel() - 1)]))   # nothing invented
+    n, _ = api.join_device(api.ALGO_RADIX, 0, 0, bk, bv, kept.clone(), hash_top_bits=top_bits)
+    assert n == exp
+    misses_kept = kept.numel() - exp
+    if nb <= 20_000_000:
+        assert misses_kept <= 0.02 * (npk - exp) + 8                                 # <= 39k keys per 1.1 Mbit filter
+    else:
+        assert misses_kept <= 0.5 * (npk - exp)                                      # 293k keys per filter: past the good range, still useful
+    # an empty build side exports all-zero filters: everything is rejected
+    z = eng.bloom_export(bk[:0], top_bits)
+    assert eng.bloom_prefilter(pk[:100_000], z, top_bits).numel() == 0
+
+
 def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
     """The whole multi-GPU step on a 1-rank nccl group, both strategies: owner split -> RCCL all_to_all_single -> join
     with hash_top_bits=48 -> all_reduce, and all-gather of the build keys overlapped with the probe passes -> join ->
@@ -383,6 +420,20 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
             n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
             assert n == exp and k.numel() == exp
             assert bool(torch.all((v + 1) * M == k))
+        # sender-side bloom precheck of the probe exchange (fj_bloom_export -> all_gather -> fj_bloom_prefilter per owner)
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle")
+        lpk, lexp = datagen.probe_device(npk, nb, "cuda:0", seed=9, hit_bp=500)
+        for pre in ("1", "0"):
+            monkeypatch.setenv("FJ_DIST_PREFILTER", pre)
+            t = {}
+            n, sec = distributed_join(bk, bv, lpk, timings=t)
+            assert n == lexp and t["prefilter"] == (pre == "1")
+            assert t["probe_rows_sent"] == npk if pre == "0" else lexp <= t["probe_rows_sent"] < 0.07 * npk
+        n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # FJ_DIST_PREFILTER=0 overrides the bloom argument
+        assert n == lexp and not t["prefilter"]
+        monkeypatch.delenv("FJ_DIST_PREFILTER")
+        n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # the *_bloom meaning of the multi-GPU join
+        assert n == lexp and t["prefilter"]
         # a build side whose keys all land in ONE partition: the streamed (replicate) join reports the overflow and the
         # one-shot join's HBM-table fallback produces the count
         def hash_w1(kk):

@@ -29,6 +29,13 @@ class HostStagedDist:
     def all_gather_into_tensor(self, out, t, group=None, async_op=False):
         ho, hi = self._h(out), self._h(t); dist.all_gather_into_tensor(ho, hi, group=group); out.copy_(ho); return self._Done()
 
+    def all_gather(self, outs, t, group=None, async_op=False):
+        hos = [self._h(o) for o in outs]
+        dist.all_gather(hos, self._h(t), group=group)
+        for o, h in zip(outs, hos):
+            o.copy_(h)
+        return self._Done()
+
     def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
         ho, hi = self._h(out), self._h(inp)
         dist.all_to_all_single(ho, hi, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
@@ -60,11 +67,14 @@ def worker(rank, world, port, q):
         pk, exp_local = datagen.probe_device(p1 - p0, nb, "cuda:0", seed=1, hit_bp=5000, first=p0)
         e = torch.tensor([exp_local]); dist.all_reduce(e); exp = int(e.item())
         res = {}
-        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1")):
-            os.environ["FJ_DIST_STRATEGY"] = strategy; os.environ["FJ_REPLICATE_PIECES"] = pieces
+        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "prefilter")):
+            os.environ["FJ_DIST_STRATEGY"] = strategy; os.environ["FJ_REPLICATE_PIECES"] = pieces if pieces.isdigit() else "1"
+            os.environ["FJ_DIST_PREFILTER"] = "1" if pieces == "prefilter" else "0"
             t = {}
             n, sec = D.distributed_join(bk, bv, pk, timings=t)
             assert n == exp, (strategy, n, exp)
+            if pieces == "prefilter":                       # half the probe rows miss; the owners' filters stop nearly all of them
+                assert t["prefilter"] and t["probe_rows_sent"] < 0.56 * (p1 - p0), t
             n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
             M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
             assert n2 == exp and bool(torch.all((v + 1) * M == k)), strategy
