@@ -269,7 +269,7 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
         return max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
 
-    scattered, filtered, sampled = None, False, None
+    filtered, sampled = False, None
     if prefilter == "off":
         # one all-to-all tells every rank what it will receive: build counts + per-piece probe counts
         flat = []
@@ -294,29 +294,18 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
         if prefilter == "auto":
             sampled = _sampled_survivors(dist, group, engine, world, probe_keys, filters)
             filtered = sampled < _prefilter_break_even(world)
-        if filtered:
-            scattered = []
-            for c in range(pieces):
-                s_c = engine.owner_scatter(views[c], world, p_counts[c])
-                off, kept = 0, []
-                for d in range(world):
-                    kept.append(engine.bloom_prefilter(s_c[off: off + p_counts[c][d]], filters[d], 48))
-                    off += p_counts[c][d]
-                p_counts[c] = [int(k.numel()) for k in kept]
-                scattered.append(engine.cat(kept))
-        del filters, mine
-        flat = []
-        for d in range(world):
-            flat += [p_counts[c][d] for c in range(pieces)]
-        rc = exchange_counts(flat, pieces)
-        p_recv = [[int(rc[src][c]) for src in range(world)] for c in range(pieces)]
-        rounds = message_rounds(max(max(pc) for pc in p_counts))
-    sent_rows = sum(sum(pc) for pc in p_counts)
-    np_total = sum(sum(p) for p in p_recv)
-    engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
+        rounds = message_rounds(max(max(pc) for pc in p_counts))          # (survivors never outnumber the rows they come from)
+        if not filtered:
+            del filters, mine
+            flat = []
+            for d in range(world):
+                flat += [p_counts[c][d] for c in range(pieces)]
+            rc = exchange_counts(flat, pieces)
+            p_recv = [[int(rc[src][c]) for src in range(world)] for c in range(pieces)]
+
     keep, works, recvs = [], [], []
-    for c in range(pieces):
-        s_c = scattered[c] if scattered is not None else engine.owner_scatter(views[c], world, p_counts[c])
+
+    def put_on_the_wire(c, s_c):
         r_c = engine.empty(sum(p_recv[c]))
         if rounds <= 1:
             w = dist.all_to_all_single(r_c, s_c, output_split_sizes=p_recv[c], input_split_sizes=p_counts[c], group=group, async_op=True)
@@ -324,13 +313,41 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
             r_c = _exchange(dist, group, engine, s_c, p_counts[c], p_recv[c], rounds)
             w = None
         keep.append(s_c); works.append(w); recvs.append(r_c)
-        if c >= 1:
-            if works[c - 1] is not None:
-                works[c - 1].wait()
-            engine.stream_append(recvs[c - 1])
-    if works[-1] is not None:
-        works[-1].wait()
-    engine.stream_append(recvs[-1])
+
+    if filtered:
+        # piece c is scattered and filtered while piece c-1 is on the wire; its survivor counts are exchanged just before it
+        # leaves.  The owner's stream join opens once every piece was filtered (fj_bloom_prefilter and an open stream join
+        # share the context's chunk pools); what it then appends is the small filtered remainder.
+        p_recv = []
+        for c in range(pieces):
+            s_c = engine.owner_scatter(views[c], world, p_counts[c])
+            off, kept = 0, []
+            for d in range(world):
+                kept.append(engine.bloom_prefilter(s_c[off: off + p_counts[c][d]], filters[d], 48))
+                off += p_counts[c][d]
+            p_counts[c] = [int(k.numel()) for k in kept]
+            p_recv.append([int(r[0]) for r in exchange_counts(p_counts[c], 1)])
+            put_on_the_wire(c, engine.cat(kept))
+        del filters, mine
+        np_total = sum(sum(p) for p in p_recv)
+        engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
+        for c in range(pieces):
+            if works[c] is not None:
+                works[c].wait()
+            engine.stream_append(recvs[c])
+    else:
+        np_total = sum(sum(p) for p in p_recv)
+        engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
+        for c in range(pieces):
+            put_on_the_wire(c, engine.owner_scatter(views[c], world, p_counts[c]))
+            if c >= 1:
+                if works[c - 1] is not None:
+                    works[c - 1].wait()
+                engine.stream_append(recvs[c - 1])
+        if works[-1] is not None:
+            works[-1].wait()
+        engine.stream_append(recvs[-1])
+    sent_rows = sum(sum(pc) for pc in p_counts)
     t2 = time.perf_counter()
     try:
         local_count = engine.stream_finish()
