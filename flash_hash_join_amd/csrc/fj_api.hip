@@ -1552,10 +1552,8 @@ int fj_join_host(int algo, int bloom, int materialize,
         };
         if (h2d_pipelined(c, dpk, pk, np * 8, piece, &cursor, on_piece)) return 1;
         uint64_t cnt = 0;
-        if (fj_stream_finish(c, js, &cnt, &t) == 0) { count = cnt; joined = true; }
-        else if (g_err.find("does not fit") == std::string::npos) return 1;
-        // (a partition beyond the LDS tables: the whole relation is in HBM by now, the one-shot join below has the HBM-table fallback)
-        if (!joined) { if (h2d_pipelined(c, dbv, bv, nb * 8, piece, &cursor, nullptr)) return 1; HIPCHK(hipStreamSynchronize(c->side)); }
+        if (fj_stream_finish(c, js, &cnt, &t)) return 1;          // (a partition beyond the LDS tables: it falls back to the HBM table by itself)
+        count = cnt; joined = true;
     }
     const double h2d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!joined) {

@@ -349,12 +349,7 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
         engine.stream_append(recvs[-1])
     sent_rows = sum(sum(pc) for pc in p_counts)
     t2 = time.perf_counter()
-    try:
-        local_count = engine.stream_finish()
-    except RuntimeError as ex:                   # a skewed partition overflows its LDS table: one-shot join with its HBM fallback
-        if "does not fit" not in str(ex):
-            raise
-        local_count = int(engine.local_join(bk_r, bv_r, engine.cat(recvs), False, False, 48, False)[0])
+    local_count = engine.stream_finish()         # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
     tot = engine.counts_tensor([local_count])
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     engine.synchronize()
@@ -508,16 +503,7 @@ def _replicated_join(dist, group, engine, world, build_keys, build_values, probe
             keep.append(out)
             engine.stream_append_build(out)
         t1 = time.perf_counter()
-        try:
-            local_count = engine.stream_finish()
-        except RuntimeError as ex:
-            # a partition of the (skewed) build side does not fit its LDS table: the streamed join has no fallback of its
-            # own, the one-shot join does (HBM table); a counting join never reads the values, the keys stand in for them
-            if "does not fit" not in str(ex):
-                raise
-            import torch
-            bk_all = keep[0] if len(keep) == 1 else torch.cat(keep)
-            local_count = int(engine.local_join(bk_all, bk_all, probe_keys, False, bloom, 64, False)[0])
+        local_count = engine.stream_finish()     # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
         res = None
         del keep
     tot = engine.counts_tensor([local_count])
