@@ -565,18 +565,52 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     t1 = time.perf_counter()
 
     # 2. counts, then payload: one all-to-all per array
-    send_c = engine.counts_tensor(b_counts + p_counts).reshape(2, world).t().contiguous().reshape(-1)
-    recv_c = engine.counts_tensor([0] * (2 * world))
-    dist.all_to_all_single(recv_c, send_c, group=group)
-    rc = recv_c.reshape(world, 2).tolist()
-    b_recv = [int(x[0]) for x in rc]
-    p_recv = [int(x[1]) for x in rc]
-    # number of rounds: the largest single message anywhere in the group decides (same value on every rank)
-    mx = engine.counts_tensor([max(b_counts + p_counts)])
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-    rounds = max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
-    bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
-    bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+    def counts_to_owners(rows):
+        send_c = engine.counts_tensor(rows)
+        recv_c = engine.counts_tensor([0] * len(rows))
+        dist.all_to_all_single(recv_c, send_c, group=group)
+        return recv_c.reshape(world, len(rows) // world).tolist()
+
+    def message_rounds(largest):                 # the largest single message anywhere in the group decides (same value on every rank)
+        mx = engine.counts_tensor([largest])
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        return max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
+
+    mode = _prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off"
+    filtered, sampled, rows_before = False, None, sum(p_counts)
+    if mode == "off":
+        flat = []
+        for d in range(world):
+            flat += [b_counts[d], p_counts[d]]
+        rc = counts_to_owners(flat)
+        b_recv = [int(x[0]) for x in rc]
+        p_recv = [int(x[1]) for x in rc]
+        rounds = message_rounds(max(b_counts + p_counts))
+        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
+        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+    else:
+        # sender-side precheck (see _pipelined_count): build side first, the owners' filters come back, survivors travel
+        b_recv = [int(x[0]) for x in counts_to_owners(list(b_counts))]
+        rounds = message_rounds(max(b_counts))
+        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
+        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+        mine = engine.bloom_export(bk_r, 48)
+        filters = [engine.empty_like(mine) for _ in range(world)]
+        dist.all_gather(filters, mine, group=group)
+        filtered = True
+        if mode == "auto":
+            sampled = _sampled_survivors(dist, group, engine, world, probe_keys, filters)
+            filtered = sampled < _prefilter_break_even(world)
+        if filtered:
+            off, kept = 0, []
+            for d in range(world):
+                kept.append(engine.bloom_prefilter(pk_s[off: off + p_counts[d]], filters[d], 48))
+                off += p_counts[d]
+            p_counts = [int(k.numel()) for k in kept]
+            pk_s = engine.cat(kept)
+        del filters, mine
+        p_recv = [int(x[0]) for x in counts_to_owners(list(p_counts))]
+        rounds = message_rounds(max(p_counts))
     pk_r = _exchange(dist, group, engine, pk_s, p_counts, p_recv, rounds)
     engine.synchronize()
     t2 = time.perf_counter()
@@ -592,7 +626,9 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2, exchange_rounds=rounds,
-                       local_build_rows=sum(b_recv), local_probe_rows=sum(p_recv), local_count=local_count)
+                       local_build_rows=sum(b_recv), local_probe_rows=sum(p_recv), local_count=local_count,
+                       prefilter=filtered, prefilter_mode=mode, prefilter_sampled_survivors=sampled,
+                       probe_rows_sent=sum(p_counts) if filtered else rows_before)
     out = (int(tot.item()), t3 - t0)
     if materialize and return_arrays:
         return out + (res[2], res[3])

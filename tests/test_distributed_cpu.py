@@ -158,10 +158,16 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             assert (tc["prefilter_sampled_survivors"] is None) == (variant == "prefilter")
             if variant != "prefilter":
                 assert 0.45 < tc["prefilter_sampled_survivors"] < 0.6          # 50 % hits + a few false positives
+        if strategy == "shuffle":
+            assert t["prefilter"] == prefilter          # the materialising (one-shot) shuffle takes the same decision
         if prefilter:                           # half the probe rows miss: the filters (load 1/40) keep nearly none of them
-            assert tc["local_probe_rows"] < t["local_probe_rows"] and tc["probe_rows_sent"] < 0.6 * (p1 - p0)
+            assert tc["local_probe_rows"] == t["local_probe_rows"] and tc["probe_rows_sent"] == t["probe_rows_sent"] < 0.6 * (p1 - p0)
+            glob = torch.tensor([tc["local_probe_rows"]]); dist.all_reduce(glob)
+            assert int(exp.item()) <= int(glob.item()) < 0.6 * npk
         else:
             assert tc["local_probe_rows"] == t["local_probe_rows"]
+            if strategy == "shuffle":
+                assert tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
         if strategy == "shuffle":
             assert tc["pieces"] == 4
             # every pair this rank owns must hash to this rank

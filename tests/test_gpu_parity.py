@@ -429,6 +429,10 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
             n, sec = distributed_join(bk, bv, lpk, timings=t)
             assert n == lexp and t["prefilter"] == (pre == "1")
             assert t["probe_rows_sent"] == npk if pre == "0" else lexp <= t["probe_rows_sent"] < 0.07 * npk
+            tm = {}
+            n, sec, k, v = distributed_join(bk, bv, lpk, materialize=True, return_arrays=True, timings=tm)      # one-shot shuffle, same precheck
+            assert n == lexp and k.numel() == lexp and bool(torch.all((v + 1) * M == k))
+            assert tm["prefilter"] == (pre == "1") and tm["probe_rows_sent"] == t["probe_rows_sent"]
         n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # FJ_DIST_PREFILTER=0 overrides the bloom argument
         assert n == lexp and not t["prefilter"]
         monkeypatch.delenv("FJ_DIST_PREFILTER")
