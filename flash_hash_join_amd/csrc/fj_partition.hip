@@ -554,13 +554,21 @@ __global__ __launch_bounds__(1024) void fj_level_scan(u32* __restrict__ bchunks,
 }
 
 // tile t -> (first list index, chunks, bucket)
+// BALANCE (the join's items): a bucket's k tiles share its chunks evenly, ceil(chunks / k) each, instead of k-1 full tiles and
+// a short one - items of one size keep the workgroup slots level (k <= tc keeps every tile non-empty).
+template <bool BALANCE>
 __device__ __forceinline__ void fj_tile_expand_one(const u32* __restrict__ boff, const u32* __restrict__ toff, u32 n, u32 tc,
                                                    uint4* __restrict__ tiles, u32 t) {
     u32 lo = 0, hi = n;                       // last p with toff[p] <= t
     while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
-    const u32 pos = boff[lo] + (t - toff[lo]) * tc;
+    u32 step = tc;
+    if (BALANCE) {
+        const u32 k = toff[lo + 1] - toff[lo], c = boff[lo + 1] - boff[lo];
+        if (k > 1 && k <= tc) step = (c + k - 1) / k;
+    }
+    const u32 pos = boff[lo] + (t - toff[lo]) * step;
     const u32 rem = boff[lo + 1] - pos;
-    tiles[t] = make_uint4(pos, rem < tc ? rem : tc, lo, 0);
+    tiles[t] = make_uint4(pos, rem < step ? rem : step, lo, 0);
 }
 
 // same for u64 outputs (result offsets can exceed 2^32)
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
         u32 total = toff[nb];
         if (total > max_tiles) total = max_tiles;
         for (u32 t = gtid; t < max_tiles; t += stride) {
-            if (t < total) fj_tile_expand_one(boff, toff, nb, tc, tiles, t);
+            if (t < total) { if (zero_tail) fj_tile_expand_one<true>(boff, toff, nb, tc, tiles, t); else fj_tile_expand_one<false>(boff, toff, nb, tc, tiles, t); }
             else if (zero_tail) zero_tail[t] = 0;
         }
     }
