@@ -258,6 +258,24 @@ def inner_join(build_keys, build_values, probe_keys, return_arrays: bool = False
     return _join(ALGO_RADIX | ALGO_MANY_TO_MANY, 0, 1, build_keys, build_values, probe_keys, return_arrays)
 
 
+def sort_pairs(keys, values):
+    """The pairs a `return_arrays=True` join handed back, in (key, value) order as unsigned 64-bit integers - the join's own
+    output order is unspecified, so comparisons go through this.  NumPy arrays or device tensors."""
+    if _is_torch_tensor(keys):
+        import torch
+        if keys.numel() == 0:
+            return keys, values
+        flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=keys.device)     # int64 storage: order as uint64
+        k, v = keys.reshape(-1) ^ flip, values.reshape(-1) ^ flip
+        i = torch.argsort(v, stable=True)
+        j = torch.argsort(k[i], stable=True)
+        o = i[j]
+        return keys.reshape(-1)[o], values.reshape(-1)[o]
+    k, v = np.asarray(keys).reshape(-1).view(np.uint64), np.asarray(values).reshape(-1).view(np.uint64)
+    o = np.lexsort((v, k))
+    return k[o], v[o]
+
+
 def initialize() -> None:
     """Replaces initialize_memory_system (hash_join.cpp:596, :639): checks that a HIP device is
     usable and warms up the native context. Returns None like the reference."""
@@ -282,4 +300,4 @@ REFERENCE_EXPORTS = [
 ]
 ALIASES = ["flash_join", "flash_join_radix", "flash_join_bloom", "flash_join_radix_bloom", "adaptive_bloom"]
 EXTENSIONS = ["inner_join", "inner_join_count"]
-__all__ = REFERENCE_EXPORTS + ALIASES + EXTENSIONS + ["last_timings", "join_device", "context", "set_option", "get_option"]
+__all__ = REFERENCE_EXPORTS + ALIASES + EXTENSIONS + ["last_timings", "join_device", "context", "set_option", "get_option", "sort_pairs"]

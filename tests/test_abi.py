@@ -71,6 +71,23 @@ def test_host_argument_normalisation():
         _as_u64_host(np.array(["a"]), "x")
 
 
+def test_sort_pairs_orders_as_unsigned_on_host_and_torch():
+    """The comparison helper for materialised pairs (output order of the joins is unspecified): (key, value) order as
+    uint64 - keys above 2^63 (negative as int64) sort last - identical for NumPy arrays and torch tensors."""
+    import torch
+    import flash_join
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 1 << 64, 5000, dtype=np.uint64); k[:2000] = k[2000:4000]           # duplicates: values break the tie
+    v = rng.integers(0, 1 << 64, 5000, dtype=np.uint64)
+    sk, sv = flash_join.sort_pairs(k, v)
+    o = np.lexsort((v, k))
+    assert np.array_equal(sk, k[o]) and np.array_equal(sv, v[o]) and sk.dtype == np.uint64
+    tk, tv = flash_join.sort_pairs(torch.from_numpy(k.view(np.int64)), torch.from_numpy(v.view(np.int64)))
+    assert np.array_equal(tk.numpy().view(np.uint64), sk) and np.array_equal(tv.numpy().view(np.uint64), sv)
+    e = flash_join.sort_pairs(np.empty(0, np.uint64), np.empty(0, np.uint64))
+    assert e[0].size == 0 and e[1].size == 0
+
+
 def test_length_mismatch_raises_before_any_device_work(lib):
     import flash_join
     with pytest.raises(ValueError):
