@@ -6,8 +6,9 @@ means the shuffle north_star names, or the model's choice once a link rate was m
 
 replicate -- every rank all-gathers the build KEYS (and values when materialising) and joins its own probe rows
   against all of them; probe rows never move, their partition passes run while the build keys are on the wire
-  (fj_stream_open / append_probe / advance_probe, then append_build / finish).  An xGMI mesh has one link per peer,
-  so an exchange is bound by bytes per link: B*8 here against (P*8 + B*16)/N for the shuffle -- fewer up to
+  (fj_stream_open / append_probe / advance_probe, then append_build per arrived piece / finish; FJ_REPLICATE_PIECES,
+  default 4 asynchronous all-gathers: the first pass over piece c runs while piece c+1 is on the wire).  An xGMI mesh
+  has one link per peer, so an exchange is bound by bytes per link: B*8 here against (P*8 + B*16)/N for the shuffle -- fewer up to
   N = 12 for the probe-heavy (P = 10 B) joins this path is built for, 6x fewer at N = 2.  Cost: every rank
   partitions all N*B build keys.  Global count = sum of local counts; pairs stay with their probe row.
 
@@ -552,7 +553,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     strategy = choose_strategy(world, max(sizes_b), max(int(x[1]) for x in allsz), materialize)
     if strategy == "replicate":
         return _replicated_join(dist, group, engine, world, build_keys, build_values, probe_keys, sizes_b, materialize, bloom,
-                                return_arrays, int(os.environ.get("FJ_REPLICATE_PIECES", "1")), timings)
+                                return_arrays, int(os.environ.get("FJ_REPLICATE_PIECES", "4")), timings)
     if timings is not None:
         timings["strategy"] = "shuffle"
     if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
