@@ -332,14 +332,17 @@ __global__ __launch_bounds__(1024) void fj_bucket_base_kernel(const unsigned lon
     if (tid == 0) base[nb] = total;
 }
 
-// chunk set -> dense array: one workgroup per bucket walks the bucket's chunk list in batches of 256 chunks (block scan of the
-// chunks' key counts -> offsets), each wave copies whole chunks (256 keys = 4 per lane)
+// chunk set -> dense array: BF_FLAT_SPLIT workgroups per bucket walk the bucket's chunk list in batches of 256 chunks (block
+// scan of the chunks' key counts -> offsets; every workgroup of the bucket computes the same offsets), and share a batch's
+// chunks among their waves: each wave copies whole chunks (256 keys = 4 per lane)
+constexpr u32 BF_FLAT_SPLIT = 4;
 __global__ __launch_bounds__(256) void fj_flatten_kernel(FjChunkSet cs, const unsigned long long* __restrict__ base, u64* __restrict__ out) {
     __shared__ u32 s_off[257];
     __shared__ u32 s_ent[256];
     __shared__ u32 wsum[4];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (u32 b = blockIdx.x; b < cs.nb; b += gridDim.x) {
+    const u32 part = blockIdx.x % BF_FLAT_SPLIT;
+    for (u32 b = blockIdx.x / BF_FLAT_SPLIT; b < cs.nb; b += gridDim.x / BF_FLAT_SPLIT) {
         const u32 l0 = cs.boff[b], n = cs.boff[b + 1] - l0;
         unsigned long long run = base[b];
         for (u32 c0 = 0; c0 < n; c0 += 256) {
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256) void fj_flatten_kernel(FjChunkSet cs, const un
             if (tid == 255) s_off[256] = pre + cnt;
             __syncthreads();
             const u32 m = n - c0 < 256 ? n - c0 : 256;
-            for (u32 j = wave; j < m; j += 4) {
+            for (u32 j = wave * BF_FLAT_SPLIT + part; j < m; j += 4 * BF_FLAT_SPLIT) {
                 const u32 ee = s_ent[j], cc = FJ_LIST_CNT(ee);
                 const u64* src = cs.keys + (u64)FJ_LIST_ID(ee) * FJ_CHUNK;
                 u64* dst = out + run + s_off[j];
@@ -382,7 +385,7 @@ hipError_t fj_launch_bloom_export(const FjChunkSet& build, u32* out, u32 grid, i
 hipError_t fj_launch_flatten(const FjChunkSet& cs, const unsigned long long* bucket_keys, unsigned long long* base, u64* out, hipStream_t s) {
     if (cs.nb > 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fj_bucket_base_kernel, dim3(1), dim3(1024), 0, s, bucket_keys, base, cs.nb);
-    hipLaunchKernelGGL(fj_flatten_kernel, dim3(cs.nb), dim3(256), 0, s, cs, base, out);
+    hipLaunchKernelGGL(fj_flatten_kernel, dim3(cs.nb * BF_FLAT_SPLIT), dim3(256), 0, s, cs, base, out);
     return hipGetLastError();
 }
 

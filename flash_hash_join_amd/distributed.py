@@ -206,9 +206,9 @@ def _prefilter_mode(bloom: bool) -> str:
 
 
 # fj_bloom_prefilter on one MI355X, 156M-row segments against 125M-key owners (profiles/r02_prefilter_probe.txt):
-# 1.33 ms at 13 % survivors ... 2.25 ms at 100 %  =  8.5 ps + 5.9 ps x survivors, per row
-_PREFILTER_S_PER_ROW = 8.5e-12
-_PREFILTER_S_PER_SURVIVOR = 5.9e-12
+# 1.26 ms at 13 % survivors ... 1.91 ms at 100 %  =  7.4 ps + 4.9 ps x survivors, per row
+_PREFILTER_S_PER_ROW = 7.4e-12
+_PREFILTER_S_PER_SURVIVOR = 4.9e-12
 _PREFILTER_SAMPLE_ROWS = 1 << 20
 
 
