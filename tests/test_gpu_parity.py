@@ -390,6 +390,39 @@ def test_sender_side_prefilter_keeps_every_hit(fj, nb, npk, hit_bp, top_bits):
     assert eng.bloom_prefilter(pk[:100_000], z, top_bits).numel() == 0
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_sender_side_prefilter_on_random_key_distributions(fj, seed):
+    """The precheck primitives on uniform, tiny-domain, sequential and sentinel-valued keys with duplicates on both sides:
+    survivors = a sub-multiset of the probe rows that keeps every row whose key is in the build side."""
+    import torch
+    from flash_hash_join_amd.distributed import HipEngine
+    rng = np.random.default_rng(700 + seed)
+    nb = int(rng.choice([1, 9, 4000, 70000, 900000]))
+    npk = int(rng.choice([1, 2, 999, 65536, 1200001]))
+    kind = seed % 4
+    if kind == 0:
+        dom = rng.integers(0, 1 << 64, max(2, nb + npk // 3), dtype=np.uint64)
+    elif kind == 1:
+        dom = rng.integers(0, 50, 40, dtype=np.uint64)
+    elif kind == 2:
+        dom = np.arange(1, max(3, 2 * nb), dtype=np.uint64)
+    else:
+        dom = np.concatenate([np.array([0, 1, (1 << 64) - 1, (1 << 63), (1 << 64) - 2], dtype=np.uint64), rng.integers(0, 1 << 64, nb + 5, dtype=np.uint64)])
+    bk = dom[rng.integers(0, dom.size, nb)]
+    other = rng.integers(0, 1 << 64, max(1, npk), dtype=np.uint64)
+    pk = np.where(rng.random(npk) < 0.4, dom[rng.integers(0, dom.size, npk)], other[:npk])
+    dbk, dpk = torch.from_numpy(bk.view(np.int64)).cuda(), torch.from_numpy(pk.view(np.int64)).cuda()
+    eng = HipEngine("cuda:0")
+    for top in (64, 48):
+        kept = eng.bloom_prefilter(dpk, eng.bloom_export(dbk, top), top).cpu().numpy().view(np.uint64)
+        hits = pk[np.isin(pk, bk)]
+        assert np.array_equal(np.sort(kept[np.isin(kept, bk)]), np.sort(hits))            # every hit, with its multiplicity
+        ku, kc = np.unique(kept, return_counts=True)
+        pu, pc = np.unique(pk, return_counts=True)
+        at = np.searchsorted(pu, ku)
+        assert np.all(at < pu.size) and np.array_equal(pu[at], ku) and np.all(kc <= pc[at])    # nothing invented or multiplied
+
+
 def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
     """The whole multi-GPU step on a 1-rank nccl group, both strategies: owner split -> RCCL all_to_all_single -> join
     with hash_top_bits=48 -> all_reduce, and all-gather of the build keys overlapped with the probe passes -> join ->
