@@ -68,6 +68,21 @@ def context(device: int) -> int:
     return _ctxs[device]
 
 
+def workspace_bytes(device: Optional[int] = None) -> int:
+    """Device memory the native contexts keep cached between joins (grow-only until trim_workspace)."""
+    L = _lib.load()
+    return sum(int(L.fj_ctx_workspace_bytes(h)) for d, h in _ctxs.items() if device is None or d == device)
+
+
+def trim_workspace(device: Optional[int] = None) -> None:
+    """Give the cached workspace back to the device (tens of GB after a 1B-row join); contexts stay usable."""
+    L = _lib.load()
+    for d, h in _ctxs.items():
+        if device is None or d == device:
+            check(L.fj_ctx_trim(h))
+    check(L.fj_ctx_trim(None))                  # the context behind the NumPy entry
+
+
 def set_option(name: str, value: int) -> None:
     """Process-wide dispatch option of the native library: "radix_threshold", "scalar_hbm_table" (include/flashjoin.h)."""
     check(_lib.load().fj_set_option(name.encode(), int(value)))
@@ -300,4 +315,4 @@ REFERENCE_EXPORTS = [
 ]
 ALIASES = ["flash_join", "flash_join_radix", "flash_join_bloom", "flash_join_radix_bloom", "adaptive_bloom"]
 EXTENSIONS = ["inner_join", "inner_join_count"]
-__all__ = REFERENCE_EXPORTS + ALIASES + EXTENSIONS + ["last_timings", "join_device", "context", "set_option", "get_option", "sort_pairs"]
+__all__ = REFERENCE_EXPORTS + ALIASES + EXTENSIONS + ["last_timings", "join_device", "context", "set_option", "get_option", "sort_pairs", "workspace_bytes", "trim_workspace"]

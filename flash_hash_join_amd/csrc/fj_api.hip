@@ -933,6 +933,20 @@ void fj_ctx_destroy(fj_ctx* c) {
 
 size_t fj_ctx_workspace_bytes(const fj_ctx* c) { return c ? c->ws_bytes : 0; }
 
+// Give the cached workspace (chunk pools, directories, tables: tens of GB after a 1B-row join) back to the device; the
+// context stays usable and grows again on demand.  A pending emit (fj_emit_pairs not yet called) is dropped.
+int fj_ctx_trim(fj_ctx* c) {
+    if (!c) c = g_host_ctx;                       // NULL: the context behind fj_join_host (nothing to do before its first call)
+    if (!c) return 0;
+    if (c->st.active) return set_err("fj_ctx_trim: a stream join is open on this context (fj_stream_finish it first)");
+    FJ_ON_DEVICE(c->device);
+    HIPCHK(hipDeviceSynchronize());               // kernels of earlier joins may still read the buffers
+    c->pend.valid = false;
+    for (auto& b : c->bufs) if (b.p) { HIPCHK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    c->ws_bytes = 0;
+    return 0;
+}
+
 int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
                    const uint64_t* d_bk, const uint64_t* d_bv, size_t nb, const uint64_t* d_pk, size_t np,
                    void* stream, int hash_top_bits, uint64_t* out_count,

@@ -108,6 +108,8 @@ long long fj_get_option(const char* name);
 fj_ctx* fj_ctx_create(int device);
 void fj_ctx_destroy(fj_ctx* ctx);
 size_t fj_ctx_workspace_bytes(const fj_ctx* ctx);
+int fj_ctx_trim(fj_ctx* ctx);                 /* free the cached workspace; the context stays usable (grows again on demand).
+                                                 NULL = the internal context of fj_join_host */
 
 /*
  * replaces: all twelve pybind entry points hash_join.cpp:603-637 for HOST (NumPy) buffers.

@@ -874,6 +874,35 @@ def test_many_to_many_refuses_a_key_with_too_many_duplicates(fj):
     assert fj.hash_join_count_radix(bk, bv, pk)[0] == 2
 
 
+def test_workspace_can_be_trimmed_between_joins(fj, oracle):
+    """fj_ctx_trim: the grow-only workspace goes back to the device, the next join re-grows it and gives the same result;
+    refused while a stream join is open."""
+    import torch
+    from flash_hash_join_amd import api, datagen, _lib
+    from flash_hash_join_amd.distributed import HipEngine
+    bk, bv = datagen.build_device(3_000_000, "cuda:0")
+    pk, exp = datagen.probe_device(20_000_000, 3_000_000, "cuda:0", seed=2, hit_bp=5000)
+    assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp
+    hbk, hbv, hpk = (x.cpu().numpy().view(np.uint64) for x in (bk[:200_000], bv[:200_000], pk[:1_000_000]))
+    n_host = fj.hash_join_count(hbk, hbv, hpk)[0]                                   # the NumPy entry's own context
+    before = api.workspace_bytes(0)
+    assert before > 20_000_000 * 8
+    free0 = torch.cuda.mem_get_info(0)[0]
+    api.trim_workspace()
+    assert api.workspace_bytes(0) == 0 and torch.cuda.mem_get_info(0)[0] >= free0 + before // 2
+    assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp and fj.hash_join_count(hbk, hbv, hpk)[0] == n_host
+    n, _, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+    assert n == exp and k.numel() == exp
+    eng = HipEngine("cuda:0")
+    eng.stream_begin(bk, bv, pk.numel(), 1, 64)
+    with pytest.raises(RuntimeError, match="stream join is open"):
+        api.trim_workspace(0)
+    eng.stream_append(pk)
+    assert eng.stream_finish() == exp
+    api.trim_workspace(0)
+    assert api.workspace_bytes(0) == 0
+
+
 def test_c_abi_rejects_bad_arguments(fj):
     """Error behaviour at the C boundary: status 1 + fj_last_error text, translated to RuntimeError; the context stays usable."""
     import ctypes
