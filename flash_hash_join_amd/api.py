@@ -23,6 +23,7 @@ Differences from the reference, all deliberate:
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
@@ -34,6 +35,7 @@ ALGO_ADAPTIVE, ALGO_SCALAR, ALGO_RADIX = 0, 1, 2
 ALGO_MANY_TO_MANY = 0x10          # FJ_ALGO_MANY_TO_MANY: OR'ed into algo (extension, include/flashjoin.h)
 
 _ctxs: Dict[int, int] = {}
+_ctx_locks: Dict[int, Any] = {}
 _last: Optional[FjTimings] = None
 
 
@@ -157,17 +159,18 @@ def join_device(algo: int, bloom: int, materialize: int, bk, bv, pk, return_arra
     stream = torch.cuda.current_stream(dev).cuda_stream
     cnt = ctypes.c_uint64(0)
     t = FjTimings()
-    check(L.fj_join_device(ctx, algo, bloom, materialize, bk.data_ptr(), bv.data_ptr(), bk.numel(), pk.data_ptr(),
-                           pk.numel(), stream, hash_top_bits, ctypes.byref(cnt), None, None, 0, ctypes.byref(t)))
-    n = int(cnt.value)
-    out = None
-    if materialize and n > 0:
-        ok = torch.empty(n, dtype=torch.int64, device=bk.device)
-        ov = torch.empty(n, dtype=torch.int64, device=bk.device)
-        check(L.fj_emit_pairs(ctx, ok.data_ptr(), ov.data_ptr(), n, stream, ctypes.byref(t)))
-        out = (ok, ov)
-    elif materialize:
-        out = (torch.empty(0, dtype=torch.int64, device=bk.device), torch.empty(0, dtype=torch.int64, device=bk.device))
+    with _ctx_locks.setdefault(dev, threading.RLock()):      # count + emit are two calls on one context: keep other threads out
+        check(L.fj_join_device(ctx, algo, bloom, materialize, bk.data_ptr(), bv.data_ptr(), bk.numel(), pk.data_ptr(),
+                               pk.numel(), stream, hash_top_bits, ctypes.byref(cnt), None, None, 0, ctypes.byref(t)))
+        n = int(cnt.value)
+        out = None
+        if materialize and n > 0:
+            ok = torch.empty(n, dtype=torch.int64, device=bk.device)
+            ov = torch.empty(n, dtype=torch.int64, device=bk.device)
+            check(L.fj_emit_pairs(ctx, ok.data_ptr(), ov.data_ptr(), n, stream, ctypes.byref(t)))
+            out = (ok, ov)
+        elif materialize:
+            out = (torch.empty(0, dtype=torch.int64, device=bk.device), torch.empty(0, dtype=torch.int64, device=bk.device))
     _last = t
     if materialize and return_arrays:
         return n, t.total_ms * 1e-3, out[0], out[1]

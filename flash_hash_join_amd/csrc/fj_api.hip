@@ -53,6 +53,11 @@ struct DeviceGuard {
 #define FJ_ON_DEVICE(dev)                                                                                   \
     DeviceGuard dev_guard_(dev);                                                                            \
     if (dev_guard_.err != hipSuccess) return set_err("selecting HIP device %d failed: %s", (int)(dev), hipGetErrorString(dev_guard_.err))
+// Entry of a C-ABI call on context c: calls on one context are serialised (the workspace, the scratch words and the events
+// are per context; fj_join_host re-enters through fj_join_device / fj_stream_*: a recursive lock), then the device guard.
+#define FJ_ENTER(c)                                                                                         \
+    std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu);                                                \
+    FJ_ON_DEVICE((c)->device)
 
 struct Scalars {                       // device scratch words, mirrored in pinned host memory
     unsigned long long total;
@@ -147,6 +152,7 @@ struct fj_ctx {
     size_t stage_bytes = 0;
     bool plan_in_flight = false;       // a plan was begun and has not completed (an error in between leaves chunk counts behind)
     bool zeros_dirty = false;          // ... in which case the next plan re-zeroes the self-cleaning buffers it uses
+    std::recursive_mutex mu;           // one C-ABI call at a time per context (FJ_ENTER)
 };
 
 namespace {
@@ -939,7 +945,7 @@ int fj_ctx_trim(fj_ctx* c) {
     if (!c) c = g_host_ctx;                       // NULL: the context behind fj_join_host (nothing to do before its first call)
     if (!c) return 0;
     if (c->st.active) return set_err("fj_ctx_trim: a stream join is open on this context (fj_stream_finish it first)");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     HIPCHK(hipDeviceSynchronize());               // kernels of earlier joins may still read the buffers
     c->pend.valid = false;
     for (auto& b : c->bufs) if (b.p) { HIPCHK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
@@ -959,7 +965,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
     if (c->st.active) return set_err("fj_join_device: a stream join is open on this context (fj_stream_finish it first)");
     if ((nb && (!d_bk || !d_bv)) || (np && !d_pk)) return set_err("fj_join_device: null input pointer");
     if (((uintptr_t)d_bk | (uintptr_t)d_bv | (uintptr_t)d_pk) & 15) return set_err("fj_join_device: input pointers must be 16-byte aligned");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     fj_timings t; memset(&t, 0, sizeof t);
     t.sampled_hit_bp = -1;
@@ -996,7 +1002,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
 
 int fj_emit_pairs(fj_ctx* c, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, void* stream, fj_timings* timings) {
     if (!c) return set_err("fj_emit_pairs: null context");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     fj_timings t = g_last;
     if (emit_pending(c, d_out_keys, d_out_vals, out_capacity, (hipStream_t)stream, &t)) return 1;
     if (timings) *timings = t;
@@ -1008,7 +1014,7 @@ int fj_owner_split(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, si
                    uint64_t* d_out_keys, uint64_t* d_out_vals, uint64_t* h_counts, void* stream) {
     if (!c) return set_err("fj_owner_split: null context");
     if (nranks < 1 || nranks > 64) return set_err("fj_owner_split: nranks must be 1..64");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(c->d_sc->owner_counts, 0, sizeof(unsigned long long) * 128, s));   // counts + cursors
     HIPCHK(fj_launch_owner_hist(d_keys, n, (u32)nranks, c->d_sc->owner_counts, s));
@@ -1141,13 +1147,13 @@ int fj_stream_open(fj_ctx* c, size_t nb_bound, int build_appends, size_t np_boun
     if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_stream_open: hash_top_bits must be 64 or 48");
     if (build_appends < 1 || build_appends > 64 || probe_appends < 1 || probe_appends > 64)
         return set_err("fj_stream_open: build_appends and probe_appends must be 1..64");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     return stream_open(c, nb_bound, build_appends, np_bound, probe_appends, (hipStream_t)stream, hash_top_bits);
 }
 
 int fj_stream_append_build(fj_ctx* c, const uint64_t* d_bk, size_t n, void* stream) {
     if (!c || !c->st.active) return set_err("fj_stream_append_build: no stream join is open on this context");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     return stream_append_build(c, (const u64*)d_bk, n, (hipStream_t)stream);
 }
 
@@ -1158,7 +1164,7 @@ int fj_stream_begin(fj_ctx* c, const uint64_t* d_bk, const uint64_t* d_bv, size_
     if (max_appends < 1 || max_appends > 64) return set_err("fj_stream_begin: max_appends must be 1..64");
     if (nb && (!d_bk || !d_bv)) return set_err("fj_stream_begin: null input pointer");
     if (((uintptr_t)d_bk | (uintptr_t)d_bv) & 15) return set_err("fj_stream_begin: input pointers must be 16-byte aligned");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     if (stream_open(c, nb, 1, np_bound, max_appends, s, hash_top_bits)) return 1;
     if (stream_append_build(c, (const u64*)d_bk, nb, s)) return 1;
@@ -1173,7 +1179,7 @@ int fj_stream_append_probe(fj_ctx* c, const uint64_t* d_pk, size_t n, void* stre
     if (!d_pk || ((uintptr_t)d_pk & 15)) return set_err("fj_stream_append_probe: probe piece must be a 16-byte aligned device pointer");
     if (st.p_appends_left == 0) return set_err("fj_stream_append_probe: more pieces than probe_appends");
     if (st.np_seen + n > st.np_bound) return set_err("fj_stream_append_probe: more probe rows than np_bound");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     --st.p_appends_left; st.np_seen += n;
     st.ppieces.emplace_back((const u64*)d_pk, n);
@@ -1188,7 +1194,7 @@ int fj_stream_advance_probe(fj_ctx* c, void* stream) {
     if (!c || !c->st.active) return set_err("fj_stream_advance_probe: no stream join is open on this context");
     StreamState& st = c->st;
     if (st.probe_done) return 0;
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     st.probe_done = true;
     if (st.plan.npass > 0 && st.np_seen > 0) {
@@ -1202,7 +1208,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
     if (!c || !c->st.active) return set_err("fj_stream_finish: no stream join is open on this context");
     StreamState& st = c->st;
     st.active = false;
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     fj_timings t; memset(&t, 0, sizeof t);
     u64 count = 0;
@@ -1258,7 +1264,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
 int fj_owner_hist(fj_ctx* c, const uint64_t* d_keys, size_t n, int nranks, uint64_t* h_counts, void* stream) {
     if (!c) return set_err("fj_owner_hist: null context");
     if (nranks < 1 || nranks > 64) return set_err("fj_owner_hist: nranks must be 1..64");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(c->d_sc->owner_counts, 0, sizeof(unsigned long long) * 64, s));
     HIPCHK(fj_launch_owner_hist(d_keys, n, (u32)nranks, c->d_sc->owner_counts, s));
@@ -1274,7 +1280,7 @@ int fj_owner_scatter(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, 
                      uint64_t* d_out_keys, uint64_t* d_out_vals, void* stream) {
     if (!c) return set_err("fj_owner_scatter: null context");
     if (nranks < 1 || nranks > 64) return set_err("fj_owner_scatter: nranks must be 1..64");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     // the offsets travel in a pinned slot that a previous asynchronous scatter may still be reading: drain first
     HIPCHK(hipStreamSynchronize(s));
@@ -1299,7 +1305,7 @@ int fj_bloom_export(fj_ctx* c, const uint64_t* d_build_keys, size_t nb, int hash
     if (hash_top_bits != 64 && hash_top_bits != 48) return set_err("fj_bloom_export: hash_top_bits must be 64 or 48");
     if (c->st.active) return set_err("fj_bloom_export: a stream join is open on this context (fj_stream_finish it first)");
     if (!d_filters || (nb && !d_build_keys) || ((uintptr_t)d_build_keys & 15) || ((uintptr_t)d_filters & 15)) return set_err("fj_bloom_export: null or misaligned pointer");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     const u32 nbuckets = 1u << FJ_PREFILTER_BITS;
     if (nb == 0) { HIPCHK(hipMemsetAsync(d_filters, 0, (size_t)nbuckets * FJ_BLOOM_WORDS * 4, s)); return 0; }   // empty filters reject everything
@@ -1327,7 +1333,7 @@ int fj_bloom_prefilter(fj_ctx* c, const uint64_t* d_probe_keys, size_t n, int ha
     if (out_capacity < n) return set_err("fj_bloom_prefilter: output capacity %zu < %zu input rows", out_capacity, n);
     *out_n = 0;
     if (n == 0) return 0;
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     Plan plan; plan.bits = FJ_PREFILTER_BITS; plan_passes(plan, true);
     plan.bloom_level = 1;
@@ -1359,7 +1365,7 @@ int fj_bloom_prefilter(fj_ctx* c, const uint64_t* d_probe_keys, size_t n, int ha
 
 int fj_generate_build(fj_ctx* c, uint64_t* d_keys, uint64_t* d_vals, uint64_t first, size_t n, void* stream) {
     if (!c) return set_err("fj_generate_build: null context");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     HIPCHK(fj_launch_gen_build(d_keys, d_vals, first, n, (hipStream_t)stream));
     return 0;
 }
@@ -1368,7 +1374,7 @@ int fj_generate_probe(fj_ctx* c, uint64_t* d_keys, uint64_t first, size_t n, uin
                       uint32_t hit_bp, uint64_t* h_expected_hits, void* stream) {
     if (!c) return set_err("fj_generate_probe: null context");
     if (build_total == 0) return set_err("fj_generate_probe: build_total must be > 0");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(&c->d_sc->expected, 0, sizeof(unsigned long long), s));
     HIPCHK(fj_launch_gen_probe(d_keys, first, n, build_total, seed, hit_bp, &c->d_sc->expected, s));
@@ -1386,7 +1392,7 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
                        uint32_t* h_bucket_of, uint64_t* h_nvalid) {
     if (!c) return set_err("fj_debug_partition: null context");
     if (total_bits < 2 || total_bits > 24) return set_err("fj_debug_partition: total_bits must be 2..24");
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     Plan plan; plan.bits = total_bits;
     plan_passes(plan, true);
@@ -1516,14 +1522,18 @@ int fj_join_host(int algo, int bloom, int materialize,
     if (out_vals) *out_vals = nullptr;
     const bool many_host = algo >= 0 && (algo & FJ_ALGO_MANY_TO_MANY) != 0;
     if (algo < 0 || (algo & ~FJ_ALGO_MANY_TO_MANY) > 2) return set_err("fj_join_host: unknown algo %d", algo);
-    if (!g_host_ctx) {
-        int dev = 0;
-        if (const char* d = getenv("FJ_DEVICE")) dev = atoi(d);
-        g_host_ctx = fj_ctx_create(dev);
-        if (!g_host_ctx) return 1;
+    {
+        static std::mutex create_mu;
+        std::lock_guard<std::mutex> lk(create_mu);
+        if (!g_host_ctx) {
+            int dev = 0;
+            if (const char* d = getenv("FJ_DEVICE")) dev = atoi(d);
+            g_host_ctx = fj_ctx_create(dev);
+            if (!g_host_ctx) return 1;
+        }
     }
     fj_ctx* c = g_host_ctx;
-    FJ_ON_DEVICE(c->device);
+    FJ_ENTER(c);
     void *dbk, *dbv, *dpk;
     if (get_buf(c, W_H_BK, nb * 8, &dbk) || get_buf(c, W_H_BV, nb * 8, &dbv) || get_buf(c, W_H_PK, np * 8, &dpk)) return 1;
     // pieces: >= 16 MiB (the ring's DMA and memcpy run at full rate), at most 48 of them for the probe side (the streamed

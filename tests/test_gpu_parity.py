@@ -874,6 +874,38 @@ def test_many_to_many_refuses_a_key_with_too_many_duplicates(fj):
     assert fj.hash_join_count_radix(bk, bv, pk)[0] == 2
 
 
+def test_concurrent_callers_on_one_device_are_serialised(fj):
+    """Four Python threads issue counting, materialising and NumPy-entry joins on the same device at once (ctypes
+    releases the GIL; the native contexts serialise their calls, SURVEY 8(b) threading row): every result exact."""
+    import threading
+    import torch
+    from flash_hash_join_amd import datagen
+    cases = []
+    for i, (nb, npk) in enumerate([(5000, 300_000), (400_000, 3_000_000), (2_000_000, 9_000_000), (60_000, 1_000_000)]):
+        bk, bv = datagen.build_device(nb, "cuda:0")
+        pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=20 + i, hit_bp=3000 + 1500 * i)
+        cases.append((bk, bv, pk, exp, tuple(x.cpu().numpy().view(np.uint64) for x in (bk, bv, pk))))
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+    errors = []
+
+    def work(tid):
+        try:
+            for rep in range(6):
+                bk, bv, pk, exp, host = cases[(tid + rep) % len(cases)]
+                assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp
+                n, _, k, v = fj.adaptive_join(bk, bv, pk, return_arrays=True)
+                assert n == exp and k.numel() == exp and bool(torch.all((v + 1) * M == k))
+                assert fj.hash_join_count(*host)[0] == exp
+        except Exception as ex:                                 # noqa: BLE001
+            errors.append((tid, repr(ex)))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_workspace_can_be_trimmed_between_joins(fj, oracle):
     """fj_ctx_trim: the grow-only workspace goes back to the device, the next join re-grows it and gives the same result;
     refused while a stream join is open."""
