@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG, "csrc")
 # every symbol include/flashjoin.h declares
 SYMBOLS = [
     "fj_initialize", "fj_last_error", "fj_device_count", "fj_version",
-    "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes", "fj_ctx_trim",
+    "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes", "fj_ctx_trim", "fj_stream_abort",
     "fj_join_host", "fj_free_host", "fj_last_timings",
     "fj_join_device", "fj_emit_pairs", "fj_owner_split", "fj_owner_hist", "fj_owner_scatter",
     "fj_set_option", "fj_get_option",
@@ -83,6 +83,7 @@ def load() -> ctypes.CDLL:
     L.fj_ctx_destroy.restype = None; L.fj_ctx_destroy.argtypes = [vp]
     L.fj_ctx_workspace_bytes.restype = sz; L.fj_ctx_workspace_bytes.argtypes = [vp]
     L.fj_ctx_trim.restype = i32; L.fj_ctx_trim.argtypes = [vp]
+    L.fj_stream_abort.restype = i32; L.fj_stream_abort.argtypes = [vp]
     L.fj_join_host.restype = i32
     L.fj_join_host.argtypes = [i32, i32, i32, vp, vp, sz, vp, sz, pu64, ctypes.POINTER(ctypes.c_double),
                                ctypes.POINTER(vp), ctypes.POINTER(vp)]

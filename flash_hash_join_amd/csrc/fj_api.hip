@@ -1204,6 +1204,17 @@ int fj_stream_advance_probe(fj_ctx* c, void* stream) {
     return 0;
 }
 
+// Drop an open stream join without a result (an error on the caller's side between two appends): the context is free for
+// other joins again; the buffers the abandoned passes left half-filled are re-zeroed by the next plan (plan_in_flight).
+int fj_stream_abort(fj_ctx* c) {
+    if (!c) return set_err("fj_stream_abort: null context");
+    FJ_ENTER(c);
+    if (!c->st.active) return 0;
+    HIPCHK(hipDeviceSynchronize());               // launched passes still read the caller's pieces
+    c->st.active = false;
+    return 0;
+}
+
 int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* timings) {
     if (!c || !c->st.active) return set_err("fj_stream_finish: no stream join is open on this context");
     StreamState& st = c->st;

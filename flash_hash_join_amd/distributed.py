@@ -159,6 +159,11 @@ class HipEngine:
                                                   out.data_ptr(), out.numel(), ctypes.byref(n), t.cuda.current_stream(self.index).cuda_stream))
         return out[: int(n.value)]
 
+    def stream_abort(self):
+        """Error recovery: drop a stream join that will not be finished, so that the context serves other joins again."""
+        self._keep = []
+        self._lib.check(self.L.fj_stream_abort(self.ctx))
+
     def local_join(self, bk, bv, pk, materialize: bool, bloom: bool, hash_top_bits: int, return_arrays: bool):
         return self.api.join_device(self.api.ALGO_RADIX, int(bloom), int(materialize), bk, bv, pk,
                                     return_arrays=return_arrays, hash_top_bits=hash_top_bits)
@@ -193,6 +198,14 @@ def _exchange(dist, group, engine, send, send_counts: List[int], recv_counts: Li
                 for q in range(len(recv_counts))]
         dist.all_to_all(outs, ins, group=group)
     return recv
+
+
+def _abort_stream(engine) -> None:
+    if hasattr(engine, "stream_abort"):
+        try:
+            engine.stream_abort()
+        except Exception:                        # noqa: BLE001  (the original error is the one to report)
+            pass
 
 
 def _prefilter_mode(bloom: bool) -> str:
@@ -331,26 +344,31 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
             put_on_the_wire(c, engine.cat(kept))
         del filters, mine
         np_total = sum(sum(p) for p in p_recv)
-        engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
-        for c in range(pieces):
-            if works[c] is not None:
-                works[c].wait()
-            engine.stream_append(recvs[c])
-    else:
-        np_total = sum(sum(p) for p in p_recv)
-        engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
-        for c in range(pieces):
-            put_on_the_wire(c, engine.owner_scatter(views[c], world, p_counts[c]))
-            if c >= 1:
-                if works[c - 1] is not None:
-                    works[c - 1].wait()
-                engine.stream_append(recvs[c - 1])
-        if works[-1] is not None:
-            works[-1].wait()
-        engine.stream_append(recvs[-1])
-    sent_rows = sum(sum(pc) for pc in p_counts)
-    t2 = time.perf_counter()
-    local_count = engine.stream_finish()         # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
+    try:
+        if filtered:
+            engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
+            for c in range(pieces):
+                if works[c] is not None:
+                    works[c].wait()
+                engine.stream_append(recvs[c])
+        else:
+            np_total = sum(sum(p) for p in p_recv)
+            engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
+            for c in range(pieces):
+                put_on_the_wire(c, engine.owner_scatter(views[c], world, p_counts[c]))
+                if c >= 1:
+                    if works[c - 1] is not None:
+                        works[c - 1].wait()
+                    engine.stream_append(recvs[c - 1])
+            if works[-1] is not None:
+                works[-1].wait()
+            engine.stream_append(recvs[-1])
+        sent_rows = sum(sum(pc) for pc in p_counts)
+        t2 = time.perf_counter()
+        local_count = engine.stream_finish()     # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
+    except BaseException:
+        _abort_stream(engine)                    # an error between begin and finish must not leave the context occupied
+        raise
     tot = engine.counts_tensor([local_count])
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     engine.synchronize()
@@ -493,18 +511,22 @@ def _replicated_join(dist, group, engine, world, build_keys, build_values, probe
         if nb_total <= 8192 or min(sizes_b) < pieces:        # (a zero-pass build side must arrive as one piece)
             pieces = 1
         gathers = [_gather_rows(dist, group, engine, world, build_keys, sizes_b, (c, pieces), async_op=True) for c in range(pieces)]
-        engine.stream_open(nb_total, pieces, probe_keys.numel(), 1, 64)
-        engine.stream_append(probe_keys)
-        engine.stream_advance_probe()
-        keep = []
-        for w, out, fix in gathers:
-            if w is not None:
-                w.wait()
-            if fix: out = fix(out)
-            keep.append(out)
-            engine.stream_append_build(out)
-        t1 = time.perf_counter()
-        local_count = engine.stream_finish()     # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
+        try:
+            engine.stream_open(nb_total, pieces, probe_keys.numel(), 1, 64)
+            engine.stream_append(probe_keys)
+            engine.stream_advance_probe()
+            keep = []
+            for w, out, fix in gathers:
+                if w is not None:
+                    w.wait()
+                if fix: out = fix(out)
+                keep.append(out)
+                engine.stream_append_build(out)
+            t1 = time.perf_counter()
+            local_count = engine.stream_finish() # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
+        except BaseException:
+            _abort_stream(engine)
+            raise
         res = None
         del keep
     tot = engine.counts_tensor([local_count])

@@ -199,6 +199,7 @@ int fj_stream_begin(fj_ctx* ctx, const uint64_t* d_build_keys, const uint64_t* d
                     int max_appends, void* stream, int hash_top_bits);
 int fj_stream_append_probe(fj_ctx* ctx, const uint64_t* d_probe_keys, size_t n, void* stream);
 int fj_stream_finish(fj_ctx* ctx, void* stream, uint64_t* out_count, fj_timings* timings);
+int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error recovery); no-op when none is open */
 
 /*
  * Deterministic synthetic relations, generated in HBM:

@@ -987,6 +987,39 @@ def test_stream_join_rejects_misuse(fj):
     assert eng.stream_finish() == exp
     with pytest.raises(RuntimeError, match="no stream join"):
         eng.stream_append(pk)
+    # a stream join that is never finished occupies the context until it is aborted; the next plan starts from clean buffers
+    big_bk, big_bv = datagen.build_device(3_000_000, "cuda:0")
+    big_pk, big_exp = datagen.probe_device(8_000_000, 3_000_000, "cuda:0", seed=3, hit_bp=5000)
+    eng.stream_begin(big_bk, big_bv, 2 * big_pk.numel(), 2, 64)
+    eng.stream_append(big_pk)                                                     # first pass ran: chunk counts are left behind
+    with pytest.raises(RuntimeError, match="stream join is open"):
+        fj.hash_join_count_radix(bk, bv, pk)
+    with pytest.raises(RuntimeError, match="stream join is open"):
+        eng.bloom_export(bk, 64)
+    eng.stream_abort()
+    eng.stream_abort()                                                            # no-op when nothing is open
+    assert fj.hash_join_count_radix(big_bk, big_bv, big_pk)[0] == big_exp
+    assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp
+    # the multi-GPU driver aborts by itself when an engine call fails mid-stream
+    import torch.distributed as dist
+    import socket
+    from flash_hash_join_amd.distributed import distributed_join
+
+    class Failing(HipEngine):
+        def stream_append(self, piece):
+            raise RuntimeError("injected failure between begin and finish")
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        os.environ["FJ_FORCE_EXCHANGE"] = "1"
+        for strategy in ("shuffle", "replicate"):
+            os.environ["FJ_DIST_STRATEGY"] = strategy
+            with pytest.raises(RuntimeError, match="injected failure"):
+                distributed_join(big_bk, big_bv, big_pk, engine=Failing("cuda:0"))
+            assert distributed_join(big_bk, big_bv, big_pk)[0] == big_exp               # the context is free again
+    finally:
+        os.environ.pop("FJ_FORCE_EXCHANGE", None); os.environ.pop("FJ_DIST_STRATEGY", None)
+        dist.destroy_process_group()
 
 
 # FJ_FUZZ_SEEDS="a-b" adds seeds for a longer campaign (the committed default stays at 24 seeds x 4 dispatch modes)
