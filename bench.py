@@ -400,8 +400,10 @@ def main() -> None:
         "probe_phase_algorithmic_bytes": (24 * k + 8) * np_gpu,
         "probe_phase_frac_of_hbm_peak": round((24 * k + 8) * np_gpu / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if probe_ms else None,
         # the implementation reads no histogram pass: it moves 16 B per key and pass + 8 B per probe
-        "probe_phase_bytes_moved": (16 * k + 8) * np_gpu,
-        "probe_phase_frac_of_hbm_peak_by_bytes_moved": round((16 * k + 8) * np_gpu / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if probe_ms else None,
+        # (a filtered plan moves fewer: not quoted there)
+        "probe_phase_bytes_moved": (16 * k + 8) * np_gpu if not lt["bloom_level"] else None,
+        "probe_phase_frac_of_hbm_peak_by_bytes_moved": round((16 * k + 8) * np_gpu / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if probe_ms and not lt["bloom_level"] else None,
         "build_phase_algorithmic_bytes": (40 * k + 16) * nb_gpu,
     }
     if world > 1 or force_dist:
