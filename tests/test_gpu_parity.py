@@ -906,6 +906,35 @@ def test_concurrent_callers_on_one_device_are_serialised(fj):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("nb,dom,npk", [(50_000_000, 35_000_000, 200_000_000), (8_000_000, 1_000_000, 150_000_000)])
+def test_two_pass_plans_with_duplicate_build_keys_against_a_device_side_oracle(fj, nb, dom, npk):
+    """Sizes the CPU oracle does not reach in seconds: random 64-bit keys with duplicates on both sides, two-pass plans;
+    expected count from sort + searchsorted on the device (torch), all count functions and the materialised pair count /
+    membership; inner_join_count against the multiplicity sum."""
+    import torch
+    g = torch.Generator(device="cuda:0"); g.manual_seed(nb + npk)
+    domain = torch.randint(-(1 << 62), 1 << 62, (dom,), dtype=torch.int64, device="cuda:0", generator=g) * 2 + 1   # odd keys
+    bk = domain[torch.randint(0, dom, (nb,), device="cuda:0", generator=g)]
+    bv = bk ^ 0x5555
+    hit = torch.rand(npk, device="cuda:0", generator=g) < 0.35
+    pk = torch.where(hit, domain[torch.randint(0, dom, (npk,), device="cuda:0", generator=g)],
+                     torch.randint(-(1 << 62), 1 << 62, (npk,), dtype=torch.int64, device="cuda:0", generator=g) * 2)   # even keys never match
+    del hit
+    ub, mult = torch.unique(bk, return_counts=True)
+    pos = torch.searchsorted(ub, pk).clamp(max=ub.numel() - 1)
+    found = ub[pos] == pk
+    exp = int(found.sum())
+    exp_many = int(mult[pos][found].sum())
+    del pos, found
+    for fn in ("hash_join_count_radix", "hash_join_count", "adaptive_join_count", "hash_join_count_radix_bloom", "adaptive_join_count_bloom"):
+        assert getattr(fj, fn)(bk, bv, pk)[0] == exp, fn
+    assert fj.inner_join_count(bk, bv, pk)[0] == exp_many
+    n, _, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+    assert n == exp and k.numel() == exp and bool(torch.all((k ^ 0x5555) == v))          # every pair carries its key's value
+    assert bool(torch.all(ub[torch.searchsorted(ub, k).clamp(max=ub.numel() - 1)] == k))
+    assert torch.equal(torch.sort(k)[0], torch.sort(pk[ub[torch.searchsorted(ub, pk).clamp(max=ub.numel() - 1)] == pk])[0])
+
+
 def test_workspace_can_be_trimmed_between_joins(fj, oracle):
     """fj_ctx_trim: the grow-only workspace goes back to the device, the next join re-grows it and gives the same result;
     refused while a stream join is open."""
