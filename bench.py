@@ -35,6 +35,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide
+HBM_SCATTER_GBS = 5038.0       # this pool's MI355X: best stream-in / scatter-out rate in >= 128-B pieces, tools/ubench_scatter.hip
+                               # (profiles/r01_ubench_scatter.csv: 4.6-5.0 TB/s by grid) - the access pattern of a radix pass
 
 WORKLOADS = {
     # name: (build rows per GPU, probe rows per GPU, hit rate in basis points, function)
@@ -356,6 +358,7 @@ def main() -> None:
         roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+                "frac_of_measured_scatter_ceiling": round(achieved / HBM_SCATTER_GBS, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 16, "units_per_launch": units_per_launch[0],
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": traffic}
     else:
