@@ -22,18 +22,21 @@ __global__ __launch_bounds__(256) void scatter_kernel(const u64x2* __restrict__ 
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool by_grid = argc > 1 && argv[1][0] == 'g';       // `ubench_scatter grid`: 128-B / 2-KiB / 1-MiB pieces over many grid sizes
     const u64 bytes = 8ull << 30;                           // 8 GiB in, 8 GiB out
     const u64 n16 = bytes / 16;
     u64x2 *in, *out;
     CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes));
     CK(hipMemset(in, 1, bytes)); CK(hipMemset(out, 0, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int grids[] = {2048, 16384};
+    std::vector<int> grids = {2048, 16384};
+    if (by_grid) grids = {512, 1024, 2048, 4096, 8192, 16384, 65536, 262144};
     printf("piece_bytes,in_piece_bytes,grid,ms,GBps(read+write)\n");
     for (int g : grids)
     for (u32 in_log : {0u, 7u}) {                            // read side linear, or random 2-KiB chunks
-        for (u32 piece_log = 0; piece_log <= 10; ++piece_log) {   // 16 B .. 16 KiB pieces
+        for (u32 piece_log = 0; piece_log <= 16; ++piece_log) {   // 16 B .. 16 KiB pieces (`grid` mode: 128 B, 2 KiB, 1 MiB)
+            if (by_grid ? (piece_log != 3 && piece_log != 7 && piece_log != 16) : piece_log > 10) continue;
             float best = 1e9;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0));
