@@ -70,7 +70,7 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     unsigned long long bloom_survivors;   // probe keys that passed the bloom precheck
     unsigned long long sample_hits;       // sampled probe rows found in the build side (adaptive bloom decision)
     u32 next_item;                     // work counter of the persistent join kernel
-    u32 pad_;
+    u32 next_emit_item;                // ... and of the persistent emitting kernel (zeroed right before its launch)
     unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
 };
 
@@ -548,7 +548,14 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
             pd.lds.out_off = (const u64*)p; pd.lds.out_keys = d_ok; pd.lds.out_vals = d_ov;
             pd.lds.dbg = nullptr;
             if (getenv("FJ_EMIT_STAMPS") && stamps_begin(&pd.lds.dbg, s)) return 1;
-            HIPCHK(fj_launch_lds_join(pd.lds, true, s));
+            static const bool resident = !getenv("FJ_EMIT_PERSISTENT") || atoi(getenv("FJ_EMIT_PERSISTENT")) != 0;   // (A/B knob)
+            if (resident) HIPCHK(hipMemsetAsync(&c->d_sc->next_emit_item, 0, sizeof(u32), s));
+            HIPCHK(fj_launch_lds_join(pd.lds, true, s, resident ? &c->d_sc->next_emit_item : nullptr, options().persistent_min_items));
+            if (resident && !pd.lds.dedup && !pd.lds.dbg && pd.lds.items && pd.lds.items_cap >= options().persistent_min_items) {
+                // the cuckoo emit kernel ran: items whose table overflowed its stash are redone on the tagged table
+                if (read_scalars(c, s)) return 1;
+                if (c->h_sc->err & FJ_STAT_EMIT_RETRY) { HIPCHK(fj_launch_lds_emit_retry(pd.lds, s)); if (t) t->lds_retries += 1; }
+            }
             if (pd.lds.dbg) { if (stamps_report("FJ_EMIT_STAMPS", pd.lds.dbg, pd.nitems, s)) return 1; pd.lds.dbg = nullptr; }
         } else if (pd.path == 2) {           // many-to-many: count per item -> scan -> emit
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;

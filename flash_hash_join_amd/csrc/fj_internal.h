@@ -7,6 +7,7 @@
 #define FJ_ERR_LDS_FULL 2u   // a final partition does not fit its LDS table -> global-table fallback
 #define FJ_STAT_DUPS 4u      // (status, not an error) the build side holds duplicate keys
 #define FJ_STAT_RETRY 8u     // (status) some counting-join items overflowed the cuckoo table: part_count[item] == FJ_ITEM_RETRY marks them
+#define FJ_STAT_EMIT_RETRY 16u // (status) some items of the emitting pass overflowed the cuckoo table: marked the same way, redone on the tagged table
 #define FJ_ITEM_RETRY 0xFFFFFFFFu
 
 // ---- partition pass ---------------------------------------------------------------------------
@@ -124,6 +125,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
 // second chance for the items whose partition overflowed the cuckoo table (load > ~0.45): the tagged 2x4-slot table
 // with linear-probing overflow holds up to 8128 keys; only a partition beyond that raises FJ_ERR_LDS_FULL
 hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a, hipStream_t s);
+hipError_t fj_launch_lds_emit_retry(const FjLdsJoinArgs& a, hipStream_t s);       // same for the emitting pass (FJ_STAT_EMIT_RETRY)
 
 // how many of `nsamples` evenly spaced probe rows have their key in the build side (final chunk set `build`, partition id =
 // (hash word 1 >> shift32) & pmask): one wave per sample scans the sample's build partition

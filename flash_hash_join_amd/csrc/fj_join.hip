@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
         return;
     }
     if (MAT && a.part_count[item] == 0) return;
-    if (!MAT && a.retry_only && a.part_count[item] != FJ_ITEM_RETRY) return;   // second chance for the cuckoo kernel's overflows only
+    if (a.retry_only && a.part_count[item] != FJ_ITEM_RETRY) return;           // second chance for the cuckoo kernels' overflows only
 
     constexpr u32 CPL = NT / (FJ_CHUNK / 2);          // chunks covered by one 16-B load per lane
     constexpr u32 CPR = 4 * CPL;                      // chunks per round (4 loads per lane = 8 keys)
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                             const u64 m = hitm[i];
                             if ((m >> lane) & 1ull) {
                                 const u64 o = obase + wb + off[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                                if (a.dbg_flags & 4u) continue;             // (ablation: no output stores)
                                 a.out_keys[o] = k2[i];
                                 a.out_vals[o] = k2[i] == FJ_EMPTY_KEY ? hdr->empty_val : tvals[where[i]];
                             }
@@ -461,7 +462,8 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
 constexpr u32 CK_STASH = 32, CK_MAXIT = 48;
 struct CkHdr { u32 cnt, has_empty, nstash, full, dups, empties, pad1[2]; u64 pad[1]; u64 stash[CK_STASH]; };
 
-__device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, CkHdr* hdr, u64 key) {
+template <typename Hdr>
+__device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, Hdr* hdr, u64 key) {
     u32 w = fj_hash_w2(key);
     u32 l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
     if (tkeys[l1] == key || tkeys[l2] == key) { hdr->dups = 1; return; }   // duplicate build key already stored (hash_join.cpp:125)
@@ -881,6 +883,264 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
     }
 }
 
+// ---- materialising join over chunk lists: the emitting pass on the cuckoo table, persistent form ----------------------
+// The tagged table of fj_lds_join_kernel<true> costs about three times the issued instructions of a cuckoo lookup, and its
+// 128 KiB (keys + values) leave one workgroup per CU: at c3 the emitting pass took 4.3 ms where the counting pass (cuckoo,
+// keys only) takes 1.8, and dropping the output stores changed it by 0.4 ms only (ablation FJ_JOIN_ABLATE=4) - the table is
+// what costs.  Here the emitting pass keeps the cuckoo KEY table and adds a value array indexed by the same slot:
+//   1. build keys go in exactly as in fj_count_join_persistent (evictions move bare keys with one 64-bit exchange each);
+//   2. after the barrier every build row looks its key up again (two reads) and drops its value into the slot the key ended
+//      up in (or the stash's value row) - plain stores, no races for unique keys;
+//   3. a probe key reads its two candidate slots; a hit fetches the value of the matching slot.
+// Unique build keys only (a.dedup == 0: duplicates were reported by the counting pass and take the first-occurrence path of
+// the tagged kernel).  A table whose stash overflows marks its item (part_count = FJ_ITEM_RETRY, FJ_STAT_EMIT_RETRY) and
+// the host runs the tagged kernel over the marked items.  Resident workgroups with next-item prefetch as in
+// fj_count_join_persistent; output positions = scanned per-item offsets + an LDS cursor bumped once per wave and 4 key slots.
+struct EkHdr { u32 has_empty, nstash, full, dups, cursor, pad1[3]; u64 empty_val; u64 pad2; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
+
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a, u32* __restrict__ next_item) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    EkHdr* hdr = reinterpret_cast<EkHdr*>(smem);
+    u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(EkHdr));
+    u64* tvals = tkeys + S;
+    u32* pm0 = reinterpret_cast<u32*>(tvals + S);           // [2][JP_META] probe-side list entries
+    u32* bm0 = pm0 + 2 * JP_META;                            // [2][JB_META] build-side list entries
+    u32* s_next = bm0 + 2 * JB_META;                         // [2] item ids handed out by the global counter
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 nitems = *a.nitems_dev;
+    constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
+    static_assert(JP_META <= NT && JB_META <= NT, "one staged list entry per thread");
+
+    struct Desc { u32 item, b0, nbc, s_lo, s_hi, cnt; };
+    auto describe = [&](u32 item) -> Desc {                  // wave-uniform scalar loads
+        Desc d; d.item = item; d.b0 = 0; d.nbc = 0; d.s_lo = 0; d.s_hi = 0; d.cnt = 0;
+        if (item >= nitems) return d;
+        const uint4 it = a.items[item];
+        d.b0 = a.build.boff[it.z]; d.nbc = a.build.boff[it.z + 1] - d.b0;
+        d.s_lo = it.x; d.s_hi = it.x + it.y;
+        d.cnt = a.part_count[item];                          // the counting pass: items without a match emit nothing
+        return d;
+    };
+    auto live = [&](const Desc& d) { return d.item < nitems && d.nbc > 0 && d.s_lo < d.s_hi && d.cnt != 0; };
+
+    u64 bk[BKPT], bv[BKPT];
+    u32 bok = 0;
+    auto load_build = [&](const u32* bm, u32 c0, u32 nbb) {  // 16 chunks = 4096 rows requested at once, unconditionally
+        bok = 0;
+#pragma unroll
+        for (u32 j = 0; j < BKPT; ++j) {
+            const u32 kidx = j * NT + tid, c = c0 + (kidx >> FJ_CHUNK_LOG), off = kidx & (FJ_CHUNK - 1);
+            const u32 e = bm[c < nbb ? c : nbb - 1];
+            const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
+            bk[j] = a.build.keys[src];
+            bv[j] = a.build.vals[src];
+            bok |= (c < nbb && off < FJ_LIST_CNT(e) ? 1u : 0u) << j;
+        }
+    };
+    auto load_round = [&](const u32* pm, u32 r, u32 nbatch, u64 (&kk)[8], u32& okm) {
+        okm = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 c = r * CPR + u * CPL + tid / (FJ_CHUNK / 2), off = (tid % (FJ_CHUNK / 2)) * 2;
+            const u32 e = pm[c < nbatch ? c : nbatch - 1], cnt = c < nbatch ? FJ_LIST_CNT(e) : 0;
+            const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + off);
+            kk[2 * u] = q.x; kk[2 * u + 1] = q.y;
+            okm |= ((off < cnt ? 1u : 0u) | (off + 1 < cnt ? 2u : 0u)) << (2 * u);
+        }
+    };
+    auto reset_table = [&]() {
+        for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
+        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->empty_val = 0ull; }
+    };
+    // step 2: the value of build row (key, val) goes where the key lives now
+    auto place = [&](u64 key, u64 val) {
+        if (key == FJ_EMPTY_KEY) { hdr->empty_val = val; return; }
+        const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+        if (tkeys[l1] == key) { tvals[l1] = val; return; }
+        if (tkeys[l2] == key) { tvals[l2] = val; return; }
+        const u32 ns = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
+        for (u32 si = 0; si < ns; ++si) if (hdr->stash[si] == key) { hdr->stash_val[si] = val; return; }
+    };
+
+    // ---- prologue: first item (static), its list entries, its first build batch ----
+    Desc d = describe(blockIdx.x);
+    if (d.item >= nitems) return;
+    u32 buf = 0;
+    {
+        const bool lv = live(d);
+        const u32 nb0 = (d.s_hi - d.s_lo) < JP_META ? (d.s_hi - d.s_lo) : JP_META;
+        if (lv && tid < nb0) pm0[tid] = a.probe.list[d.s_lo + tid];
+        const u32 nbb0 = d.nbc < JB_META ? d.nbc : JB_META;
+        if (lv && tid < nbb0) bm0[tid] = a.build.list[d.b0 + tid];
+        reset_table();
+        if (tid == 0) s_next[0] = atomicAdd(next_item, 1u) + gridDim.x;
+        __syncthreads();
+        if (lv) load_build(bm0, 0, nbb0);
+    }
+
+    for (;;) {
+        // invariant: table empty, hdr reset, pm/bm[buf] hold d's first batches, bk/bv[] = d's first build batch (in flight),
+        // s_next[buf] = id of the item after d
+        u32* pm = pm0 + buf * JP_META; u32* bm = bm0 + buf * JB_META;
+        u32* pmn = pm0 + (buf ^ 1) * JP_META; u32* bmn = bm0 + (buf ^ 1) * JB_META;
+        const bool lv = live(d);
+        const bool one_batch = d.nbc <= 16;                  // all build rows of the partition are in bk/bv: step 2 needs no reload
+        u64 ka[8], kb[8];
+        u32 oka = 0, okb = 0;
+        u32 nbatch = (d.s_hi - d.s_lo) < JP_META ? (d.s_hi - d.s_lo) : JP_META;
+        u32 nrounds = (nbatch + CPR - 1) / CPR;
+        if (lv) {
+            load_round(pm, 0, nbatch, ka, oka);
+            if (nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
+            // ---- build, step 1: keys ----
+            u32 nbb = d.nbc < JB_META ? d.nbc : JB_META;
+            for (u32 bb = 0; bb < d.nbc; bb += JB_META) {
+                if (bb) {
+                    nbb = (d.nbc - bb) < JB_META ? (d.nbc - bb) : JB_META;
+                    __syncthreads();
+                    if (tid < nbb) bm[tid] = a.build.list[d.b0 + bb + tid];
+                    __syncthreads();
+                }
+                for (u32 c0 = 0; c0 < nbb; c0 += 16) {
+                    if (bb | c0) load_build(bm, c0, nbb);
+#pragma unroll
+                    for (u32 j = 0; j < BKPT; ++j) {
+                        if (bok & (1u << j)) {
+                            if (bk[j] == FJ_EMPTY_KEY) hdr->has_empty = 1;
+                            else cuckoo_insert(tkeys, hdr, bk[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                     // keys are final; s_next[buf] visible
+        // ---- P1: request the next item's list entries ----
+        const Desc dn = describe(__builtin_amdgcn_readfirstlane(s_next[buf]));   // uniform: keeps the descriptor in SGPRs
+        const bool lvn = live(dn);
+        const u32 nbn = (dn.s_hi - dn.s_lo) < JP_META ? (dn.s_hi - dn.s_lo) : JP_META;
+        const u32 nbbn = dn.nbc < JB_META ? dn.nbc : JB_META;
+        u32 mp = 0, mb = 0;
+        if (lvn && tid < nbn) mp = a.probe.list[dn.s_lo + tid];
+        if (lvn && tid < nbbn) mb = a.build.list[dn.b0 + tid];
+        bool parked = false;                                  // next item's list entries still in registers?
+        auto park = [&]() {
+            if (tid < nbn) pmn[tid] = mp;
+            if (tid < nbbn) bmn[tid] = mb;
+            if (tid == 0) s_next[buf ^ 1] = atomicAdd(next_item, 1u) + gridDim.x;
+            parked = true;
+        };
+
+        bool full = false;
+        if (lv) {
+            full = hdr->full != 0;
+            // ---- build, step 2: values ----
+            if (!full) {
+                if (one_batch) {
+#pragma unroll
+                    for (u32 j = 0; j < BKPT; ++j) if (bok & (1u << j)) place(bk[j], bv[j]);
+                } else {
+                    u32 nbb = d.nbc < JB_META ? d.nbc : JB_META;
+                    for (u32 bb = 0; bb < d.nbc; bb += JB_META) {
+                        nbb = (d.nbc - bb) < JB_META ? (d.nbc - bb) : JB_META;
+                        if (d.nbc > JB_META) {               // (the staged entries were overwritten by later batches)
+                            __syncthreads();
+                            if (tid < nbb) bm[tid] = a.build.list[d.b0 + bb + tid];
+                            __syncthreads();
+                        }
+                        for (u32 c0 = 0; c0 < nbb; c0 += 16) {
+                            load_build(bm, c0, nbb);
+#pragma unroll
+                            for (u32 j = 0; j < BKPT; ++j) if (bok & (1u << j)) place(bk[j], bv[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                     // values are in place
+        if (lv && full) {                                    // stash overflow: the host redoes this item on the tagged table
+            if (tid == 0) { atomicOr(a.err, FJ_STAT_EMIT_RETRY); a.part_count[d.item] = FJ_ITEM_RETRY; }
+        } else if (lv) {
+            const u64 he = hdr->has_empty ? ~0ull : 0ull;
+            const u32 nstash = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
+            const u64 obase = a.out_off[d.item];
+            // ---- probe + emit ----
+            for (u32 pb = d.s_lo; pb < d.s_hi; pb += JP_META) {
+                if (pb != d.s_lo) {
+                    nbatch = (d.s_hi - pb) < JP_META ? (d.s_hi - pb) : JP_META;
+                    __syncthreads();
+                    if (tid < nbatch) pm[tid] = a.probe.list[pb + tid];
+                    __syncthreads();
+                    nrounds = (nbatch + CPR - 1) / CPR;
+                    load_round(pm, 0, nbatch, ka, oka);
+                    if (nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
+                }
+                for (u32 r = 0; r < nrounds; ++r) {
+                    u64 k[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { k[i] = ka[i]; ka[i] = kb[i]; }
+                    const u32 okm = oka;
+                    oka = okb;
+                    if (r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4) {              // two halves of 4 keys: 8 LDS reads in flight per lane
+                        u64 c1[4], c2[4];
+                        u32 l1[4], l2[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32 w = fj_hash_w2(k[h + i]);
+                            l1[i] = w & (S - 1); l2[i] = (w >> 13) & (S - 1);
+                            c1[i] = tkeys[l1[i]];
+                            c2[i] = tkeys[l2[i]];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        u64 hitm[4];
+                        u64 val[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u64 key = k[h + i];
+                            const bool h1 = c1[i] == key, h2 = c2[i] == key;
+                            bool hit = h1 | h2;
+                            val[i] = tvals[h1 ? l1[i] : l2[i]];          // (unconditional read: independent of the compare, harmless on a miss)
+                            if (nstash) {
+                                for (u32 si = 0; si < nstash; ++si) if (hdr->stash[si] == key) { hit = true; val[i] = hdr->stash_val[si]; }
+                            }
+                            const bool ise = key == FJ_EMPTY_KEY;        // the empty marker is never stored in the table
+                            if (ise) { hit = he != 0; val[i] = hdr->empty_val; }
+                            hitm[i] = __ballot(hit && ((okm >> (h + i)) & 1u));
+                        }
+                        // ONE LDS cursor bump per wave for the four key slots; lanes ranked inside the ballots
+                        const u32 n0 = (u32)__popcll(hitm[0]), n1 = (u32)__popcll(hitm[1]), n2 = (u32)__popcll(hitm[2]), n3 = (u32)__popcll(hitm[3]);
+                        if (n0 + n1 + n2 + n3) {
+                            u32 wb = 0;
+                            if (lane == 0) wb = atomicAdd(&hdr->cursor, n0 + n1 + n2 + n3);
+                            wb = (u32)__builtin_amdgcn_readfirstlane((int)wb);
+                            const u32 off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const u64 m = hitm[i];
+                                if ((m >> lane) & 1ull) {
+                                    const u64 o = obase + wb + off[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                                    a.out_keys[o] = k[h + i];
+                                    a.out_vals[o] = val[i];
+                                }
+                            }
+                        }
+                    }
+                    if (!parked) park();                      // after the first round: the entries have long arrived
+                }
+            }
+        }
+        if (!parked) park();                                  // skipped probe loop
+        __syncthreads();                                      // every wave is done with the table; the parked entries are visible
+        if (lvn) load_build(bmn, 0, nbbn); else bok = 0;      // the next item's build rows fly during the reset
+        if (dn.item >= nitems) break;
+        reset_table();
+        __syncthreads();
+        d = dn; buf ^= 1;
+    }
+}
+
 // ---- hit-rate sample for the adaptive joins' bloom decision ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void fj_sample_hits_kernel(FjChunkSet build, const u64* __restrict__ pk, u64 np, u32 nsamples,
                                                              u32 shift32, u32 pmask, unsigned long long* __restrict__ hits) {
@@ -1168,6 +1428,16 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item, u32 persistent_min_items) {
     const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;       // grid of the one-workgroup-per-item kernels
     if (materialize) {
+        // many items over chunk lists, unique build keys: the resident form (one workgroup per CU, next item prefetched)
+        if (a.build.list && a.probe.list && a.items && next_item && nb >= persistent_min_items && !a.dedup && !a.dbg && !a.dbg_flags) {
+            const u32 ldsp = sizeof(EkHdr) + 2 * S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
+            auto pk = fj_emit_join_persistent<1024>;
+            hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
+            if (e != hipSuccess) return e;
+            const u32 grid = nb < 256 ? nb : 256;            // (*next_item is zero: the emitting pass has its own counter word)
+            hipLaunchKernelGGL(pk, dim3(grid), dim3(1024), ldsp, s, a, next_item);
+            return hipGetLastError();
+        }
         const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
         auto kern = (a.build.list && a.probe.list) ? fj_lds_join_kernel<true, 1024, true> : fj_lds_join_kernel<true, 1024, false>;
         hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
@@ -1193,6 +1463,19 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a);
     }
+    return hipGetLastError();
+}
+
+// emitting pass: the items the cuckoo emit kernel could not place (FJ_STAT_EMIT_RETRY) on the tagged table
+hipError_t fj_launch_lds_emit_retry(const FjLdsJoinArgs& a0, hipStream_t s) {
+    FjLdsJoinArgs a = a0;
+    a.retry_only = 1;
+    const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;
+    const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
+    auto kern = (a.build.list && a.probe.list) ? fj_lds_join_kernel<true, 1024, true> : fj_lds_join_kernel<true, 1024, false>;
+    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     return hipGetLastError();
 }
 
