@@ -117,7 +117,7 @@ struct FjLdsJoinArgs {
     u32 dedup;                   // materialising pass: build 'values' are row indices, the smallest wins, then orig_vals[idx]
     const u64* orig_vals;        // the caller's build_values (dedup only)
     unsigned long long* dbg;     // diagnostic: per-item phase stamps (s_memrealtime), nullptr in production
-    u32 dbg_flags;               // diagnostic ablations: 1 = skip lookups, 2 = skip inserts (results wrong on purpose)
+    u32 dbg_flags;               // diagnostic ablations: 1 = skip lookups, 2 = skip inserts, 4 = no output stores (results wrong on purpose); 8 = test hook: the cuckoo emit kernel sends every 7th item down its retry path (results exact)
 };
 // next_item: device word for the persistent counting kernel's work counter (nullptr: one workgroup per item)
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item = nullptr,

@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
 
         bool full = false;
         if (lv) {
-            full = hdr->full != 0;
+            full = hdr->full != 0 || ((a.dbg_flags & 8u) && d.item % 7u == 3u);   // (8: test hook - every 7th item takes the retry path)
             // ---- build, step 2: values ----
             if (!full) {
                 if (one_batch) {
@@ -1429,7 +1429,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
     const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;       // grid of the one-workgroup-per-item kernels
     if (materialize) {
         // many items over chunk lists, unique build keys: the resident form (one workgroup per CU, next item prefetched)
-        if (a.build.list && a.probe.list && a.items && next_item && nb >= persistent_min_items && !a.dedup && !a.dbg && !a.dbg_flags) {
+        if (a.build.list && a.probe.list && a.items && next_item && nb >= persistent_min_items && !a.dedup && !a.dbg && !(a.dbg_flags & ~8u)) {
             const u32 ldsp = sizeof(EkHdr) + 2 * S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
             auto pk = fj_emit_join_persistent<1024>;
             hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
