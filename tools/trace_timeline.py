@@ -2,10 +2,12 @@
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# the last join starts at the last fill/memset that follows a copyBuffer (read-back of the previous join's scalars)
+# a join starts with the memset of its plan's scalars: the last fill that directly follows a copyBuffer (the read-back that
+# ended the previous join; a materialising join reads back more than once, its later stages do not start with a fill)
 idx = [i for i, r in enumerate(rows) if "copyBuffer" in r["Kernel_Name"]]
-start = idx[-2] + 1 if len(idx) >= 2 else 0
-last = rows[start: idx[-1] + 1] if idx else rows[-int(sys.argv[2]) if len(sys.argv) > 2 else -40:]
+starts = [i for i, r in enumerate(rows) if "fillBuffer" in r["Kernel_Name"] and (i == 0 or "copyBuffer" in rows[i - 1]["Kernel_Name"])]
+start = starts[-1] if starts else 0
+last = rows[start: idx[-1] + 1] if idx and idx[-1] > start else rows[-int(sys.argv[2]) if len(sys.argv) > 2 else -40:]
 t0 = int(last[0]["Start_Timestamp"]); prev_end = t0; busy = 0
 for r in last:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
