@@ -550,12 +550,7 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
             if (getenv("FJ_EMIT_STAMPS") && stamps_begin(&pd.lds.dbg, s)) return 1;
             static const bool resident = !getenv("FJ_EMIT_PERSISTENT") || atoi(getenv("FJ_EMIT_PERSISTENT")) != 0;   // (A/B knob)
             if (resident) HIPCHK(hipMemsetAsync(&c->d_sc->next_emit_item, 0, sizeof(u32), s));
-            HIPCHK(fj_launch_lds_join(pd.lds, true, s, resident ? &c->d_sc->next_emit_item : nullptr, options().persistent_min_items));
-            if (resident && !pd.lds.dedup && !pd.lds.dbg && pd.lds.items && pd.lds.items_cap >= options().persistent_min_items) {
-                // the cuckoo emit kernel ran: items whose table overflowed its stash are redone on the tagged table
-                if (read_scalars(c, s)) return 1;
-                if (c->h_sc->err & FJ_STAT_EMIT_RETRY) { HIPCHK(fj_launch_lds_emit_retry(pd.lds, s)); if (t) t->lds_retries += 1; }
-            }
+            HIPCHK(fj_launch_lds_join(pd.lds, true, s, resident ? &c->d_sc->next_emit_item : nullptr, 1u));
             if (pd.lds.dbg) { if (stamps_report("FJ_EMIT_STAMPS", pd.lds.dbg, pd.nitems, s)) return 1; pd.lds.dbg = nullptr; }
         } else if (pd.path == 2) {           // many-to-many: count per item -> scan -> emit
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
@@ -574,6 +569,13 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
         // the emitting kernel can still refuse an item (a table that the counting pass's stricter cuckoo table accepted should
         // never do so, but nothing else enforces that): unwritten output rows must not be handed back with status 0
         if (read_scalars(c, s)) return 1;
+        if (pd.path == 0 && (c->h_sc->err & FJ_STAT_EMIT_RETRY)) {
+            // the cuckoo emit kernel marked items whose table overflowed its stash: those are redone on the tagged table
+            HIPCHK(fj_launch_lds_emit_retry(pd.lds, s));
+            HIPCHK(hipEventRecord(c->ev[E_EMIT1], s));
+            if (read_scalars(c, s)) return 1;
+            if (t) t->lds_retries += 1;
+        }
         if (c->h_sc->err & (FJ_ERR_LDS_FULL | FJ_ERR_POOL)) { pd.valid = false; return set_err("fj_emit_pairs: the emitting pass could not place every partition in LDS (device error word 0x%x)", c->h_sc->err); }
     }
     HIPCHK(hipStreamSynchronize(s));

@@ -1428,7 +1428,7 @@ __global__ void fj_gen_probe_kernel(u64* __restrict__ keys, u64 first, u64 n, u6
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item, u32 persistent_min_items) {
     const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;       // grid of the one-workgroup-per-item kernels
     if (materialize) {
-        // many items over chunk lists, unique build keys: the resident form (one workgroup per CU, next item prefetched)
+        // chunk lists on both sides, unique build keys: the cuckoo form (resident workgroups, one per CU, next item prefetched)
         if (a.build.list && a.probe.list && a.items && next_item && nb >= persistent_min_items && !a.dedup && !a.dbg && !(a.dbg_flags & ~8u)) {
             const u32 ldsp = sizeof(EkHdr) + 2 * S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
             auto pk = fj_emit_join_persistent<1024>;

@@ -200,19 +200,16 @@ def test_partition_over_the_cuckoo_limit_is_redone_on_the_tagged_table(fj, oracl
     # overflows there marks its item and the host redoes the marked items on the tagged table.  (A partition the COUNTING
     # pass already had to retry reports "duplicates possible" and takes the tagged kernel anyway, so the path is driven by
     # the kernel's test hook: FJ_JOIN_ABLATE=8 sends every 7th item through it.)
-    from flash_hash_join_amd import api
     ubk = np.concatenate([one[:3000], rest])
     ubv = np.arange(ubk.size, dtype=np.uint64) * np.uint64(3) + np.uint64(1)
     upk = np.concatenate([ubk, ubk[::2], cand[:50000]])
     exp, ek, ev = oracle.np_join(ubk, ubv, upk, return_arrays=True)
-    api.set_option("persistent_min_items", 1)
     os.environ["FJ_JOIN_ABLATE"] = "8"
     try:
         n, _, k, v = fj.hash_join_radix(ubk, ubv, upk, return_arrays=True)
         t = fj.last_timings()
     finally:
         os.environ.pop("FJ_JOIN_ABLATE")
-        api.set_option("persistent_min_items", 8192)
     assert n == exp and t["fell_back"] == 0 and t["lds_retries"] == 1, t      # the emitting pass's retry launch
     a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
