@@ -892,13 +892,15 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
 //   2. after the barrier every build row looks its key up again (two reads) and drops its value into the slot the key ended
 //      up in (or the stash's value row) - plain stores, no races for unique keys;
 //   3. a probe key reads its two candidate slots; a hit fetches the value of the matching slot.
-// Unique build keys only (a.dedup == 0: duplicates were reported by the counting pass and take the first-occurrence path of
-// the tagged kernel).  A table whose stash overflows marks its item (part_count = FJ_ITEM_RETRY, FJ_STAT_EMIT_RETRY) and
+// A table whose stash overflows marks its item (part_count = FJ_ITEM_RETRY, FJ_STAT_EMIT_RETRY) and
 // the host runs the tagged kernel over the marked items.  Resident workgroups with next-item prefetch as in
 // fj_count_join_persistent; output positions = scanned per-item offsets + an LDS cursor bumped once per wave and 4 key slots.
 struct EkHdr { u32 has_empty, nstash, full, dups, cursor, pad1[3]; u64 empty_val; u64 pad2; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
 
-template <int NT>
+// DEDUP (the counting pass saw duplicate build keys): the build "values" are original row indices, every copy of a key
+// lowers its slot's index with an LDS atomic minimum, and the winners are turned into values with one gather from the
+// caller's build_values - the reference's first-occurrence rule (hash_join.cpp:125 on a stable partition).
+template <int NT, bool DEDUP>
 __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a, u32* __restrict__ next_item) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EkHdr* hdr = reinterpret_cast<EkHdr*>(smem);
@@ -950,17 +952,22 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
         }
     };
     auto reset_table = [&]() {
-        for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
-        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->empty_val = 0ull; }
+        for (u32 i = tid; i < S; i += NT) { tkeys[i] = FJ_EMPTY_KEY; if (DEDUP) tvals[i] = ~0ull; }
+        if (DEDUP && tid < CK_STASH) hdr->stash_val[tid] = ~0ull;
+        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->empty_val = DEDUP ? ~0ull : 0ull; }
     };
-    // step 2: the value of build row (key, val) goes where the key lives now
+    // step 2: the value of build row (key, val) goes where the key lives now (table before stash, first location before the
+    // second: the order the probe uses).  DEDUP: val is the row index, the smallest one stays.
+    auto put = [&](u64* where, u64 val) {
+        if (DEDUP) atomicMin((unsigned long long*)where, (unsigned long long)val); else *where = val;
+    };
     auto place = [&](u64 key, u64 val) {
-        if (key == FJ_EMPTY_KEY) { hdr->empty_val = val; return; }
+        if (key == FJ_EMPTY_KEY) { put(&hdr->empty_val, val); return; }
         const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
-        if (tkeys[l1] == key) { tvals[l1] = val; return; }
-        if (tkeys[l2] == key) { tvals[l2] = val; return; }
+        if (tkeys[l1] == key) { put(&tvals[l1], val); return; }
+        if (tkeys[l2] == key) { put(&tvals[l2], val); return; }
         const u32 ns = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
-        for (u32 si = 0; si < ns; ++si) if (hdr->stash[si] == key) { hdr->stash_val[si] = val; return; }
+        for (u32 si = 0; si < ns; ++si) if (hdr->stash[si] == key) { put(&hdr->stash_val[si], val); return; }
     };
 
     // ---- prologue: first item (static), its list entries, its first build batch ----
@@ -1058,6 +1065,24 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
             }
         }
         __syncthreads();                                     // values are in place
+        if (DEDUP && lv && !full) {                          // winning row indices -> values (one gather from the caller's array)
+            {   // all gathers of a thread in flight together (unconditional loads: row 0 stands in where there is nothing to fetch)
+                u64 v[S / NT]; u32 okm = 0;
+#pragma unroll
+                for (u32 j = 0; j < S / NT; ++j) {
+                    const u32 i = tid + j * NT;
+                    const u64 r = tvals[i];
+                    const bool ok = tkeys[i] != FJ_EMPTY_KEY && r != ~0ull;
+                    v[j] = a.orig_vals[ok ? r : 0ull];
+                    okm |= (ok ? 1u : 0u) << j;
+                }
+#pragma unroll
+                for (u32 j = 0; j < S / NT; ++j) if (okm & (1u << j)) tvals[tid + j * NT] = v[j];
+            }
+            if (tid < CK_STASH && tid < hdr->nstash) { const u64 r = hdr->stash_val[tid]; if (r != ~0ull) hdr->stash_val[tid] = a.orig_vals[r]; }
+            if (tid == 0 && hdr->has_empty && hdr->empty_val != ~0ull) hdr->empty_val = a.orig_vals[hdr->empty_val];
+            __syncthreads();
+        }
         if (lv && full) {                                    // stash overflow: the host redoes this item on the tagged table
             if (tid == 0) { atomicOr(a.err, FJ_STAT_EMIT_RETRY); a.part_count[d.item] = FJ_ITEM_RETRY; }
         } else if (lv) {
@@ -1102,8 +1127,8 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                             const bool h1 = c1[i] == key, h2 = c2[i] == key;
                             bool hit = h1 | h2;
                             val[i] = tvals[h1 ? l1[i] : l2[i]];          // (unconditional read: independent of the compare, harmless on a miss)
-                            if (nstash) {
-                                for (u32 si = 0; si < nstash; ++si) if (hdr->stash[si] == key) { hit = true; val[i] = hdr->stash_val[si]; }
+                            if (nstash) {                                // (table before stash: the order step 2 used)
+                                for (u32 si = 0; si < nstash; ++si) if (!hit && hdr->stash[si] == key) { hit = true; val[i] = hdr->stash_val[si]; }
                             }
                             const bool ise = key == FJ_EMPTY_KEY;        // the empty marker is never stored in the table
                             if (ise) { hit = he != 0; val[i] = hdr->empty_val; }
@@ -1429,9 +1454,9 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
     const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;       // grid of the one-workgroup-per-item kernels
     if (materialize) {
         // chunk lists on both sides, unique build keys: the cuckoo form (resident workgroups, one per CU, next item prefetched)
-        if (a.build.list && a.probe.list && a.items && next_item && nb >= persistent_min_items && !a.dedup && !a.dbg && !(a.dbg_flags & ~8u)) {
+        if (a.build.list && a.probe.list && a.items && next_item && nb >= persistent_min_items && !a.dbg && !(a.dbg_flags & ~8u)) {
             const u32 ldsp = sizeof(EkHdr) + 2 * S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
-            auto pk = fj_emit_join_persistent<1024>;
+            auto pk = a.dedup ? fj_emit_join_persistent<1024, true> : fj_emit_join_persistent<1024, false>;
             hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
             if (e != hipSuccess) return e;
             const u32 grid = nb < 256 ? nb : 256;            // (*next_item is zero: the emitting pass has its own counter word)
