@@ -460,7 +460,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
 // whose eviction chain does not terminate goes to a 32-entry stash that lookups scan only when it is
 // non-empty (a wave-uniform branch); a full stash raises FJ_ERR_LDS_FULL like a full table.
 constexpr u32 CK_STASH = 32, CK_MAXIT = 48;
-struct CkHdr { u32 cnt, has_empty, nstash, full, dups, empties, pad1[2]; u64 pad[1]; u64 stash[CK_STASH]; };
+struct CkHdr { u32 cnt, has_empty, nstash, full, dups, empties, novf, pad1; u64 pad[1]; u64 stash[CK_STASH]; };
 
 template <typename Hdr>
 __device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, Hdr* hdr, u64 key) {
@@ -482,6 +482,31 @@ __device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, Hdr* hdr,
     if (sidx < CK_STASH) hdr->stash[sidx] = key; else hdr->full = 1;
 }
 
+// Two-phase build (the resident kernels).  A 64-bit returning LDS exchange costs a wave-instruction ~64 LDS cycles whatever
+// the number of active lanes, and at load 0.37 nine in ten inserts only need an EMPTY candidate slot: phase 1 claims one
+// with a 32-bit atomic OR on a slot bitmap and stores the key with a plain write; a key that finds both candidates taken
+// goes to a dense overflow list (unless a copy of it is already visible: a duplicate, dropped as hash_join.cpp:125 does).
+// After a barrier - every phase-1 store has landed - phase 2 runs the evicting insert over the list only: full waves instead
+// of a few lanes per wave.  tools/ubench: 3052 keys 8.0 -> 4.8 us per table, 3950 keys 16 -> 8.6 us.  A duplicated key may
+// end up stored twice (both candidates) as before; a list overflow (heavy duplication racing the stores) reports a full table.
+constexpr u32 CK_OVF = 1024;
+template <typename Hdr>
+__device__ __forceinline__ void cuckoo_claim(u64* __restrict__ tkeys, u32* __restrict__ bits, u64* __restrict__ ovf, Hdr* hdr, u64 key) {
+    const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+    const u32 o1 = atomicOr(&bits[l1 >> 5], 1u << (l1 & 31));
+    if (!((o1 >> (l1 & 31)) & 1u)) { tkeys[l1] = key; return; }
+    const u32 o2 = atomicOr(&bits[l2 >> 5], 1u << (l2 & 31));
+    if (!((o2 >> (l2 & 31)) & 1u)) { tkeys[l2] = key; return; }
+    if (tkeys[l1] == key || tkeys[l2] == key) { hdr->dups = 1; return; }
+    const u32 i = atomicAdd(&hdr->novf, 1u);
+    if (i < CK_OVF) ovf[i] = key; else hdr->full = 1;
+}
+template <int NT, typename Hdr>
+__device__ __forceinline__ void cuckoo_finish(u64* __restrict__ tkeys, const u64* __restrict__ ovf, Hdr* hdr, u32 tid) {   // after the barrier
+    const u32 n = hdr->novf < CK_OVF ? hdr->novf : CK_OVF;
+    for (u32 i = tid; i < n; i += NT) cuckoo_insert(tkeys, hdr, ovf[i]);
+}
+
 template <int NT, bool LIST>
 __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -489,6 +514,8 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(CkHdr));
     u32* pm = reinterpret_cast<u32*>(tkeys + S);
     u32* bm = pm + JP_META;
+    u32* bits = bm + JB_META;                                // slot bitmap of the two-phase build
+    u64* ovf = reinterpret_cast<u64*>(bits + S / 32);        // its overflow list
     const u32 tid = threadIdx.x, lane = tid & 63;
     FJ_STAMP(0);
     // work item -> (partition p, probe chunk-list range [p0 + s_lo, p0 + s_hi))
@@ -565,7 +592,8 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
     u32 nbb = nbc < JB_META ? nbc : JB_META;
     if (tid < nbb) bm[tid] = chunk_entry(a.build, b0 + tid);
     for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
-    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->empties = 0; }
+    if (tid < S / 32) bits[tid] = 0;
+    if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->empties = 0; hdr->novf = 0; }
     __syncthreads();
     FJ_STAMP(1);
     u64 ka[8], kb[8];
@@ -589,12 +617,14 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
             for (u32 j = 0; j < BKPT; ++j) {
                 if (bok & (1u << j)) {
                     if (bk[j] == FJ_EMPTY_KEY) { hdr->has_empty = 1; if (a.want_dups && atomicAdd(&hdr->empties, 1u) > 0) hdr->dups = 1; }
-                    else if (!(a.dbg_flags & 2u)) cuckoo_insert(tkeys, hdr, bk[j]);
+                    else if (!(a.dbg_flags & 2u)) cuckoo_claim(tkeys, bits, ovf, hdr, bk[j]);
                 }
             }
         }
     }
     FJ_STAMP(2);
+    __syncthreads();                                 // phase-1 stores have landed
+    cuckoo_finish<NT>(tkeys, ovf, hdr, tid);
     __syncthreads();
     FJ_STAMP(3);
     if (hdr->full) {                                 // stash overflow: the item is redone with the tagged table (fj_launch_lds_join_retry)
@@ -688,6 +718,8 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
     u32* pm0 = reinterpret_cast<u32*>(tkeys + S);          // [2][JP_META] probe-side list entries
     u32* bm0 = pm0 + 2 * JP_META;                            // [2][JB_META] build-side list entries
     u32* s_next = bm0 + 2 * JB_META;                         // [2] item ids handed out by the global counter
+    u32* bits = s_next + 4;                                  // slot bitmap of the two-phase build
+    u64* ovf = reinterpret_cast<u64*>(bits + S / 32);        // its overflow list
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 nitems = *a.nitems_dev;                       // chunk-list inputs only: items come from the item table
     constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
@@ -729,7 +761,8 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
     };
     auto reset_table = [&]() {
         for (u32 i = tid; i < S; i += NT) tkeys[i] = FJ_EMPTY_KEY;
-        if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->empties = 0; }
+        if (tid < S / 32) bits[tid] = 0;
+        if (tid == 0) { hdr->cnt = 0; hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->empties = 0; hdr->novf = 0; }
     };
 
     // ---- prologue: first item (static), its list entries, its first build batch ----
@@ -776,12 +809,14 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
                     for (u32 j = 0; j < BKPT; ++j) {
                         if (bok & (1u << j)) {
                             if (bk[j] == FJ_EMPTY_KEY) { hdr->has_empty = 1; if (a.want_dups && atomicAdd(&hdr->empties, 1u) > 0) hdr->dups = 1; }
-                            else cuckoo_insert(tkeys, hdr, bk[j]);
+                            else cuckoo_claim(tkeys, bits, ovf, hdr, bk[j]);
                         }
                     }
                 }
             }
         }
+        __syncthreads();                                     // phase-1 stores have landed
+        if (lv) cuckoo_finish<NT>(tkeys, ovf, hdr, tid);
         __syncthreads();                                     // table complete; s_next[buf] visible
         // ---- P1: request the next item's list entries ----
         const Desc dn = describe(__builtin_amdgcn_readfirstlane(s_next[buf]));   // uniform: keeps the descriptor in SGPRs
@@ -895,7 +930,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
 // A table whose stash overflows marks its item (part_count = FJ_ITEM_RETRY, FJ_STAT_EMIT_RETRY) and
 // the host runs the tagged kernel over the marked items.  Resident workgroups with next-item prefetch as in
 // fj_count_join_persistent; output positions = scanned per-item offsets + an LDS cursor bumped once per wave and 4 key slots.
-struct EkHdr { u32 has_empty, nstash, full, dups, cursor, pad1[3]; u64 empty_val; u64 pad2; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
+struct EkHdr { u32 has_empty, nstash, full, dups, cursor, novf, pad1[2]; u64 empty_val; u64 pad2; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
 
 // DEDUP (the counting pass saw duplicate build keys): the build "values" are original row indices, every copy of a key
 // lowers its slot's index with an LDS atomic minimum, and the winners are turned into values with one gather from the
@@ -909,6 +944,8 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
     u32* pm0 = reinterpret_cast<u32*>(tvals + S);           // [2][JP_META] probe-side list entries
     u32* bm0 = pm0 + 2 * JP_META;                            // [2][JB_META] build-side list entries
     u32* s_next = bm0 + 2 * JB_META;                         // [2] item ids handed out by the global counter
+    u32* bits = s_next + 4;                                  // slot bitmap of the two-phase build
+    u64* ovf = reinterpret_cast<u64*>(bits + S / 32);        // its overflow list
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 nitems = *a.nitems_dev;
     constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
@@ -954,7 +991,8 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
     auto reset_table = [&]() {
         for (u32 i = tid; i < S; i += NT) { tkeys[i] = FJ_EMPTY_KEY; if (DEDUP) tvals[i] = ~0ull; }
         if (DEDUP && tid < CK_STASH) hdr->stash_val[tid] = ~0ull;
-        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->empty_val = DEDUP ? ~0ull : 0ull; }
+        if (tid < S / 32) bits[tid] = 0;
+        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->novf = 0; hdr->empty_val = DEDUP ? ~0ull : 0ull; }
     };
     // step 2: the value of build row (key, val) goes where the key lives now (table before stash, first location before the
     // second: the order the probe uses).  DEDUP: val is the row index, the smallest one stays.
@@ -1015,12 +1053,14 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                     for (u32 j = 0; j < BKPT; ++j) {
                         if (bok & (1u << j)) {
                             if (bk[j] == FJ_EMPTY_KEY) hdr->has_empty = 1;
-                            else cuckoo_insert(tkeys, hdr, bk[j]);
+                            else cuckoo_claim(tkeys, bits, ovf, hdr, bk[j]);
                         }
                     }
                 }
             }
         }
+        __syncthreads();                                     // phase-1 stores have landed
+        if (lv) cuckoo_finish<NT>(tkeys, ovf, hdr, tid);
         __syncthreads();                                     // keys are final; s_next[buf] visible
         // ---- P1: request the next item's list entries ----
         const Desc dn = describe(__builtin_amdgcn_readfirstlane(s_next[buf]));   // uniform: keeps the descriptor in SGPRs
@@ -1455,7 +1495,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
     if (materialize) {
         // chunk lists on both sides, unique build keys: the cuckoo form (resident workgroups, one per CU, next item prefetched)
         if (a.build.list && a.probe.list && a.items && next_item && nb >= persistent_min_items && !a.dbg && !(a.dbg_flags & ~8u)) {
-            const u32 ldsp = sizeof(EkHdr) + 2 * S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
+            const u32 ldsp = sizeof(EkHdr) + 2 * S * 8 + 2 * (JP_META + JB_META) * 4 + 16 + S / 8 + CK_OVF * 8;
             auto pk = a.dedup ? fj_emit_join_persistent<1024, true> : fj_emit_join_persistent<1024, false>;
             hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
             if (e != hipSuccess) return e;
@@ -1469,12 +1509,12 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(1024), lds, s, a);
     } else {
-        const u32 lds = sizeof(CkHdr) + S * 8 + (JP_META + JB_META) * 4;
+        const u32 lds = sizeof(CkHdr) + S * 8 + (JP_META + JB_META) * 4 + S / 8 + CK_OVF * 8;
         const bool lists = a.build.list && a.probe.list;
         // many items: resident workgroups that prefetch the next item's lists and build keys (join -3 % at c3, -3.5 % at
         // 262144 items); few items (c2: 2048): one workgroup per item balances better
         if (lists && next_item && nb >= persistent_min_items && !a.dbg && !a.dbg_flags) {
-            const u32 ldsp = sizeof(CkHdr) + S * 8 + 2 * (JP_META + JB_META) * 4 + 16;
+            const u32 ldsp = sizeof(CkHdr) + S * 8 + 2 * (JP_META + JB_META) * 4 + 16 + S / 8 + CK_OVF * 8;
             auto pk = fj_count_join_persistent<512>;
             hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
             if (e != hipSuccess) return e;
