@@ -482,12 +482,12 @@ __device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, Hdr* hdr,
     if (sidx < CK_STASH) hdr->stash[sidx] = key; else hdr->full = 1;
 }
 
-// Two-phase build (the resident kernels).  A 64-bit returning LDS exchange costs a wave-instruction ~64 LDS cycles whatever
-// the number of active lanes, and at load 0.37 nine in ten inserts only need an EMPTY candidate slot: phase 1 claims one
-// with a 32-bit atomic OR on a slot bitmap and stores the key with a plain write; a key that finds both candidates taken
-// goes to a dense overflow list (unless a copy of it is already visible: a duplicate, dropped as hash_join.cpp:125 does).
-// After a barrier - every phase-1 store has landed - phase 2 runs the evicting insert over the list only: full waves instead
-// of a few lanes per wave.  tools/ubench: 3052 keys 8.0 -> 4.8 us per table, 3950 keys 16 -> 8.6 us.  A duplicated key may
+// Two-phase build.  An evicting insert is a chain of dependent LDS operations (~100 clocks each, tools/ubench_lds_atomics)
+// and a wave stays in its loop until its unluckiest lane is done, while at load 0.37 nine in ten inserts only need an EMPTY
+// candidate slot: phase 1 claims one with a 32-bit atomic OR on a slot bitmap and stores the key with a plain write (no
+// loop: a thread's keys overlap); a key that finds both candidates taken goes to a dense overflow list (unless a copy of it
+// is already visible: a duplicate, dropped as hash_join.cpp:125 does).  After a barrier - every phase-1 store has landed -
+// phase 2 runs the evicting insert over the list only: full waves, a tenth of the keys.  tools/ubench: 3052 keys 8.0 -> 4.8 us per table, 3950 keys 16 -> 8.6 us.  A duplicated key may
 // end up stored twice (both candidates) as before; a list overflow (heavy duplication racing the stores) reports a full table.
 constexpr u32 CK_OVF = 1024;
 template <typename Hdr>
