@@ -631,7 +631,7 @@ hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
 
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
 hipError_t launch_part(const FjPartArgs& a, u32 grid, hipStream_t s) {
-    if constexpr (!HAS_VALS && NT == 512) {
+    if constexpr (!HAS_VALS) {
         if (a.side == 0) return launch_part1<NT, KPT, LINE_LOG, HAS_VALS, FLAT, false>(a, grid, s);
     }
     return launch_part1<NT, KPT, LINE_LOG, HAS_VALS, FLAT, true>(a, grid, s);
@@ -668,11 +668,11 @@ hipError_t fj_set_max_lds_once(const void* fn, u32 bytes) {
 
 u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
     const u32 F = 1u << fan_log;
-    if (vals) return part_lds_layout(512 * 4, F, 1u << line_log, true, 8).total;
-    return part_lds_layout(512 * 8, F, 1u << line_log, false, 8).total;
+    if (vals) return part_lds_layout(1024 * 4, F, 1u << line_log, true, 16).total;
+    return part_lds_layout(1024 * 8, F, 1u << line_log, false, 16).total;
 }
 
-u32 fj_partition_tile_chunks(u32 fan_log, bool vals) { return (fan_log == 9 && !vals) ? 32u : 16u; }
+u32 fj_partition_tile_chunks(u32 fan_log, bool vals) { (void)fan_log; return vals ? 16u : 32u; }
 
 // One partition pass.  Tiles are 4096 rows (512 threads x 8 keys, or 1024 threads x 4 rows with values); the
 // keys-only 512-bucket pass takes 8192-key tiles (it is alone on its CU: half as many barriers per key).
@@ -683,13 +683,16 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
         // 512 buckets: one bucket per thread needs >= 512 threads and the open lines take 64 KiB (keys) -- one
         // 1024-thread workgroup per CU; with values the lines shrink to 64 B so that both payloads still fit
         if (vals) return line_log == 3 ? launch_part2<1024, 4, true>(a, 3, grid, s) : hipErrorInvalidValue;
-        return launch_part2<1024, 8, false>(a, line_log, grid, s);
+        return launch_part2<1024, 8, false>(a, line_log, grid, s);     // (all 512 workgroups: capping them at 256 cost 2 % at c4)
     }
     if (vals) {
         // 1024 threads x 4 rows: one workgroup per CU (LDS), but 16 waves of it: 1.63 -> 1.42 ms build phase at c3
         return launch_part2<1024, 4, true>(a, line_log, grid, s);
     }
-    return launch_part2<512, 8, false>(a, line_log, grid, s);
+    // keys only: ONE 1024-thread workgroup per CU over 8192-key tiles (late round 2: 3.31 -> 3.22 ms per 1B-key pass against
+    // two 512-thread workgroups over 4096-key tiles, the shape of round 1; the per-tile costs - scan, descriptors, barriers -
+    // are paid half as often and 16 waves share one set of open lines)
+    return launch_part2<1024, 8, false>(a, line_log, grid < 256 ? grid : 256, s);
 }
 
 // After a pass, two launches: per-bucket chunk counts -> offsets (+ the consumer's tile offsets), then chunk lists
