@@ -389,10 +389,10 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
 # passes run while the build keys are on the wire.  The price is local: every rank partitions all N*B build keys.
 _LINK_BYTES_PER_S = 45e9          # one xGMI link, one direction, effective (153.6 GB/s bidirectional raw)
 # local work, measured on one MI355X (profiles/r01_replicate_local.txt; c3 = 100M x 1B rows per GPU):
-_PROBE_PASS_S_PER_ROW = 3.4e-12    # one probe-side partition pass
+_PROBE_PASS_S_PER_ROW = 3.25e-12   # one probe-side partition pass (3.1-3.3 ms per 1B rows, profiles/r02_c3_kernel_stats.csv)
 _BUILD_S_PER_ROW = 15e-12          # a build row's share of passes + table build, counting join (800M rows: 6.4 + 5.2 ms)
 _SPLIT_S_PER_ROW = 2.7e-12         # shuffle: owner histogram + the un-overlapped first owner scatter
-_JOIN_S_PER_ROW = 2.0e-12          # per-partition join, per probe row
+_JOIN_S_PER_ROW = 1.7e-12          # per-partition join, per probe row
 
 
 def _npass(bits: int) -> int:
