@@ -225,7 +225,7 @@ int get_zeroed_buf(fj_ctx* c, int slot, size_t bytes, void** out, hipStream_t s)
     return 0;
 }
 
-// passes for `bits` radix bits: one pass up to 9 bits (256 buckets, 128-B lines, two workgroups per CU; 512 buckets for
+// passes for `bits` radix bits: one pass up to 9 bits (256 buckets, 128-B lines, one 1024-thread workgroup per CU; 512 buckets for
 // exactly 9 bits: slower per row than an 8-bit pass, far cheaper than two passes), two passes up to 18 bits (8-bit passes
 // while they reach, a 9-bit pass beyond 16 bits), three beyond
 int plan_npass(int bits) { return bits <= FJ_MAX_FAN_LOG ? (bits > 0 ? 1 : 0) : (bits <= 2 * FJ_MAX_FAN_LOG ? 2 : (bits + FJ_MAX_FAN_LOG - 1) / FJ_MAX_FAN_LOG); }

@@ -674,8 +674,8 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log) {
 
 u32 fj_partition_tile_chunks(u32 fan_log, bool vals) { (void)fan_log; return vals ? 16u : 32u; }
 
-// One partition pass.  Tiles are 4096 rows (512 threads x 8 keys, or 1024 threads x 4 rows with values); the
-// keys-only 512-bucket pass takes 8192-key tiles (it is alone on its CU: half as many barriers per key).
+// One partition pass, one 1024-thread workgroup per CU: keys only 8192-key tiles (8 keys per thread; half as many barriers
+// and bucket scans per key as the 4096-key tiles of two 512-thread workgroups), with values 4096-row tiles (4 rows per thread).
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
     if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
     if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < 48 + (1u << a.fan_log)) return hipErrorInvalidValue;
