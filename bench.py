@@ -371,27 +371,11 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 8, "units_per_launch": np_gpu,
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": args.steps, "traffic": None}
 
-    # phase-level accounting with SURVEY 8(d)'s formula for the declared k.  The timed steps run the default schedule, in
-    # which the two relations' partition passes overlap (two streams) and a "build phase" is not a separate interval; the
-    # disjoint phases SURVEY defines are measured on a few extra steps with the serial schedule, outside the timed region.
+    # phase-level accounting with SURVEY 8(d)'s formula for the declared k
     k = lt["passes"]
     probe_ms, build_ms = mean(phase["probe_ms"]), mean(phase["build_ms"])
-    phase_schedule = "as timed" + (" (interleaved one-stream schedule: build_phase = the build relation's passes, probe_phase = the rest)" if lt.get("overlapped") == 2 else "")
+    phase_schedule = "as timed (build relation first, then the probe relation, one stream: disjoint phases)"
     serial_total_ms = None
-    if lt.get("overlapped") == 1 and world == 1 and not force_dist:
-        was = api.get_option("overlap_relations")
-        api.set_option("overlap_relations", 0)
-        try:
-            sb, sp, stot = [], [], []
-            for i in range(4):
-                api.join_device(algo, bloom, materialize, bk, bv, pk, return_arrays=False)
-                l2 = api.last_timings()
-                if i:                                   # first one re-warms
-                    sb.append(l2["build_phase_ms"]); sp.append(l2["probe_phase_ms"]); stot.append(l2["total_ms"])
-            build_ms, probe_ms, serial_total_ms = mean(sb), mean(sp), mean(stot)
-            phase_schedule = "serial schedule (overlap_relations=0), 3 extra steps after the timed region"
-        finally:
-            api.set_option("overlap_relations", was)
     phases = {
         "k_radix_passes": k, "radix_bits": lt["radix_bits"], "partitions": lt["partitions"], "path": lt["path"],
         "build_phase_ms": round(build_ms, 3), "probe_phase_ms": round(probe_ms, 3), "join_kernel_ms": round(mean(phase["join_ms"]), 3),
@@ -427,7 +411,7 @@ def main() -> None:
                                   + (" = the full 1B x 10B)" if world == 8 else ")") if args.workload == "c5" and args.scale == 1.0 else ""),
                    "function": fn_name, "build_rows_total": nb_total, "probe_rows_total": np_total,
                    "matches": exp_total, "bench_workload": args.workload,
-                   "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "overlap_relations", "interleave_relations", "persistent_min_items", "radix_threshold", "bloom_auto")},
+                   "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "persistent_min_items", "radix_threshold", "bloom_auto")},
                    "parallelism": f"{strategy_seen[0]} x{world}" if (world > 1 or force_dist) else "single GPU"},
         "build_time_ms": round(build_ms, 3),
         "phases": phases,

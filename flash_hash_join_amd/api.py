@@ -79,9 +79,10 @@ def workspace_bytes(device: Optional[int] = None) -> int:
 def trim_workspace(device: Optional[int] = None) -> None:
     """Give the cached workspace back to the device (tens of GB after a 1B-row join); contexts stay usable."""
     L = _lib.load()
-    for d, h in _ctxs.items():
+    for d, h in list(_ctxs.items()):
         if device is None or d == device:
-            check(L.fj_ctx_trim(h))
+            with _ctx_locks.setdefault(d, threading.RLock()):     # not between another thread's count and emit calls
+                check(L.fj_ctx_trim(h))
     check(L.fj_ctx_trim(None))                  # the context behind the NumPy entry
 
 

@@ -84,7 +84,7 @@ enum Slot {
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
 
-enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_SB0, E_SB1, E_FORK, E_BF0, E_BF1, E_H0, E_H1, E_H2, E_X0, E_X1, E_X2, E_X3, E_X4, E_X5, E_X6, E_X7, E_PK0, E_NEV = E_PK0 + 8 };
+enum Ev { E_START = 0, E_BUILD, E_PPART, E_JOIN, E_EMIT0, E_EMIT1, E_SB0, E_SB1, E_BF0, E_BF1, E_H0, E_H1, E_H2, E_PK0, E_NEV = E_PK0 + 8 };
 
 struct Pending {
     bool valid = false;
@@ -114,7 +114,7 @@ struct PassIter {
     // lists) and per-item count array are produced by the final level's bookkeeping launches
     bool want_items = false; u32 items_cap = 0; u32* part_count = nullptr;
     // bloom precheck (probe side): run the filter stage once `bloom_level` passes are complete, against bloom_build
-    bool bloom_done = false; const FjChunkSet* bloom_build = nullptr; bool bloom_wait_build = false;
+    bool bloom_done = false; const FjChunkSet* bloom_build = nullptr;
     const u32* bloom_prebuilt = nullptr;            // filters shipped by another GPU (sender-side precheck) instead of bloom_build's keys
     unsigned long long* bloom_bucket_keys = nullptr; // [buckets] survivors per bucket (for flattening the survivors)
     // build side: keep a copy of the level the probe side's filter will read
@@ -141,7 +141,7 @@ struct fj_ctx {
     int device = 0;
     Buf bufs[W_NSLOTS];
     hipEvent_t ev[E_NEV];
-    hipStream_t side = nullptr;        // the build relation's partition passes run here, beside the probe relation's
+    hipStream_t side = nullptr;        // copy stream of the host-buffer entry (fj_join_host)
     Scalars* d_sc = nullptr;
     Scalars* h_sc = nullptr;
     Pending pend;
@@ -151,7 +151,7 @@ struct fj_ctx {
     void* stage[3] = {nullptr, nullptr, nullptr};     // pinned staging ring of the host-buffer entry (fj_join_host)
     size_t stage_bytes = 0;
     bool plan_in_flight = false;       // a plan was begun and has not completed (an error in between leaves chunk counts behind)
-    bool zeros_dirty = false;          // ... in which case the next plan re-zeroes the self-cleaning buffers it uses
+    bool slot_dirty[W_NSLOTS] = {};    // ... in which case every self-cleaning buffer is re-zeroed IN FULL before its next use (get_zeroed_buf)
     std::recursive_mutex mu;           // one C-ABI call at a time per context (FJ_ENTER)
 };
 
@@ -161,12 +161,8 @@ namespace {
 //   radix_threshold  : adaptive joins take the non-partitioned HBM table below this many build rows.  MI355X: the
 //                      partitioned driver wins at every build size (<= 4096 rows it runs zero passes: one LDS table per
 //                      workgroup over the flat inputs), so the switch point is 0 (tools/sweep_adaptive.py).
-//   overlap_relations : one-shot partitioned joins partition the two relations one after the other on the caller's stream
-//                      (default: disjoint build / probe phase timings) or beside each other on two streams.  Round 1's
-//                      default was the two-stream schedule (it hid ~0.25 ms of bookkeeping launches: 9.42 -> 9.27 ms at c3);
-//                      with the bookkeeping fused into two launches per level there is little left to hide and the
-//                      contention costs more: 9.43 ms serial against 9.70 ms overlapped (3 alternating runs of 30 steps on
-//                      each of two boxes).
+//   (schedule: build relation first, then the probe relation, on the caller's stream.  The two-stream and interleaved
+//    schedules of rounds 1-2 were measured slower once the level bookkeeping was fused - EXPERIMENTS.md - and are gone.)
 //   persistent_min_items : counting joins with at least this many (partition, slice) items run the persistent join
 //                      kernel (resident workgroups that prefetch the next item); below it one workgroup per item.
 //   scalar_hbm_table : 1 = the reference's "scalar" functions (hash_join*, one table for the whole build side) use the
@@ -175,15 +171,13 @@ namespace {
 //                      per probe in HBM -- more traffic than the 40 B per probe the two streaming passes + LDS join
 //                      move -- so on this machine "scalar" is the slower way to the same result at every size.
 struct Options {
-    size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; int overlap_relations; u32 plan_target_keys;
-    int bloom_variant, bloom_overlap, bloom_auto, bloom_auto_max_hit_bp, interleave_relations;
+    size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; u32 plan_target_keys;
+    int bloom_variant, bloom_auto, bloom_auto_max_hit_bp;
     Options() {
-        interleave_relations = getenv("FJ_INTERLEAVE_RELATIONS") ? atoi(getenv("FJ_INTERLEAVE_RELATIONS")) : 0;
         bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
         bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2500;     // measured break-even at c4 sizes: 28 % hits (profiles/r02_bloom_threshold.csv)
-        bloom_overlap = getenv("FJ_BLOOM_OVERLAP") ? atoi(getenv("FJ_BLOOM_OVERLAP")) : 0;
         const char* bvr = getenv("FJ_BLOOM_VARIANT");
-        bloom_variant = bvr ? atoi(bvr) : 0;
+        bloom_variant = bvr ? (atoi(bvr) == 1 ? 1 : 0) : 0;
         const char* pt = getenv("FJ_PLAN_TARGET_KEYS");
         plan_target_keys = pt ? (u32)strtoul(pt, nullptr, 10) : FJ_PART_TARGET_KEYS;
         if (plan_target_keys < 16 || plan_target_keys > FJ_PART_TARGET_KEYS) plan_target_keys = FJ_PART_TARGET_KEYS;
@@ -193,8 +187,6 @@ struct Options {
         scalar_hbm_table = sg ? atoi(sg) : 0;
         const char* pm = getenv("FJ_PERSISTENT_MIN_ITEMS");
         persistent_min_items = pm ? (u32)strtoul(pm, nullptr, 10) : 8192u;
-        const char* ov = getenv("FJ_OVERLAP_RELATIONS");
-        overlap_relations = ov ? atoi(ov) : 0;
     }
 };
 Options& options() { static Options o; return o; }
@@ -215,13 +207,16 @@ int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
 
 
 // A buffer that is zero whenever nobody is using it: its consumer clears what it read (bucket chunk counts: fj_level_scan),
-// so a join needs no memset for it.  Zeroed here when it is (re)allocated, and when the previous join on this context did
-// not run to completion (c->zeros_dirty).
+// so a join needs no memset for it.  Zeroed here - the WHOLE allocation, not just the bytes this plan asks for: a later,
+// wider plan must not find what an abandoned one left behind - when it is (re)allocated, and when a plan on this context did
+// not run to completion since the slot was last cleared (slot_dirty, set for every slot by begin_plan, cleared per slot here).
 int get_zeroed_buf(fj_ctx* c, int slot, size_t bytes, void** out, hipStream_t s) {
     const size_t before = c->bufs[slot].bytes;          // (a re-allocation may well return the old address: compare sizes)
     if (get_buf(c, slot, bytes, out)) return 1;
-    if (c->bufs[slot].bytes != before) HIPCHK(hipMemsetAsync(*out, 0, c->bufs[slot].bytes, s));
-    else if (c->zeros_dirty) HIPCHK(hipMemsetAsync(*out, 0, bytes ? bytes : 16, s));
+    if (c->bufs[slot].bytes != before || c->slot_dirty[slot]) {
+        HIPCHK(hipMemsetAsync(*out, 0, c->bufs[slot].bytes, s));
+        c->slot_dirty[slot] = false;
+    }
     return 0;
 }
 
@@ -443,7 +438,6 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs; a.err = &c->d_sc->err; a.survivors = &c->d_sc->bloom_survivors;
     a.prebuilt = it.bloom_prebuilt; a.bucket_keys = it.bloom_bucket_keys;
     a.dbg_flags = getenv("FJ_BLOOM_ABLATE") ? (u32)atoi(getenv("FJ_BLOOM_ABLATE")) : 0u;
-    if (it.bloom_wait_build) HIPCHK(hipStreamWaitEvent(s, c->ev[E_BUILD], 0));      // the build relation is partitioned on the side stream
     HIPCHK(hipEventRecord(c->ev[E_BF0], s));
     HIPCHK(fj_launch_bloom_filter(a, G, options().bloom_variant, s));
     HIPCHK(hipEventRecord(c->ev[E_BF1], s));
@@ -480,7 +474,10 @@ int clear_plan_scalars(fj_ctx* c, hipStream_t s) {
 
 // Bracket of a partitioned plan: the self-cleaning buffers (get_zeroed_buf) are trusted only if the previous plan on this
 // context ran all its bookkeeping.  begin_plan before the first pass_prepare, end_plan once the result was read back.
-void begin_plan(fj_ctx* c) { c->zeros_dirty = c->plan_in_flight; c->plan_in_flight = true; }
+void begin_plan(fj_ctx* c) {
+    if (c->plan_in_flight) for (bool& d : c->slot_dirty) d = true;
+    c->plan_in_flight = true;
+}
 void end_plan(fj_ctx* c) { c->plan_in_flight = false; }
 
 int read_scalars(fj_ctx* c, hipStream_t s) {
@@ -627,7 +624,7 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
 
 // launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
 int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, const PassIter& pit, hipStream_t s,
-                    fj_timings* t, int evc, u64* out_count, bool* lds_full, bool overlapped = false) {
+                    fj_timings* t, int evc, u64* out_count, bool* lds_full) {
     ja.nparts = 1u << plan.bits;
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
     void* p;
@@ -670,14 +667,12 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
     end_plan(c);                              // every prepared pass ran its bookkeeping: the self-cleaning buffers are clean
     t->path = 0; t->passes = plan.npass; t->radix_bits = plan.bits; t->partitions = ja.nparts;
-    // one-shot joins: build_phase_ms = wall interval of the build relation's passes, which run BESIDE the probe relation's
-    // passes; probe_phase_ms = wall interval from the first probe-side pass to the end of the join (it contains the
-    // overlapped build work: the conservative attribution).  Streamed joins overwrite both in fj_stream_finish.
-    t->build_phase_ms = ev_ms(c, overlapped ? E_FORK : E_START, E_BUILD);
+    // one-shot joins: build_phase_ms = the build relation's passes, probe_phase_ms = first probe-side pass .. end of the join
+    // (disjoint intervals of one stream).  Streamed joins overwrite both in fj_stream_finish.
+    t->build_phase_ms = ev_ms(c, E_START, E_BUILD);
     t->join_ms = ev_ms(c, E_PPART, E_JOIN);
-    t->probe_phase_ms = ev_ms(c, overlapped ? E_FORK : E_BUILD, E_JOIN);
+    t->probe_phase_ms = ev_ms(c, E_BUILD, E_JOIN);
     t->total_ms = ev_ms(c, E_START, E_JOIN);
-    t->overlapped = overlapped ? 1 : 0;
     for (int i = 0; i < evc && i < 4; ++i) t->probe_part_kernel_ms[i] = ev_ms(c, E_PK0 + 2 * i, E_PK0 + 2 * i + 1);
     t->bloom_level = plan.bloom_level;
     if (plan.bloom_level > 0) { t->filter_ms = ev_ms(c, E_BF0, E_BF1); t->filter_survivors = c->h_sc->bloom_survivors; }
@@ -711,105 +706,32 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     // a counting join never looks at a value: its build side moves keys only (half the build-phase bytes)
     pass_init(bit, 0, materialize != 0, nb, plan, top_bits);
     int evc = 0;
-    bool overlap = options().overlap_relations != 0;
-    // bloom plans: the filter stage needs the whole build side, and a build relation squeezed in beside the 1024-thread
-    // first probe pass finishes late (measured: 9.5 ms overlapped against 8.4 ms one after the other at c4): build first
-    if (plan.bloom_level > 0 && !options().bloom_overlap) overlap = false;
     if (plan.bloom_level > 0) bit.save_level = plan.bloom_level;
+    // build relation first, then the probe relation, on the caller's stream (the build-side filter of a bloom plan needs
+    // the whole build side anyway)
+    if (run_passes(c, bit, bk, materialize ? bv : nullptr, s, &ja.build, nullptr)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+    Plan pplan = plan;
     if (bloom == 2) {
-        // Decide from a sample.  The build relation is partitioned first, with the filterable plan (its final partitions
-        // are the same under either plan: digits are consecutive hash bits); FJ_SAMPLE_KEYS probe rows, evenly spaced, are
-        // looked up in their final build partitions (a wave scans the partition's ~3000 keys: 25 MB of reads in all); the
-        // host reads the hit count and picks the probe side's plan.  Costs the overlap of the two relations and ~50 us.
-        if (run_passes(c, bit, bk, materialize ? bv : nullptr, s, &ja.build, nullptr)) return 1;
-        HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
+        // Decide from a sample.  The build relation was partitioned with the filterable plan (its final partitions are the
+        // same under either plan: digits are consecutive hash bits); FJ_SAMPLE_KEYS probe rows, evenly spaced, are looked
+        // up in their final build partitions (a wave scans the partition's ~3000 keys: 25 MB of reads in all); the host
+        // reads the hit count and picks the probe side's plan (~50 us).
         const u32 nsamp = FJ_SAMPLE_KEYS;
         HIPCHK(fj_launch_sample_hits(ja.build, pk, np, nsamp, (u32)(top_bits - 32 - plan.bits), (1u << plan.bits) - 1u, &c->d_sc->sample_hits, s));
         HIPCHK(hipMemcpyAsync(&c->h_sc->sample_hits, &c->d_sc->sample_hits, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const u32 hit_bp = (u32)(c->h_sc->sample_hits * 10000ull / nsamp);
         t->sampled_hit_bp = (int)hit_bp;
-        Plan pplan = plan;
-        const bool on = hit_bp <= (u32)options().bloom_auto_max_hit_bp;
-        if (!on) { pplan = make_plan(nb, top_bits, false); plan.bloom_level = 0; }
-        pass_init(pit, 1, false, np, pplan, top_bits);
-        pit.want_items = true;
-        if (on) { pit.bloom_build = &bit.saved; pit.bloom_wait_build = false; }
-        if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
-        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-        plan.npass = pplan.npass;
-        if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, false)) return 1;
-        if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
-        return 0;
+        if (hit_bp > (u32)options().bloom_auto_max_hit_bp) { pplan = make_plan(nb, top_bits, false); plan.bloom_level = 0; plan.npass = pplan.npass; }
     }
-    pass_init(pit, 1, false, np, plan, top_bits);
+    pass_init(pit, 1, false, np, pplan, top_bits);
     pit.want_items = true;
-    bool interleaved = false;
-    if (plan.bloom_level > 0) {
-        // bloom precheck: the probe side's level `bloom_level` is filtered against the build side's same level
-        pit.bloom_build = &bit.saved; pit.bloom_wait_build = overlap;
-    }
-    if (overlap && plan.bloom_level > 0 && options().bloom_overlap) {
-        // as below, but the build relation is enqueued first: the filter stage needs its level descriptor on the host
-        HIPCHK(hipEventRecord(c->ev[E_FORK], s));
-        HIPCHK(hipStreamWaitEvent(c->side, c->ev[E_FORK], 0));
-        if (run_passes(c, bit, bk, materialize ? bv : nullptr, c->side, &ja.build, nullptr)) return 1;
-        HIPCHK(hipEventRecord(c->ev[E_BUILD], c->side));
-        if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
-        HIPCHK(hipStreamWaitEvent(s, c->ev[E_BUILD], 0));
-        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-    } else if (overlap) {
-        // The two relations are partitioned on two streams: their passes do not depend on each other, and the small
-        // bookkeeping kernels between the passes of one relation (scans, list build, tile table: ~0.25 ms during which
-        // HBM idles) run while the other relation's pass streams (c3: 9.42 -> 9.20 ms).  The join waits for both.
-        HIPCHK(hipEventRecord(c->ev[E_FORK], s));
-        HIPCHK(hipStreamWaitEvent(c->side, c->ev[E_FORK], 0));
-        if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
-        if (run_passes(c, bit, bk, materialize ? bv : nullptr, c->side, &ja.build, nullptr)) return 1;
-        HIPCHK(hipEventRecord(c->ev[E_BUILD], c->side));
-        HIPCHK(hipStreamWaitEvent(s, c->ev[E_BUILD], 0));
-        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-    } else if (options().interleave_relations && plan.bloom_level == 0 && plan.npass >= 1 && plan.npass <= 2) {
-        // Interleaved schedule (option; measured and not kept as the default: the build pass slows down by what the
-        // bookkeeping beside it costs - c3 9.41-9.45 ms against 9.38-9.39 ms build-first, three alternating runs of 30
-        // steps on one box): the streaming passes of both relations run one after the other on the caller's
-        // stream, but the bookkeeping of a probe-side level (scan + chunk lists of ~4M chunks: 80-90 us during which HBM
-        // idles) runs on the side stream under the build relation's pass of the same depth:
-        //   probe pass i | build pass i + its bookkeeping  ||  probe level i bookkeeping   (i = 0 .. npass-1), then the join.
-        // Unlike the two-stream schedule no two streaming kernels ever compete.
-        interleaved = true;
-        for (int i = 0; i < plan.npass; ++i) {
-            if (pass_prepare(c, pit, 1, s)) return 1;
-            if (pass_launch(c, pit, pk, nullptr, pit.n, s, &evc)) return 1;
-            HIPCHK(hipEventRecord(c->ev[E_X0 + 2 * i], s));
-            HIPCHK(hipStreamWaitEvent(c->side, c->ev[E_X0 + 2 * i], 0));
-            if (pass_complete(c, pit, c->side)) return 1;
-            HIPCHK(hipEventRecord(c->ev[E_X1 + 2 * i], c->side));
-            HIPCHK(hipEventRecord(c->ev[E_X4 + 2 * i], s));                      // build pass i: [E_X4+2i, E_X5+2i]
-            if (pass_prepare(c, bit, 1, s)) return 1;
-            if (pass_launch(c, bit, bk, materialize ? bv : nullptr, bit.n, s, nullptr)) return 1;
-            if (pass_complete(c, bit, s)) return 1;
-            HIPCHK(hipEventRecord(c->ev[E_X5 + 2 * i], s));
-            HIPCHK(hipStreamWaitEvent(s, c->ev[E_X1 + 2 * i], 0));
-        }
-        ja.build = bit.prev; ja.probe = pit.prev;
-        HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
-        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-    } else {
-        if (run_passes(c, bit, bk, materialize ? bv : nullptr, s, &ja.build, nullptr)) return 1;
-        HIPCHK(hipEventRecord(c->ev[E_BUILD], s));
-        if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
-        HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-    }
-
-    if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, overlap)) return 1;
-    if (interleaved) {
-        // the build relation's passes are the intervals [E_X4+2i, E_X5+2i]; everything else on the stream touches probe rows
-        t->build_phase_ms = 0;
-        for (int i = 0; i < plan.npass; ++i) t->build_phase_ms += ev_ms(c, E_X4 + 2 * i, E_X5 + 2 * i);
-        t->probe_phase_ms = t->total_ms - t->build_phase_ms;
-        t->overlapped = 2;
-    }
+    // bloom precheck: the probe side's level `bloom_level` is filtered against the build side's same level
+    if (plan.bloom_level > 0) pit.bloom_build = &bit.saved;
+    if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
+    HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+    if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full)) return 1;
     if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
     return 0;
 }
@@ -879,12 +801,10 @@ int fj_set_option(const char* name, long long value) {
     if (!name) return set_err("fj_set_option: null name");
     if (!strcmp(name, "radix_threshold")) { if (value < 0) return set_err("fj_set_option: radix_threshold must be >= 0"); options().radix_threshold = (size_t)value; return 0; }
     if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
-    if (!strcmp(name, "overlap_relations")) { options().overlap_relations = value != 0; return 0; }
     if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); options().plan_target_keys = (u32)value; return 0; }
     if (!strcmp(name, "bloom_auto")) { options().bloom_auto = value != 0; return 0; }
-    if (!strcmp(name, "interleave_relations")) { options().interleave_relations = value != 0; return 0; }
     if (!strcmp(name, "bloom_auto_max_hit_bp")) { if (value < 0 || value > 10000) return set_err("fj_set_option: bloom_auto_max_hit_bp must be 0..10000"); options().bloom_auto_max_hit_bp = (int)value; return 0; }
-    if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); options().bloom_variant = (int)value; return 0; }
+    if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 1) return set_err("fj_set_option: bloom_variant must be 0 or 1"); options().bloom_variant = (int)value; return 0; }
     if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
     return set_err("fj_set_option: unknown option '%s'", name);
 }
@@ -893,11 +813,9 @@ long long fj_get_option(const char* name) {
     if (name && !strcmp(name, "radix_threshold")) return (long long)options().radix_threshold;
     if (name && !strcmp(name, "scalar_hbm_table")) return options().scalar_hbm_table;
     if (name && !strcmp(name, "persistent_min_items")) return options().persistent_min_items;
-    if (name && !strcmp(name, "overlap_relations")) return options().overlap_relations;
     if (name && !strcmp(name, "plan_target_keys")) return options().plan_target_keys;
     if (name && !strcmp(name, "bloom_variant")) return options().bloom_variant;
     if (name && !strcmp(name, "bloom_auto")) return options().bloom_auto;
-    if (name && !strcmp(name, "interleave_relations")) return options().interleave_relations;
     if (name && !strcmp(name, "bloom_auto_max_hit_bp")) return options().bloom_auto_max_hit_bp;
     set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
     return -1;
@@ -1327,6 +1245,7 @@ int fj_bloom_export(fj_ctx* c, const uint64_t* d_build_keys, size_t nb, int hash
     if (!d_filters || (nb && !d_build_keys) || ((uintptr_t)d_build_keys & 15) || ((uintptr_t)d_filters & 15)) return set_err("fj_bloom_export: null or misaligned pointer");
     FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
+    c->pend.valid = false;                                 // the passes below reuse the chunk pools a pending emit would read
     const u32 nbuckets = 1u << FJ_PREFILTER_BITS;
     if (nb == 0) { HIPCHK(hipMemsetAsync(d_filters, 0, (size_t)nbuckets * FJ_BLOOM_WORDS * 4, s)); return 0; }   // empty filters reject everything
     Plan plan; plan.bits = FJ_PREFILTER_BITS; plan_passes(plan, true);
@@ -1355,6 +1274,7 @@ int fj_bloom_prefilter(fj_ctx* c, const uint64_t* d_probe_keys, size_t n, int ha
     if (n == 0) return 0;
     FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
+    c->pend.valid = false;                                 // the passes below reuse the chunk pools a pending emit would read
     Plan plan; plan.bits = FJ_PREFILTER_BITS; plan_passes(plan, true);
     plan.bloom_level = 1;
     begin_plan(c);
@@ -1554,6 +1474,10 @@ int fj_join_host(int algo, int bloom, int materialize,
     }
     fj_ctx* c = g_host_ctx;
     FJ_ENTER(c);
+    if (c->st.active) {            // an earlier streamed call failed between stream_open and fj_stream_finish: nobody else can
+        HIPCHK(hipDeviceSynchronize());   // abort a stream join on this internal context, so drop it here
+        c->st.active = false;
+    }
     void *dbk, *dbv, *dpk;
     if (get_buf(c, W_H_BK, nb * 8, &dbk) || get_buf(c, W_H_BV, nb * 8, &dbv) || get_buf(c, W_H_PK, np * 8, &dpk)) return 1;
     // pieces: >= 16 MiB (the ring's DMA and memcpy run at full rate), at most 48 of them for the probe side (the streamed

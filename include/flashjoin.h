@@ -51,9 +51,8 @@ typedef struct fj_timings {
     int radix_bits;              /* total partition bits                                       */
     int fell_back;               /* 1 if the radix path overflowed an LDS table and the global path re-ran */
     uint64_t partitions;
-    int overlapped;              /* 2: interleaved one-stream schedule (see "interleave_relations"); 1: the build relation's partition passes ran beside the probe relation's (two streams):
-                                    build_phase_ms is then the wall interval of the build passes INSIDE probe_phase_ms, and
-                                    probe_phase_ms spans from the first probe-side pass to the end of the join            */
+    int overlapped;              /* always 0: build_phase_ms and probe_phase_ms are disjoint intervals (the two-stream schedules of
+                                    rounds 1-2 are gone; the field keeps the struct layout)                              */
     int lds_retries;             /* 1 if some partitions overflowed the counting join's cuckoo table and were redone on the tagged table */
     /* bloom precheck of the partitioned plan (the *_bloom functions): */
     double filter_ms;            /* the filter kernel between the probe side's passes (part of probe_phase_ms)              */
@@ -81,15 +80,6 @@ const char* fj_version(void);
  *                        ONE table for the whole build side in HBM, as the reference does in DRAM; 0 (default): they
  *                        run the same partitioned plan as the radix functions (identical results, 2-4x faster here)
  *                        and the HBM table is only the overflow fallback (env FJ_SCALAR_HBM_TABLE).
- *   "overlap_relations" - 0 (default): build relation first, then probe relation, one stream - build_phase_ms and
- *                        probe_phase_ms are disjoint; 1: one-shot partitioned joins run the two relations' partition passes
- *                        on two streams (the join waits for both) - measured slower since the per-level bookkeeping was
- *                        fused into two launches (env FJ_OVERLAP_RELATIONS).
- *   "interleave_relations" - 0 (default): build relation, then probe relation.  1: within the one-stream schedule the probe relation's pass i runs before the build
- *                        relation's pass i, whose streaming hides the probe level's bookkeeping launches (they run on a
- *                        second stream; no two streaming kernels overlap); build_phase_ms = the build passes' intervals,
- *                        probe_phase_ms = the rest, fj_timings.overlapped = 2 - measured no faster than
- *                        build-first (env FJ_INTERLEAVE_RELATIONS).  Plans with a bloom precheck or three passes always run build first.
  *   "persistent_min_items" - counting joins whose plan has at least this many (partition, probe slice) work items use
  *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
  *   "bloom_auto"       - 1 (default): the adaptive_* functions decide on the bloom precheck of the partitioned plan from a

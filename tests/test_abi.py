@@ -127,13 +127,16 @@ def test_dispatch_options_round_trip(lib):
     """fj_set_option / fj_get_option are host-only: defaults, round trip, unknown names and bad values are errors."""
     from flash_hash_join_amd import api
     assert api.get_option("radix_threshold") == 0 and api.get_option("scalar_hbm_table") == 0
-    assert api.get_option("persistent_min_items") == 8192 and api.get_option("overlap_relations") == 0
+    assert api.get_option("persistent_min_items") == 8192
     assert api.get_option("bloom_auto") == 1 and api.get_option("bloom_auto_max_hit_bp") == 2500 and api.get_option("plan_target_keys") == 4096
     try:
         api.set_option("radix_threshold", 123456); assert api.get_option("radix_threshold") == 123456
         api.set_option("scalar_hbm_table", 7); assert api.get_option("scalar_hbm_table") == 1
         api.set_option("persistent_min_items", 0); assert api.get_option("persistent_min_items") == 0
-        api.set_option("overlap_relations", 1); assert api.get_option("overlap_relations") == 1
+        with pytest.raises(RuntimeError, match="unknown option"):
+            api.set_option("overlap_relations", 1)          # the two-stream schedule of rounds 1-2 is gone
+        with pytest.raises(RuntimeError, match="bloom_variant"):
+            api.set_option("bloom_variant", 2)
         api.set_option("bloom_auto", 0); assert api.get_option("bloom_auto") == 0
         api.set_option("plan_target_keys", 64); assert api.get_option("plan_target_keys") == 64
         with pytest.raises(RuntimeError, match="plan_target_keys"):
@@ -145,7 +148,7 @@ def test_dispatch_options_round_trip(lib):
         with pytest.raises(KeyError):
             api.get_option("no_such_option")
     finally:
-        api.set_option("radix_threshold", 0); api.set_option("scalar_hbm_table", 0); api.set_option("persistent_min_items", 8192); api.set_option("overlap_relations", 0)
+        api.set_option("radix_threshold", 0); api.set_option("scalar_hbm_table", 0); api.set_option("persistent_min_items", 8192)
         api.set_option("bloom_auto", 1); api.set_option("plan_target_keys", 4096)
 
 

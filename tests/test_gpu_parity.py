@@ -28,26 +28,21 @@ def fj():
     return flash_join
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "overlapped_relations", "deep_plans", "interleaved_relations"])
+@pytest.fixture(params=[0, 1, 2, 4], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "deep_plans"])
 def scalar_mode(request, fj):
     """Run a test under the dispatch variants of the native library: the hash_join* functions served by the partitioned
-    plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); and every
-    partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it); and the
-    two relations partitioned beside each other on two streams instead of one after the other on one (the default); and
+    plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); every
+    partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it); and
     "deep_plans": 32 build keys per final partition instead of 4096, so that the small inputs of these tests run the two-
     and three-pass plans -- and, in the *_bloom functions, the bloom precheck between the probe side's passes -- that
     production only takes for build sides above a million rows."""
     fj.set_option("plan_target_keys", 32 if request.param == 4 else 4096)
-    fj.set_option("interleave_relations", 1 if request.param == 5 else 0)       # probe level bookkeeping under the build passes
     fj.set_option("scalar_hbm_table", int(request.param == 1))
     fj.set_option("persistent_min_items", 0 if request.param == 2 else 8192)
-    fj.set_option("overlap_relations", 1 if request.param == 3 else 0)
     yield request.param
     fj.set_option("scalar_hbm_table", 0)
     fj.set_option("persistent_min_items", 8192)
-    fj.set_option("overlap_relations", 0)
     fj.set_option("plan_target_keys", 4096)
-    fj.set_option("interleave_relations", 0)
 
 
 def _digest(oracle, k, v):
@@ -1050,6 +1045,19 @@ def test_stream_join_rejects_misuse(fj):
     eng.stream_abort()                                                            # no-op when nothing is open
     assert fj.hash_join_count_radix(big_bk, big_bv, big_pk)[0] == big_exp
     assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp
+    # stale chunk counts of an abandoned plan must not reach a LATER plan that uses more of the self-cleaning buffers than the
+    # plan right after the abort did: abort a two-pass stream, run a small one-pass join (32 buckets), then wide / deep ones
+    eng.stream_begin(big_bk, big_bv, 2 * big_pk.numel(), 2, 64)
+    eng.stream_append(big_pk)
+    eng.stream_abort()
+    small_bk, small_bv = datagen.build_device(60_000, "cuda:0")
+    small_pk, small_exp = datagen.probe_device(500_000, 60_000, "cuda:0", seed=5, hit_bp=5000)
+    assert fj.hash_join_count_radix(small_bk, small_bv, small_pk)[0] == small_exp
+    mid_bk, mid_bv = datagen.build_device(1_000_000, "cuda:0")
+    mid_pk, mid_exp = datagen.probe_device(4_000_000, 1_000_000, "cuda:0", seed=6, hit_bp=5000)
+    assert fj.hash_join_count_radix(mid_bk, mid_bv, mid_pk)[0] == mid_exp                 # one 256-bucket pass
+    assert fj.hash_join_count_radix(big_bk, big_bv, big_pk)[0] == big_exp                 # two passes, both ping-pong slots
+    del small_bk, small_bv, small_pk, mid_bk, mid_bv, mid_pk
     # the multi-GPU driver aborts by itself when an engine call fails mid-stream
     import torch.distributed as dist
     import socket

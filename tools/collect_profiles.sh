@@ -13,7 +13,7 @@ for w in c3 c4 c3_mat c2 c2_hbm_table c4_hbm_table_bloom; do
   cp $(find gpurun_out/stats_${TAG}_$w -name "*kernel_stats.csv" | head -1) $O/${w}_kernel_stats.csv
   grep "^{\"metric" gpurun_out/stats_${TAG}_$w.log | tail -1 > $O/${w}_bench_under_rocprof.json
 done
-FJ_OVERLAP_RELATIONS=0 python tools/trace_timeline.py gpurun_out/stats_${TAG}_c3 > $O/c3_timeline.txt 2>&1
+python tools/trace_timeline.py gpurun_out/stats_${TAG}_c3 > $O/c3_timeline.txt 2>&1
 python tools/trace_timeline.py gpurun_out/stats_${TAG}_c4 > $O/c4_timeline.txt 2>&1
 python tools/trace_timeline.py gpurun_out/stats_${TAG}_c3_mat > $O/c3_mat_timeline.txt 2>&1
 python tools/traffic_json.py $O/c3_pmc_summary.txt $O/traffic_latest.json > /dev/null 2>&1
