@@ -117,9 +117,9 @@ def _host_cpu_facts() -> dict:
     return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cpus": len(aff), "affinity_mask": ",".join(ranges)}
 
 
-def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int) -> dict:
-    """Oracle restatement of the reference CPU path (hash_join.cpp:498-534 radix count), all host cores,
-    on a bounded sample of the same generator.  A reported baseline, not a target."""
+def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int, algo: str = "adaptive", budget_s: float = 25.0) -> dict:
+    """Oracle restatement of the reference CPU path (hash_join.cpp:498-534 radix count; algo="scalar": :536-567), all host
+    cores, on a bounded sample of the same generator.  A reported baseline, not a target."""
     import numpy as np
     from flash_hash_join_amd import datagen
     from oracle import oracle as O
@@ -132,13 +132,15 @@ def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int) -> dict:
     best = None
     t_all = time.perf_counter()
     for _ in range(3):                                   # bounded: stop after ~25 s of CPU runs
-        n, sec = O.c_join(hbk, hbv, hpk, algo="adaptive", bloom=False, materialize=False, threads=0)
+        n, sec = O.c_join(hbk, hbv, hpk, algo=algo, bloom=False, materialize=False, threads=0)
         assert n == exp, (n, exp)
         best = sec if best is None else min(best, sec)
-        if time.perf_counter() - t_all > 25:
+        if time.perf_counter() - t_all > budget_s:
             break
+    fn = {"adaptive": "adaptive_join_count (radix path)", "scalar": "hash_join_count (one table)", "radix": "hash_join_count_radix"}[algo]
     return {"value": round(sample_p / best / 1e9, 5), "unit": "Gprobes/s", "cores": int(cores), "kind": "port",
-            "sample": f"adaptive_join_count (radix path) restatement, {sample_b} build x {sample_p} probe rows, "
+            "core_seconds": round(best, 4),
+            "sample": f"{fn} restatement, {sample_b} build x {sample_p} probe rows, "
                       f"{hit_bp / 100:.0f}% hits, best of <=3, core_duration_sec={best:.3f}s",
             "hw_crc32c": bool(O.lib().fjo_uses_hw_crc()), **_host_cpu_facts()}
 
@@ -272,8 +274,28 @@ def main() -> None:
     units_per_launch = [float(np_gpu)]
     strategy_seen = ["single GPU"]
     part_ms, part_launches, phase = [], 0, {"build_ms": [], "probe_ms": [], "join_ms": [], "total_ms": [], "emit_ms": [], "filter_ms": []}
+    kern = {}                       # single GPU: kernel name -> [(launch ms, algorithmic bytes)] over the timed steps
     dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
     dlast = {}
+
+    def record_kernels(lt) -> None:
+        """Algorithmic HBM bytes of every timed kernel launch of one single-GPU join: a plain probe-side
+        pass reads and writes every key it is given (16 B); the bloom filter kernel reads every probe key, writes the
+        survivors and reads the level's build keys once (8 P + 8 S + 8 B); passes behind it see survivors only; the join reads its probe keys and the build keys once (+ 16 B per emitted pair in the emit pass)."""
+        P, B, S = float(np_gpu), float(nb_gpu), float(lt["filter_survivors"])
+        L = lt["bloom_level"]
+        for i in range(min(4, lt["passes"])):
+            ms = lt["probe_part_kernel_ms"][i]
+            if L and i >= L:
+                kern.setdefault("fj_partition_kernel<keys> over the filter's survivors", []).append((ms, 16 * S))
+            else:
+                kern.setdefault("fj_partition_kernel<keys> (probe-side radix pass)", []).append((ms, 16 * P))
+        if L:
+            kern.setdefault("fj_bloom_filter_kernel (bloom precheck between the probe-side passes)", []).append((lt["filter_ms"], 8 * P + 8 * S + 8 * B))
+        if lt["path"] == 0:
+            kern.setdefault("join kernel (per-partition LDS table build + probe)", []).append((lt["join_ms"], 8 * (S if L else P) + (16 if materialize else 8) * B))
+            if materialize and lt["emit_ms"] > 0:
+                kern.setdefault("emitting join kernel (second pass of a materialising join)", []).append((lt["emit_ms"], 8 * (S if L else P) + 16 * B + 16.0 * exp_local))
 
     def step(record: bool) -> int:
         nonlocal part_launches
@@ -289,7 +311,8 @@ def main() -> None:
         if record:
             lt = api.last_timings()
             if world == 1 and not force_dist:
-                npart = lt["passes"]                       # one launch per pass over all probe rows
+                npart = 0
+                record_kernels(lt)
             elif t.get("strategy") == "replicate":
                 npart = 1                                  # probe rows never move: one first-pass launch over all of them
                 units_per_launch[0] = t.get("local_probe_rows", np_gpu)
@@ -340,13 +363,25 @@ def main() -> None:
     # launch per pass over all of this rank's probe rows; its duration comes from HIP events recorded around
     # each launch on the join's stream (fj_timings.probe_part_kernel_ms).
     roof = None
-    if part_ms:
-        avg_ms = mean(part_ms)
-        alg_bytes = 16.0 * units_per_launch[0]
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    roof_all = None
+    if kern:
+        # single GPU: every timed kernel with its own bytes; the DOMINANT kernel is the one with the largest share of the step
+        rows = []
+        for name, xs in kern.items():
+            avg_ms = mean([x[0] for x in xs]); alg = mean([x[1] for x in xs])
+            per_step = len(xs) / args.steps
+            ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+            rows.append({"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(per_step, 2),
+                         "algorithmic_bytes_per_launch": alg, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)})
+        for r in rows:
+            if r["frac"] > 1.0 and not (os.environ.get("FJ_JOIN_ABLATE") or os.environ.get("FJ_BLOOM_ABLATE")):   # a kernel cannot beat the HBM peak on its own bytes: the accounting above must be wrong
+                raise SystemExit(f"bench.py: roofline accounting error, {r['kernel']} shows {r['frac']} of the HBM peak: {r}")
+        rows.sort(key=lambda r: -r["avg_launch_ms"] * r["launches_per_step"])
+        roof_all = rows
+        d = rows[0]
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp) and world == 1 and not force_dist and args.workload == "c3" and args.scale == 1.0:
+        if os.path.exists(tp) and args.workload == "c3" and args.scale == 1.0:
             try:      # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc.sh + tools/traffic_json.py), committed together
                       # with the hash of the kernel sources they measured: stale numbers (a kernel changed since) are not reported
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -355,18 +390,28 @@ def main() -> None:
                 traffic = tj.get("fj_partition_kernel_keys_bytes_per_launch") if tj.get("source_sha256") == kernel_source_hash() else None
             except Exception:
                 traffic = None
+        roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+                "frac_of_copy_ceiling": round(d["achieved"] / HBM_COPY_GBS, 4),
+                "frac_of_measured_scatter_ceiling": round(d["achieved"] / HBM_SCATTER_GBS, 4),
+                "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
+                "launches_timed": int(round(d["launches_per_step"] * args.steps)), "traffic": traffic}
+    elif part_ms:
+        # multi-GPU: the first probe-side pass over what this rank received (one launch per piece / per step)
+        avg_ms = mean(part_ms)
+        alg_bytes = 16.0 * units_per_launch[0]
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
                 "frac_of_measured_scatter_ceiling": round(achieved / HBM_SCATTER_GBS, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 16, "units_per_launch": units_per_launch[0],
-                "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": traffic}
+                "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": None}
     else:
-        # zero-pass / non-partitioned workloads: the join (probe) kernel dominates; 8 B per probe key
+        # non-partitioned workloads (one table in HBM): the probe kernel dominates; 8 B per probe key
         avg_ms = mean(phase["join_ms"])
         alg_bytes = 8.0 * np_gpu
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
-        roof = {"bound": "hbm", "kernel": "join kernel (no partition pass in this plan)", "achieved": round(achieved, 1),
+        roof = {"bound": "hbm", "kernel": "fj_gt_probe_kernel (one table in HBM)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 8, "units_per_launch": np_gpu,
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": args.steps, "traffic": None}
@@ -411,12 +456,14 @@ def main() -> None:
                                   + (" = the full 1B x 10B)" if world == 8 else ")") if args.workload == "c5" and args.scale == 1.0 else ""),
                    "function": fn_name, "build_rows_total": nb_total, "probe_rows_total": np_total,
                    "matches": exp_total, "bench_workload": args.workload,
-                   "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "persistent_min_items", "radix_threshold", "bloom_auto")},
+                   "options": {k: api.get_option(k) for k in ("scalar_hbm_table", "persistent_min_items", "radix_threshold", "bloom_auto", "bloom_variant")},
                    "parallelism": f"{strategy_seen[0]} x{world}" if (world > 1 or force_dist) else "single GPU"},
         "build_time_ms": round(build_ms, 3),
         "phases": phases,
         "roofline": roof,
     }
+    if roof_all:
+        out["roofline_kernels"] = roof_all
     if rank == 0 and world == 1 and not args.no_host_entry and not force_dist:
         try:
             del bk, bv, pk
@@ -442,6 +489,13 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
         except Exception as ex:      # the baseline never blocks the GPU measurement
             out["cpu_baseline"] = {"error": repr(ex)}
+        # "Configs 1-2 always" - the reference's own CPU-runnable cases (hash_join_count, one table),
+        # a few seconds each
+        for tag, cb, cp in (("cpu_baseline_c1", 1_000_000, 10_000_000), ("cpu_baseline_c2", 1_000_000, 100_000_000)):
+            try:
+                out[tag] = cpu_baseline(device, cb, cp, 5000, algo="scalar", budget_s=6.0)
+            except Exception as ex:
+                out[tag] = {"error": repr(ex)}
     if link is not None:
         out["xgmi_all_to_all"] = link
     if priming:

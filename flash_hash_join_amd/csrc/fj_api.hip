@@ -177,7 +177,7 @@ struct Options {
         bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
         bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2500;     // measured break-even at c4 sizes: 28 % hits (profiles/r02_bloom_threshold.csv)
         const char* bvr = getenv("FJ_BLOOM_VARIANT");
-        bloom_variant = bvr ? (atoi(bvr) == 1 ? 1 : 0) : 0;
+        bloom_variant = bvr ? std::min(2, std::max(0, atoi(bvr))) : 0;
         const char* pt = getenv("FJ_PLAN_TARGET_KEYS");
         plan_target_keys = pt ? (u32)strtoul(pt, nullptr, 10) : FJ_PART_TARGET_KEYS;
         if (plan_target_keys < 16 || plan_target_keys > FJ_PART_TARGET_KEYS) plan_target_keys = FJ_PART_TARGET_KEYS;
@@ -432,12 +432,12 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * 4, &p)) return 1; cs.seg_off = (u32*)p;
     cs.alloc = &c->d_sc->alloc[it.side * 4 + 3];
     FjBloomArgs a{};
-    a.build = *it.bloom_build; a.probe = in; a.tiles = it.tiles; a.toff = it.toff; a.ntiles = it.ntiles;
+    a.pkeys = in.keys; a.plist = in.list; a.pnb = in.nb; a.tiles = it.tiles; a.toff = it.toff;
+    a.bkeys = it.bloom_build->keys; a.blist = it.bloom_build->list; a.bboff = it.bloom_build->boff;
     a.out_keys = cs.keys; a.out_dir = cs.dir; a.out_rel = cs.rel; a.seg_off = cs.seg_off; a.bchunks = cs.bchunks;
     a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + 3];
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs; a.err = &c->d_sc->err; a.survivors = &c->d_sc->bloom_survivors;
     a.prebuilt = it.bloom_prebuilt; a.bucket_keys = it.bloom_bucket_keys;
-    a.dbg_flags = getenv("FJ_BLOOM_ABLATE") ? (u32)atoi(getenv("FJ_BLOOM_ABLATE")) : 0u;
     HIPCHK(hipEventRecord(c->ev[E_BF0], s));
     HIPCHK(fj_launch_bloom_filter(a, G, options().bloom_variant, s));
     HIPCHK(hipEventRecord(c->ev[E_BF1], s));
@@ -675,7 +675,9 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     t->total_ms = ev_ms(c, E_START, E_JOIN);
     for (int i = 0; i < evc && i < 4; ++i) t->probe_part_kernel_ms[i] = ev_ms(c, E_PK0 + 2 * i, E_PK0 + 2 * i + 1);
     t->bloom_level = plan.bloom_level;
-    if (plan.bloom_level > 0) { t->filter_ms = ev_ms(c, E_BF0, E_BF1); t->filter_survivors = c->h_sc->bloom_survivors; }
+    if (plan.bloom_level > 0) {
+        t->filter_ms = ev_ms(c, E_BF0, E_BF1); t->filter_survivors = c->h_sc->bloom_survivors;
+    }
     if (c->h_sc->err & FJ_ERR_LDS_FULL) { *lds_full = true; return 0; }
     *out_count = c->h_sc->total;
     c->pend.valid = false;
@@ -804,7 +806,7 @@ int fj_set_option(const char* name, long long value) {
     if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); options().plan_target_keys = (u32)value; return 0; }
     if (!strcmp(name, "bloom_auto")) { options().bloom_auto = value != 0; return 0; }
     if (!strcmp(name, "bloom_auto_max_hit_bp")) { if (value < 0 || value > 10000) return set_err("fj_set_option: bloom_auto_max_hit_bp must be 0..10000"); options().bloom_auto_max_hit_bp = (int)value; return 0; }
-    if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 1) return set_err("fj_set_option: bloom_variant must be 0 or 1"); options().bloom_variant = (int)value; return 0; }
+    if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); options().bloom_variant = (int)value; return 0; }
     if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
     return set_err("fj_set_option: unknown option '%s'", name);
 }
@@ -1236,7 +1238,7 @@ int fj_owner_scatter(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, 
 // LDS-sized Bloom filter per bucket; a peer partitions the probe rows it is about to send by the same bits, tests them against
 // the owner's filters (the bloom stage of the partitioned plan, csrc/fj_bloom.hip, with the filters read from HBM) and sends
 // only the survivors.
-size_t fj_bloom_filter_words(void) { return ((size_t)1 << FJ_PREFILTER_BITS) * FJ_BLOOM_WORDS; }
+size_t fj_bloom_filter_words(void) { return ((size_t)1 << FJ_PREFILTER_BITS) * FJ_BLOOM_WORDS + 4; }   // + header (variant)
 
 int fj_bloom_export(fj_ctx* c, const uint64_t* d_build_keys, size_t nb, int hash_top_bits, uint32_t* d_filters, void* stream) {
     if (!c) return set_err("fj_bloom_export: null context");
@@ -1247,7 +1249,11 @@ int fj_bloom_export(fj_ctx* c, const uint64_t* d_build_keys, size_t nb, int hash
     hipStream_t s = (hipStream_t)stream;
     c->pend.valid = false;                                 // the passes below reuse the chunk pools a pending emit would read
     const u32 nbuckets = 1u << FJ_PREFILTER_BITS;
-    if (nb == 0) { HIPCHK(hipMemsetAsync(d_filters, 0, (size_t)nbuckets * FJ_BLOOM_WORDS * 4, s)); return 0; }   // empty filters reject everything
+    if (nb == 0) {                                          // empty filters reject everything
+        HIPCHK(hipMemsetAsync(d_filters, 0, fj_bloom_filter_words() * 4, s));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(d_filters + (size_t)nbuckets * FJ_BLOOM_WORDS), (int)(FJ_BLOOM_HDR_MAGIC | (u32)options().bloom_variant), 1, s));
+        return 0;
+    }
     Plan plan; plan.bits = FJ_PREFILTER_BITS; plan_passes(plan, true);
     begin_plan(c);
     if (clear_plan_scalars(c, s)) return 1;
@@ -1298,6 +1304,8 @@ int fj_bloom_prefilter(fj_ctx* c, const uint64_t* d_probe_keys, size_t n, int ha
     HIPCHK(hipStreamSynchronize(s));
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
     end_plan(c);
+    if (c->h_sc->err & FJ_ERR_VARIANT)
+        return set_err("fj_bloom_prefilter: these filters were not exported with bloom_variant %d (every rank must use the same FJ_BLOOM_VARIANT)", options().bloom_variant);
     if (c->h_sc->expected != c->h_sc->bloom_survivors) return set_err("internal error: prefilter flattened %llu of %llu survivors", c->h_sc->expected, c->h_sc->bloom_survivors);
     *out_n = c->h_sc->expected;
     return 0;

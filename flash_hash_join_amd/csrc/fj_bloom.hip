@@ -21,22 +21,27 @@
 //     512-B pieces for wave-private 2-KiB chunks of an output chunk pool with the same bucket structure, so the next
 //     partition pass reads it like any other level.
 //
-// Measured at config 4 (1B probe keys, 5 % hits, 512 level-1 buckets of ~195K build keys; FJ_BLOOM_ABLATE): reading the
-// chunk lists and counting only 1.75 ms (4.6 TB/s, the rate the join kernel also reads chunk lists at; includes the ~770
-// filter builds), + hashing and the LDS lookup 1.86 ms, + staging survivors in LDS 2.14 ms, + writing them 2.3-2.4 ms.
-// A wave's four loads of a tile each cover half of ONE chunk, so chunk ids and counts live in SGPRs (scalar address
-// arithmetic); survivors go through LDS so that the global store is one 512-B instruction per 64 survivors.  The hash
-// is not what bounds it (two-multiply mixer + 2 bits per key: 2.29 ms, 13.8 % pass; hash word 2 + 4 bits: 2.33 ms,
-// 12.0 % pass), so the stronger one is the default.
+// Measured at config 4 (1B probe keys, 5 % hits, 512 level-1 buckets of ~195K build keys): 2.26 ms (round 2: 2.4) for 8 GB of
+// probe keys + 1.5 GB of build keys (~770 filter builds) read and 0.96 GB of survivors written.  Reading and counting alone
+// takes 1.73 ms (5.5 TB/s; this box reads 6.1-6.4 TB/s at best), hashing and the LDS lookup add 0.03, compacting the survivors
+// through LDS 0.35, storing them 0.17 (round 3, -DFJ_BLOOM_DIAG_COUNT_ONLY and store-less builds).  A wave's four loads of a
+// tile each cover half of ONE chunk, so chunk ids and counts live in SGPRs (scalar address arithmetic); survivors go through
+// LDS so that the global store is one 512-B instruction per 64 survivors.  The kernel has ~45 kernel arguments and three
+// register-resident key buffers: round 2's form spilled 94 scalar registers into vector lanes (2187 v_readlane in the code);
+// the cold arguments are now read from the kernel-argument segment where they are used (bf_late_args: 17 spills left).
+// What was tried instead of this kernel + a plain pass over its survivors (round 3, profiles/r03_*): the filter test fused
+// into the last radix pass (tile-synchronous, bucket sort of the survivors only: 4.2 ms against 2.26 + 0.43 - the pass's
+// per-tile machinery, carry / scan / line descriptors behind six barriers, costs ~13K clocks per tile whether it sorts 8192
+// keys or 980), and survivors stored one by one into 64 wave-private sub-bucket streams without LDS write-combining
+// (tools/ubench_sparse_scatter.hip: +1.4 ms per 1B keys at 13 % survivors against +0.33 for the compacted 512-B stores).
 //
 // No false negatives by construction (insert and test use the same bits); false positives only cost the work the
 // filter would have saved.  Algorithmic HBM bytes: 8 B per probe key read + 8 B per survivor written (+ the build
 // keys of the level once or twice).
-#include "fj_internal.h"
+#include "fj_bloom_dev.h"
 
 namespace {
 
-constexpr u32 BF_NT = 1024;                 // threads per workgroup (one workgroup per CU)
 constexpr u32 BF_NW = BF_NT / 64;
 constexpr u32 BF_KPT = 8;                   // probe keys per thread and tile
 constexpr u32 BF_T = BF_NT * BF_KPT;        // 8192 keys = 32 chunks per tile
@@ -45,74 +50,14 @@ constexpr u32 BF_STG = 128;                 // staging row of a wave: keys
 // pipeline, so it must be rare - 128 chunks = 32768 survivors cover a wave's share of a 1B-row probe side at 13 % survivors
 constexpr u32 BF_SLAB = 128;
 
-__device__ __forceinline__ u32 bf_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
-
-// Filter position of a key: byte offset of its LDS word / block and the mask to test or set.
-//   VAR 1: two-multiply mixer over a fold of the key, 2 bits in one 32-bit word.  (A mixer from 24-bit
-//   multiplies - full rate - spread (i+1)*M keys so badly that 32 % of the probe keys passed at 5 % hits.)
-//   VAR 0 (default): the join's hash word 2 (five 32-bit multiplies), 4 bits in one 64-bit block.
-// Either is independent of the radix digits (hash word 1); a weak spot costs false positives, never a wrong result.
-template <int VAR>
-__device__ __forceinline__ void bf_bits(u64 key, u32& byte_off, u32& mlo, u32& mhi) {
-    if (VAR == 0) {
-        const u32 w = fj_hash_w2(key), h = w * 0x9E3779B1u;
-        byte_off = __umulhi(w, FJ_BLOOM_WORDS / 2u) * 8u;
-        mlo = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
-        mhi = (1u << ((h >> 10) & 31u)) | (1u << ((h >> 15) & 31u));
-        return;
-    }
-    u32 x = (u32)key ^ __builtin_rotateleft32((u32)(key >> 32), 15);
-    x *= 0x9E3779B1u; x ^= x >> 15;
-    x *= 0x85EBCA77u; x ^= x >> 13;
-    byte_off = __umulhi(x, FJ_BLOOM_WORDS) * 4u;
-    mlo = (1u << (x & 31u)) | (1u << ((x >> 5) & 31u));
-    mhi = 0;
-}
-template <int VAR>
-__device__ __forceinline__ void bf_insert(unsigned char* filt, u64 key) {
-    u32 o, mlo, mhi;
-    bf_bits<VAR>(key, o, mlo, mhi);
-    if (VAR == 0) atomicOr(reinterpret_cast<unsigned long long*>(filt + o), ((unsigned long long)mhi << 32) | mlo);
-    else atomicOr(reinterpret_cast<u32*>(filt + o), mlo);
-}
-
-// Build the LDS filter of one bucket from the build relation's chunks of that bucket (all threads of the workgroup; ends
-// with a barrier).  32 chunks = 8192 build keys per step: the step's four list entries per thread, then its four 16-B key
-// loads; the entries of the NEXT step are requested before this step's keys are used.
-template <int VAR>
-__device__ __forceinline__ void bf_build_filter(unsigned char* filt, const FjChunkSet& build, u32 bucket, u32 tid, u32 jb, u32 off, u32 off16) {
-    for (u32 i = tid; i < FJ_BLOOM_WORDS / 2; i += BF_NT) reinterpret_cast<u64*>(filt)[i] = 0;
-    __syncthreads();
-    const u32 b0 = build.boff[bucket], nbc = build.boff[bucket + 1] - b0;
-    auto bentries = [&](u32 c0, u32 (&e)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 j = c0 + (u32)i * 8u + jb;
-            e[i] = build.list[b0 + (j < nbc ? j : (nbc ? nbc - 1 : 0u))];
-        }
-    };
-    u32 be[4];
-    if (nbc) bentries(0, be);
-    for (u32 c0 = 0; c0 < nbc; c0 += 32) {
-        u64x2 q[4]; u32 cn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 eu = bf_uni(be[i]);
-            cn[i] = (c0 + (u32)i * 8u + jb) < nbc ? FJ_LIST_CNT(eu) : 0u;
-            const unsigned char* base = reinterpret_cast<const unsigned char*>(build.keys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
-            q[i] = *reinterpret_cast<const u64x2*>(base + off16);
-        }
-        u32 bn[4];
-        bentries(c0 + 32 < nbc ? c0 + 32 : c0, bn);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (off < cn[i]) bf_insert<VAR>(filt, q[i].x);
-            if (off + 1 < cn[i]) bf_insert<VAR>(filt, q[i].y);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) be[i] = bn[i];
-    }
-    __syncthreads();
+// The kernel's cold arguments, read from the kernel-argument segment AT THE POINT OF USE: the empty asm makes the pointer
+// opaque, so the compiler can neither preload these fields at kernel entry nor hoist their loads out of the loop - where they
+// would occupy (and, as in round 2, overflow) the scalar register file.  FjBloomArgs is the kernel's only parameter: offset 0.
+typedef const __attribute__((address_space(4))) FjBloomArgs* BfLateArgs;
+__device__ __forceinline__ BfLateArgs bf_late_args() {
+    BfLateArgs p = (BfLateArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
 }
 
 template <int VAR>
@@ -121,24 +66,33 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
     unsigned char* filt = smem;                                          // FJ_BLOOM_WORDS * 4 bytes
     const u32 tid = threadIdx.x, lane = tid & 63, wave = bf_uni(tid >> 6);
     u64* stg = reinterpret_cast<u64*>(smem + FJ_BLOOM_WORDS * 4) + wave * BF_STG;   // this wave's staging row
-    const u32 ntiles = *a.ntiles;
     const u32 G = gridDim.x, g = blockIdx.x;
-    const u32 nb = a.probe.nb;
+    // hot arguments (see FjBloomArgs)
+    const u64* __restrict__ pkeys = a.pkeys; const u32* __restrict__ plist = a.plist; const uint4* __restrict__ tiles = a.tiles;
+    u64* __restrict__ out_keys = a.out_keys; u32* __restrict__ out_dir = a.out_dir; u64* __restrict__ out_rel = a.out_rel;
+    const u32 cap = a.cap_chunks;
 
     // contiguous run of tiles [t0, t1); a boundary that falls close to a bucket boundary is moved onto it, so that with
     // balanced buckets no filter is built twice (both neighbours compute the same snapped value)
-    auto boundary = [&](u32 gg) -> u32 {
-        u32 t = (u32)(((u64)gg * ntiles) / G);
-        if (gg == 0 || gg >= G || ntiles == 0) return gg >= G ? ntiles : t;
-        u32 lo = 0, hi = nb;                                 // last bucket p with toff[p] <= t
-        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (a.toff[mid] <= t) lo = mid; else hi = mid; }
-        const u32 b0 = a.toff[lo], b1 = a.toff[lo + 1], slack = (b1 - b0) >> 4;
-        if (t - b0 <= slack) t = b0; else if (b1 - t <= slack) t = b1;
-        return t;
-    };
-    const u32 t0 = boundary(g), t1 = boundary(g + 1);
-    if (t0 >= t1) return;
-    const u32 nmine = t1 - t0;
+    u32 t0, nmine;
+    {
+        BfLateArgs la = bf_late_args();
+        const u32* toff = la->toff;
+        const u32 nb = la->pnb, ntiles = toff[nb];
+        auto boundary = [&](u32 gg) -> u32 {
+            u32 t = (u32)(((u64)gg * ntiles) / G);
+            if (gg == 0 || gg >= G || ntiles == 0) return gg >= G ? ntiles : t;
+            u32 lo = 0, hi = nb;                                 // last bucket p with toff[p] <= t
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
+            const u32 b0 = toff[lo], b1 = toff[lo + 1], slack = (b1 - b0) >> 4;
+            if (t - b0 <= slack) t = b0; else if (b1 - t <= slack) t = b1;
+            return t;
+        };
+        t0 = boundary(g);
+        const u32 t1 = boundary(g + 1);
+        if (t0 >= t1) return;
+        nmine = t1 - t0;
+    }
 
     // ---- input side: descriptors -> chunk-list entries -> keys, each a step earlier than its consumer ------------
     // thread tid reads key pairs (i*NT + tid)*2, i = 0..3: chunk j = i*8 + tid/128 of the tile, byte offset (tid%128)*16.
@@ -146,7 +100,7 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
     const u32 jb = bf_uni(tid >> 7), off = (tid & 127u) * 2u, off16 = (tid & 127u) * 16u;
     struct Desc { u32 pos, len, bucket; };
     auto get_desc = [&](u32 tt) -> Desc {                    // (vector load of a uniform address; made uniform at use)
-        const uint4 d = a.tiles[t0 + (tt < nmine ? tt : nmine - 1)];
+        const uint4 d = tiles[t0 + (tt < nmine ? tt : nmine - 1)];
         Desc r; r.pos = d.x; r.len = tt < nmine ? d.y : 0u; r.bucket = d.z; return r;
     };
     auto get_entries = [&](const Desc& d, u32 (&e)[4]) {     // unconditional loads (index clamped): straight-line code
@@ -154,7 +108,7 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const u32 j = (u32)i * 8u + jb;
-            e[i] = a.probe.list[pos + (j < len ? j : (len ? len - 1 : 0u))];
+            e[i] = plist[pos + (j < len ? j : (len ? len - 1 : 0u))];
         }
     };
     // request the keys of a tile: scalar base per chunk + constant lane offset; the chunks' key counts stay in SGPRs
@@ -164,7 +118,7 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
         for (int i = 0; i < 4; ++i) {
             const u32 eu = bf_uni(e[i]);
             const u32 cnt = ((u32)i * 8u + jb) < len ? FJ_LIST_CNT(eu) : 0u;
-            const unsigned char* base = reinterpret_cast<const unsigned char*>(a.probe.keys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(pkeys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
             const u64x2 q = *reinterpret_cast<const u64x2*>(base + off16);
             kk[2 * i] = q.x; kk[2 * i + 1] = q.y;
             cn[i] = cnt;
@@ -173,38 +127,44 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
 
     // ---- output side: wave-private chunks, filled 64 keys at a time from the wave's staging row --------------------
     u32 cur = FJ_DIR_INVALID, fill = FJ_CHUNK;      // current chunk and its fill (wave-uniform; a multiple of 64 until the segment ends)
-    u32 ns = 0;                                     // staged survivors of this wave (< 64 between key slots)
+    u32 ns = 0;                                     // staged survivors of this wave (< 64 between half steps)
     u32 nch = 0, seg = 0;                           // chunks of this (wave, bucket run) = one segment of the bucket's chunk list
     u32 seg_keys = 0;                               // survivors of this wave inside the current bucket run
     u32 slab_cur = 0, slab_rem = 0;
     unsigned long long survivors = 0;
-    const u32 cap = a.cap_chunks;
     auto next_chunk = [&](u32 bucket) {             // wave-uniform: close `cur` (full), open a fresh chunk
-        if (cur != FJ_DIR_INVALID && lane == 0 && cur < cap) a.out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | FJ_CHUNK;
+        if (cur != FJ_DIR_INVALID && lane == 0 && cur < cap) out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | FJ_CHUNK;
         if (slab_rem == 0) {
+            BfLateArgs la = bf_late_args();
             u32 base = 0;
-            if (lane == 0) { base = atomicAdd(a.alloc, BF_SLAB); if (base + BF_SLAB > cap) atomicOr(a.err, FJ_ERR_POOL); }
+            if (lane == 0) { base = atomicAdd(la->alloc, BF_SLAB); if (base + BF_SLAB > cap) atomicOr(la->err, FJ_ERR_POOL); }
             slab_cur = bf_uni(base); slab_rem = BF_SLAB;
         }
         cur = slab_cur; ++slab_cur; --slab_rem;
-        if (lane == 0 && cur < cap) a.out_rel[cur] = ((u64)seg << 32) | nch;
+        if (lane == 0 && cur < cap) out_rel[cur] = ((u64)seg << 32) | nch;
         ++nch; fill = 0;
     };
-    auto flush = [&](u32 bucket, u32 n) {           // write staged keys [0, n), n <= 64, behind the chunk's fill
+    // The staging row is a RING of BF_STG keys: survivors are appended behind `head + ns`, whole 512-B pieces leave from `head`
+    // (nothing is ever moved inside the row).
+    u32 head = 0;
+    auto flush = [&](u32 bucket, u32 n) {           // write staged keys [head, head + n), n <= 64, behind the chunk's fill
         if (fill == FJ_CHUNK) next_chunk(bucket);
-        if (lane < n && cur < cap && !(a.dbg_flags & 4u)) {     // (4: diagnostic, everything but the store itself)
-            unsigned char* base = reinterpret_cast<unsigned char*>(a.out_keys + (u64)((a.dbg_flags & 8u) ? (cur & 1023u) : cur) * FJ_CHUNK + fill);   // (8: diagnostic, stores stay in L2)
-            *reinterpret_cast<u64*>(base + lane * 8u) = stg[lane];
+        if (lane < n && cur < cap) {
+            unsigned char* base = reinterpret_cast<unsigned char*>(out_keys + (u64)cur * FJ_CHUNK + fill);
+            *reinterpret_cast<u64*>(base + lane * 8u) = stg[(head + lane) & (BF_STG - 1)];
         }
-        fill += n;
+        fill += n; head = (head + n) & (BF_STG - 1);
     };
     auto end_segment = [&](u32 bucket) {            // close this wave's run inside `bucket`
         if (ns) { flush(bucket, ns); ns = 0; }
+        head = 0;
         if (nch > 0 && lane == 0) {
-            if (cur < cap) a.out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | fill;
-            const u32 o = atomicAdd(&a.bchunks[bucket], nch);
-            if (seg < a.max_segs) a.seg_off[seg] = o;
-            if (a.bucket_keys && seg_keys) atomicAdd(&a.bucket_keys[bucket], (unsigned long long)seg_keys);
+            BfLateArgs la = bf_late_args();
+            if (cur < cap) out_dir[cur] = (bucket << FJ_DIR_CNT_BITS) | fill;
+            const u32 o = atomicAdd(&la->bchunks[bucket], nch);
+            if (seg < la->max_segs) la->seg_off[seg] = o;
+            unsigned long long* bkc = la->bucket_keys;
+            if (bkc && seg_keys) atomicAdd(&bkc[bucket], (unsigned long long)seg_keys);
         }
         cur = FJ_DIR_INVALID; fill = FJ_CHUNK; nch = 0; seg_keys = 0;
     };
@@ -250,42 +210,61 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
         if (bucket != cur_bucket) {                 // workgroup-uniform: rebuild the filter for this bucket
             if (cur_bucket != 0xFFFFFFFFu) end_segment(cur_bucket);
             __syncthreads();                        // every wave is done testing against the old filter
-            if (a.prebuilt) {                       // filters built elsewhere (another GPU's build keys: the sender-side precheck of the owner shuffle)
-                const uint4* src = reinterpret_cast<const uint4*>(a.prebuilt + (u64)bucket * FJ_BLOOM_WORDS);
+            BfLateArgs la = bf_late_args();
+            const u32* prebuilt = la->prebuilt;
+            if (prebuilt) {                         // filters built elsewhere (another GPU's build keys: the sender-side precheck of the owner shuffle)
+                // (they end with a header word naming the variant they were built with: insert and test must use the same bits)
+                if (tid == 0 && prebuilt[(u64)la->pnb * FJ_BLOOM_WORDS] != (FJ_BLOOM_HDR_MAGIC | (u32)VAR)) atomicOr(la->err, FJ_ERR_VARIANT);
+                const uint4* src = reinterpret_cast<const uint4*>(prebuilt + (u64)bucket * FJ_BLOOM_WORDS);
                 for (u32 i = tid; i < FJ_BLOOM_WORDS / 4; i += BF_NT) reinterpret_cast<uint4*>(filt)[i] = src[i];
                 __syncthreads();
             } else {
-                bf_build_filter<VAR>(filt, a.build, bucket, tid, jb, off, off16);
+                bf_build_filter<VAR>(filt, la->bkeys, la->blist, la->bboff, bucket, tid);
             }
-            if (lane == 0) { seg = atomicAdd(a.seg_counter, 1u); if (seg >= a.max_segs) atomicOr(a.err, FJ_ERR_POOL); }
+            if (lane == 0) { seg = atomicAdd(la->seg_counter, 1u); if (seg >= la->max_segs) atomicOr(la->err, FJ_ERR_POOL); }
             seg = bf_uni(seg);
             cur_bucket = bucket;
         }
 
         // ---- test the 8 keys of this lane, compact the survivors of the wave into its staging row -------------------
-        u32 wlo[BF_KPT], whi[BF_KPT], mlo[BF_KPT], mhi[BF_KPT];
+        // All eight tests first (two batches of four independent LDS reads), their ballots stay in scalar registers; then
+        // the survivors are appended half a tile-step at a time: four masked LDS writes at scalar prefix offsets and ONE
+        // check whether a 512-B piece can leave.
+        u64 m[BF_KPT];
 #pragma unroll
-        for (int i = 0; i < (int)BF_KPT; ++i) {
-            u32 o; bf_bits<VAR>(kCur[i], o, mlo[i], mhi[i]);
-            if (a.dbg_flags & 2u) { wlo[i] = (u32)kCur[i]; whi[i] = 0; mlo[i] = 1; mhi[i] = 0; continue; }   // diagnostic: no hash use, no LDS read
-            if (VAR == 0) { const u64 w = *reinterpret_cast<const u64*>(filt + o); wlo[i] = (u32)w; whi[i] = (u32)(w >> 32); }
-            else { wlo[i] = *reinterpret_cast<const u32*>(filt + o); whi[i] = 0; }
+        for (int h = 0; h < (int)BF_KPT; h += 4) {
+            u32 wlo[4], whi[4], mlo[4], mhi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { u32 o; bf_bits<VAR>(kCur[h + i], o, mlo[i], mhi[i]); bf_fetch<VAR>(filt, o, wlo[i], whi[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                m[h + i] = __ballot(bf_pass<VAR>(wlo[i], whi[i], mlo[i], mhi[i]) && (off + (u32)((h + i) & 1)) < cnCur[(h + i) >> 1]);
         }
 #pragma unroll
-        for (int i = 0; i < (int)BF_KPT; ++i) {
-            const bool hit = (wlo[i] & mlo[i]) == mlo[i] && (VAR != 0 || (whi[i] & mhi[i]) == mhi[i]);
-            u64 m = __ballot(hit && (off + (u32)(i & 1)) < cnCur[i >> 1]);
-            if (a.dbg_flags & 1u) { survivors += (u32)__popcll(m); m = 0; }      // diagnostic: count, do not compact
-            if (m) {
-                const u32 n = (u32)__popcll(m);
-                if ((m >> lane) & 1ull) stg[ns + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = kCur[i];
-                ns += n;
-                survivors += n;
-                seg_keys += n;
-                if (ns >= 64) {                     // a whole 512-B piece leaves; the rest moves to the front of the row
-                    flush(bucket, 64);
-                    ns -= 64;
-                    if (lane < ns) { const u64 v = stg[64 + lane]; stg[lane] = v; }
+        for (int h = 0; h < (int)BF_KPT; h += 4) {
+            const u32 n0 = (u32)__popcll(m[h]), n1 = (u32)__popcll(m[h + 1]), n2 = (u32)__popcll(m[h + 2]), n3 = (u32)__popcll(m[h + 3]);
+            const u32 tot = n0 + n1 + n2 + n3;
+            survivors += tot;
+#ifdef FJ_BLOOM_DIAG_COUNT_ONLY
+            continue;                                  // diagnostic build: test and count, do not compact or write
+#endif
+            seg_keys += tot;
+            if (ns + tot <= BF_STG) {                  // (always, unless more than half of the keys survive: ns < 64)
+                const u32 pre[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+                const u32 tail = head + ns;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if ((m[h + i] >> lane) & 1ull)
+                        stg[(tail + pre[i] + __builtin_amdgcn_mbcnt_hi((u32)(m[h + i] >> 32), __builtin_amdgcn_mbcnt_lo((u32)m[h + i], 0u))) & (BF_STG - 1)] = kCur[h + i];
+                ns += tot;
+                if (ns >= 64) { flush(bucket, 64); ns -= 64; }      // a whole 512-B piece leaves
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {          // key slot by key slot (each adds <= 64 to fewer than 64 staged keys)
+                    const u64 mm = m[h + i];
+                    if ((mm >> lane) & 1ull) stg[(head + ns + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))) & (BF_STG - 1)] = kCur[h + i];
+                    ns += (u32)__popcll(mm);
+                    if (ns >= 64) { flush(bucket, 64); ns -= 64; }
                 }
             }
         }
@@ -297,8 +276,8 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
     }
     if (cur_bucket != 0xFFFFFFFFu) end_segment(cur_bucket);
     // unused chunk ids of this wave's slab stay unlisted (the directory needs no memset: every id is defined by its owner)
-    for (u32 j = lane; j < slab_rem; j += 64) { const u32 id = slab_cur + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
-    if (lane == 0 && survivors) atomicAdd(a.survivors, survivors);
+    for (u32 j = lane; j < slab_rem; j += 64) { const u32 id = slab_cur + j; if (id < cap) out_dir[id] = FJ_DIR_INVALID; }
+    if (lane == 0 && survivors) atomicAdd(bf_late_args()->survivors, survivors);
 }
 
 // Write the filters of ALL buckets of a build-side level to HBM (FJ_BLOOM_WORDS words each): what an owner GPU ships to its
@@ -307,13 +286,13 @@ template <int VAR>
 __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_export_kernel(FjChunkSet build, u32* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 tid = threadIdx.x;
-    const u32 jb = bf_uni(tid >> 7), off = (tid & 127u) * 2u, off16 = (tid & 127u) * 16u;
     for (u32 b = blockIdx.x; b < build.nb; b += gridDim.x) {
-        bf_build_filter<VAR>(smem, build, b, tid, jb, off, off16);
+        bf_build_filter<VAR>(smem, build.keys, build.list, build.boff, b, tid);
         uint4* dst = reinterpret_cast<uint4*>(out + (u64)b * FJ_BLOOM_WORDS);
         for (u32 i = tid; i < FJ_BLOOM_WORDS / 4; i += BF_NT) dst[i] = reinterpret_cast<const uint4*>(smem)[i];
         __syncthreads();
     }
+    if (blockIdx.x == 0 && tid < 4) out[(u64)build.nb * FJ_BLOOM_WORDS + tid] = tid == 0 ? (FJ_BLOOM_HDR_MAGIC | (u32)VAR) : 0u;
 }
 
 // exclusive scan of per-bucket key counts (nb <= 1024: one workgroup) -> base[0..nb]
@@ -375,7 +354,7 @@ __global__ __launch_bounds__(256) void fj_flatten_kernel(FjChunkSet cs, const un
 
 hipError_t fj_launch_bloom_export(const FjChunkSet& build, u32* out, u32 grid, int variant, hipStream_t s) {
     const u32 lds = FJ_BLOOM_WORDS * 4;
-    auto kern = variant == 0 ? fj_bloom_export_kernel<0> : fj_bloom_export_kernel<1>;
+    auto kern = variant == 0 ? fj_bloom_export_kernel<0> : (variant == 1 ? fj_bloom_export_kernel<1> : fj_bloom_export_kernel<2>);
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid < build.nb ? grid : build.nb), dim3(BF_NT), lds, s, build, out);
@@ -395,7 +374,7 @@ u32 fj_bloom_slab_chunks() { return BF_SLAB; }
 
 hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, int variant, hipStream_t s) {
     const u32 lds = FJ_BLOOM_WORDS * 4 + BF_NW * BF_STG * 8;
-    auto kern = variant == 0 ? fj_bloom_filter_kernel<0> : fj_bloom_filter_kernel<1>;
+    auto kern = variant == 0 ? fj_bloom_filter_kernel<0> : (variant == 1 ? fj_bloom_filter_kernel<1> : fj_bloom_filter_kernel<2>);
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BF_NT), lds, s, a);

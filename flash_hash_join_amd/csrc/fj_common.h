@@ -36,8 +36,8 @@ static inline unsigned fj_slab_for(unsigned fan) { return fan > 256u ? 2u * FJ_S
 #define FJ_PART_TARGET_KEYS 4096u               // average build keys per final partition (load <= 0.5)
 #define FJ_PLAN_BUMP_KEYS 3950u                 // ... above this average the plan takes one more radix bit when that is free (c2's 3906 stays: 0.79 ms with 256 partitions, 0.81 with 512)
 
-// Bloom precheck of the partitioned join (csrc/fj_bloom.hip): an LDS-resident blocked Bloom filter over one bucket of an
-// intermediate partition level: 35840 32-bit words = 140 KiB of the CU's 160 KiB (the rest stages survivors).
+// Bloom precheck of the partitioned join (csrc/fj_bloom.hip, fj_bloom_dev.h): an LDS-resident blocked Bloom filter over one
+// bucket of an intermediate partition level: 35840 32-bit words = 140 KiB of the CU's 160 KiB (the rest stages survivors).
 #define FJ_BLOOM_WORDS 35840u
 #define FJ_BLOOM_BITS (FJ_BLOOM_WORDS * 32u)
 #define FJ_BLOOM_MAX_KEYS 400000u                // build keys per filtered bucket above which the filter is not worth running (< 3 bits per key)

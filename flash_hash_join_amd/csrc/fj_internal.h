@@ -8,6 +8,8 @@
 #define FJ_STAT_DUPS 4u      // (status, not an error) the build side holds duplicate keys
 #define FJ_STAT_RETRY 8u     // (status) some counting-join items overflowed the cuckoo table: part_count[item] == FJ_ITEM_RETRY marks them
 #define FJ_STAT_EMIT_RETRY 16u // (status) some items of the emitting pass overflowed the cuckoo table: marked the same way, redone on the tagged table
+#define FJ_ERR_VARIANT 32u   // filters handed to the filter kernel were built with another bloom_variant (sender-side precheck across ranks)
+#define FJ_BLOOM_HDR_MAGIC 0xB100F000u   // exported filter sets end with 4 header words: [0] = magic | variant
 #define FJ_ITEM_RETRY 0xFFFFFFFFu
 
 // ---- partition pass ---------------------------------------------------------------------------
@@ -70,19 +72,24 @@ hipError_t fj_launch_scan_u32_to_u64(const u32* in, u64* out, u32 n, hipStream_t
 
 // ---- bloom precheck between two probe-side passes (csrc/fj_bloom.hip) ----------------------------
 struct FjBloomArgs {
-    FjChunkSet build;            // build relation at the filtered level: keys, list, boff
-    FjChunkSet probe;            // probe relation at the same level: keys, list, nb
-    const uint4* tiles;          // tile table over the probe chunk lists (tiles of fj_bloom_tile_chunks() chunks)
-    const u32* toff;             // [nb+1] first tile of every bucket; toff[nb] = number of tiles
-    const u32* ntiles;           // == toff + nb
-    // output chunk pool: same bucket structure, survivors only (a level with fan-out 1: seg_off[segment])
-    u64* out_keys; u32* out_dir; u64* out_rel; u32* seg_off; u32* bchunks; u32* alloc; u32* seg_counter;
-    u32 cap_chunks, max_segs;
+    // hot: read for every tile - these stay in scalar registers across the kernel's loop
+    const u64* pkeys;            // probe relation at the filtered level: chunk pool,
+    const u32* plist;            // chunk lists,
+    const uint4* tiles;          // and the tile table over them (tiles of fj_bloom_tile_chunks() chunks)
+    u64* out_keys; u32* out_dir; u64* out_rel;   // output chunk pool: same bucket structure, survivors only (a level with fan-out 1)
+    u32 cap_chunks;
+    u32 pnb;                     // buckets of the level
+    // cold: read at kernel start, at a bucket change, or once per slab of output chunks.  The kernel reads them through
+    // bf_late_args() at the point of use, so that they do not occupy scalar registers across the loop (round 2's form of this
+    // kernel spilled ~95 scalar registers into vector lanes: a v_readlane per use)
+    const u32* toff;             // [pnb+1] first tile of every bucket; toff[pnb] = number of tiles
+    const u64* bkeys; const u32* blist; const u32* bboff;   // build relation at the filtered level (filter source)
+    u32* seg_off; u32* bchunks; u32* alloc; u32* seg_counter;
+    u32 max_segs;
     u32* err;
     unsigned long long* survivors;   // device scalar: probe keys that passed
-    const u32* prebuilt;             // non-null: filters come from HBM (FJ_BLOOM_WORDS words per bucket) instead of being built from `build`
-    unsigned long long* bucket_keys; // non-null: [nb] survivors per bucket are accumulated here (zeroed by the caller)
-    u32 dbg_flags;                   // diagnostic ablations (FJ_BLOOM_ABLATE): 1 = count survivors but do not write them, 2 = no filter lookup (results wrong on purpose)
+    const u32* prebuilt;             // non-null: filters come from HBM (FJ_BLOOM_WORDS words per bucket) instead of being built from the build keys
+    unsigned long long* bucket_keys; // non-null: [pnb] survivors per bucket are accumulated here (zeroed by the caller)
 };
 u32 fj_bloom_tile_chunks();
 u32 fj_bloom_waves_per_group();

@@ -87,6 +87,8 @@ const char* fj_version(void);
  *                        "bloom_auto_max_hit_bp" (default 2500 = 25 %; measured break-even 28 %) of them hit; 0: adaptive_*_bloom filter, adaptive_* do
  *                        not, as named (env FJ_BLOOM_AUTO, FJ_BLOOM_AUTO_MAX_HIT_BP).  The explicit hash_join*_bloom
  *                        functions always run the precheck when the plan has two or more passes; hash_join* never do.
+ *   "bloom_variant"    - hash / bit layout of the filter, 0..2 (csrc/fj_bloom_dev.h; default 2; env FJ_BLOOM_VARIANT).  Must be
+ *                        the same on every rank of a multi-GPU job (fj_bloom_prefilter checks it against the exporter's).
  *   "plan_target_keys" - average build keys per final partition the plan aims for (default and maximum 4096 = half an LDS
  *                        table; env FJ_PLAN_TARGET_KEYS).  A testing knob: small values make small inputs take the deep
  *                        (two- and three-pass, bloom-filtered) plans that production only uses for >1M-row build sides.
@@ -162,7 +164,8 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
  * match, densely, into d_out_keys (capacity >= n); *out_n = how many (synchronous).  No key that is in the owner's build
  * side is ever dropped.
  */
-size_t fj_bloom_filter_words(void);        /* words per owner = 512 * words per bucket */
+size_t fj_bloom_filter_words(void);        /* words per owner = 512 * words per bucket + 4 header words (the bloom_variant
+                                              the filters were built with: fj_bloom_prefilter refuses another one)      */
 int fj_bloom_export(fj_ctx* ctx, const uint64_t* d_build_keys, size_t nb, int hash_top_bits, uint32_t* d_filters, void* stream);
 int fj_bloom_prefilter(fj_ctx* ctx, const uint64_t* d_probe_keys, size_t n, int hash_top_bits, const uint32_t* d_filters,
                        uint64_t* d_out_keys, size_t out_capacity, uint64_t* out_n, void* stream);

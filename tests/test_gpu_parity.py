@@ -406,6 +406,28 @@ def test_sender_side_prefilter_keeps_every_hit(fj, nb, npk, hit_bp, top_bits):
     assert eng.bloom_prefilter(pk[:100_000], z, top_bits).numel() == 0
 
 
+def test_sender_side_prefilter_refuses_filters_of_another_variant(fj):
+    """Exporter and sender must set the same bits: filters carry the variant they were built with, and a sender configured
+    for another one gets an error instead of silently dropping matching rows."""
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    bk, _ = datagen.build_device(2_000_000, "cuda:0")
+    pk, _ = datagen.probe_device(1_000_000, 2_000_000, "cuda:0", seed=9, hit_bp=5000)
+    eng = HipEngine("cuda:0")
+    was = fj.get_option("bloom_variant")
+    try:
+        fj.set_option("bloom_variant", 0)
+        filters = eng.bloom_export(bk, 64)
+        assert eng.bloom_prefilter(pk, filters, 64).numel() >= 500_000 * 0.99
+        fj.set_option("bloom_variant", 2)
+        with pytest.raises(RuntimeError, match="bloom_variant"):
+            eng.bloom_prefilter(pk, filters, 64)
+        filters2 = eng.bloom_export(bk, 64)
+        assert eng.bloom_prefilter(pk, filters2, 64).numel() >= 500_000 * 0.99
+    finally:
+        fj.set_option("bloom_variant", was)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_sender_side_prefilter_on_random_key_distributions(fj, seed):
     """The precheck primitives on uniform, tiny-domain, sequential and sentinel-valued keys with duplicates on both sides:
