@@ -224,6 +224,7 @@ def main() -> None:
     # FJ_BENCH_FORCE_DIST=1 drives the multi-GPU code path (owner split -> RCCL all-to-all -> join -> all-reduce)
     # on a single rank: a self-test of the N>1 branch on boxes with one GPU; results are identical.
     force_dist = bool(os.environ.get("FJ_BENCH_FORCE_DIST")) and world == 1
+    transport = None                             # what distributed_join uses instead of torch.distributed (share_gpu only)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
@@ -231,14 +232,17 @@ def main() -> None:
             dist.init_process_group("gloo", rank=rank, world_size=world)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from two_ranks_one_gpu import HostStagedDist
-            dist = HostStagedDist()
-            sys.modules["torch.distributed"] = dist
-            torch.distributed = dist
+            transport = dist = HostStagedDist()
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         _flush_c_stdio()
         if force_dist:
             os.environ["FJ_FORCE_EXCHANGE"] = "1"
+        # `value` at N > 1 is always the strategy north_star names (the owner shuffle over an all-to-all); the cost model's
+        # alternative is measured beside it as `alt_strategy`, never instead of it
+        if os.environ.get("FJ_DIST_STRATEGY", "shuffle") != "shuffle":
+            print(f"bench.py: ignoring FJ_DIST_STRATEGY={os.environ['FJ_DIST_STRATEGY']} for the timed steps (value is the shuffle's)", file=sys.stderr)
+        os.environ["FJ_DIST_STRATEGY"] = "shuffle"
 
     nb_gpu, np_gpu, hit_bp, fn_name = WORKLOADS[args.workload]
     nb_gpu, np_gpu = max(1, int(nb_gpu * args.scale)), max(1, int(np_gpu * args.scale))
@@ -261,15 +265,48 @@ def main() -> None:
     engine = HipEngine(device) if (world > 1 or force_dist) else None
     link = None
     if world > 1 and not share_gpu:
-        # one all-to-all of 128 MiB per peer: the per-link rate this node delivers (recorded; also what FJ_DIST_STRATEGY=auto prices with)
+        # one all-to-all of 128 MiB per peer: the per-link rate this node delivers (recorded; what FJ_DIST_STRATEGY=auto and the
+        # sender-side precheck's break-even price with).  Every rank must end up with the same rate, or with none.
+        from flash_hash_join_amd import distributed as _D
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import xgmi_probe
-            from flash_hash_join_amd import distributed as _D
             link = xgmi_probe.measure(dist, device, 128)
-            _D.set_link_rate(link["link_GBps"] * 1e9)
         except Exception as ex:
             link = {"error": repr(ex)}
+        okf = torch.tensor([0 if "error" in link else 1], dtype=torch.int64, device=device)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 1:
+            _D.set_link_rate(link["link_GBps"] * 1e9)
+        elif "error" not in link:
+            link = {"error": "the link probe failed on another rank", **link}
+
+    # ---- self-check before anything is timed (N > 1): the exchange transport at the step's largest message size, and one
+    #      small join against its closed-form count; a failure is ONE JSON line with `error` and a non-zero exit code ----------
+    selfcheck = None
+    if world > 1 or force_dist:
+        from flash_hash_join_amd.distributed import self_check
+        nb_s, np_s = max(400_000, 3_200_000 // world), 4_000_000
+        sbk, sbv = datagen.build_device(nb_s, device, first=rank * nb_s)
+        spk, sexp = datagen.probe_device(np_s, nb_s * world, device, seed=3, hit_bp=5000, first=rank * np_s)
+        e = torch.tensor([sexp], dtype=torch.int64, device=device)
+        dist.all_reduce(e)
+        pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
+        msg = int(1.3 * np_gpu / max(1, pieces) / world) + 4096          # int64 per peer and piece in the chunk form
+        selfcheck = self_check(dist, None, engine, (sbk, sbv, spk), int(e.item()), msg)
+        del sbk, sbv, spk
+        if not selfcheck["ok"]:
+            if rank == 0:
+                print(json.dumps({"error": selfcheck["error"] or "self-check failed on another rank", "self_check": selfcheck, "rank": rank,
+                                  "n_gpus": world, "torch": torch.__version__, "hip": getattr(torch.version, "hip", None),
+                                  "rccl": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                                  "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",
+                                  "value": None}), flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+            sys.exit(3)
 
     units_per_launch = [float(np_gpu)]
     strategy_seen = ["single GPU"]
@@ -303,7 +340,7 @@ def main() -> None:
             res = api.join_device(algo, bloom, materialize, bk, bv, pk, return_arrays=False)
         else:
             t = {}
-            res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t)
+            res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t, transport=transport)
             if record:
                 for k in dtimes:
                     dtimes[k].append(t.get(k, 0.0))
@@ -443,7 +480,7 @@ def main() -> None:
                                                                  ("local_join_ms", dtimes["join_s"]))})
         phases.update({"shuffle_prefilter": dlast.get("prefilter"), "shuffle_prefilter_mode": dlast.get("prefilter_mode"),
                        "shuffle_prefilter_sampled_survivors": dlast.get("prefilter_sampled_survivors"),
-                       "probe_rows_sent_rank0": dlast.get("probe_rows_sent")})
+                       "probe_rows_sent_rank0": dlast.get("probe_rows_sent"), "shuffle_form": dlast.get("shuffle_form")})
 
     out = {
         "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",
@@ -498,6 +535,28 @@ def main() -> None:
                 out[tag] = {"error": repr(ex)}
     if link is not None:
         out["xgmi_all_to_all"] = link
+    if selfcheck is not None:
+        out["self_check"] = selfcheck
+    if world > 1 and not materialize:
+        # the cost model's alternative (build side replicated by all-gather, probe rows stay), a second, labelled measurement
+        os.environ["FJ_DIST_STRATEGY"] = "replicate"
+        try:
+            asteps = max(1, min(3, args.steps))
+            got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport)[0]      # untimed (workspace growth)
+            sync()
+            ta = time.perf_counter()
+            for _ in range(asteps):
+                got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport)[0]
+            sync()
+            ea = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=device)
+            dist.all_reduce(ea, op=dist.ReduceOp.MAX)
+            out["alt_strategy"] = {"strategy": "replicate-build", "steps": asteps, "ms_per_step": round(float(ea.item()) / asteps * 1e3, 3),
+                                   "value": round(np_total * asteps / float(ea.item()) / 1e9, 3), "unit": "Gprobes/s", "count_ok": int(got) == exp_total,
+                                   "note": "not `value`: the strategy north_star names is the owner shuffle"}
+        except Exception as ex:
+            out["alt_strategy"] = {"strategy": "replicate-build", "error": repr(ex)}
+        finally:
+            os.environ["FJ_DIST_STRATEGY"] = "shuffle"
     if priming:
         out["priming_steps"] = priming
     if share_gpu:

@@ -23,6 +23,8 @@ SYMBOLS = [
     "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe",
     "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
     "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
+    "fj_shuffle_plan", "fj_shuffle_region_chunks", "fj_shuffle_pack", "fj_stream_open_shuffled",
+    "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
     "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h",
 ]
@@ -109,6 +111,12 @@ def load() -> ctypes.CDLL:
     L.fj_bloom_filter_words.restype = sz; L.fj_bloom_filter_words.argtypes = []
     L.fj_bloom_export.restype = i32; L.fj_bloom_export.argtypes = [vp, vp, sz, i32, vp, vp]
     L.fj_bloom_prefilter.restype = i32; L.fj_bloom_prefilter.argtypes = [vp, vp, sz, i32, vp, vp, sz, pu64, vp]
+    L.fj_shuffle_plan.restype = i32; L.fj_shuffle_plan.argtypes = [sz, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.fj_shuffle_region_chunks.restype = sz; L.fj_shuffle_region_chunks.argtypes = [sz, sz, i32, i32]
+    L.fj_shuffle_pack.restype = i32; L.fj_shuffle_pack.argtypes = [vp, vp, vp, sz, sz, i32, vp, vp, vp, sz, pu64, vp]
+    L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, vp]
+    L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, sz, vp]
+    L.fj_stream_append_probe_chunks.restype = i32; L.fj_stream_append_probe_chunks.argtypes = [vp, vp, vp, sz, vp]
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]
     L.fj_generate_probe.restype = i32
     L.fj_generate_probe.argtypes = [vp, vp, u64, sz, u64, u64, ctypes.c_uint32, pu64, vp]

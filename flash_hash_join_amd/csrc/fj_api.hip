@@ -72,6 +72,9 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     u32 next_item;                     // work counter of the persistent join kernel
     u32 next_emit_item;                // ... and of the persistent emitting kernel (zeroed right before its launch)
     unsigned long long owner_counts[64], owner_cursors[64], owner_offsets[64];
+    // owner shuffle, sender side (fj_shuffle_pack: may run while a stream join is open, so it has words of its own)
+    u32 own_alloc[64];                 // chunks allocated in each owner's region
+    u32 pack_err, pack_seg, pack_alloc_unused, rx_alloc;   // error word / segment counter of the packing pass; chunk count of a received piece
 };
 
 enum Slot {
@@ -79,7 +82,10 @@ enum Slot {
     W_POOL_K = 0, W_POOL_V, W_DIR, W_LIST, W_BCHUNKS, W_REL, W_BOFF, W_SEGOFF, W_TOFF, W_TILES, W_KINDS,
     W_SIDE_STRIDE = 2 * W_KINDS,
     W_PART_COUNT = 2 * W_SIDE_STRIDE, W_OUT_OFF, W_GT_KEYS, W_GT_VALS, W_GT_BLOOM, W_WG_COUNT,
-    W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_BKEYS, W_BBASE, W_NSLOTS
+    W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_BKEYS, W_BBASE,
+    W_SH_REL, W_SH_SEGOFF, W_SH_BCH,                                   // fj_shuffle_pack scratch
+    W_RX_REL, W_RX_LIST, W_RX_SEGOFF, W_RX_BCH, W_RX_BOFF, W_RX_TOFF, W_RX_TILES,   // a received piece as a chunk set
+    W_NSLOTS
 };
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
@@ -135,6 +141,9 @@ struct StreamState {            // fj_stream_*: a counting join whose relations 
     const u64* flat_probe[64]; size_t flat_np[64]; u32 nflat = 0;
     // every piece appended so far (they stay allocated until fj_stream_finish returns): what the HBM-table fallback reads
     std::vector<std::pair<const u64*, size_t>> bpieces, ppieces;
+    // owner shuffle, receiver side (fj_stream_open_shuffled): the pieces are chunk pools that peers filled with the FIRST pass of
+    // the global plan; this rank owns level-1 buckets [b_lo, b_lo + nbk) and runs the plan from its second pass on
+    bool shuffled = false; u32 b_lo = 0, nbk = 0, nbk_pad = 0;
 };
 
 struct fj_ctx {
@@ -625,7 +634,7 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
 // launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
 int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, const PassIter& pit, hipStream_t s,
                     fj_timings* t, int evc, u64* out_count, bool* lds_full) {
-    ja.nparts = 1u << plan.bits;
+    ja.nparts = ja.probe.list ? ja.probe.nb : 1u << plan.bits;      // (an owner of a shuffled join holds a slice of the plan's partitions)
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
     void* p;
     u32 nitems;
@@ -1162,6 +1171,8 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
         if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full)) return 1;
+        if (lds_full && st.shuffled)
+            return set_err("shuffled stream join: a final partition holds more than 8128 distinct build keys (skewed build side); no fallback for chunk pieces");
         if (lds_full) {
             // a partition of more than 8128 distinct build keys: count over ONE table in HBM, piece by piece (the streamed
             // join's own fallback; the one-shot join has the same one)
@@ -1198,6 +1209,173 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
     if (timings) *timings = t;
     g_last = t;
     return 0;
+}
+
+// ---- owner shuffle in the shape of SURVEY 8(e): the first radix pass of the GLOBAL plan is the owner split ------------------
+// Every rank plans for the TOTAL build side (all ranks' rows): pass 1 of that plan has F0 = 256 or 512 buckets, bucket b
+// belongs to owner GPU (b * nranks) >> log2(F0).  A sender runs that pass over its local rows in the owner-grouped form of
+// the partition kernel (fj_shuffle_pack): the chunks of owner r's buckets land in region r of one pool, so what goes to a peer
+// is one contiguous piece (whole 2-KiB chunks + one directory word per chunk; ~3 % of partial chunks and abandoned slab
+// ids travel along).  The owner appends what it received as level-1 chunk sets (fj_stream_append_*_chunks: directory words ->
+// chunk lists, then the plan's SECOND pass over them) and finishes like any stream join.  No separate owner histogram, no
+// owner scatter, no first pass at the receiver: three passes over every probe row per rank become two.
+namespace {
+int shuffle_plan(size_t nb_total, int nranks, Plan* out) {
+    if (nranks < 1 || nranks > 64) return set_err("owner shuffle: nranks must be 1..64");
+    const Plan p = make_plan(nb_total, 64);
+    if (p.npass < 2) return set_err("owner shuffle: a build side of %zu rows in all has a %d-pass plan (the chunk form needs two or more: use fj_owner_split)", nb_total, p.npass);
+    if ((1 << p.fan_log[0]) < nranks) return set_err("owner shuffle: %d ranks but only %d first-pass buckets", nranks, 1 << p.fan_log[0]);
+    *out = p;
+    return 0;
+}
+u32 shuffle_groups(size_t n, u32 tile_chunks, u32 F) { return std::min<u32>(256u, pass_groups((n + FJ_CHUNK - 1) / FJ_CHUNK, n, tile_chunks, F)); }
+}  // namespace
+
+int fj_shuffle_plan(size_t nb_total, int nranks, int* fan_log0, int* npass) {
+    Plan p;
+    if (shuffle_plan(nb_total, nranks, &p)) return 1;
+    if (fan_log0) *fan_log0 = p.fan_log[0];
+    if (npass) *npass = p.npass;
+    return 0;
+}
+
+size_t fj_shuffle_region_chunks(size_t n, size_t nb_total, int nranks, int with_vals) {
+    Plan p;
+    if (shuffle_plan(nb_total, nranks, &p)) return 0;
+    const u32 F = 1u << p.fan_log[0], tc = fj_partition_tile_chunks((u32)p.fan_log[0], with_vals != 0);
+    const u64 G = shuffle_groups(n, tc, F), FO = (F + nranks - 1) / nranks + 1, slab = fj_own_slab((u32)p.fan_log[0], with_vals != 0, (u32)nranks);
+    // an even share of the rows + 25 % for the hash's imbalance, the partial chunk of every (workgroup, bucket) pair at either
+    // end of a segment, and one abandoned slab remainder per (workgroup, owner)
+    const u64 share = (n / FJ_CHUNK + nranks - 1) / nranks;
+    return (size_t)(share + share / 4 + 2 * G * FO + (G + 1) * slab + 64);
+}
+
+int fj_shuffle_pack(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks,
+                    uint64_t* d_out_keys, uint64_t* d_out_vals, uint32_t* d_out_dir, size_t region_chunks, uint64_t* h_used, void* stream) {
+    if (!c) return set_err("fj_shuffle_pack: null context");
+    if (!h_used || (n && (!d_keys || !d_out_keys || !d_out_dir)) || (d_vals && !d_out_vals)) return set_err("fj_shuffle_pack: null pointer");
+    if (((uintptr_t)d_keys | (uintptr_t)d_vals | (uintptr_t)d_out_keys | (uintptr_t)d_out_vals) & 15) return set_err("fj_shuffle_pack: pointers must be 16-byte aligned");
+    Plan plan;
+    if (shuffle_plan(nb_total, nranks, &plan)) return 1;
+    for (int r = 0; r < nranks; ++r) h_used[r] = 0;
+    if (n == 0) return 0;
+    if (region_chunks * (size_t)nranks >= (1ull << 24)) return set_err("fj_shuffle_pack: %d regions of %zu chunks exceed one chunk directory (send the relation in pieces)", nranks, region_chunks);
+    FJ_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vals = d_vals != nullptr;
+    const u32 fan_log = (u32)plan.fan_log[0], F = 1u << fan_log, tc = fj_partition_tile_chunks(fan_log, vals);
+    const u32 G = shuffle_groups(n, tc, F), slab = fj_own_slab(fan_log, vals, (u32)nranks);
+    if (region_chunks < (size_t)2 * slab) return set_err("fj_shuffle_pack: region of %zu chunks is too small", region_chunks);
+    const u32 cap = (u32)(region_chunks * nranks), max_segs = G + 3;
+    void* p;
+    FjPartArgs a{};
+    if (get_buf(c, W_SH_REL, (size_t)cap * 8, &p)) return 1; a.out_rel = (u64*)p;
+    if (get_buf(c, W_SH_SEGOFF, (size_t)max_segs * F * 4, &p)) return 1; a.seg_off = (u32*)p;
+    if (get_buf(c, W_SH_BCH, (size_t)F * 4, &p)) return 1; a.bchunks = (u32*)p;
+    a.in_keys = (const u64*)d_keys; a.in_vals = (const u64*)d_vals; a.n_flat = n; a.parent0 = 0;
+    a.out_keys = (u64*)d_out_keys; a.out_vals = (u64*)d_out_vals; a.out_dir = d_out_dir;
+    a.alloc = &c->d_sc->pack_alloc_unused; a.seg_counter = &c->d_sc->pack_seg; a.cap_chunks = cap; a.max_segs = max_segs; a.err = &c->d_sc->pack_err;
+    a.shift = 64u - fan_log; a.fan_log = fan_log; a.side = vals ? 0u : 1u; a.slab = slab;
+    a.own_nranks = (u32)nranks; a.own_region = (u32)region_chunks; a.own_alloc = c->d_sc->own_alloc;
+    HIPCHK(hipMemsetAsync(c->d_sc->own_alloc, 0, sizeof(u32) * 67, s));          // allocators + error word + segment counter + unused allocator
+    const int line_log = (vals && F > 256) ? 3 : 4;
+    HIPCHK(fj_launch_partition(a, vals, line_log, G, s));
+    HIPCHK(hipMemcpyAsync(c->h_sc->own_alloc, c->d_sc->own_alloc, sizeof(u32) * 67, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->h_sc->pack_err & FJ_ERR_POOL)
+        return set_err("fj_shuffle_pack: an owner's region of %zu chunks overflowed (skewed keys: more than 1.25x an even share go to one GPU)", region_chunks);
+    for (int r = 0; r < nranks; ++r) h_used[r] = std::min<u64>(c->h_sc->own_alloc[r], region_chunks);
+    return 0;
+}
+
+int fj_stream_open_shuffled(fj_ctx* c, size_t nb_total, int nranks, int rank, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends,
+                            void* stream) {
+    if (!c) return set_err("fj_stream_open_shuffled: null context");
+    if (rank < 0 || rank >= nranks) return set_err("fj_stream_open_shuffled: rank %d of %d", rank, nranks);
+    if (build_appends < 1 || build_appends > 64 || probe_appends < 1 || probe_appends > 64) return set_err("fj_stream_open_shuffled: build_appends and probe_appends must be 1..64");
+    Plan plan;
+    if (shuffle_plan(nb_total, nranks, &plan)) return 1;
+    FJ_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    StreamState& st = c->st;
+    st = StreamState();
+    c->pend.valid = false;
+    st.plan = plan; st.top_bits = 64; st.shuffled = true;
+    const u32 F0 = 1u << plan.fan_log[0];
+    st.b_lo = (u32)(((u64)rank * F0 + nranks - 1) / nranks);                     // first bucket b with (b * nranks) >> log2(F0) == rank
+    st.nbk = (u32)(((u64)(rank + 1) * F0 + nranks - 1) / nranks) - st.b_lo;
+    st.nbk_pad = (st.nbk + 3u) & ~3u;                                            // (fj_level_scan works in 16-B pieces)
+    st.np_bound = np_bound; st.nb_bound = nb_bound;
+    st.p_appends_left = (u32)probe_appends; st.b_appends_left = (u32)build_appends;
+    begin_plan(c);
+    HIPCHK(hipEventRecord(c->ev[E_START], s));
+    if (clear_plan_scalars(c, s)) return 1;
+    auto init = [&](PassIter& it, int side, size_t n, u32 appends) -> int {
+        pass_init(it, side, false, std::max<size_t>(n, 1), plan, 64);
+        it.i = 1; it.used = 64 - plan.fan_log[0]; it.parents = st.nbk_pad; it.slot = 1;     // pass 1 of the plan ran at the senders
+        it.lbound = it.n / FJ_CHUNK + 1 + (u64)appends * (2ull * 256 * F0 + 4096);          // their partial chunks and abandoned ids arrive too
+        return pass_prepare(c, it, appends, s);
+    };
+    if (init(st.bit, 0, nb_bound, (u32)build_appends)) return 1;
+    if (init(st.pit, 1, np_bound, (u32)probe_appends)) return 1;
+    st.pit.want_items = true;
+    st.active = true;
+    return 0;
+}
+
+namespace {
+// one received piece (whole chunks + their directory words) -> chunk lists + tile table -> the plan's second pass over it
+int stream_append_chunks(fj_ctx* c, int side, const u64* d_chunks, u32* d_dir, size_t nchunks, hipStream_t s) {
+    StreamState& st = c->st;
+    PassIter& it = side ? st.pit : st.bit;
+    if (nchunks >= (1ull << 24)) return set_err("fj_stream_append_*_chunks: a piece of %zu chunks exceeds one chunk directory", nchunks);
+    const u32 n = (u32)nchunks, nblocks = (n + 4095u) / 4096u;
+    u32 fan = 4; while (fan < st.nbk_pad) fan <<= 1;
+    const u32 tc = fj_partition_tile_chunks((u32)st.plan.fan_log[1], false);
+    const u64 max_tiles = n / tc + st.nbk_pad + 1;
+    FjChunkSet cs{};
+    void* p;
+    cs.keys = const_cast<u64*>(d_chunks); cs.vals = nullptr; cs.dir = d_dir; cs.cap = n; cs.nb = st.nbk_pad; cs.fan_mask = fan - 1; cs.max_segs = nblocks;
+    if (get_buf(c, W_RX_REL, (size_t)n * 8, &p)) return 1; cs.rel = (u64*)p;
+    if (get_buf(c, W_RX_LIST, (size_t)n * 4, &p)) return 1; cs.list = (u32*)p;
+    if (get_buf(c, W_RX_SEGOFF, (size_t)nblocks * fan * 4, &p)) return 1; cs.seg_off = (u32*)p;
+    if (get_zeroed_buf(c, W_RX_BCH, (size_t)fan * 4, &p, s)) return 1; cs.bchunks = (u32*)p;
+    if (get_buf(c, W_RX_BOFF, ((size_t)st.nbk_pad + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
+    if (get_buf(c, W_RX_TOFF, ((size_t)st.nbk_pad + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
+    if (get_buf(c, W_RX_TILES, (size_t)max_tiles * sizeof(uint4), &p)) return 1; uint4* tiles = (uint4*)p;
+    cs.alloc = &c->d_sc->rx_alloc;
+    HIPCHK(fj_launch_dir_rank(d_dir, n, st.b_lo, st.nbk, fan, cs.rel, cs.seg_off, cs.bchunks, cs.alloc, s));
+    HIPCHK(fj_launch_group(cs, tc, toff, tiles, (u32)max_tiles, nullptr, s));
+    it.prev = cs; it.have_prev = true; it.tiles = tiles; it.ntiles = toff + st.nbk_pad; it.toff = toff;
+    return pass_launch(c, it, nullptr, nullptr, 0, s, side && st.evc < 4 ? &st.evc : nullptr);
+}
+}  // namespace
+
+int fj_stream_append_build_chunks(fj_ctx* c, const uint64_t* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream) {
+    if (!c || !c->st.active || !c->st.shuffled) return set_err("fj_stream_append_build_chunks: no shuffled stream join is open on this context");
+    StreamState& st = c->st;
+    if (st.build_done) return set_err("fj_stream_append_build_chunks: the build side is already closed");
+    if (st.b_appends_left == 0) return set_err("fj_stream_append_build_chunks: more pieces than build_appends");
+    if (nchunks && (!d_chunks || !d_dir || ((uintptr_t)d_chunks & 15))) return set_err("fj_stream_append_build_chunks: null or misaligned piece");
+    FJ_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    --st.b_appends_left;
+    if (nchunks) { st.nb_seen += nchunks * FJ_CHUNK; if (stream_append_chunks(c, 0, (const u64*)d_chunks, d_dir, nchunks, s)) return 1; }
+    if (st.b_appends_left == 0) return stream_flush_build(c, st, s);          // the build side is complete: its remaining passes run now
+    return 0;
+}
+
+int fj_stream_append_probe_chunks(fj_ctx* c, const uint64_t* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream) {
+    if (!c || !c->st.active || !c->st.shuffled) return set_err("fj_stream_append_probe_chunks: no shuffled stream join is open on this context");
+    StreamState& st = c->st;
+    if (st.probe_done) return set_err("fj_stream_append_probe_chunks: the probe side is already closed");
+    if (st.p_appends_left == 0) return set_err("fj_stream_append_probe_chunks: more pieces than probe_appends");
+    if (nchunks && (!d_chunks || !d_dir || ((uintptr_t)d_chunks & 15))) return set_err("fj_stream_append_probe_chunks: null or misaligned piece");
+    FJ_ENTER(c);
+    --st.p_appends_left;
+    if (nchunks == 0) return 0;
+    st.np_seen += nchunks * FJ_CHUNK;
+    return stream_append_chunks(c, 1, (const u64*)d_chunks, d_dir, nchunks, (hipStream_t)stream);
 }
 
 // split fj_owner_split into its two halves so that a caller can size its exchange before scattering

@@ -40,6 +40,13 @@ struct FjPartArgs {
     u32 fan_log;
     u32 side;                // 0 = build relation, 1 = probe relation (selects the kernel's name only)
     u32 slab;                // chunks a workgroup takes per allocator hit: >= tile chunks + fan-out (fj_slab_for)
+    // owner-grouped form (multi-GPU sender, flat input only): bucket b belongs to owner GPU (b * own_nranks) >> fan_log, and
+    // the chunks of owner r's buckets are allocated from region r of the output pool, ids [r * own_region, (r + 1) * own_region),
+    // through own_alloc[r] - so that what goes to one peer is ONE contiguous piece of the pool (the first radix
+    // pass IS the owner split).  own_nranks == 0: one allocator for the whole pool (a.alloc).
+    u32 own_nranks;
+    u32 own_region;          // chunks per region
+    u32* own_alloc;          // [own_nranks] device words, zeroed before the pass: chunks allocated in each region
 };
 
 // a chunk pool plus its per-bucket chunk lists (output of one pass, input of the next)
@@ -64,11 +71,15 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log);
 // chunks (of 256 rows) per input tile of the pass kernel chosen for this fan-out and payload
 u32 fj_partition_tile_chunks(u32 fan_log, bool vals);
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s);
+// chunks a workgroup takes per allocator hit in the owner-grouped form (per owner: tile chunks + the owner's buckets + slack)
+u32 fj_own_slab(u32 fan_log, bool vals, u32 nranks);
 // level bookkeeping after a pass: chunk-list offsets (clears cs.bchunks for the next join), chunk lists, and the tile table
 // of the level's consumer (tc chunks per tile; 0 = none); zero_tail: optional [max_tiles] array whose entries past the
 // number of tiles are cleared
 hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s);
 hipError_t fj_launch_scan_u32_to_u64(const u32* in, u64* out, u32 n, hipStream_t s);
+// received chunks (directory words only) -> (segment, rank, span offset) for fj_launch_group; fan = power of two >= nbk
+hipError_t fj_launch_dir_rank(u32* dir, u32 n, u32 b_lo, u32 nbk, u32 fan, u64* rel, u32* seg_off, u32* bchunks, u32* nalloc, hipStream_t s);
 
 // ---- bloom precheck between two probe-side passes (csrc/fj_bloom.hip) ----------------------------
 struct FjBloomArgs {

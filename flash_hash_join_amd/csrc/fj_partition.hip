@@ -27,9 +27,10 @@ namespace {
 
 // dynamic-LDS layout, shared by kernel and host-side size computation
 struct PartLds {
-    u32 sorted_k, sorted_v, lo_k, lo_v, hist, toff, line_desc, t_chunk, t_cnt, wsum, misc, total;
+    u32 sorted_k, sorted_v, lo_k, lo_v, hist, toff, line_desc, t_chunk, t_cnt, wsum, misc, own, total;
 };
-__host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool vals, u32 nwaves) {
+constexpr u32 OWN_MAX = 64;            // owner GPUs of the owner-grouped form
+__host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool vals, u32 nwaves, bool own = false) {
     PartLds L;
     const u32 nsorted = T + 2;                             // bucket-sorted tile (remainders stay in lo_*)
     const u32 maxl = (T + (line - 1) * F) / line + 2;
@@ -45,6 +46,7 @@ __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool 
     L.t_chunk = o; o += (T / FJ_CHUNK) * 4;
     L.t_cnt = o; o += (T / FJ_CHUNK) * 4;
     L.misc = o; o += 16 * 4;
+    L.own = o; if (own) o += (5 * OWN_MAX + 4) * 4;        // per-owner slab state: cur, rem, new, flush count, kb0[OWN_MAX + 1]
     L.total = (o + 15) & ~15u;
     return L;
 }
@@ -57,16 +59,19 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG 
 // only by the waves that own buckets, whole contiguous lines per store instruction in the write-out.
 // PROBE_SIDE only names the instantiation (identical code): a counting join runs the keys-only kernel over both
 // relations, and per-kernel profiler statistics should not average 100M-row and 1B-row launches together.
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE>
+// OWN: the owner-grouped form (see FjPartArgs): every workgroup keeps one open slab PER OWNER GPU, taken from that owner's
+// region of the output pool; everything else is the same pass.
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false>
 __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
+    static_assert(!OWN || FLAT, "the owner-grouped form reads a flat relation");
     const u32 F = 1u << a.fan_log, FM = F - 1;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const PartLds Lo = part_lds_layout(T, F, LINE, HAS_VALS, NW);
+    const PartLds Lo = part_lds_layout(T, F, LINE, HAS_VALS, NW, OWN);
     u64* tile_k = (u64*)(smem + Lo.sorted_k);
     u64* tile_v = (u64*)(smem + Lo.sorted_v);
     u64* lo_k = (u64*)(smem + Lo.lo_k);
@@ -78,6 +83,13 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     u32* t_chunk = (u32*)(smem + Lo.t_chunk);
     u32* t_cnt = (u32*)(smem + Lo.t_cnt);
     u32* misc = (u32*)(smem + Lo.misc);
+    u32* own_cur = (u32*)(smem + Lo.own);            // OWN: current slab position / ids left / fresh slab / flush count per owner,
+    u32* own_rem = own_cur + OWN_MAX;                //      and the tile's chunk-prefix at each owner's first bucket
+    u32* own_new = own_rem + OWN_MAX;
+    u32* own_fl = own_new + OWN_MAX;
+    u32* own_kb0 = own_fl + OWN_MAX;
+    const u32 NR = OWN ? a.own_nranks : 1u;
+    auto owner_of = [&](u32 b) -> u32 { return (b * NR) >> a.fan_log; };
 
     const u32 Lc = FLAT ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : 0u;
     const u32 ntiles = FLAT ? (Lc + TC - 1) / TC : *a.in_ntiles;
@@ -142,6 +154,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     };
 
     if (tid == 0) { misc[M_SLAB_CUR] = 0; misc[M_SLAB_REM] = 0; misc[M_NEW_BASE] = 0; misc[M_SEG] = 0; }
+    if (OWN && tid < OWN_MAX) { own_cur[tid] = 0; own_rem[tid] = 0; own_new[tid] = 0; own_fl[tid] = 0; own_kb0[tid] = 0; if (tid == 0) own_kb0[OWN_MAX] = 0; }
     // per-bucket state lives in the registers of thread b (b < F)
     u32 st_left = 0, st_fill = FJ_CHUNK, st_cur = FJ_DIR_INVALID, st_nch = 0;
     u32 pend_cnt = 0, pend_nf = 0, pend_tb = 0;
@@ -168,27 +181,51 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         }
     };
 
-    // id of the j-th chunk this workgroup allocates in the current tile
-    auto alloc_id = [&](u32 j) -> u32 {
+    // id of the j-th chunk this workgroup allocates in the current tile (j counts over all buckets in bucket order; b = the
+    // bucket the chunk is for: in the owner-grouped form it comes out of the slab of b's owner)
+    auto alloc_id = [&](u32 j, u32 b) -> u32 {
+        if constexpr (OWN) {
+            const u32 o = owner_of(b), jr = j - own_kb0[o], rem = own_rem[o];
+            return jr < rem ? own_cur[o] + jr : own_new[o] + (jr - rem);
+        }
         const u32 rem = misc[M_SLAB_REM];
         return j < rem ? misc[M_SLAB_CUR] + j : misc[M_NEW_BASE] + (j - rem);
+    };
+    // OWN: a fresh slab out of owner o's region (thread o)
+    auto own_take_slab = [&](u32 o) -> u32 {
+        u32 nb = atomicAdd(&a.own_alloc[o], a.slab);
+        if (nb + a.slab > a.own_region) { atomicOr(a.err, FJ_ERR_POOL); nb = 0; }     // (stay inside the region: the result is discarded)
+        return o * a.own_region + nb;
     };
 
     // end of a segment (= this workgroup's share of one parent bucket): write the carried
     // remainders, fix the last chunk's count, reserve the chunk-list spans, reset the state
     auto flush = [&](u32 parent) {
-        {   // a slab remainder too small for the flush is abandoned below: its ids stay unlisted (the directory has no memset)
-            const u32 rem0 = misc[M_SLAB_REM], cur0 = misc[M_SLAB_CUR];
-            if (rem0 < F && tid < rem0 && cur0 + tid < cap) a.out_dir[cur0 + tid] = FJ_DIR_INVALID;
-            __syncthreads();
-        }
-        if (tid == 0) {
-            if (misc[M_SLAB_REM] < F) {
-                const u32 nb = atomicAdd(a.alloc, a.slab);
-                if (nb + a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
-                misc[M_SLAB_CUR] = nb; misc[M_SLAB_REM] = a.slab;
+        if constexpr (OWN) {
+            // every owner's open slab must cover one chunk per bucket of that owner; a remainder too small is abandoned
+            const u32 FO = (F + NR - 1) / NR + 1;
+            if (tid < NR) {
+                const u32 rem0 = own_rem[tid], cur0 = own_cur[tid];
+                if (rem0 < FO) {
+                    for (u32 j = 0; j < rem0; ++j) if (cur0 + j < cap) a.out_dir[cur0 + j] = FJ_DIR_INVALID;
+                    own_cur[tid] = own_take_slab(tid); own_rem[tid] = a.slab;
+                }
+                own_fl[tid] = 0;
             }
-            misc[M_FLUSH] = 0;
+        } else {
+            {   // a slab remainder too small for the flush is abandoned below: its ids stay unlisted (the directory has no memset)
+                const u32 rem0 = misc[M_SLAB_REM], cur0 = misc[M_SLAB_CUR];
+                if (rem0 < F && tid < rem0 && cur0 + tid < cap) a.out_dir[cur0 + tid] = FJ_DIR_INVALID;
+                __syncthreads();
+            }
+            if (tid == 0) {
+                if (misc[M_SLAB_REM] < F) {
+                    const u32 nb = atomicAdd(a.alloc, a.slab);
+                    if (nb + a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
+                    misc[M_SLAB_CUR] = nb; misc[M_SLAB_REM] = a.slab;
+                }
+                misc[M_FLUSH] = 0;
+            }
         }
         __syncthreads();
         if (tid < F) {
@@ -196,7 +233,9 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             u32 f0 = st_fill, c = st_cur, n = st_nch;
             const u32 outb = parent * F + b;
             if (l > 0 && f0 == FJ_CHUNK) {
-                c = misc[M_SLAB_CUR] + atomicAdd(&misc[M_FLUSH], 1u); f0 = 0;
+                if constexpr (OWN) { const u32 o = owner_of(b); c = own_cur[o] + atomicAdd(&own_fl[o], 1u); }
+                else c = misc[M_SLAB_CUR] + atomicAdd(&misc[M_FLUSH], 1u);
+                f0 = 0;
                 if (c < cap) a.out_rel[c] = ((u64)seg << 32) | n;
                 ++n;
             }
@@ -215,7 +254,8 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             st_left = 0; st_fill = FJ_CHUNK; st_cur = FJ_DIR_INVALID; st_nch = 0;
         }
         __syncthreads();
-        if (tid == 0) { const u32 n = misc[M_FLUSH]; misc[M_SLAB_CUR] += n; misc[M_SLAB_REM] -= n; }
+        if constexpr (OWN) { if (tid < NR) { const u32 n = own_fl[tid]; own_cur[tid] += n; own_rem[tid] -= n; } }
+        else if (tid == 0) { const u32 n = misc[M_FLUSH]; misc[M_SLAB_CUR] += n; misc[M_SLAB_REM] -= n; }
         __syncthreads();
     };
 
@@ -345,12 +385,17 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 toff[tid] = to;
                 l0 += (u32)((woff >> 20) & 0xFFFFFu);
                 kb += (u32)(woff >> 40);
+                if constexpr (OWN) {                       // the tile's chunk prefix at each owner's first bucket
+                    const u32 o = owner_of(tid);
+                    if (tid == 0 || owner_of(tid - 1) != o) own_kb0[o] = kb;
+                    if (tid == F - 1) own_kb0[NR] = kb + km;
+                }
                 if (tid == F - 1) {
                     toff[F] = to + cnt;                    // dummy bucket goes behind everything
                     const u32 need = kb + km;
                     misc[M_NLINES] = l0 + (nf >> LINE_LOG);
                     misc[M_NEED] = need;
-                    if (need > misc[M_SLAB_REM]) {
+                    if (!OWN && need > misc[M_SLAB_REM]) {
                         const u32 nb = atomicAdd(a.alloc, a.slab);
                         if (nb + a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
                         misc[M_NEW_BASE] = nb;
@@ -359,6 +404,10 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             }
         }
         __syncthreads();
+        if constexpr (OWN) {                               // an owner whose slab cannot cover this tile's new chunks gets a fresh one
+            if (tid < NR && own_kb0[tid + 1] - own_kb0[tid] > own_rem[tid]) own_new[tid] = own_take_slab(tid);
+            __syncthreads();
+        }
 
         // ---- bucket-sort the tile's new keys in LDS ---------------------------------------------
 #pragma unroll
@@ -377,7 +426,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u32 nl = own ? (nf >> LINE_LOG) : 0u;
             auto put = [&](u32 pb, u32 pf0, u32 pc0, u32 pkb, u32 ptb, u32 pleft, u32 pl0, u32 j) {
                 const u32 q = j << LINE_LOG, pq = pf0 + q, kk = pq >> FJ_CHUNK_LOG, off = pq & (FJ_CHUNK - 1);
-                const u32 id = kk == 0 ? pc0 : alloc_id(pkb + kk - 1);
+                const u32 id = kk == 0 ? pc0 : alloc_id(pkb + kk - 1, pb);
                 const u32 dst = id < cap ? id * FJ_CHUNK + off : FJ_DIR_INVALID;
                 const u32 lc = j == 0 ? pleft : 0u;
                 const u32 sidx = ptb + q + 32u - pleft;             // tile index of virtual key q (may precede the run for line 0)
@@ -402,12 +451,12 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u32 outb = (parent * F + b) << FJ_DIR_CNT_BITS;
             const u64 segw = (u64)misc[M_SEG] << 32;
             for (u32 kk = 1; kk <= km; ++kk) {
-                const u32 id = alloc_id(kb + kk - 1);
+                const u32 id = alloc_id(kb + kk - 1, b);
                 if (id < cap) { a.out_dir[id] = outb | FJ_CHUNK; a.out_rel[id] = segw | (n0 + kk - 1); }
             }
             // remember what the carry step needs (it runs at the top of the next iteration)
             pend_cnt = cnt; pend_nf = nf; pend_tb = tb;
-            st_cur = km ? alloc_id(kb + km - 1) : c0;
+            st_cur = km ? alloc_id(kb + km - 1, b) : c0;
             st_fill = f0 + nf - (km << FJ_CHUNK_LOG);
             st_nch = n0 + km;
         }
@@ -441,7 +490,13 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 if (HAS_VALS) { u64x2 w0; w0.x = rv[0]; w0.y = rv[1]; *reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + q) = w0; }
             }
         }
-        if (tid == 0) {
+        if constexpr (OWN) {
+            if (tid < NR) {
+                const u32 need = own_kb0[tid + 1] - own_kb0[tid], rem = own_rem[tid];
+                if (need <= rem) { own_cur[tid] += need; own_rem[tid] = rem - need; }
+                else { const u32 used = need - rem; own_cur[tid] = own_new[tid] + used; own_rem[tid] = a.slab - used; }
+            }
+        } else if (tid == 0) {
             const u32 need = misc[M_NEED], rem = misc[M_SLAB_REM];
             if (need <= rem) { misc[M_SLAB_CUR] += need; misc[M_SLAB_REM] = rem - need; }
             else { const u32 used = need - rem; misc[M_SLAB_CUR] = misc[M_NEW_BASE] + used; misc[M_SLAB_REM] = a.slab - used; }
@@ -452,7 +507,12 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     flush(cur_parent);
     // The chunk ids this workgroup took from the allocator but never used stay unlisted: their directory words say so.
     // (Every id below the allocator's high-water mark is thus defined by its owner - the directory needs no memset.)
-    for (u32 j = tid; j < misc[M_SLAB_REM]; j += NT) { const u32 id = misc[M_SLAB_CUR] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
+    if constexpr (OWN) {
+        for (u32 o = 0; o < NR; ++o)
+            for (u32 j = tid; j < own_rem[o]; j += NT) { const u32 id = own_cur[o] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
+    } else {
+        for (u32 j = tid; j < misc[M_SLAB_REM]; j += NT) { const u32 id = misc[M_SLAB_CUR] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
+    }
 }
 
 // Single-workgroup exclusive scan (bucket counts -> offsets): sweeps of 16384 elements.  A thread takes four groups of four
@@ -618,11 +678,45 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
     }
 }
 
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE>
+// Chunks that arrived from other GPUs (owner shuffle: every sender's region for this owner, concatenated) -> a chunk set the
+// level bookkeeping understands.  Per chunk only its directory word came over the wire; this kernel gives every chunk its
+// rank inside (block of 4096 chunks, bucket) with LDS atomics and every (block, bucket) a span of the bucket's chunk list with
+// one global atomic - the same (segment, rank, span offset) scheme the partition pass produces for its own output, so that
+// fj_level_scan / fj_level_lists run unchanged.  Directory words are rewritten with bucket ids relative to b_lo (this owner's
+// first bucket); foreign or unused ids become FJ_DIR_INVALID.
+__global__ __launch_bounds__(1024) void fj_dir_rank_kernel(u32* __restrict__ dir, u32 n, u32 b_lo, u32 nbk, u32 fan, u64* __restrict__ rel,
+                                                           u32* __restrict__ seg_off, u32* __restrict__ bchunks, u32* __restrict__ nalloc) {
+    __shared__ u32 h[1u << FJ_MAX_FAN_LOG];
+    const u32 tid = threadIdx.x, base = blockIdx.x * 4096u;
+    if (tid < (1u << FJ_MAX_FAN_LOG)) h[tid] = 0;
+    __syncthreads();
+    u32 bb[4], rr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const u32 i = base + (u32)u * 1024u + tid;
+        bb[u] = FJ_DIR_INVALID; rr[u] = 0;
+        if (i < n) {
+            const u32 e = dir[i], b = (e >> FJ_DIR_CNT_BITS) - b_lo, cnt = e & FJ_DIR_CNT_MASK;
+            const bool ok = e != FJ_DIR_INVALID && b < nbk && cnt >= 1u && cnt <= FJ_CHUNK;
+            if (ok) { rr[u] = atomicAdd(&h[b], 1u); bb[u] = b; }
+            dir[i] = ok ? ((b << FJ_DIR_CNT_BITS) | cnt) : FJ_DIR_INVALID;
+        }
+    }
+    __syncthreads();
+    if (tid < nbk) { const u32 c = h[tid]; if (c) seg_off[(u64)blockIdx.x * fan + tid] = atomicAdd(&bchunks[tid], c); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const u32 i = base + (u32)u * 1024u + tid;
+        if (bb[u] != FJ_DIR_INVALID) rel[i] = ((u64)blockIdx.x << 32) | rr[u];
+    }
+    if (blockIdx.x == 0 && tid == 0) *nalloc = n;
+}
+
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false>
 hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
-    const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64);
-    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE>;
+    const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64, OWN);
+    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, OWN>;
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, s, a);
@@ -676,8 +770,23 @@ u32 fj_partition_tile_chunks(u32 fan_log, bool vals) { (void)fan_log; return val
 
 // One partition pass, one 1024-thread workgroup per CU: keys only 8192-key tiles (8 keys per thread; half as many barriers
 // and bucket scans per key as the 4096-key tiles of two 512-thread workgroups), with values 4096-row tiles (4 rows per thread).
+u32 fj_own_slab(u32 fan_log, bool vals, u32 nranks) {
+    const u32 F = 1u << fan_log, need = fj_partition_tile_chunks(fan_log, vals) + (F + nranks - 1) / nranks + 1 + 16;   // per owner and tile: <= tile chunks + its buckets (+ slack)
+    u32 s = 64; while (s < need) s <<= 1;
+    return s;
+}
+
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
     if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
+    if (a.own_nranks) {
+        // owner-grouped form (multi-GPU sender): flat input, one open slab per owner and workgroup
+        if (a.in_list || a.own_nranks > OWN_MAX || (1u << a.fan_log) < a.own_nranks || a.fan_log > FJ_MAX_FAN_LOG || !a.own_alloc ||
+            a.slab < fj_own_slab(a.fan_log, vals, a.own_nranks) || a.parent0 != 0) return hipErrorInvalidValue;
+        const u32 g = grid < 256 ? grid : 256;
+        if (vals) return line_log == 3 ? launch_part1<1024, 4, 3, true, true, true, true>(a, g, s) : launch_part1<1024, 4, 4, true, true, true, true>(a, g, s);
+        if (line_log != 4) return hipErrorInvalidValue;
+        return a.side == 0 ? launch_part1<1024, 8, 4, false, true, false, true>(a, g, s) : launch_part1<1024, 8, 4, false, true, true, true>(a, g, s);
+    }
     if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < 48 + (1u << a.fan_log)) return hipErrorInvalidValue;
     if (a.fan_log == 9) {
         // 512 buckets: one bucket per thread needs >= 512 threads and the open lines take 64 KiB (keys) -- one
@@ -702,6 +811,12 @@ hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles
     hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
     hipLaunchKernelGGL(fj_level_lists, dim3(2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
                        cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_dir_rank(u32* dir, u32 n, u32 b_lo, u32 nbk, u32 fan, u64* rel, u32* seg_off, u32* bchunks, u32* nalloc, hipStream_t s) {
+    if (nbk > (1u << FJ_MAX_FAN_LOG) || fan < nbk || n == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fj_dir_rank_kernel, dim3((n + 4095u) / 4096u), dim3(1024), 0, s, dir, n, b_lo, nbk, fan, rel, seg_off, bchunks, nalloc);
     return hipGetLastError();
 }
 

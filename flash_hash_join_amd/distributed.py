@@ -2,7 +2,7 @@
 
 The reference is single-process; this is new design.  Two exchange strategies, chosen per call
 by FJ_DIST_STRATEGY = shuffle | replicate | auto (a per-link byte + local-work cost model, choose_strategy); unset it
-means the shuffle north_star names, or the model's choice once a link rate was measured on the node (set_link_rate):
+means the shuffle north_star names:
 
 replicate -- every rank all-gathers the build KEYS (and values when materialising) and joins its own probe rows
   against all of them; probe rows never move, their partition passes run while the build keys are on the wire
@@ -15,6 +15,11 @@ replicate -- every rank all-gathers the build KEYS (and values when materialisin
 shuffle -- radix partitions are independent join units (hash_join.cpp:340-356, :515-525), so the level-0 digit is
   the owner GPU:   owner(key) = (top 16 bits of hash(key) * world) >> 16
 
+  Counting joins whose GLOBAL plan has two or more passes take the CHUNK form (_chunk_shuffle_count): the first
+  radix pass of the plan for the total build side IS the owner split - bucket b of its 256 / 512 buckets belongs to rank
+  (b * world) >> log2(buckets); a sender runs that pass with the chunks grouped by owner (fj_shuffle_pack), ships whole chunks
+  + directory words (grouped RCCL sends / receives), and the owner starts at the plan's second pass.  Everything else
+  (materialising joins, small build sides, the sender-side precheck) takes the OWNER-SCATTER form:
   1. every rank splits its local rows of both relations by owner (fj_owner_split: LDS counting
      sort per tile, contiguous per-owner segments);
   2. ONE all-to-all per relation moves each segment to its owner (torch.distributed
@@ -159,6 +164,55 @@ class HipEngine:
                                                   out.data_ptr(), out.numel(), ctypes.byref(n), t.cuda.current_stream(self.index).cuda_stream))
         return out[: int(n.value)]
 
+    # ---- owner shuffle in chunk form (the first radix pass of the global plan is the owner split) ----
+    def empty_i32(self, n: int):
+        return self.torch.empty(n, dtype=self.torch.int32, device=self.device)
+
+    def shuffle_plan(self, nb_total: int, world: int) -> Optional[int]:
+        """log2 of the first-pass fan-out of the plan for a build side of nb_total rows in all, or None when the chunk form
+        does not apply (a one-pass plan: build sides under ~2M rows)."""
+        f0, npass = ctypes.c_int(0), ctypes.c_int(0)
+        if self.L.fj_shuffle_plan(nb_total, world, ctypes.byref(f0), ctypes.byref(npass)):
+            return None
+        return int(f0.value)
+
+    def shuffle_pack(self, keys, vals, nb_total: int, world: int):
+        """First pass of the global plan over local rows, chunks grouped by owner GPU.  Returns (pool_keys, pool_vals, dir,
+        region_chunks, used): owner r's chunks are [r * region_chunks, r * region_chunks + used[r]) of the pool (256 keys
+        each), with one directory word per chunk."""
+        t = self.torch
+        keys = self._aligned(keys)
+        n = keys.numel()
+        region = int(self.L.fj_shuffle_region_chunks(n, nb_total, world, int(vals is not None)))
+        if region == 0:
+            raise RuntimeError(self._lib.last_error())
+        pool_k = self.empty(world * region * 256)
+        pool_v = self.empty(world * region * 256) if vals is not None else None
+        dirw = self.empty_i32(world * region)
+        used = (ctypes.c_uint64 * 64)()
+        self._lib.check(self.L.fj_shuffle_pack(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, n, nb_total, world,
+                                               pool_k.data_ptr(), pool_v.data_ptr() if pool_v is not None else None, dirw.data_ptr(), region,
+                                               used, t.cuda.current_stream(self.index).cuda_stream))
+        return pool_k, pool_v, dirw, region, [int(used[r]) for r in range(world)]
+
+    def stream_open_shuffled(self, nb_total: int, world: int, rank: int, nb_bound: int, build_appends: int, np_bound: int, probe_appends: int):
+        self._keep = []
+        self._lib.check(self.L.fj_stream_open_shuffled(self.ctx, nb_total, world, rank, nb_bound, build_appends, np_bound, probe_appends,
+                                                       self.torch.cuda.current_stream(self.index).cuda_stream))
+
+    def stream_append_chunks(self, side: int, chunks, dirw):
+        """A received piece: whole 256-key chunks + their directory words (rewritten in place)."""
+        self._keep += [chunks, dirw]
+        fn = self.L.fj_stream_append_probe_chunks if side else self.L.fj_stream_append_build_chunks
+        self._lib.check(fn(self.ctx, chunks.data_ptr(), dirw.data_ptr(), dirw.numel(), self.torch.cuda.current_stream(self.index).cuda_stream))
+
+    def chunk_rows(self, dirw) -> int:
+        """Rows in a set of chunks, from their directory words (bucket << 9 | count; unused ids are all ones)."""
+        if dirw.numel() == 0:
+            return 0
+        cnt = dirw & 0x1FF
+        return int(cnt[dirw != -1].sum().item())
+
     def stream_abort(self):
         """Error recovery: drop a stream join that will not be finished, so that the context serves other joins again."""
         self._keep = []
@@ -175,6 +229,26 @@ class HipEngine:
 # RCCL moves wrong data when one peer-to-peer message of an all-to-all exceeds 4 GiB (measured here: an int64
 # all_to_all_single is exact at 0.8 GB per peer, wrong at 4.8 GB), so larger segments travel in several rounds.
 _MAX_ELEMS_PER_MESSAGE = 1 << 27          # 1 GiB of int64 per (source, destination) and round
+
+
+def _views_all_to_all(dist, group, ins, outs):
+    """All-to-all over per-peer VIEWS (slices of larger tensors, not adjacent in memory): grouped point-to-point sends and
+    receives - ncclSend / ncclRecv inside one group call under RCCL, isend / irecv under gloo (whose list-form all_to_all does
+    not exist) - plus a local copy for this rank's own slice.  Empty slices are skipped on both sides (sender and receiver
+    know the sizes).  Returns the list of outstanding works (wait on all of them)."""
+    me = dist.get_rank(group)
+    world = len(ins)
+    if outs[me].numel():
+        outs[me].copy_(ins[me])
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    ops = []
+    for r in range(world):
+        if r != me and ins[r].numel():
+            ops.append(dist.P2POp(dist.isend, ins[r], peer(r), group))
+    for r in range(world):
+        if r != me and outs[r].numel():
+            ops.append(dist.P2POp(dist.irecv, outs[r], peer(r), group))
+    return list(dist.batch_isend_irecv(ops)) if ops else []
 
 
 def _exchange(dist, group, engine, send, send_counts: List[int], recv_counts: List[int], rounds: int):
@@ -196,7 +270,8 @@ def _exchange(dist, group, engine, send, send_counts: List[int], recv_counts: Li
                for d in range(len(send_counts))]
         outs = [recv[roff[q] + recv_counts[q] * r // rounds: roff[q] + recv_counts[q] * (r + 1) // rounds]
                 for q in range(len(recv_counts))]
-        dist.all_to_all(outs, ins, group=group)
+        for w in _views_all_to_all(dist, group, ins, outs):
+            w.wait()
     return recv
 
 
@@ -381,6 +456,138 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
     return int(tot.item()), t3 - t0
 
 
+def _chunk_shuffle_count(dist, group, engine, world, build_keys, probe_keys, nb_total: int, np_global: int, pieces: int,
+                         timings: Optional[dict]):
+    """Counting join, owner shuffle in CHUNK form: the first radix pass of the plan for the TOTAL build side is
+    the owner split.  A sender runs that pass over its local rows with the chunks grouped by owner GPU (engine.shuffle_pack:
+    no owner histogram, no owner scatter), ships every owner its chunks and their directory words, and the owner starts at
+    the plan's SECOND pass (engine.stream_append_chunks).  The probe side travels in `pieces` rounds: piece c is packed while
+    piece c-1 is on the wire and the second pass runs over piece c-2.  Per rank: two passes over every probe row instead of
+    three (owner scatter + two passes).  A failure on any rank (a skewed key set overflowing an owner's region, a pool
+    error) is agreed on by all ranks before anybody raises."""
+    t0 = time.perf_counter()
+    rank = dist.get_rank(group)
+    CH = 256
+    FAIL = 1 << 60
+    split_s = 0.0
+
+    def pack(rows):
+        nonlocal split_s
+        t = time.perf_counter()
+        try:
+            out = engine.shuffle_pack(rows, None, nb_total, world)
+        except RuntimeError as ex:               # agreed on below (largest_message), then raised everywhere
+            out = ex
+        split_s += time.perf_counter() - t
+        return out
+
+    def counts_and_rounds(packed):
+        """chunks per source for this piece; rounds such that no message exceeds the RCCL-safe size; raises on every rank
+        when any rank failed to pack."""
+        used = [0] * world if isinstance(packed, Exception) else packed[4]
+        send_c = engine.counts_tensor(used)
+        recv_c = engine.counts_tensor([0] * world)
+        dist.all_to_all_single(recv_c, send_c, group=group)
+        mx = engine.counts_tensor([FAIL if isinstance(packed, Exception) else max(used) * CH])
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        if int(mx.item()) >= FAIL:
+            raise _PackFailed("owner shuffle (chunk form) failed on a rank: " + (str(packed) if isinstance(packed, Exception) else
+                               "see that rank's error") + "; FJ_DIST_CHUNK_SHUFFLE=0 selects the owner-scatter form")
+        return [int(x) for x in recv_c.tolist()], max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
+
+    def put_on_the_wire(packed, recv_n, rounds, async_op):
+        pool_k, _, dirw, region, used = packed
+        rk, rd = engine.empty(sum(recv_n) * CH), engine.empty_i32(sum(recv_n))
+        works = []
+        roff = [0]
+        for c in recv_n:
+            roff.append(roff[-1] + c)
+        for r in range(rounds):                  # round r moves slice r of every (source, destination) message
+            lo = lambda n_: n_ * r // rounds
+            hi = lambda n_: n_ * (r + 1) // rounds
+            ins_k = [pool_k[(d * region + lo(used[d])) * CH: (d * region + hi(used[d])) * CH] for d in range(world)]
+            outs_k = [rk[(roff[q] + lo(recv_n[q])) * CH: (roff[q] + hi(recv_n[q])) * CH] for q in range(world)]
+            ins_d = [dirw[d * region + lo(used[d]): d * region + hi(used[d])] for d in range(world)]
+            outs_d = [rd[roff[q] + lo(recv_n[q]): roff[q] + hi(recv_n[q])] for q in range(world)]
+            works += _views_all_to_all(dist, group, ins_k, outs_k)
+            works += _views_all_to_all(dist, group, ins_d, outs_d)
+        if not async_op:
+            for w in works:
+                w.wait()
+            works = []
+        return rk, rd, works, packed             # (the packed pool stays alive until the wait)
+
+    def wait(sent):
+        for w in sent[2]:
+            w.wait()
+        return sent[0], sent[1]
+
+    class _PackFailed(RuntimeError):
+        pass
+
+    # A failure of this rank's ENGINE calls (open / append / finish) must not take it out of step with its peers: the first
+    # one is remembered, later engine calls are skipped, every collective still runs, and the ranks agree at the end.
+    failed: List[Exception] = []
+
+    def guarded(fn, *a):
+        if failed:
+            return None
+        try:
+            return fn(*a)
+        except RuntimeError as ex:
+            failed.append(ex)
+            return None
+
+    inflight = []
+    try:
+        # build side: one piece
+        pb = pack(build_keys)
+        recv_b, rounds_b = counts_and_rounds(pb)
+        rkb, rdb = wait(put_on_the_wire(pb, recv_b, rounds_b, False))
+        del pb
+        n = probe_keys.numel()
+        bounds = [(n * c // pieces) & ~1 for c in range(pieces)] + [n]      # even row offsets: every piece stays 16-byte aligned
+        np_bound = int(1.5 * np_global / world) + (1 << 22) + 2 * CH * 512 * world * pieces   # an even share + 50 % + the partial chunks
+        rows_recv = 0
+        guarded(engine.stream_open_shuffled, nb_total, world, rank, sum(recv_b) * CH, 1, np_bound, pieces)
+        guarded(engine.stream_append_chunks, 0, rkb, rdb)
+        for c in range(pieces + 1):              # piece c is packed and sent while piece c-1 arrives and is appended
+            if c < pieces:
+                pp = pack(probe_keys[bounds[c]: bounds[c + 1]])
+                recv_p, rounds_p = counts_and_rounds(pp)
+                inflight.append(put_on_the_wire(pp, recv_p, rounds_p, True))
+                del pp
+            if c >= 1:
+                rk, rd = wait(inflight.pop(0))
+                guarded(engine.stream_append_chunks, 1, rk, rd)
+                if timings is not None:
+                    rows_recv += engine.chunk_rows(rd)
+        t2 = time.perf_counter()
+        local_count = guarded(engine.stream_finish) or 0
+    except BaseException:                        # a failure every rank has seen (packing), or one no rank can recover from
+        for sent in inflight:
+            try:
+                wait(sent)
+            except Exception:                    # noqa: BLE001
+                pass
+        _abort_stream(engine)
+        raise
+    tot = engine.counts_tensor([local_count, 1 if failed else 0])
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    engine.synchronize()
+    t3 = time.perf_counter()
+    total, nfailed = (int(x) for x in tot.tolist())
+    if nfailed:
+        _abort_stream(engine)
+        raise RuntimeError(f"owner shuffle (chunk form): the local join failed on {nfailed} rank(s)" + (f"; this rank: {failed[0]}" if failed else ""))
+    if timings is not None:
+        timings.update(split_s=split_s, exchange_s=max(0.0, (t2 - t0) - split_s), join_s=t3 - t2, exchange_rounds=rounds_b, pieces=pieces,
+                       local_build_rows=engine.chunk_rows(rdb), local_probe_rows=rows_recv, local_count=local_count,
+                       prefilter=False, prefilter_mode="off", prefilter_sampled_survivors=None, probe_rows_sent=n,
+                       shuffle_form="chunks")
+    return total, t3 - t0
+
+
 # ---- strategy 2: replicate the build side ------------------------------------------------------------------
 # xGMI is a point-to-point mesh: a GPU has ONE link to each peer, so what bounds an exchange is the bytes per link.
 # The owner shuffle puts (P*8 + B*16)/N bytes on every link (P, B = local probe / build rows); sending every rank's
@@ -431,8 +638,8 @@ _LINK_MEASURED = False
 
 
 def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
-    """Replace the built-in per-link rate of the strategy model by a measured one (tools/xgmi_probe.py; bench.py does this
-    once at N > 1).  With a measured rate the default strategy becomes the model's choice."""
+    """Replace the built-in per-link rate of the cost model (FJ_DIST_STRATEGY=auto, the sender-side precheck's break-even)
+    by a measured one (tools/xgmi_probe.py; bench.py does this once at N > 1)."""
     global _LINK_BYTES_PER_S, _LINK_MEASURED
     if bytes_per_s > 0:
         _LINK_BYTES_PER_S = float(bytes_per_s)
@@ -441,17 +648,68 @@ def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
 
 def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
     """'shuffle' (the owner exchange north_star names) or 'replicate', for per-rank relation sizes nb x np_ (the maxima
-    over the ranks).  FJ_DIST_STRATEGY=replicate|shuffle forces one, =auto lets the cost model decide.  Unset: the shuffle,
-    unless a link rate was MEASURED on this node (set_link_rate; bench.py measures one all-to-all at N > 1) - then the model
-    decides with that rate: on a point-to-point mesh the probe-heavy shuffle puts (P*8 + B*16)/N bytes on every link
-    (6 GB per step at N = 2 for config 5's shards) where replicating the build side puts B*8 (1 GB)."""
-    forced = os.environ.get("FJ_DIST_STRATEGY", "auto" if _LINK_MEASURED else "shuffle")
+    over the ranks).  FJ_DIST_STRATEGY=replicate|shuffle forces one, =auto lets the cost model decide (with the link rate
+    of set_link_rate when one was measured).  Unset: ALWAYS the shuffle - a measured link rate informs the model, it never
+    changes what an unconfigured job runs (round 2 switched silently; a scaling curve must measure what it says)."""
+    forced = os.environ.get("FJ_DIST_STRATEGY", "shuffle")
     if forced in ("replicate", "shuffle"):
         return forced
     if world * nb >= (1 << 31):               # replicated build side must stay inside one GPU's chunk directory
         return "shuffle"
     c = strategy_costs(world, nb, np_, materialize)
     return "replicate" if c["replicate"] <= c["shuffle"] else "shuffle"
+
+
+def self_check(dist, group, engine, small_inputs, expected_small: int, message_elems: int) -> dict:
+    """A few seconds before a multi-rank job's first timed step: (1) one exchange of per-peer VIEWS at the largest message size
+    the step will use (`message_elems` int64 per peer, capped at the RCCL-safe size), every element a function of (source,
+    destination, index), verified in full on arrival - the transport of the chunk-form shuffle, and the > 4 GiB defect the
+    bounded rounds work around, on real ranks; (2) one small distributed_join against its closed-form count.  Every rank
+    returns the same verdict: {"ok", "error", "failed_ranks", "message_bytes", "seconds"}."""
+    import torch
+    t0 = time.perf_counter()
+    me, world = dist.get_rank(group), dist.get_world_size(group)
+    n = int(max(1, min(message_elems, _MAX_ELEMS_PER_MESSAGE)))
+    err = None
+    try:
+        send = engine.empty(n * world)
+        dev = send.device
+        idx = torch.arange(n, dtype=torch.int64, device=dev)
+        for d in range(world):
+            send[d * n: (d + 1) * n] = idx * 1000003 + (me * 64 + d) * 7919 + 12345
+        pad = engine.empty(n * world + 1024)                        # receive through views with gaps between them, like the chunk regions
+        stride = n + (1024 // max(1, world))
+        stride -= stride % 2
+        outs = [pad[q * stride: q * stride + n] for q in range(world)]
+        ins = [send[d * n: (d + 1) * n] for d in range(world)]
+        for w in _views_all_to_all(dist, group, ins, outs):
+            w.wait()
+        if os.environ.get("FJ_SELFCHECK_CORRUPT") and me == 0:      # test hook: what a transport that moves wrong data looks like
+            outs[world - 1][n // 2] ^= 1
+        for q in range(world):
+            want = idx * 1000003 + (q * 64 + me) * 7919 + 12345
+            bad = int((outs[q] != want).sum().item())
+            if bad:
+                err = f"exchange self-check: {bad} of {n} elements received from rank {q} are wrong ({n * 8} bytes per peer)"
+                break
+        del send, pad, outs, ins, idx
+    except Exception as ex:                                        # noqa: BLE001
+        err = f"exchange self-check raised {ex!r}"
+    flag = engine.counts_tensor([1 if err else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+    nbad = int(flag.item())
+    if nbad == 0:
+        try:
+            bk, bv, pk = small_inputs
+            got = distributed_join(bk, bv, pk, group=group, engine=engine, transport=dist)[0]
+            if int(got) != int(expected_small):
+                err = f"join self-check: count {got} != closed form {expected_small}"
+        except Exception as ex:                                    # noqa: BLE001  (raised on every rank, or agreed on inside)
+            err = f"join self-check raised {ex!r}"
+        flag = engine.counts_tensor([1 if err else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+        nbad = int(flag.item())
+    return {"ok": nbad == 0, "error": err, "failed_ranks": nbad, "message_bytes": n * 8, "seconds": round(time.perf_counter() - t0, 3)}
 
 
 def _gather_rows(dist, group, engine, world, t, sizes: List[int], lo_frac=(0, 1), async_op=False):
@@ -543,14 +801,17 @@ def _replicated_join(dist, group, engine, world, build_keys, build_values, probe
 
 
 def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool = False, bloom: bool = False,
-                     group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None):
+                     group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None, transport=None):
     """Join relations whose rows are block-distributed over the ranks of `group`.
 
     Every rank passes its LOCAL rows (int64 tensors on its GPU) and gets back
     `(global_match_count, seconds)`; with `materialize and return_arrays` also the pairs this
     rank owns.  `seconds` is this rank's wall time for the whole step (split + exchange + join).
+    `transport`: an object with torch.distributed's collective functions (default: torch.distributed itself) - the
+    self-tests that run several ranks on one GPU pass one that stages device tensors through the host for gloo.
     """
-    import torch.distributed as dist
+    import torch.distributed as _td
+    dist = transport if transport is not None else _td
     if engine is None:
         engine = HipEngine()
     if hasattr(engine, "normalize"):             # int64/uint64, contiguous, 16-byte aligned: what the C ABI's pointers must be
@@ -579,8 +840,16 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     if timings is not None:
         timings["strategy"] = "shuffle"
     if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
-        return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings,
-                                prefilter=_prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off")
+        mode = _prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off"
+        nb_total, np_global = sum(sizes_b), sum(int(x[1]) for x in allsz)
+        # the chunk form (the first radix pass of the global plan is the owner split) serves every counting shuffle whose
+        # global plan has two or more passes; the owner-scatter form below the small ones and the sender-side precheck
+        if (mode == "off" and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
+                and min(int(x[1]) for x in allsz) >= 2 * pieces and engine.shuffle_plan(nb_total, world) is not None):
+            return _chunk_shuffle_count(dist, group, engine, world, build_keys, probe_keys, nb_total, np_global, pieces, timings)
+        if timings is not None:
+            timings["shuffle_form"] = "owner-scatter"
+        return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings, prefilter=mode)
 
     # 1. split by owner
     bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)

@@ -157,6 +157,37 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
                      uint64_t* d_out_keys, uint64_t* d_out_vals, void* stream);
 
 /*
+ * Owner shuffle in the shape of SURVEY.md 8(e) (no reference counterpart; radix partitions are independent join units,
+ * hash_join.cpp:340-356, :515-525): the FIRST radix pass of the plan for the TOTAL build side is the owner split.
+ * Every rank plans for nb_total = all ranks' build rows; pass 1 of that plan has 2^fan_log0 buckets (256 or 512) and bucket
+ * b belongs to rank (b * nranks) >> fan_log0.
+ *   fj_shuffle_plan          - 0 if the chunk form applies (a plan of two or more passes, at least nranks first-pass buckets:
+ *                              build sides above ~2M rows in all); else an error (use fj_owner_split + fj_stream_begin).
+ *   fj_shuffle_region_chunks - capacity to give each owner's region when packing n local rows (an even share + 25 % + the
+ *                              partial chunks); the output pool is nranks regions of that many 2-KiB chunks.
+ *   fj_shuffle_pack          - runs that first pass over n local rows (values too when d_vals != NULL): the chunks of rank r's
+ *                              buckets are chunks [r * region_chunks, r * region_chunks + h_used[r]) of d_out_keys (d_out_vals),
+ *                              one directory word per chunk in d_out_dir (same indexing).  Synchronous (h_used is valid on
+ *                              return); may run while a stream join is open on the context.  A region that overflows
+ *                              (skewed keys) is an error: fall back to fj_owner_split.
+ * The caller sends rank r its region's used prefix (keys and directory words; RCCL all-to-all) and the owner appends what it
+ * received - every sender's piece concatenated, in any order - as level-1 chunk sets:
+ *   fj_stream_open_shuffled        - as fj_stream_open, for the rows this rank will OWN (bounds; appends = pieces per side)
+ *   fj_stream_append_build_chunks /
+ *   fj_stream_append_probe_chunks  - chunk lists from the directory words (rewritten in place), then the plan's second pass
+ *                                    over the piece; asynchronous on `stream`, the piece stays allocated until the finish
+ *   fj_stream_finish               - remaining passes, join, count (counting joins only).
+ */
+int fj_shuffle_plan(size_t nb_total, int nranks, int* fan_log0, int* npass);
+size_t fj_shuffle_region_chunks(size_t n, size_t nb_total, int nranks, int with_vals);
+int fj_shuffle_pack(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks,
+                    uint64_t* d_out_keys, uint64_t* d_out_vals, uint32_t* d_out_dir, size_t region_chunks, uint64_t* h_used, void* stream);
+int fj_stream_open_shuffled(fj_ctx* ctx, size_t nb_total, int nranks, int rank, size_t nb_bound, int build_appends,
+                            size_t np_bound, int probe_appends, void* stream);
+int fj_stream_append_build_chunks(fj_ctx* ctx, const uint64_t* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
+int fj_stream_append_probe_chunks(fj_ctx* ctx, const uint64_t* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
+
+/*
  * Sender-side bloom precheck of the owner shuffle (no reference counterpart).  fj_bloom_export: an owner partitions the
  * nb build keys it owns by 9 radix bits (at the hash_top_bits it will join with) and writes one Bloom filter per bucket,
  * fj_bloom_filter_words() 32-bit words each, 512 buckets, into d_filters (the caller all-gathers them).  fj_bloom_prefilter:

@@ -171,14 +171,16 @@ def test_multi_gpu_strategy_model():
     assert c["shuffle"] > 3 * c["replicate"]                                           # one xGMI link between two GPUs
     os.environ.pop("FJ_DIST_STRATEGY")
     old = D._LINK_BYTES_PER_S
-    D.set_link_rate(400e9)                                                                   # a MEASURED, much faster link: the model decides by default
+    D.set_link_rate(45e9)                                                                    # a MEASURED link rate informs the model ...
     try:
-        assert D.choose_strategy(8, 100_000_000, 1_000_000_000, False) == "shuffle"
-        D.set_link_rate(45e9)
+        assert D.choose_strategy(2, 125_000_000, 1_250_000_000, False) == "shuffle"          # ... but never changes what an unconfigured job runs
+        os.environ["FJ_DIST_STRATEGY"] = "auto"
         assert D.choose_strategy(2, 125_000_000, 1_250_000_000, False) == "replicate"        # one link would carry half of everything
+        D.set_link_rate(400e9)
+        assert D.choose_strategy(8, 100_000_000, 1_000_000_000, False) == "shuffle"
     finally:
+        os.environ.pop("FJ_DIST_STRATEGY", None)
         D.set_link_rate(old, measured=False)
-    assert D.choose_strategy(2, 125_000_000, 1_250_000_000, False) == "shuffle"              # nothing measured: the named default
     os.environ["FJ_DIST_STRATEGY"] = "replicate"
     try:
         assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == "replicate"

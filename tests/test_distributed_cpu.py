@@ -77,6 +77,53 @@ class OracleEngine:
         assert c == list(counts)
         return out
 
+    # stand-ins for the chunk form of the owner shuffle (fj_shuffle_pack / fj_stream_open_shuffled / fj_stream_append_*_chunks):
+    # 32 first-pass buckets from the top hash bits, bucket b belongs to rank (b * world) >> 5; chunks of up to 256 keys with a
+    # directory word (bucket << 9 | count) each, deliberately ragged (200-key chunks, an unused id per owner)
+    _F0LOG = 5
+
+    def empty_i32(self, n):
+        return torch.empty(n, dtype=torch.int32)
+
+    def shuffle_plan(self, nb_total, world):
+        return self._F0LOG if nb_total >= 10000 and world <= 32 else None
+
+    def shuffle_pack(self, keys, vals, nb_total, world):
+        assert vals is None
+        k = keys.numpy().view(np.uint64)
+        b = (_fmix64(k.copy()) >> np.uint64(64 - self._F0LOG)).astype(np.int64)
+        region = k.size // 200 + 2 * 32 + 4
+        pool = np.zeros(world * region * 256, dtype=np.int64)
+        dirw = np.full(world * region, -1, dtype=np.int32)
+        used = [1] * world                                  # id 0 of every region stays unused (directory word: all ones)
+        for bb in range(32):
+            rows, o = k[b == bb].view(np.int64), (bb * world) >> self._F0LOG
+            for i in range(0, rows.size, 200):
+                ch = rows[i: i + 200]
+                cid = o * region + used[o]
+                pool[cid * 256: cid * 256 + ch.size] = ch
+                dirw[cid] = (bb << 9) | ch.size
+                used[o] += 1
+        return torch.from_numpy(pool), None, torch.from_numpy(dirw), region, used
+
+    def stream_open_shuffled(self, nb_total, world, rank, nb_bound, build_appends, np_bound, probe_appends):
+        self._b = None; self._bp = []; self._pieces = []; self._closed = False
+        self._chunks = {0: [], 1: []}; self._left = {0: build_appends, 1: probe_appends}; self._cbound = {0: nb_bound, 1: np_bound}
+        self._mine = [bb for bb in range(32) if (bb * world) >> self._F0LOG == rank]
+
+    def stream_append_chunks(self, side, chunks, dirw):
+        assert self._left[side] > 0 and chunks.numel() == dirw.numel() * 256
+        self._left[side] -= 1
+        d, c = dirw.numpy(), chunks.numpy().reshape(-1, 256)
+        for i in np.nonzero(d != -1)[0]:
+            assert (int(d[i]) >> 9) in self._mine and 1 <= (int(d[i]) & 0x1FF) <= 256
+            self._chunks[side].append(c[i, : int(d[i]) & 0x1FF].copy())
+        assert sum(x.size for x in self._chunks[side]) <= self._cbound[side]
+
+    def chunk_rows(self, dirw):
+        d = dirw.numpy()
+        return int((d[d != -1] & 0x1FF).sum())
+
     def stream_begin(self, bk, bv, np_bound, max_appends, hash_top_bits):
         self._b = (bk, bv); self._pieces = []; self._bound = np_bound; self._max = max_appends; self._closed = False
 
@@ -98,6 +145,11 @@ class OracleEngine:
         assert len(self._pieces) <= self._max and sum(p.numel() for p in self._pieces) <= self._bound
 
     def stream_finish(self):
+        if getattr(self, "_chunks", None) is not None and (self._chunks[0] or self._chunks[1]):
+            cat = lambda xs: np.concatenate(xs) if xs else np.empty(0, dtype=np.int64)
+            bk, pk = cat(self._chunks[0]), cat(self._chunks[1])
+            self._chunks = None
+            return self.O.c_join(bk, np.zeros_like(bk), pk, algo="radix", threads=2)[0]
         pk = torch.cat(self._pieces) if self._pieces else torch.empty(0, dtype=torch.int64)
         assert pk.numel() == self._bound
         if self._b is None:                     # replicate strategy: build keys arrived in pieces, no values
@@ -127,6 +179,7 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     strategy = strategy.split("_")[0]
     os.environ["FJ_DIST_PREFILTER"] = {"prefilter": "1", "prefilterauto": "auto", "prefilterdeclined": "auto"}.get(variant, "0")
     os.environ["FJ_DIST_STRATEGY"] = strategy
+    os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if variant == "scatter" else "1"
     if strategy == "replicate":
         os.environ["FJ_REPLICATE_PIECES"] = "3"
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -146,6 +199,19 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         pk, exp_local = datagen.probe_numpy(p1 - p0, nb, seed=1, hit_bp=5000, first=p0)
         t = {}
         tb, tv, tp = (torch.from_numpy(x.view(np.int64)) for x in (bk, bv, pk))
+        if strategy == "shuffle" and variant == "":
+            # the pre-flight check of a multi-rank job: the exchange of per-peer views + one small join, the same verdict on
+            # every rank; a transport that moves wrong data (test hook on rank 0) is reported by everybody
+            from flash_hash_join_amd.distributed import self_check
+            e0 = torch.tensor([exp_local]); dist.all_reduce(e0)
+            chk = self_check(dist, None, OracleEngine(), (tb, tv, tp), int(e0.item()), 5000)
+            assert chk["ok"] and chk["failed_ranks"] == 0 and chk["message_bytes"] == 40000, chk
+            os.environ["FJ_SELFCHECK_CORRUPT"] = "1"
+            chk = self_check(dist, None, OracleEngine(), (tb, tv, tp), int(e0.item()), 5000)
+            del os.environ["FJ_SELFCHECK_CORRUPT"]
+            assert not chk["ok"] and chk["failed_ranks"] == 1 and (rank != 0 or "elements received from rank" in chk["error"]), chk
+            chk = self_check(dist, None, OracleEngine(), (tb, tv, tp), int(e0.item()) + 1, 5000)        # a wrong expectation: the join check fires
+            assert not chk["ok"] and chk["failed_ranks"] == world and "join self-check" in chk["error"], chk
         res = distributed_join(tb, tv, tp, materialize=True, return_arrays=True, engine=OracleEngine(), timings=t)
         exp = torch.tensor([exp_local]); dist.all_reduce(exp)
         tc = {}
@@ -164,10 +230,16 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             assert tc["local_probe_rows"] == t["local_probe_rows"] and tc["probe_rows_sent"] == t["probe_rows_sent"] < 0.6 * (p1 - p0)
             glob = torch.tensor([tc["local_probe_rows"]]); dist.all_reduce(glob)
             assert int(exp.item()) <= int(glob.item()) < 0.6 * npk
+        elif strategy == "shuffle" and variant == "":
+            # the counting join took the chunk form (its owners are whole first-pass buckets: another split of the hash range than
+            # the owner-scatter form the materialising join uses, so only the totals agree)
+            assert tc["shuffle_form"] == "chunks" and tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
+            glob = torch.tensor([tc["local_probe_rows"], tc["local_build_rows"]]); dist.all_reduce(glob)
+            assert glob.tolist() == [npk, nb]
         else:
             assert tc["local_probe_rows"] == t["local_probe_rows"]
             if strategy == "shuffle":
-                assert tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
+                assert tc["shuffle_form"] == "owner-scatter" and tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
         if strategy == "shuffle":
             assert tc["pieces"] == 4
             # every pair this rank owns must hash to this rank
@@ -187,7 +259,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
+@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
                                       "replicate_small_messages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):

@@ -369,6 +369,72 @@ def test_owner_split_then_local_joins_equals_global_join(fj):
     assert total == exp
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("nb_total,nb,npk,bpieces,ppieces", [(3_000_000, 1_000_000, 2_500_000, 1, 2), (40_000_000, 5_000_000, 30_000_000, 1, 3),
+                                                              (300_000_000, 3_000_000, 20_000_000, 2, 1)])
+def test_owner_shuffle_in_chunk_form_on_one_gpu(fj, world, nb_total, nb, npk, bpieces, ppieces):
+    """The SURVEY 8(e) sender shape (the first radix pass of the GLOBAL plan is the owner split) with all ranks played by
+    one GPU: fj_shuffle_pack groups the chunks of a relation by owner rank - every chunk sits in the region of the rank that
+    owns its bucket, its keys hash to that bucket, nothing is lost or invented - and every owner, fed the regions that the
+    `senders` packed for it (fj_stream_open_shuffled / append_*_chunks), counts its share of the join: the shares add up to
+    the closed-form count.  nb_total (the plan's build size) > nb emulates a rank of a larger job: plans of 256 and 512
+    first-pass buckets (and 32 for the small plan)."""
+    import torch
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    eng = HipEngine("cuda:0")
+    f0 = eng.shuffle_plan(nb_total, world)
+    assert 5 <= f0 <= 9 and (1 << f0) >= world                    # 5 + 5, 7 + 7 and 9 + 8 bits for the three plan sizes
+    bk, _ = datagen.build_device(nb, "cuda:0")
+    pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=21, hit_bp=4000)
+
+    def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
+        lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+            x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+            x ^= x >> np.uint32(16)
+        return x
+
+    def pack_pieces(rel, pieces):
+        """[piece][owner] -> (chunks, dir) exactly as they would travel, + a check of the packed form"""
+        out, seen = [], []
+        bounds = [(rel.numel() * c // pieces) & ~1 for c in range(pieces)] + [rel.numel()]
+        for c in range(pieces):
+            pool, _, dirw, region, used = eng.shuffle_pack(rel[bounds[c]: bounds[c + 1]], None, nb_total, world)
+            per_owner = []
+            for r in range(world):
+                assert used[r] <= region
+                ch = pool[r * region * 256: (r * region + used[r]) * 256].clone()
+                dw = dirw[r * region: r * region + used[r]].clone()
+                per_owner.append((ch, dw))
+                d = dw.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+                ok = d != 0xFFFFFFFF
+                bucket, cnt = d[ok] >> 9, d[ok] & 0x1FF
+                assert np.all((bucket * world) >> f0 == r) and np.all((cnt >= 1) & (cnt <= 256))
+                rows = ch.cpu().numpy().view(np.uint64).reshape(-1, 256)[ok]
+                mask = np.arange(256)[None, :] < cnt[:, None]
+                assert np.array_equal((hash_w1(rows[mask]) >> np.uint32(32 - f0)).astype(np.int64), np.repeat(bucket, cnt))
+                seen.append(rows[mask])
+            out.append(per_owner)
+        assert np.array_equal(np.sort(np.concatenate(seen)), np.sort(rel.cpu().numpy().view(np.uint64)))      # a permutation of the rows
+        return out
+
+    bp, pp = pack_pieces(bk, bpieces), pack_pieces(pk, ppieces)
+    total = 0
+    for r in range(world):                                         # every owner in turn
+        eng.stream_open_shuffled(nb_total, world, r, nb + 65536, bpieces, npk + 65536, ppieces)
+        for c in range(bpieces):
+            eng.stream_append_chunks(0, bp[c][r][0].clone(), bp[c][r][1].clone())
+        for c in range(ppieces):
+            eng.stream_append_chunks(1, pp[c][r][0].clone(), pp[c][r][1].clone())
+        total += eng.stream_finish()
+        lt = fj.last_timings()
+        assert lt["fell_back"] == 0 and lt["passes"] >= 2
+    assert total == exp
+
+
 @pytest.mark.parametrize("top_bits", [64, 48])
 @pytest.mark.parametrize("nb,npk,hit_bp", [(1, 1000, 5000), (3000, 200_000, 0), (1_000_000, 5_000_000, 500), (20_000_000, 30_000_000, 2500),
                                             (150_000_000, 40_000_000, 100)])
@@ -383,7 +449,7 @@ def test_sender_side_prefilter_keeps_every_hit(fj, nb, npk, hit_bp, top_bits):
     pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=13, hit_bp=hit_bp)
     eng = HipEngine("cuda:0")
     filt = eng.bloom_export(bk, top_bits)
-    assert filt.numel() == 512 * 35840
+    assert filt.numel() == 512 * 35840 + 4                       # + header words (the variant the filters were built with)
     kept = eng.bloom_prefilter(pk, filt, top_bits)
     assert exp <= kept.numel() <= npk
     hit = torch.isin(pk, bk)
@@ -1088,6 +1154,11 @@ def test_stream_join_rejects_misuse(fj):
     class Failing(HipEngine):
         def stream_append(self, piece):
             raise RuntimeError("injected failure between begin and finish")
+
+        def stream_append_chunks(self, side, chunks, dirw):            # (the chunk form of the shuffle appends chunk pieces)
+            if side:
+                raise RuntimeError("injected failure between begin and finish")
+            return HipEngine.stream_append_chunks(self, side, chunks, dirw)
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:

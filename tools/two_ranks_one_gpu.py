@@ -41,13 +41,24 @@ class HostStagedDist:
         dist.all_to_all_single(ho, hi, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
         out.copy_(ho); return self._Done()
 
-    def all_to_all(self, outs, ins, group=None, async_op=False):
-        """List form (the bounded-message rounds of distributed._exchange): views of device tensors on both sides."""
-        hos, his = [self._h(o) for o in outs], [self._h(i) for i in ins]
-        dist.all_to_all(hos, his, group=group)
-        for o, h in zip(outs, hos):
-            o.copy_(h)
-        return self._Done()
+    def batch_isend_irecv(self, ops):
+        """Grouped point-to-point transfers of device-tensor views (distributed._views_all_to_all), through host copies."""
+        reqs, backs = [], []
+        for op in ops:
+            if op.op is dist.isend:
+                reqs.append(dist.isend(op.tensor.cpu(), op.peer, group=op.group))
+            else:
+                h = torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                reqs.append(dist.irecv(h, op.peer, group=op.group)); backs.append((op.tensor, h))
+
+        class _Work:
+            def wait(self_inner):
+                for r in reqs:
+                    r.wait()
+                for t, h in backs:
+                    t.copy_(h)
+                return True
+        return [_Work()]
 
 
 def worker(rank, world, port, q):
@@ -57,9 +68,7 @@ def worker(rank, world, port, q):
         import flash_hash_join_amd.distributed as D
         from flash_hash_join_amd import datagen, api
         api.initialize()
-        shim = HostStagedDist()
-        sys.modules["torch.distributed"] = shim            # distributed_join does `import torch.distributed as dist`
-        torch.distributed = shim
+        shim = HostStagedDist()                            # handed to distributed_join as its transport
         nb, npk = 6_000_000, 40_000_000                    # global rows; block-distributed
         b0, b1 = rank * nb // world, (rank + 1) * nb // world
         p0, p1 = rank * npk // world, (rank + 1) * npk // world
@@ -67,19 +76,32 @@ def worker(rank, world, port, q):
         pk, exp_local = datagen.probe_device(p1 - p0, nb, "cuda:0", seed=1, hit_bp=5000, first=p0)
         e = torch.tensor([exp_local]); dist.all_reduce(e); exp = int(e.item())
         res = {}
-        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "prefilter")):
+        # the pre-flight check of a multi-rank job (distributed.self_check): passes, and reports a transport that moves wrong data
+        sk, sv = datagen.build_device(500_000, "cuda:0", first=rank * 500_000)
+        sp, se = datagen.probe_device(1_500_000, 500_000 * world, "cuda:0", seed=3, hit_bp=5000, first=rank * 1_500_000)
+        et = torch.tensor([se]); dist.all_reduce(et)
+        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000)
+        assert chk["ok"] and chk["failed_ranks"] == 0, chk
+        os.environ["FJ_SELFCHECK_CORRUPT"] = "1"
+        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000)
+        del os.environ["FJ_SELFCHECK_CORRUPT"]
+        assert not chk["ok"] and chk["failed_ranks"] == 1 and (rank != 0 or "elements received from rank" in chk["error"]), chk
+        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "scatter"), ("shuffle", "prefilter")):
             os.environ["FJ_DIST_STRATEGY"] = strategy; os.environ["FJ_REPLICATE_PIECES"] = pieces if pieces.isdigit() else "1"
             os.environ["FJ_DIST_PREFILTER"] = "1" if pieces == "prefilter" else "0"
+            os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if pieces == "scatter" else "1"
             t = {}
-            n, sec = D.distributed_join(bk, bv, pk, timings=t)
+            n, sec = D.distributed_join(bk, bv, pk, timings=t, transport=shim)
             assert n == exp, (strategy, n, exp)
             if pieces == "prefilter":                       # half the probe rows miss; the owners' filters stop nearly all of them
                 assert t["prefilter"] and t["probe_rows_sent"] < 0.56 * (p1 - p0), t
-            n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
+            n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True, transport=shim)
             M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
             assert n2 == exp and bool(torch.all((v + 1) * M == k)), strategy
             tot = torch.tensor([k.numel()]); dist.all_reduce(tot)
             assert int(tot.item()) == exp                   # the ranks' pair sets add up to the global result
+            if strategy == "shuffle":
+                assert t["shuffle_form"] == ("chunks" if pieces == "1" else "owner-scatter"), t
             res[strategy + pieces] = (t["strategy"], t["pieces"], t["local_build_rows"], t["local_probe_rows"])
         q.put((rank, exp, res))
     finally:
