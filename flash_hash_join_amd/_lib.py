@@ -25,6 +25,8 @@ SYMBOLS = [
     "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
     "fj_shuffle_plan", "fj_shuffle_region_chunks", "fj_shuffle_pack", "fj_stream_open_shuffled",
     "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
+    "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
+    "fj_dist_join_count",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
     "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h",
 ]
@@ -44,6 +46,15 @@ class FjTimings(ctypes.Structure):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "probe_part_kernel_ms"}
         d["probe_part_kernel_ms"] = list(self.probe_part_kernel_ms)
         return d
+
+
+class FjDistTimings(ctypes.Structure):
+    _fields_ = [
+        ("total_ms", ctypes.c_double), ("split_ms", ctypes.c_double), ("exchange_ms", ctypes.c_double), ("join_ms", ctypes.c_double),
+        ("local_count", ctypes.c_uint64), ("local_build_chunks", ctypes.c_uint64), ("local_probe_chunks", ctypes.c_uint64),
+        ("pieces", ctypes.c_int), ("nranks", ctypes.c_int), ("fan_log0", ctypes.c_int), ("reserved", ctypes.c_int),
+        ("local", FjTimings),
+    ]
 
 
 def build_native(force: bool = False) -> str:
@@ -117,6 +128,13 @@ def load() -> ctypes.CDLL:
     L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, vp]
     L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, sz, vp]
     L.fj_stream_append_probe_chunks.restype = i32; L.fj_stream_append_probe_chunks.argtypes = [vp, vp, vp, sz, vp]
+    L.fj_dist_unique_id.restype = i32; L.fj_dist_unique_id.argtypes = [ctypes.c_char_p]
+    L.fj_dist_comm_create.restype = vp; L.fj_dist_comm_create.argtypes = [vp, ctypes.c_char_p, i32, i32]
+    L.fj_dist_comm_from_nccl.restype = vp; L.fj_dist_comm_from_nccl.argtypes = [vp, vp]
+    L.fj_dist_comm_destroy.restype = None; L.fj_dist_comm_destroy.argtypes = [vp]
+    L.fj_dist_comm_rank.restype = i32; L.fj_dist_comm_rank.argtypes = [vp]
+    L.fj_dist_comm_size.restype = i32; L.fj_dist_comm_size.argtypes = [vp]
+    L.fj_dist_join_count.restype = i32; L.fj_dist_join_count.argtypes = [vp, vp, sz, vp, sz, i32, vp, pu64, ctypes.POINTER(FjDistTimings)]
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]
     L.fj_generate_probe.restype = i32
     L.fj_generate_probe.argtypes = [vp, vp, u64, sz, u64, u64, ctypes.c_uint32, pu64, vp]

@@ -803,6 +803,8 @@ fj_ctx* g_host_ctx = nullptr;
 
 }  // namespace
 
+void fj_set_error_string(const char* msg) { g_err = msg ? msg : ""; }     // (csrc/fj_dist.hip reports through the same thread-local string)
+
 extern "C" {
 
 const char* fj_last_error(void) { return g_err.c_str(); }
@@ -1228,7 +1230,14 @@ int shuffle_plan(size_t nb_total, int nranks, Plan* out) {
     *out = p;
     return 0;
 }
-u32 shuffle_groups(size_t n, u32 tile_chunks, u32 F) { return std::min<u32>(256u, pass_groups((n + FJ_CHUNK - 1) / FJ_CHUNK, n, tile_chunks, F)); }
+// workgroups of the packing pass: every (workgroup, owner) pair abandons half a slab of chunk ids on average and every
+// (workgroup, bucket) pair ends in a partial chunk - all of which travels - so a small piece gets few workgroups (<= 1/8 of
+// its chunks lost to abandoned ids; config 5's 312M-row pieces still get one workgroup per CU)
+u32 shuffle_groups(size_t n, u32 tile_chunks, u32 F, u32 nranks, u32 slab) {
+    const u64 chunks = (n + FJ_CHUNK - 1) / FJ_CHUNK;
+    const u64 by_slabs = std::max<u64>(1, chunks / ((u64)nranks * 4 * slab));
+    return (u32)std::min<u64>(std::min<u64>(256u, by_slabs), pass_groups(chunks, n, tile_chunks, F));
+}
 }  // namespace
 
 int fj_shuffle_plan(size_t nb_total, int nranks, int* fan_log0, int* npass) {
@@ -1243,7 +1252,8 @@ size_t fj_shuffle_region_chunks(size_t n, size_t nb_total, int nranks, int with_
     Plan p;
     if (shuffle_plan(nb_total, nranks, &p)) return 0;
     const u32 F = 1u << p.fan_log[0], tc = fj_partition_tile_chunks((u32)p.fan_log[0], with_vals != 0);
-    const u64 G = shuffle_groups(n, tc, F), FO = (F + nranks - 1) / nranks + 1, slab = fj_own_slab((u32)p.fan_log[0], with_vals != 0, (u32)nranks);
+    const u64 FO = (F + nranks - 1) / nranks + 1, slab = fj_own_slab((u32)p.fan_log[0], with_vals != 0, (u32)nranks);
+    const u64 G = shuffle_groups(n, tc, F, (u32)nranks, (u32)slab);
     // an even share of the rows + 25 % for the hash's imbalance, the partial chunk of every (workgroup, bucket) pair at either
     // end of a segment, and one abandoned slab remainder per (workgroup, owner)
     const u64 share = (n / FJ_CHUNK + nranks - 1) / nranks;
@@ -1264,7 +1274,7 @@ int fj_shuffle_pack(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, s
     hipStream_t s = (hipStream_t)stream;
     const bool vals = d_vals != nullptr;
     const u32 fan_log = (u32)plan.fan_log[0], F = 1u << fan_log, tc = fj_partition_tile_chunks(fan_log, vals);
-    const u32 G = shuffle_groups(n, tc, F), slab = fj_own_slab(fan_log, vals, (u32)nranks);
+    const u32 slab = fj_own_slab(fan_log, vals, (u32)nranks), G = shuffle_groups(n, tc, F, (u32)nranks, slab);
     if (region_chunks < (size_t)2 * slab) return set_err("fj_shuffle_pack: region of %zu chunks is too small", region_chunks);
     const u32 cap = (u32)(region_chunks * nranks), max_segs = G + 3;
     void* p;

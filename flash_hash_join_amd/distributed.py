@@ -213,6 +213,53 @@ class HipEngine:
         cnt = dirw & 0x1FF
         return int(cnt[dirw != -1].sum().item())
 
+    # ---- the native multi-GPU entry (csrc/fj_dist.hip): the same chunk-form protocol, driven from C++ over an RCCL communicator
+    #      of the library's own (torch does not hand out its ncclComm_t) ----
+    _native_comms: dict = {}
+
+    def native_comm(self, dist, group):
+        """fj_dist_comm for (this device, group): rank 0's unique id travels by a torch.distributed broadcast, every rank then
+        joins ncclCommInitRank inside fj_dist_comm_create.  Cached for the life of the process."""
+        key = (self.index, id(group) if group is not None else 0)
+        comm = HipEngine._native_comms.get(key)
+        if comm:
+            return comm
+        t = self.torch
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        idt = t.zeros(128, dtype=t.uint8, device=self.device)
+        if rank == 0:
+            raw = ctypes.create_string_buffer(128)
+            self._lib.check(self.L.fj_dist_unique_id(raw))
+            idt.copy_(t.frombuffer(bytearray(raw.raw), dtype=t.uint8))
+        dist.broadcast(idt, 0 if group is None else dist.get_global_rank(group, 0), group=group)
+        raw = bytes(idt.cpu().numpy().tobytes())
+        with t.cuda.device(self.index):
+            comm = self.L.fj_dist_comm_create(self.ctx, raw, world, rank)
+        if not comm:
+            raise RuntimeError(self._lib.last_error())
+        HipEngine._native_comms[key] = comm
+        return comm
+
+    def native_count(self, dist, group, build_keys, probe_keys, pieces: int, timings: Optional[dict]):
+        """fj_dist_join_count: the global match count of the block-distributed relations (collective)."""
+        t = self.torch
+        comm = self.native_comm(dist, group)
+        bk, pk = self._aligned(build_keys), self._aligned(probe_keys)
+        cnt = ctypes.c_uint64(0)
+        dt = self._lib.FjDistTimings()
+        t0 = time.perf_counter()
+        with t.cuda.device(self.index):
+            self._lib.check(self.L.fj_dist_join_count(comm, bk.data_ptr(), bk.numel(), pk.data_ptr(), pk.numel(), pieces,
+                                                      t.cuda.current_stream(self.index).cuda_stream, ctypes.byref(cnt), ctypes.byref(dt)))
+        sec = time.perf_counter() - t0
+        self.api._last = dt.local
+        if timings is not None:
+            timings.update(strategy="shuffle", shuffle_form="chunks (native fj_dist_join_count)", split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
+                           join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces), local_build_rows=int(dt.local_build_chunks) * 256,
+                           local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=False, prefilter_mode="off",
+                           prefilter_sampled_survivors=None, probe_rows_sent=pk.numel(), rows_are_chunk_capacity=True)
+        return int(cnt.value), sec
+
     def stream_abort(self):
         """Error recovery: drop a stream join that will not be finished, so that the context serves other joins again."""
         self._keep = []
@@ -846,6 +893,11 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
         # global plan has two or more passes; the owner-scatter form below the small ones and the sender-side precheck
         if (mode == "off" and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
                 and min(int(x[1]) for x in allsz) >= 2 * pieces and engine.shuffle_plan(nb_total, world) is not None):
+            # under RCCL the protocol runs natively (csrc/fj_dist.hip, fj_dist_join_count); _chunk_shuffle_count is the same
+            # protocol over torch.distributed - what gloo, a transport object and the stand-in engines of the CPU tests use
+            if (transport is None and hasattr(engine, "native_count") and os.environ.get("FJ_DIST_NATIVE", "1") != "0"
+                    and dist.get_backend(group) == "nccl"):
+                return engine.native_count(dist, group, build_keys, probe_keys, pieces, timings)
             return _chunk_shuffle_count(dist, group, engine, world, build_keys, probe_keys, nb_total, np_global, pieces, timings)
         if timings is not None:
             timings["shuffle_form"] = "owner-scatter"

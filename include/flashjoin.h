@@ -226,6 +226,39 @@ int fj_stream_finish(fj_ctx* ctx, void* stream, uint64_t* out_count, fj_timings*
 int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error recovery); no-op when none is open */
 
 /*
+ * Native multi-GPU entry (no reference counterpart: the reference is one process, hash_join.cpp:318; SURVEY.md 5 row
+ * "Distributed communication backend", 7.1 dist/alltoall): the counting radix join of relations whose rows are block-distributed
+ * over the ranks of an RCCL communicator - BASELINE configs[4].  One process per GPU; every rank calls fj_dist_join_count
+ * with its LOCAL rows and gets the GLOBAL match count.  The owner shuffle runs in chunk form (above): sizes and per-piece
+ * chunk counts travel by ncclAllGather, every owner's region by grouped ncclSend / ncclRecv on a second stream while the
+ * next piece is packed and the previous one gets its second radix pass, the count by ncclAllReduce.  RCCL is bound at run
+ * time (dlopen of librccl.so.1): a host that never calls these functions does not need it.
+ *   fj_dist_unique_id      - rank 0: 128 bytes for the other ranks (any out-of-band channel), as ncclGetUniqueId
+ *   fj_dist_comm_create    - every rank, after selecting its device and creating its fj_ctx: ncclCommInitRank inside
+ *   fj_dist_comm_from_nccl - or wrap an ncclComm_t the host already has (not destroyed by fj_dist_comm_destroy)
+ *   fj_dist_join_count     - collective.  pieces: rounds of the probe exchange (4 is the measured default).  A build side of
+ *                            less than ~2M rows in all is refused (one-pass plan: join it on one GPU).  A failure on any rank
+ *                            is reported by every rank (non-zero return, fj_last_error()).
+ */
+typedef struct fj_dist_comm fj_dist_comm;
+typedef struct fj_dist_timings {
+    double total_ms, split_ms, exchange_ms, join_ms;   /* host wall clock of this rank: whole step; packing (first radix pass);
+                                                          the rest up to the local join's finish; finish + all-reduce */
+    uint64_t local_count;                              /* matches this rank found in what it owns                 */
+    uint64_t local_build_chunks, local_probe_chunks;   /* 256-key chunks this rank received                        */
+    int pieces, nranks, fan_log0, reserved;
+    fj_timings local;                                  /* device timings of this rank's local join (fj_stream_finish) */
+} fj_dist_timings;
+int fj_dist_unique_id(char* out128);
+fj_dist_comm* fj_dist_comm_create(fj_ctx* ctx, const char* unique_id128, int nranks, int rank);
+fj_dist_comm* fj_dist_comm_from_nccl(fj_ctx* ctx, void* nccl_comm);
+void fj_dist_comm_destroy(fj_dist_comm* comm);
+int fj_dist_comm_rank(const fj_dist_comm* comm);
+int fj_dist_comm_size(const fj_dist_comm* comm);
+int fj_dist_join_count(fj_dist_comm* comm, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
+                       void* stream, uint64_t* out_global_count, fj_dist_timings* timings);
+
+/*
  * Deterministic synthetic relations, generated in HBM:
  *   build_keys[i] = (first+i+1)*M, build_vals[i] = first+i, M = 0x9E3779B97F4A7C15;
  *   probe j = first+i: r = 1 + mix(seed,j) % B, hit = mix(seed^1,j) % 10000 < hit_bp,

@@ -546,12 +546,21 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
         bk, bv = datagen.build_device(nb, "cuda:0")
         pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=4, hit_bp=5000)
         M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
-        for strategy, rp in (("shuffle", "1"), ("replicate", "1"), ("replicate", "3")):
+        for strategy, rp in (("shuffle", "1"), ("shuffle", "python"), ("shuffle", "scatter"), ("replicate", "1"), ("replicate", "3")):
             monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
-            monkeypatch.setenv("FJ_REPLICATE_PIECES", rp)
+            monkeypatch.setenv("FJ_REPLICATE_PIECES", rp if rp.isdigit() else "1")
+            monkeypatch.setenv("FJ_DIST_NATIVE", "0" if rp == "python" else "1")            # the chunk form through torch.distributed instead of fj_dist_join_count
+            monkeypatch.setenv("FJ_DIST_CHUNK_SHUFFLE", "0" if rp == "scatter" else "1")    # the owner-scatter form
             t = {}
             n, sec = distributed_join(bk, bv, pk, timings=t)
-            assert n == exp and t["local_probe_rows"] == npk and t["local_build_rows"] == nb and t["strategy"] == strategy
+            assert n == exp and t["strategy"] == strategy
+            if strategy == "shuffle":
+                form = {"1": "chunks (native fj_dist_join_count)", "python": "chunks", "scatter": "owner-scatter"}[rp]
+                assert t["shuffle_form"] == form and t["pieces"] == 4 and t["local_count"] == exp
+            if t.get("rows_are_chunk_capacity"):        # the native entry reports received chunks x 256 (partial chunks counted whole)
+                assert npk <= t["local_probe_rows"] <= 1.3 * npk and nb <= t["local_build_rows"] <= 1.3 * nb
+            else:
+                assert t["local_probe_rows"] == npk and t["local_build_rows"] == nb
             if strategy == "replicate":
                 assert t["pieces"] == int(rp)
             n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
@@ -1165,11 +1174,13 @@ def test_stream_join_rejects_misuse(fj):
         os.environ["FJ_FORCE_EXCHANGE"] = "1"
         for strategy in ("shuffle", "replicate"):
             os.environ["FJ_DIST_STRATEGY"] = strategy
+            os.environ["FJ_DIST_NATIVE"] = "0"                               # the engine hooks live in the torch.distributed form of the protocol
             with pytest.raises(RuntimeError, match="injected failure"):
                 distributed_join(big_bk, big_bv, big_pk, engine=Failing("cuda:0"))
+            os.environ.pop("FJ_DIST_NATIVE")
             assert distributed_join(big_bk, big_bv, big_pk)[0] == big_exp               # the context is free again
     finally:
-        os.environ.pop("FJ_FORCE_EXCHANGE", None); os.environ.pop("FJ_DIST_STRATEGY", None)
+        os.environ.pop("FJ_FORCE_EXCHANGE", None); os.environ.pop("FJ_DIST_STRATEGY", None); os.environ.pop("FJ_DIST_NATIVE", None)
         dist.destroy_process_group()
 
 
