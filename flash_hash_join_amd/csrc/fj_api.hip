@@ -85,6 +85,7 @@ enum Slot {
     W_H_BK, W_H_BV, W_H_PK, W_H_OK, W_H_OV, W_ROWIDX, W_BKEYS, W_BBASE,
     W_SH_REL, W_SH_SEGOFF, W_SH_BCH,                                   // fj_shuffle_pack scratch
     W_RX_REL, W_RX_LIST, W_RX_SEGOFF, W_RX_BCH, W_RX_BOFF, W_RX_TOFF, W_RX_TILES,   // a received piece as a chunk set
+    W_SK_TILES_B, W_SK_TILES_P, W_SK_NT, W_PART_COUNT2, W_OUT_OFF2,                 // re-partitioning of oversized final partitions (skew_join)
     W_NSLOTS
 };
 
@@ -99,6 +100,8 @@ struct Pending {
     FjGtArgs gt{};
     u32 nitems = 0, gt_grid = 0;
     u64 count = 0;
+    // oversized partitions that skew_join re-partitioned: their sub-partitions are a second item set, emitted behind the first
+    bool has_second = false; FjLdsJoinArgs lds2{}; u32 nitems2 = 0; u64 count_main = 0; std::vector<u32> flagged;
     // duplicate build keys seen by the counting pass: the emitting pass must pick the FIRST occurrence's value
     bool has_dups = false;
     const u64* bk = nullptr; const u64* bv = nullptr; size_t nb = 0; int top_bits = 64;
@@ -118,7 +121,7 @@ struct PassIter {
     int slot = 0, cs_base = 0;           // ping-pong workspace slot of the next output level / base index of cs's buffers
     // probe side of a join: the final level's consumer is the join kernel; its item table (tiles of the final probe chunk
     // lists) and per-item count array are produced by the final level's bookkeeping launches
-    bool want_items = false; u32 items_cap = 0; u32* part_count = nullptr;
+    bool want_items = false; u32 items_cap = 0; u32* part_count = nullptr; int part_count_slot = W_PART_COUNT;
     // bloom precheck (probe side): run the filter stage once `bloom_level` passes are complete, against bloom_build
     bool bloom_done = false; const FjChunkSet* bloom_build = nullptr;
     const u32* bloom_prebuilt = nullptr;            // filters shipped by another GPU (sender-side precheck) instead of bloom_build's keys
@@ -397,7 +400,7 @@ int level_finish(fj_ctx* c, PassIter& it, bool final_level, hipStream_t s) {
         if (get_buf(c, it.cs_base + W_TOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; toff = (u32*)p;
         if (get_buf(c, it.cs_base + W_TILES, max_tiles * sizeof(uint4), &p)) return 1; tiles = (uint4*)p;
         if (final_level) {
-            if (get_buf(c, W_PART_COUNT, (size_t)max_tiles * 4, &p)) return 1;
+            if (get_buf(c, it.part_count_slot, (size_t)max_tiles * 4, &p)) return 1;
             it.part_count = zero_tail = (u32*)p; it.items_cap = (u32)max_tiles;
         }
     }
@@ -549,6 +552,8 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
                 end_plan(c);                  // (a pool error of these passes surfaces through the emit kernel's missing rows: same sizes as the counted join)
                 pd.lds.dedup = 1; pd.lds.orig_vals = pd.bv;
             }
+            if (pd.has_second)                  // the items of re-partitioned partitions emit nothing themselves: their sub-partitions do, below
+                for (u32 idx : pd.flagged) HIPCHK(hipMemsetAsync(&pd.lds.part_count[idx], 0, 4, s));
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
             HIPCHK(fj_launch_scan_u32_to_u64(pd.lds.part_count, (u64*)p, pd.nitems, s));
             pd.lds.out_off = (const u64*)p; pd.lds.out_keys = d_ok; pd.lds.out_vals = d_ov;
@@ -558,6 +563,13 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
             if (resident) HIPCHK(hipMemsetAsync(&c->d_sc->next_emit_item, 0, sizeof(u32), s));
             HIPCHK(fj_launch_lds_join(pd.lds, true, s, resident ? &c->d_sc->next_emit_item : nullptr, 1u));
             if (pd.lds.dbg) { if (stamps_report("FJ_EMIT_STAMPS", pd.lds.dbg, pd.nitems, s)) return 1; pd.lds.dbg = nullptr; }
+            if (pd.has_second) {                // second item set: the sub-partitions of the oversized partitions, behind the first set's pairs
+                if (get_buf(c, W_OUT_OFF2, ((size_t)pd.nitems2 + 1) * 8, &p)) return 1;
+                HIPCHK(fj_launch_scan_u32_to_u64(pd.lds2.part_count, (u64*)p, pd.nitems2, s));
+                pd.lds2.out_off = (const u64*)p; pd.lds2.out_keys = d_ok + pd.count_main; pd.lds2.out_vals = d_ov + pd.count_main;
+                pd.lds2.dedup = 0; pd.lds2.orig_vals = nullptr; pd.lds2.dbg = nullptr;
+                HIPCHK(fj_launch_lds_emit_retry(pd.lds2, s, false));  // (the tagged emit kernel over every item of the set: a few hundred items)
+            }
         } else if (pd.path == 2) {           // many-to-many: count per item -> scan -> emit
             if (get_buf(c, W_OUT_OFF, ((size_t)pd.nitems + 1) * 8, &p)) return 1;
             HIPCHK(fj_launch_scan_u32_to_u64(pd.lds.part_count, (u64*)p, pd.nitems, s));
@@ -631,9 +643,100 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
     return 0;
 }
 
+// Build-side skew, recovered per partition (the reference maps partitions to threads statically and has no answer to skew,
+// hash_join.cpp:507-510; rounds 1-2 re-ran the WHOLE join on one table in HBM, a 4.5x cliff at config-3 sizes for one bad
+// partition).  The tagged kernel marked the items whose partition holds more distinct build keys than an LDS table takes
+// (FJ_ITEM_TOOBIG); everything else has been joined.  Those partitions - a handful - are re-partitioned by S more radix
+// bits of hash word 1 (one more pass over just their chunk lists, both sides: the pass kernel reads any tile table) and
+// their sub-partitions are joined by the same kernels; the matches add to the same device total.  *ok = false when that is
+// not possible (more than 64 such partitions, no hash bits left, sub-partitions still too large): the caller falls back.
+int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits, u32 nitems, int probe_slot, int materialize, hipStream_t s, bool* ok,
+              u32* nparts_redone, Pending* pend) {
+    *ok = false;
+    if (!ja.items || !ja.build.list || !ja.probe.list || nitems == 0) return 0;
+    std::vector<u32> pc(nitems);
+    std::vector<uint4> items(nitems);
+    HIPCHK(hipMemcpyAsync(pc.data(), ja.part_count, (size_t)nitems * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(items.data(), ja.items, (size_t)nitems * sizeof(uint4), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<u32> parts, flagged;
+    for (u32 i = 0; i < nitems; ++i) if (pc[i] == FJ_ITEM_TOOBIG) { parts.push_back(items[i].z); flagged.push_back(i); }
+    std::sort(parts.begin(), parts.end());
+    parts.erase(std::unique(parts.begin(), parts.end()), parts.end());
+    const u32 m = (u32)parts.size();
+    if (m == 0 || m > 64) return 0;
+    // chunk-list ranges of those partitions on both sides
+    std::vector<u32> bo(2 * m), po(2 * m);
+    for (u32 j = 0; j < m; ++j) {
+        HIPCHK(hipMemcpyAsync(&bo[2 * j], ja.build.boff + parts[j], 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&po[2 * j], ja.probe.boff + parts[j], 8, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    u64 bchunks = 0, pchunks = 0, bmax = 0;
+    for (u32 j = 0; j < m; ++j) { const u64 nb_j = bo[2 * j + 1] - bo[2 * j]; bchunks += nb_j; bmax = std::max(bmax, nb_j); pchunks += po[2 * j + 1] - po[2 * j]; }
+    int S = 1;
+    while (S < FJ_MAX_FAN_LOG && ((bmax * FJ_CHUNK) >> S) > 2048) ++S;          // aim at half a cuckoo table per sub-partition
+    if (((bmax * FJ_CHUNK) >> S) > 6000 || top_bits - plan.bits - S < 32) return 0;
+    if (S < 5) S = std::min(5, top_bits - plan.bits - 32);                       // (a pass with a tiny fan-out serialises on its bucket threads)
+    if (S < 1) return 0;
+    Plan p2; p2.bits = S; p2.npass = 1; p2.fan_log[0] = S;
+    auto run_side = [&](PassIter& it, int side, const FjChunkSet& in, const std::vector<u32>& off, u64 chunks, int tiles_slot, u32* d_nt) -> int {
+        const bool vals = materialize && side == 0;               // a materialising join's build rows travel with their values
+        const u32 tc = fj_partition_tile_chunks((u32)S, vals);
+        std::vector<uint4> tiles;
+        for (u32 j = 0; j < m; ++j)
+            for (u32 pos = off[2 * j]; pos < off[2 * j + 1]; pos += tc) tiles.push_back(make_uint4(pos, std::min(tc, off[2 * j + 1] - pos), j, 0));
+        const u32 nt = (u32)tiles.size();
+        void* p;
+        if (get_buf(c, tiles_slot, std::max<size_t>(1, tiles.size()) * sizeof(uint4), &p)) return 1;
+        if (nt) HIPCHK(hipMemcpyAsync(p, tiles.data(), tiles.size() * sizeof(uint4), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_nt, &nt, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));                                         // (`tiles` and `nt` live on this stack frame)
+        pass_init(it, side, vals, std::max<u64>(1, chunks * FJ_CHUNK), p2, top_bits - plan.bits);
+        it.parents = m; it.lbound = chunks;
+        it.slot = side ? probe_slot : plan.npass;            // the ping-pong half that does NOT hold the final level (a bloom stage took a slot of its own on the probe side)
+        it.have_prev = true; it.prev = in; it.tiles = (const uint4*)p; it.ntiles = d_nt;
+        if (side) { it.want_items = true; it.part_count_slot = W_PART_COUNT2; }
+        // the main plan is done with its first pass's allocator and segment counter: they serve this pass
+        HIPCHK(hipMemsetAsync(&c->d_sc->alloc[side * 4], 0, 4, s));
+        HIPCHK(hipMemsetAsync(&c->d_sc->seg_counter[side * 4], 0, 4, s));
+        if (pass_prepare(c, it, 1, s) || pass_launch(c, it, nullptr, nullptr, 0, s, nullptr) || pass_complete(c, it, s)) return 1;
+        return 0;
+    };
+    void* p;
+    if (get_buf(c, W_SK_NT, 16, &p)) return 1;
+    u32* d_nt = (u32*)p;
+    PassIter bit2, pit2;
+    const u64 count_main = c->h_sc->total;                                       // what every other partition found
+    const bool had_dups = (c->h_sc->err & FJ_STAT_DUPS) != 0;
+    HIPCHK(hipMemsetAsync(&c->d_sc->err, 0, 4, s));                              // the main join's status bits have been acted on
+    if (run_side(bit2, 0, ja.build, bo, bchunks, W_SK_TILES_B, d_nt)) return 1;
+    if (run_side(pit2, 1, ja.probe, po, pchunks, W_SK_TILES_P, d_nt + 1)) return 1;
+    FjLdsJoinArgs j2 = ja;
+    j2.build = bit2.prev; j2.probe = pit2.prev; j2.nparts = j2.probe.nb; j2.nsplit = 1;
+    j2.items = pit2.tiles; j2.nitems_dev = pit2.ntiles; j2.items_cap = pit2.items_cap; j2.part_count = pit2.part_count;
+    j2.retry_only = 0; j2.mark_toobig = 0; j2.want_dups = materialize ? 1u : 0u; j2.dbg = nullptr;
+    HIPCHK(fj_launch_lds_join(j2, false, s, nullptr, 0xFFFFFFFFu));              // one workgroup per item: a few hundred items
+    if (read_scalars(c, s)) return 1;
+    if ((c->h_sc->err & FJ_STAT_RETRY) && !(c->h_sc->err & (FJ_ERR_POOL | FJ_ERR_LDS_FULL))) {
+        HIPCHK(fj_launch_lds_join_retry(j2, s));
+        if (read_scalars(c, s)) return 1;
+    }
+    if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted while re-partitioning a skewed partition");
+    if (c->h_sc->err & FJ_ERR_LDS_FULL) return 0;                                // sub-partitions still too large (keys colliding in all of hash word 1)
+    if (materialize) {
+        // duplicate build keys need the first-occurrence emit path, which re-partitions the whole build side: not combined with this one
+        if (had_dups || (c->h_sc->err & FJ_STAT_DUPS)) return 0;
+        pend->has_second = true; pend->lds2 = j2; pend->nitems2 = pit2.items_cap; pend->count_main = count_main; pend->flagged = flagged;
+    }
+    *ok = true; *nparts_redone = m;
+    return 0;
+}
+
 // launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
 int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, const PassIter& pit, hipStream_t s,
-                    fj_timings* t, int evc, u64* out_count, bool* lds_full) {
+                    fj_timings* t, int evc, u64* out_count, bool* lds_full, int top_bits) {
+    c->pend.has_second = false;
     ja.nparts = ja.probe.list ? ja.probe.nb : 1u << plan.bits;      // (an owner of a shuffled join holds a slice of the plan's partitions)
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
     void* p;
@@ -665,13 +768,22 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     if (read_scalars(c, s)) return 1;
     t->lds_retries = 0;
     if ((c->h_sc->err & FJ_STAT_RETRY) && !(c->h_sc->err & (FJ_ERR_POOL | FJ_ERR_LDS_FULL))) {
-        // some partitions overflowed the cuckoo table (load above ~0.45): those items run again on the tagged table
-        ja.retry_only = 1;
+        // some partitions overflowed the cuckoo table (load above ~0.45): those items run again on the tagged table; a
+        // partition beyond that table too is marked (counting joins over chunk lists) and re-partitioned alone below
+        ja.retry_only = 1; ja.mark_toobig = ja.items ? 1u : 0u;
         HIPCHK(fj_launch_lds_join_retry(ja, s));
         ja.retry_only = 0;
         HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
         if (read_scalars(c, s)) return 1;
         t->lds_retries = 1;
+        if ((c->h_sc->err & FJ_STAT_TOOBIG) && !(c->h_sc->err & (FJ_ERR_POOL | FJ_ERR_LDS_FULL))) {
+            bool ok = false; u32 redone = 0;
+            if (skew_join(c, ja, plan, top_bits, nitems, pit.slot, materialize, s, &ok, &redone, &c->pend)) return 1;
+            HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+            if (read_scalars(c, s)) return 1;
+            if (ok) t->lds_retries = 1 + (int)redone;            // 1 + the partitions that were re-partitioned
+            else c->h_sc->err |= FJ_ERR_LDS_FULL;                // not recoverable this way: the caller's whole-join fallback
+        }
     }
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
     end_plan(c);                              // every prepared pass ran its bookkeeping: the self-cleaning buffers are clean
@@ -742,7 +854,7 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     if (plan.bloom_level > 0) pit.bloom_build = &bit.saved;
     if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
     HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-    if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full)) return 1;
+    if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, top_bits)) return 1;
     if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
     return 0;
 }
@@ -1172,7 +1284,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         }
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
-        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full)) return 1;
+        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full, st.top_bits)) return 1;
         if (lds_full && st.shuffled)
             return set_err("shuffled stream join: a final partition holds more than 8128 distinct build keys (skewed build side); no fallback for chunk pieces");
         if (lds_full) {

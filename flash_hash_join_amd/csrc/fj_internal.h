@@ -10,7 +10,9 @@
 #define FJ_STAT_EMIT_RETRY 16u // (status) some items of the emitting pass overflowed the cuckoo table: marked the same way, redone on the tagged table
 #define FJ_ERR_VARIANT 32u   // filters handed to the filter kernel were built with another bloom_variant (sender-side precheck across ranks)
 #define FJ_BLOOM_HDR_MAGIC 0xB100F000u   // exported filter sets end with 4 header words: [0] = magic | variant
+#define FJ_STAT_TOOBIG 64u   // (status) some items' partitions hold more distinct build keys than even the tagged LDS table takes: part_count[item] == FJ_ITEM_TOOBIG marks them; the host re-partitions just those
 #define FJ_ITEM_RETRY 0xFFFFFFFFu
+#define FJ_ITEM_TOOBIG 0xFFFFFFFEu
 
 // ---- partition pass ---------------------------------------------------------------------------
 struct FjPartArgs {
@@ -131,6 +133,7 @@ struct FjLdsJoinArgs {
     u64* out_keys;
     u64* out_vals;
     u32 retry_only;              // tagged-table counting kernel: process only the items the cuckoo kernel marked FJ_ITEM_RETRY
+    u32 mark_toobig;             // tagged-table counting kernel: a partition beyond the table marks its item FJ_ITEM_TOOBIG (FJ_STAT_TOOBIG) instead of raising FJ_ERR_LDS_FULL
     u32 want_dups;               // counting pass of a materialising join: report duplicate build keys (FJ_STAT_DUPS)
     u32 dedup;                   // materialising pass: build 'values' are row indices, the smallest wins, then orig_vals[idx]
     const u64* orig_vals;        // the caller's build_values (dedup only)
@@ -143,7 +146,7 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
 // second chance for the items whose partition overflowed the cuckoo table (load > ~0.45): the tagged 2x4-slot table
 // with linear-probing overflow holds up to 8128 keys; only a partition beyond that raises FJ_ERR_LDS_FULL
 hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a, hipStream_t s);
-hipError_t fj_launch_lds_emit_retry(const FjLdsJoinArgs& a, hipStream_t s);       // same for the emitting pass (FJ_STAT_EMIT_RETRY)
+hipError_t fj_launch_lds_emit_retry(const FjLdsJoinArgs& a, hipStream_t s, bool only_marked = true);   // same for the emitting pass (FJ_STAT_EMIT_RETRY); only_marked = false: every item
 
 // how many of `nsamples` evenly spaced probe rows have their key in the build side (final chunk set `build`, partition id =
 // (hash word 1 >> shift32) & pmask): one wave per sample scans the sample's build partition

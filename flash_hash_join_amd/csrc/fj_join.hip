@@ -59,6 +59,7 @@ __device__ __forceinline__ u32 tag_matches(u32 tags, u32 pattern) {      // bit 
 }
 
 
+constexpr u32 LDS_MAX_WALK = 128;                 // groups (512 slots) an insert's linear-probing overflow walk may visit
 template <bool MAT>
 __device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restrict__ tvals, u32* __restrict__ ttags,
                                         u32* __restrict__ gcnt, JoinHdr* hdr, u64 key, u64 val, bool dedup) {
@@ -82,8 +83,11 @@ __device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restr
     const u32 e1 = (u32)__popc(tag_zero_bytes(t1)), e2 = (u32)__popc(tag_zero_bytes(t2));
     u32 g = e1 >= e2 ? g1 : g2;
     const u32 galt = e1 >= e2 ? g2 : g1;
+    // The overflow walk gives up after LDS_MAX_WALK groups: a table that full (load > ~0.95) is reported like an overflowing
+    // one - the caller redoes the partition another way - instead of being squeezed in by walks over the whole table (a
+    // partition of 30K keys spent 0.6 ms per item filling the table to the last slot before it failed).
 #pragma unroll 1
-    for (u32 step = 0; step < NGRP + 2; ++step) {
+    for (u32 step = 0; step < LDS_MAX_WALK + 2; ++step) {
         const u32 sh = (g & 1u) * 16u;
         const u32 idx = (atomicAdd(&gcnt[g >> 1], 1u << sh) >> sh) & 0xFFFFu;
         if (idx < FJ_LDS_GROUP) {
@@ -95,6 +99,8 @@ __device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restr
         }
         if (step == 0) { g = galt; continue; }
         if (step == 1) { hdr->ovf = 1; g = g1; }           // both candidate groups full: walk from g1
+        // (somebody else already walked the whole table in vain: an oversized partition - do not repeat the 2048-step walk per key)
+        if ((step & 31u) == 31u && *reinterpret_cast<volatile u32*>(&hdr->full)) return false;
         g = (g + 1) & (NGRP - 1);
     }
     hdr->full = 1;
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
             __syncthreads();
         }
         for (u32 c0 = 0; c0 < nbb; c0 += 16) {
+            if (*reinterpret_cast<volatile u32*>(&hdr->full)) break;       // the table is full: the item is reported below, no point in more inserts
             if (bb | c0) load_build(c0, nbb);
 #pragma unroll
             for (u32 j = 0; j < BKPT; ++j) {
@@ -342,7 +349,10 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
     __syncthreads();
     FJ_STAMP(3);
     if (hdr->full || hdr->claimed > S - 64) {       // table (nearly) full: host falls back to the global-table path
-        if (tid == 0) { atomicOr(a.err, FJ_ERR_LDS_FULL); if (!MAT) a.part_count[item] = 0; }
+        if (tid == 0) {
+            if (!MAT && a.mark_toobig) { atomicOr(a.err, FJ_STAT_TOOBIG); a.part_count[item] = FJ_ITEM_TOOBIG; }   // the host re-partitions this partition alone
+            else { atomicOr(a.err, FJ_ERR_LDS_FULL); if (!MAT) a.part_count[item] = 0; }
+        }
         return;
     }
     // counting pass of a materialising join, second-chance table: racing copies of a duplicated key can sit in the table
@@ -1532,9 +1542,9 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
 }
 
 // emitting pass: the items the cuckoo emit kernel could not place (FJ_STAT_EMIT_RETRY) on the tagged table
-hipError_t fj_launch_lds_emit_retry(const FjLdsJoinArgs& a0, hipStream_t s) {
+hipError_t fj_launch_lds_emit_retry(const FjLdsJoinArgs& a0, hipStream_t s, bool only_marked) {
     FjLdsJoinArgs a = a0;
-    a.retry_only = 1;
+    a.retry_only = only_marked ? 1u : 0u;
     const u32 nb = a.items ? a.items_cap : a.nparts * a.nsplit;
     const u32 lds = sizeof(JoinHdr) + 2 * S * 8 + S + S / 2 + (JP_META + JB_META) * 4;
     auto kern = (a.build.list && a.probe.list) ? fj_lds_join_kernel<true, 1024, true> : fj_lds_join_kernel<true, 1024, false>;
