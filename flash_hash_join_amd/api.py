@@ -146,6 +146,17 @@ def _dev_tensor(t, name: str):
     return t
 
 
+def _room_for(np_rows: int, dev: int) -> bool:
+    """Output buffers for ANY result of a materialising join (16 bytes per probe row) are worth allocating when they take at
+    most a third of the device memory that is free right now."""
+    import torch
+    try:
+        free, _ = torch.cuda.mem_get_info(dev)
+    except Exception:                                          # noqa: BLE001
+        return False
+    return 16 * np_rows <= free // 3
+
+
 def join_device(algo: int, bloom: int, materialize: int, bk, bv, pk, return_arrays: bool = False,
                 hash_top_bits: int = 64):
     """Device-resident join on torch ROCm tensors (int64 storage, bit-identical to uint64)."""
@@ -161,10 +172,23 @@ def join_device(algo: int, bloom: int, materialize: int, bk, bv, pk, return_arra
     cnt = ctypes.c_uint64(0)
     t = FjTimings()
     with _ctx_locks.setdefault(dev, threading.RLock()):      # count + emit are two calls on one context: keep other threads out
+        out = None
+        if (materialize and not (algo & ALGO_MANY_TO_MANY) and pk.numel() > 0 and bk.numel() > 0 and get_option("mat_single_pass")
+                and _room_for(pk.numel(), dev)):      # (a many-to-many join can return more pairs than probe rows)
+            # room for ANY result (the reference allocates the same, hash_join.cpp:330-334): the join may run in one pass over
+            # the probe side; the pairs are the first n rows
+            ok = torch.empty(pk.numel(), dtype=torch.int64, device=bk.device)
+            ov = torch.empty(pk.numel(), dtype=torch.int64, device=bk.device)
+            check(L.fj_join_device(ctx, algo, bloom, materialize, bk.data_ptr(), bv.data_ptr(), bk.numel(), pk.data_ptr(),
+                                   pk.numel(), stream, hash_top_bits, ctypes.byref(cnt), ok.data_ptr(), ov.data_ptr(), pk.numel(), ctypes.byref(t)))
+            n = int(cnt.value)
+            _last = t
+            if return_arrays:
+                return n, t.total_ms * 1e-3, ok[:n], ov[:n]
+            return n, t.total_ms * 1e-3
         check(L.fj_join_device(ctx, algo, bloom, materialize, bk.data_ptr(), bv.data_ptr(), bk.numel(), pk.data_ptr(),
                                pk.numel(), stream, hash_top_bits, ctypes.byref(cnt), None, None, 0, ctypes.byref(t)))
         n = int(cnt.value)
-        out = None
         if materialize and n > 0:
             ok = torch.empty(n, dtype=torch.int64, device=bk.device)
             ov = torch.empty(n, dtype=torch.int64, device=bk.device)

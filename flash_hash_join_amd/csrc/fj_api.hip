@@ -107,6 +107,9 @@ struct Pending {
     const u64* bk = nullptr; const u64* bv = nullptr; size_t nb = 0; int top_bits = 64;
 };
 
+// caller-provided output buffers large enough for ANY result (>= probe rows): the materialising join may run in one pass
+struct SingleOut { u64* keys = nullptr; u64* vals = nullptr; size_t cap = 0; bool done = false; };
+
 // bloom_level: 0 = no bloom precheck; L >= 1 = the probe side's level-L chunk set (output of its L-th pass) is filtered
 // against per-bucket Bloom filters of the build side's level L before pass L+1 (csrc/fj_bloom.hip)
 struct Plan { int bits = 0, npass = 0; int fan_log[4] = {0, 0, 0, 0}; int bloom_level = 0; };
@@ -184,8 +187,9 @@ namespace {
 //                      move -- so on this machine "scalar" is the slower way to the same result at every size.
 struct Options {
     size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; u32 plan_target_keys;
-    int bloom_variant, bloom_auto, bloom_auto_max_hit_bp;
+    int bloom_variant, bloom_auto, bloom_auto_max_hit_bp, mat_single_pass;
     Options() {
+        mat_single_pass = getenv("FJ_MAT_SINGLE_PASS") ? atoi(getenv("FJ_MAT_SINGLE_PASS")) : 1;
         bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
         bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2500;     // measured break-even at c4 sizes: 28 % hits (profiles/r02_bloom_threshold.csv)
         const char* bvr = getenv("FJ_BLOOM_VARIANT");
@@ -735,7 +739,7 @@ int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits
 
 // launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
 int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, const PassIter& pit, hipStream_t s,
-                    fj_timings* t, int evc, u64* out_count, bool* lds_full, int top_bits) {
+                    fj_timings* t, int evc, u64* out_count, bool* lds_full, int top_bits, SingleOut* so = nullptr) {
     c->pend.has_second = false;
     ja.nparts = ja.probe.list ? ja.probe.nb : 1u << plan.bits;      // (an owner of a shuffled join holds a slice of the plan's partitions)
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
@@ -761,6 +765,37 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr; ja.retry_only = 0;
     ja.dbg = nullptr;
     ja.dbg_flags = getenv("FJ_JOIN_ABLATE") ? (u32)atoi(getenv("FJ_JOIN_ABLATE")) : 0u;
+    if (so && materialize && ja.probe.list && ja.build.list && ja.build.vals && ja.items && !ja.dbg_flags) {
+        // Single-pass materialising join: every item is probed ONCE; a probe round reserves its pairs' range on a device cursor
+        // (the plan's `total` word) and writes them - no counting pass, no scan, no second read of the probe side (c3 sizes:
+        // 13.4 -> ~12 ms).  It serves unique build keys; duplicates (reported exactly), a partition beyond the cuckoo table or
+        // an output buffer that turns out too small leave the partitions in place and the two-pass path below takes over.
+        FjLdsJoinArgs js = ja;
+        js.out_cursor = &c->d_sc->total; js.out_capacity = so->cap; js.out_keys = so->keys; js.out_vals = so->vals; js.out_off = nullptr;
+        HIPCHK(hipMemsetAsync(&c->d_sc->next_emit_item, 0, sizeof(u32), s));
+        HIPCHK(fj_launch_emit_single(js, s, &c->d_sc->next_emit_item));
+        HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
+        if (read_scalars(c, s)) return 1;
+        if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
+        if (!(c->h_sc->err & (FJ_STAT_DUPS | FJ_STAT_EMIT_RETRY | FJ_ERR_LDS_FULL | FJ_ERR_OUTCAP))) {
+            end_plan(c);
+            t->path = 0; t->passes = plan.npass; t->radix_bits = plan.bits; t->partitions = ja.nparts; t->lds_retries = 0;
+            t->build_phase_ms = ev_ms(c, E_START, E_BUILD);
+            t->join_ms = ev_ms(c, E_PPART, E_JOIN);
+            t->probe_phase_ms = ev_ms(c, E_BUILD, E_JOIN);
+            t->total_ms = ev_ms(c, E_START, E_JOIN);
+            for (int i = 0; i < evc && i < 4; ++i) t->probe_part_kernel_ms[i] = ev_ms(c, E_PK0 + 2 * i, E_PK0 + 2 * i + 1);
+            t->bloom_level = plan.bloom_level;
+            if (plan.bloom_level > 0) { t->filter_ms = ev_ms(c, E_BF0, E_BF1); t->filter_survivors = c->h_sc->bloom_survivors; }
+            *out_count = c->h_sc->total;
+            c->pend.valid = false;
+            so->done = true;
+            return 0;
+        }
+        // not this time: clear what the attempt left in the scalars (the item counts are rewritten by the counting pass)
+        HIPCHK(hipMemsetAsync(&c->d_sc->total, 0, sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(&c->d_sc->err, 0, sizeof(u32), s));
+    }
     if (getenv("FJ_JOIN_STAMPS") && stamps_begin(&ja.dbg, s)) return 1;
     HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item, options().persistent_min_items));
     if (ja.dbg) { if (stamps_report("FJ_JOIN_STAMPS", ja.dbg, nitems, s)) return 1; ja.dbg = nullptr; }
@@ -813,7 +848,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
 // bloom: 0 = no precheck, 1 = precheck whenever the plan allows one (the *_bloom functions), 2 = decide from a sample
 // of the probe side (the adaptive_* functions): SURVEY 8(f) "bloom auto-enable by sampled hit rate"
 int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* bv, size_t nb, const u64* pk, size_t np, int top_bits,
-               hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full) {
+               hipStream_t s, fj_timings* t, u64* out_count, bool* lds_full, SingleOut* so = nullptr) {
     Plan plan = make_plan(nb, top_bits, bloom != 0);
     *lds_full = false;
     t->sampled_hit_bp = -1;
@@ -854,7 +889,7 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     if (plan.bloom_level > 0) pit.bloom_build = &bit.saved;
     if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
     HIPCHK(hipEventRecord(c->ev[E_PPART], s));
-    if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, top_bits)) return 1;
+    if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, top_bits, so)) return 1;
     if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
     return 0;
 }
@@ -928,6 +963,7 @@ int fj_set_option(const char* name, long long value) {
     if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
     if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); options().plan_target_keys = (u32)value; return 0; }
     if (!strcmp(name, "bloom_auto")) { options().bloom_auto = value != 0; return 0; }
+    if (!strcmp(name, "mat_single_pass")) { options().mat_single_pass = value != 0; return 0; }
     if (!strcmp(name, "bloom_auto_max_hit_bp")) { if (value < 0 || value > 10000) return set_err("fj_set_option: bloom_auto_max_hit_bp must be 0..10000"); options().bloom_auto_max_hit_bp = (int)value; return 0; }
     if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); options().bloom_variant = (int)value; return 0; }
     if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
@@ -941,6 +977,7 @@ long long fj_get_option(const char* name) {
     if (name && !strcmp(name, "plan_target_keys")) return options().plan_target_keys;
     if (name && !strcmp(name, "bloom_variant")) return options().bloom_variant;
     if (name && !strcmp(name, "bloom_auto")) return options().bloom_auto;
+    if (name && !strcmp(name, "mat_single_pass")) return options().mat_single_pass;
     if (name && !strcmp(name, "bloom_auto_max_hit_bp")) return options().bloom_auto_max_hit_bp;
     set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
     return -1;
@@ -1034,7 +1071,11 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
         bool lds_full = false;
         // adaptive_*: the precheck is decided from a sample of the probe side; *_bloom by name: always on; otherwise off
         const int bloom_mode = algo == FJ_ALGO_ADAPTIVE ? (options().bloom_auto ? 2 : (bloom ? 1 : 0)) : (bloom ? 1 : 0);
-        if (join_radix(c, materialize, bloom_mode, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count, &lds_full)) return 1;
+        SingleOut so;
+        so.keys = (u64*)d_out_keys; so.vals = (u64*)d_out_vals; so.cap = out_capacity;
+        const bool try_single = materialize && d_out_keys && d_out_vals && out_capacity >= np && options().mat_single_pass &&
+                                !(((uintptr_t)d_out_keys | (uintptr_t)d_out_vals) & 7);
+        if (join_radix(c, materialize, bloom_mode, d_bk, d_bv, nb, d_pk, np, hash_top_bits, s, &t, &count, &lds_full, try_single ? &so : nullptr)) return 1;
         if (lds_full) {
             fj_timings t2; memset(&t2, 0, sizeof t2);
             if (join_global(c, bloom, materialize, d_bk, d_bv, nb, d_pk, np, s, &t2, &count)) return 1;

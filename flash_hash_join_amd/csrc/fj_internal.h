@@ -11,6 +11,7 @@
 #define FJ_ERR_VARIANT 32u   // filters handed to the filter kernel were built with another bloom_variant (sender-side precheck across ranks)
 #define FJ_BLOOM_HDR_MAGIC 0xB100F000u   // exported filter sets end with 4 header words: [0] = magic | variant
 #define FJ_STAT_TOOBIG 64u   // (status) some items' partitions hold more distinct build keys than even the tagged LDS table takes: part_count[item] == FJ_ITEM_TOOBIG marks them; the host re-partitions just those
+#define FJ_ERR_OUTCAP 128u   // single-pass materialising join: more pairs than the caller's output buffers hold
 #define FJ_ITEM_RETRY 0xFFFFFFFFu
 #define FJ_ITEM_TOOBIG 0xFFFFFFFEu
 
@@ -132,6 +133,11 @@ struct FjLdsJoinArgs {
     const u64* out_off;          // [items+1] exclusive scan of part_count
     u64* out_keys;
     u64* out_vals;
+    // single-pass materialising join (fj_emit_join_persistent<SINGLE>): no counting pass, no per-item offsets - every probe round
+    // reserves its pairs' output range on this device cursor (one atomic per workgroup and round); out_capacity = pairs the
+    // output buffers hold.  The cursor ends as the join's match count.
+    unsigned long long* out_cursor;
+    u64 out_capacity;
     u32 retry_only;              // tagged-table counting kernel: process only the items the cuckoo kernel marked FJ_ITEM_RETRY
     u32 mark_toobig;             // tagged-table counting kernel: a partition beyond the table marks its item FJ_ITEM_TOOBIG (FJ_STAT_TOOBIG) instead of raising FJ_ERR_LDS_FULL
     u32 want_dups;               // counting pass of a materialising join: report duplicate build keys (FJ_STAT_DUPS)
@@ -143,6 +149,8 @@ struct FjLdsJoinArgs {
 // next_item: device word for the persistent counting kernel's work counter (nullptr: one workgroup per item)
 hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStream_t s, u32* next_item = nullptr,
                               u32 persistent_min_items = 8192);
+// the single-pass materialising join over chunk lists (a.out_cursor != nullptr; unique build keys: duplicates are reported, FJ_STAT_DUPS)
+hipError_t fj_launch_emit_single(const FjLdsJoinArgs& a, hipStream_t s, u32* next_item);
 // second chance for the items whose partition overflowed the cuckoo table (load > ~0.45): the tagged 2x4-slot table
 // with linear-probing overflow holds up to 8128 keys; only a partition beyond that raises FJ_ERR_LDS_FULL
 hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a, hipStream_t s);

@@ -940,13 +940,21 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
 // A table whose stash overflows marks its item (part_count = FJ_ITEM_RETRY, FJ_STAT_EMIT_RETRY) and
 // the host runs the tagged kernel over the marked items.  Resident workgroups with next-item prefetch as in
 // fj_count_join_persistent; output positions = scanned per-item offsets + an LDS cursor bumped once per wave and 4 key slots.
-struct EkHdr { u32 has_empty, nstash, full, dups, cursor, novf, pad1[2]; u64 empty_val; u64 pad2; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
+struct EkHdr { u32 has_empty, nstash, full, dups, cursor, novf, item_cnt, pad1; u64 empty_val; u64 gbase; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
 
 // DEDUP (the counting pass saw duplicate build keys): the build "values" are original row indices, every copy of a key
 // lowers its slot's index with an LDS atomic minimum, and the winners are turned into values with one gather from the
 // caller's build_values - the reference's first-occurrence rule (hash_join.cpp:125 on a stable partition).
-template <int NT, bool DEDUP>
+// SINGLE: the single-pass materialising join - no counting pass ran and nobody knows the items' match counts.  Every probe
+// round (8 keys per thread) first counts: the waves add their hit counts to the LDS cursor (which hands each its offset inside
+// the round), one thread reserves the round's range on the GLOBAL cursor a.out_cursor (one returning atomic per workgroup and
+// round: ~130K per 1B probe rows, far below the 83 M/s one cursor sustains, tools/ubench_atomic_cursor.hip), then the pairs
+// are written there - the keys, values and hit masks of the round wait in registers meanwhile.  Pair order is unspecified
+// (as everywhere); the cursor ends as the match count.  Duplicate build keys are reported exactly (FJ_STAT_DUPS, the sweep of
+// the counting kernels) and the host then discards the output and runs the two-pass first-occurrence path.
+template <int NT, bool DEDUP, bool SINGLE = false>
 __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a, u32* __restrict__ next_item) {
+    static_assert(!(SINGLE && DEDUP), "the single-pass form serves unique build keys");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EkHdr* hdr = reinterpret_cast<EkHdr*>(smem);
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(EkHdr));
@@ -968,7 +976,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
         const uint4 it = a.items[item];
         d.b0 = a.build.boff[it.z]; d.nbc = a.build.boff[it.z + 1] - d.b0;
         d.s_lo = it.x; d.s_hi = it.x + it.y;
-        d.cnt = a.part_count[item];                          // the counting pass: items without a match emit nothing
+        d.cnt = SINGLE ? 1u : a.part_count[item];            // the counting pass: items without a match emit nothing
         return d;
     };
     auto live = [&](const Desc& d) { return d.item < nitems && d.nbc > 0 && d.s_lo < d.s_hi && d.cnt != 0; };
@@ -1002,7 +1010,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
         for (u32 i = tid; i < S; i += NT) { tkeys[i] = FJ_EMPTY_KEY; if (DEDUP) tvals[i] = ~0ull; }
         if (DEDUP && tid < CK_STASH) hdr->stash_val[tid] = ~0ull;
         if (tid < S / 32) bits[tid] = 0;
-        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->novf = 0; hdr->empty_val = DEDUP ? ~0ull : 0ull; }
+        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->novf = 0; hdr->item_cnt = 0; hdr->empty_val = DEDUP ? ~0ull : 0ull; }
     };
     // step 2: the value of build row (key, val) goes where the key lives now (table before stash, first location before the
     // second: the order the probe uses).  DEDUP: val is the row index, the smallest one stays.
@@ -1133,12 +1141,29 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
             if (tid == 0 && hdr->has_empty && hdr->empty_val != ~0ull) hdr->empty_val = a.orig_vals[hdr->empty_val];
             __syncthreads();
         }
+        if (SINGLE && lv && !full) {
+            // exact duplicate report (as the counting kernels do it): a second copy of a key was noticed by its insert, or it
+            // raced past the check and the key now sits in both of its slots / the stash
+            const u32 nst = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
+            for (u32 sl = tid; sl < S; sl += NT) {
+                const u64 key = tkeys[sl];
+                if (key == FJ_EMPTY_KEY) continue;
+                const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+                const u32 other = sl == l1 ? l2 : l1;
+                if (other != sl && tkeys[other] == key) hdr->dups = 1;
+                for (u32 si = 0; si < nst; ++si) if (hdr->stash[si] == key) hdr->dups = 1;
+            }
+            for (u32 si = tid; si < nst; si += NT)
+                for (u32 sj = si + 1; sj < nst; ++sj) if (hdr->stash[si] == hdr->stash[sj]) hdr->dups = 1;
+            __syncthreads();
+            if (tid == 0 && hdr->dups) atomicOr(a.err, FJ_STAT_DUPS);
+        }
         if (lv && full) {                                    // stash overflow: the host redoes this item on the tagged table
             if (tid == 0) { atomicOr(a.err, FJ_STAT_EMIT_RETRY); a.part_count[d.item] = FJ_ITEM_RETRY; }
         } else if (lv) {
             const u64 he = hdr->has_empty ? ~0ull : 0ull;
             const u32 nstash = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
-            const u64 obase = a.out_off[d.item];
+            const u64 obase = SINGLE ? 0ull : a.out_off[d.item];
             // ---- probe + emit ----
             for (u32 pb = d.s_lo; pb < d.s_hi; pb += JP_META) {
                 if (pb != d.s_lo) {
@@ -1156,7 +1181,8 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                     for (int i = 0; i < 8; ++i) { k[i] = ka[i]; ka[i] = kb[i]; }
                     const u32 okm = oka;
                     oka = okb;
-                    if (r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);
+                    if (!SINGLE && r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);      // (SINGLE issues it under the reservation's latency, below)
+                    u64 hit8[8], val8[8];                          // SINGLE: the round's hit masks (wave-uniform) and values wait for the reservation
 #pragma unroll
                     for (int h = 0; h < 8; h += 4) {              // two halves of 4 keys: 8 LDS reads in flight per lane
                         u64 c1[4], c2[4];
@@ -1184,6 +1210,11 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                             if (ise) { hit = he != 0; val[i] = hdr->empty_val; }
                             hitm[i] = __ballot(hit && ((okm >> (h + i)) & 1u));
                         }
+                        if constexpr (SINGLE) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { hit8[h + i] = hitm[i]; val8[h + i] = val[i]; }
+                            continue;
+                        }
                         // ONE LDS cursor bump per wave for the four key slots; lanes ranked inside the ballots
                         const u32 n0 = (u32)__popcll(hitm[0]), n1 = (u32)__popcll(hitm[1]), n2 = (u32)__popcll(hitm[2]), n3 = (u32)__popcll(hitm[3]);
                         if (n0 + n1 + n2 + n3) {
@@ -1202,12 +1233,47 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                             }
                         }
                     }
+                    if constexpr (SINGLE) {
+                        // the round's pairs: wave offsets from the LDS cursor, the round's range from the global cursor
+                        u32 nw = 0, pre[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { pre[i] = nw; nw += (u32)__popcll(hit8[i]); }
+                        u32 wb = 0;
+                        if (lane == 0 && nw) wb = atomicAdd(&hdr->cursor, nw);
+                        wb = (u32)__builtin_amdgcn_readfirstlane((int)wb);
+                        __syncthreads();                              // every wave of the round has counted
+                        if (tid == 0) {
+                            const u32 tot = hdr->cursor;
+                            u64 gb = 0;
+                            if (tot) {
+                                gb = atomicAdd(a.out_cursor, (unsigned long long)tot);
+                                if (gb + tot > a.out_capacity) { atomicOr(a.err, FJ_ERR_OUTCAP); gb = ~0ull; }
+                            }
+                            hdr->gbase = gb; hdr->cursor = 0; hdr->item_cnt += tot;
+                        }
+                        if (r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);          // ~1-2 us of returning-atomic latency to fill
+                        if (!parked) park();
+                        __syncthreads();
+                        const u64 gb = hdr->gbase;
+                        if (nw && gb != ~0ull) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const u64 m = hit8[i];
+                                if ((m >> lane) & 1ull) {
+                                    const u64 o = gb + wb + pre[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                                    a.out_keys[o] = k[i];
+                                    a.out_vals[o] = val8[i];
+                                }
+                            }
+                        }
+                    }
                     if (!parked) park();                      // after the first round: the entries have long arrived
                 }
             }
         }
         if (!parked) park();                                  // skipped probe loop
         __syncthreads();                                      // every wave is done with the table; the parked entries are visible
+        if (SINGLE && tid == 0 && d.item < nitems && !(lv && full)) a.part_count[d.item] = lv ? hdr->item_cnt : 0u;
         if (lvn) load_build(bmn, 0, nbbn); else bok = 0;      // the next item's build rows fly during the reset
         if (dn.item >= nitems) break;
         reset_table();
@@ -1538,6 +1604,17 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nb), dim3(512), lds, s, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_emit_single(const FjLdsJoinArgs& a, hipStream_t s, u32* next_item) {
+    if (!a.build.list || !a.probe.list || !a.items || !next_item || !a.out_cursor || a.dedup || !a.build.vals) return hipErrorInvalidValue;
+    const u32 nb = a.items_cap;
+    const u32 ldsp = sizeof(EkHdr) + 2 * S * 8 + 2 * (JP_META + JB_META) * 4 + 16 + S / 8 + CK_OVF * 8;
+    auto pk = fj_emit_join_persistent<1024, false, true>;
+    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(pk), ldsp);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pk, dim3(nb < 256 ? nb : 256), dim3(1024), ldsp, s, a, next_item);
     return hipGetLastError();
 }
 

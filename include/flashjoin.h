@@ -89,6 +89,8 @@ const char* fj_version(void);
  *                        functions always run the precheck when the plan has two or more passes; hash_join* never do.
  *   "bloom_variant"    - hash / bit layout of the filter, 0..2 (csrc/fj_bloom_dev.h; default 2; env FJ_BLOOM_VARIANT).  Must be
  *                        the same on every rank of a multi-GPU job (fj_bloom_prefilter checks it against the exporter's).
+ *   "mat_single_pass"  - 1 (default): a materialising join whose output buffers hold >= np pairs runs single-pass (above);
+ *                        0: always count, scan, emit (env FJ_MAT_SINGLE_PASS).
  *   "plan_target_keys" - average build keys per final partition the plan aims for (default and maximum 4096 = half an LDS
  *                        table; env FJ_PLAN_TARGET_KEYS).  A testing knob: small values make small inputs take the deep
  *                        (two- and three-pass, bloom-filtered) plans that production only uses for >1M-row build sides.
@@ -128,7 +130,10 @@ int fj_last_timings(fj_timings* out);
  * 48 after fj_owner_split (the top 16 hash bits chose the owner GPU).
  * Materialising joins: with d_out_keys == NULL the call counts only and keeps its partitions
  * resident; fj_emit_pairs() then writes exactly *out_count pairs into caller-allocated buffers.
- * With d_out_keys != NULL and out_capacity >= count both steps happen in this call.
+ * With d_out_keys != NULL and out_capacity >= count both steps happen in this call.  With out_capacity >= np - room for
+ * ANY result, what the reference allocates too (hash_join.cpp:330-334) - a partitioned join with unique build keys runs in
+ * ONE pass over the probe side (no counting pass; option "mat_single_pass", default 1): the first *out_count rows of the
+ * buffers are the pairs.
  */
 int fj_join_device(fj_ctx* ctx, int algo, int bloom, int materialize,
                    const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb,

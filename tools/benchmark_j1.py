@@ -35,8 +35,10 @@ IMPLS = [("adaptive_join", "adaptive_join_count", "adaptive_join"), ("adaptive_b
 
 
 def result_line(label, task, case, threads, wall, core, res):
+    """The reference's line, field for field (benchmark.py:83: RESULT,Library=,Task=,Threads=,Time=,Result=) so that logs diff;
+    what this harness adds (the J1 case, the core time) follows Result=."""
     core_s = "" if core is None else f",Core={core:.5f}"
-    print(f"RESULT,Library={label},Task={task},Case={case},Threads={threads},Time={wall:.4f}{core_s},Result={res}", flush=True)
+    print(f"RESULT,Library={label},Task={task},Threads={threads},Time={wall:.4f},Result={res},Case={case}{core_s}", flush=True)
 
 
 def best_of(reps, call, sync):
