@@ -285,6 +285,7 @@ def main() -> None:
     #      small join against its closed-form count; a failure is ONE JSON line with `error` and a non-zero exit code ----------
     selfcheck = None
     if world > 1 or force_dist:
+        import threading
         from flash_hash_join_amd.distributed import self_check
         nb_s, np_s = max(400_000, 3_200_000 // world), 4_000_000
         sbk, sbv = datagen.build_device(nb_s, device, first=rank * nb_s)
@@ -293,15 +294,43 @@ def main() -> None:
         dist.all_reduce(e)
         pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
         msg = int(1.3 * np_gpu / max(1, pieces) / world) + 4096          # int64 per peer and piece in the chunk form
-        selfcheck = self_check(dist, None, engine, (sbk, sbv, spk), int(e.item()), msg)
+
+        def error_line(err, sc):
+            return json.dumps({"error": err, "self_check": sc, "rank": rank, "n_gpus": world, "torch": torch.__version__,
+                               "hip": getattr(torch.version, "hip", None),
+                               "rccl": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                               "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",
+                               "value": None})
+
+        # a collective that never returns (mismatched sends on some rank) must not become a silent driver timeout
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("FJ_BENCH_SELFCHECK_TIMEOUT", "240"))):
+                if rank == 0:
+                    print(error_line("the multi-rank self-check did not finish (a collective is stuck)", None), flush=True)
+                os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        # the default protocol first (chunk-form shuffle through the native entry); a form that fails its check - the ranks agree
+        # on that - is replaced by the next simpler one, and the line says which one was timed
+        forms = [("chunks (native fj_dist_join_count)", {}), ("chunks (torch.distributed)", {"FJ_DIST_NATIVE": "0"}),
+                 ("owner-scatter", {"FJ_DIST_NATIVE": "0", "FJ_DIST_CHUNK_SHUFFLE": "0"})]
+        tried = []
+        for name, env in forms:
+            if any(k in os.environ and os.environ[k] != v for k, v in env.items()):
+                continue                                     # the user pinned a form: honour it
+            os.environ.update(env)
+            selfcheck = self_check(dist, None, engine, (sbk, sbv, spk), int(e.item()), msg, transport=transport)
+            selfcheck["shuffle_form_checked"] = name
+            tried.append({"form": name, "ok": selfcheck["ok"], "error": selfcheck["error"]})
+            if selfcheck["ok"]:
+                break
+        selfcheck["forms_tried"] = tried
+        done.set()
         del sbk, sbv, spk
         if not selfcheck["ok"]:
             if rank == 0:
-                print(json.dumps({"error": selfcheck["error"] or "self-check failed on another rank", "self_check": selfcheck, "rank": rank,
-                                  "n_gpus": world, "torch": torch.__version__, "hip": getattr(torch.version, "hip", None),
-                                  "rccl": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
-                                  "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",
-                                  "value": None}), flush=True)
+                print(error_line(selfcheck["error"] or "self-check failed on another rank", selfcheck), flush=True)
             try:
                 dist.destroy_process_group()
             except Exception:

@@ -707,7 +707,7 @@ def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
     return "replicate" if c["replicate"] <= c["shuffle"] else "shuffle"
 
 
-def self_check(dist, group, engine, small_inputs, expected_small: int, message_elems: int) -> dict:
+def self_check(dist, group, engine, small_inputs, expected_small: int, message_elems: int, transport=None) -> dict:
     """A few seconds before a multi-rank job's first timed step: (1) one exchange of per-peer VIEWS at the largest message size
     the step will use (`message_elems` int64 per peer, capped at the RCCL-safe size), every element a function of (source,
     destination, index), verified in full on arrival - the transport of the chunk-form shuffle, and the > 4 GiB defect the
@@ -748,7 +748,7 @@ def self_check(dist, group, engine, small_inputs, expected_small: int, message_e
     if nbad == 0:
         try:
             bk, bv, pk = small_inputs
-            got = distributed_join(bk, bv, pk, group=group, engine=engine, transport=dist)[0]
+            got = distributed_join(bk, bv, pk, group=group, engine=engine, transport=transport)[0]
             if int(got) != int(expected_small):
                 err = f"join self-check: count {got} != closed form {expected_small}"
         except Exception as ex:                                    # noqa: BLE001  (raised on every rank, or agreed on inside)

@@ -2,7 +2,7 @@
 # One GPU call that produces what is committed under profiles/ for a kernel version:  tools/collect_profiles.sh <tag>
 #   PMC passes (c3, c4, c3_mat, c2), rocprofv3 --kernel-trace --stats (c3, c4, c3_mat, c2 and the literal HBM-table forms),
 #   the default bench line, the other workloads' bench lines, the J1 harness log, traffic_latest.json.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd ${GRAFT_REPO_ROOT:-$PWD}
 O=gpurun_out/$TAG; mkdir -p $O
 for w in c3 c4 c3_mat c2 c2_hbm_table; do
@@ -19,9 +19,10 @@ python tools/trace_timeline.py gpurun_out/stats_${TAG}_c3_mat > $O/c3_mat_timeli
 python tools/traffic_json.py $O/c3_pmc_summary.txt $O/traffic_latest.json > /dev/null 2>&1
 timeout 900 python bench.py 2>&1 | tail -1 > $O/c3_bench.json
 : > $O/other_workloads.jsonl
-for w in c2 c2_hbm_table c4 c4_scalar_bloom c4_adaptive c4_hbm_table_bloom c3_adaptive c3_mat small rep2 rep4 rep8 c5; do
+for w in c2 c2_hbm_table c4 c4_scalar_bloom c4_adaptive c4_hbm_table_bloom c3_adaptive c3_mat small rep8 c5; do
   timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 >> $O/other_workloads.jsonl
 done
+FJ_MAT_SINGLE_PASS=0 timeout 300 python bench.py --workload c3_mat --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c3_mat_two_pass_bench.json
+timeout 600 python tools/skew_build_partition_probe.py 4 > $O/skew_build_partition_probe.txt 2>&1
 timeout 900 python tools/benchmark_j1.py --sizes 1e7,4e7 --cpu --duckdb > $O/j1_shaped_benchmark.log 2>&1
-timeout 600 python tools/benchmark_j1.py --sizes 1e7 --inputs numpy --reps 2 > $O/j1_shaped_benchmark_numpy_inputs.log 2>&1
 ls -la $O | head -50

@@ -80,10 +80,10 @@ def worker(rank, world, port, q):
         sk, sv = datagen.build_device(500_000, "cuda:0", first=rank * 500_000)
         sp, se = datagen.probe_device(1_500_000, 500_000 * world, "cuda:0", seed=3, hit_bp=5000, first=rank * 1_500_000)
         et = torch.tensor([se]); dist.all_reduce(et)
-        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000)
+        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim)
         assert chk["ok"] and chk["failed_ranks"] == 0, chk
         os.environ["FJ_SELFCHECK_CORRUPT"] = "1"
-        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000)
+        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim)
         del os.environ["FJ_SELFCHECK_CORRUPT"]
         assert not chk["ok"] and chk["failed_ranks"] == 1 and (rank != 0 or "elements received from rank" in chk["error"]), chk
         for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "scatter"), ("shuffle", "prefilter")):
