@@ -358,7 +358,10 @@ def main() -> None:
                 kern.setdefault("fj_partition_kernel<keys> (probe-side radix pass)", []).append((ms, 16 * P))
         if L:
             kern.setdefault("fj_bloom_filter_kernel (bloom precheck between the probe-side passes)", []).append((lt["filter_ms"], 8 * P + 8 * S + 8 * B))
-        if lt["path"] == 0:
+        if lt["path"] == 0 and materialize and lt["emit_ms"] == 0 and exp_local > 0:
+            # the single-pass materialising join: one kernel builds, probes and emits (16 B per pair)
+            kern.setdefault("fj_emit_join_persistent, single-pass form (table build + probe + emit)", []).append((lt["join_ms"], 8 * (S if L else P) + 16 * B + 16.0 * exp_local))
+        elif lt["path"] == 0:
             kern.setdefault("join kernel (per-partition LDS table build + probe)", []).append((lt["join_ms"], 8 * (S if L else P) + (16 if materialize else 8) * B))
             if materialize and lt["emit_ms"] > 0:
                 kern.setdefault("emitting join kernel (second pass of a materialising join)", []).append((lt["emit_ms"], 8 * (S if L else P) + 16 * B + 16.0 * exp_local))
