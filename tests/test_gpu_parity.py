@@ -668,6 +668,57 @@ def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["probe_rows_total"] == 2 * 25_000_000     # default at N > 1: c5 (x 0.02)
     assert d["config"]["bench_workload"] == "c5" and d["config"]["build_rows_total"] == 2 * 2_500_000
     assert d["config"]["parallelism"].endswith("x2") and "cpu_baseline" not in d and d["value"] > 0
+    # the pre-flight self-check ran (under the host-staged transport only the torch.distributed forms apply) and is in the line;
+    # value is the shuffle's, the replicate strategy rides along as a labelled second measurement
+    assert d["self_check"]["ok"] and d["self_check"]["forms_tried"][-1]["ok"]
+    assert d["config"]["parallelism"].startswith("owner-shuffle") and d["phases"]["shuffle_form"] == "chunks"
+    assert d["alt_strategy"]["strategy"] == "replicate-build" and d["alt_strategy"]["count_ok"] is True
+    # a transport that moves wrong data (test hook): every shuffle form fails its check, ONE JSON line says so, exit code 3
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=900, env=dict(env, FJ_SELFCHECK_CORRUPT="1"), cwd=ROOT)
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and "elements received from rank" in d["error"] and d["n_gpus"] == 2
+    assert [f["ok"] for f in d["self_check"]["forms_tried"]] == [False] * len(d["self_check"]["forms_tried"]) and len(d["self_check"]["forms_tried"]) >= 2
+
+
+def test_shuffled_stream_recovers_from_an_oversized_partition(fj):
+    """The chunk form of the owner shuffle on one GPU (one owner, world 1) with a build side that puts 9000 keys into ONE final
+    partition: fj_stream_finish re-partitions that partition alone (no fallback exists for chunk pieces) - exact count."""
+    import torch
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
+        lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+            x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+            x ^= x >> np.uint32(16)
+        return x
+    nb_total = 3_000_000                                           # plan: 10 bits = 5 + 5
+    cand = np.arange(1, 40_000_000, dtype=np.uint64)
+    skew = cand[(hash_w1(cand) >> np.uint32(22)) == 77][:9000]     # top 10 hash bits equal: one final partition
+    assert skew.size == 9000
+    bk0, _ = datagen.build_device(nb_total - 9000, "cuda:0")
+    bk = torch.cat([bk0, torch.from_numpy(skew.view(np.int64)).cuda()])
+    pk0, exp0 = datagen.probe_device(8_000_000, nb_total - 9000, "cuda:0", seed=2, hit_bp=5000)
+    pk = torch.cat([pk0, torch.from_numpy(np.tile(skew, 5).view(np.int64)).cuda()])
+    assert not bool(torch.isin(bk[-9000:], bk0).any())
+    eng = HipEngine("cuda:0")
+    assert eng.shuffle_plan(nb_total, 1) == 5
+    pool, _, dirw, region, used = eng.shuffle_pack(bk, None, nb_total, 1)
+    ppool, _, pdirw, pregion, pused = eng.shuffle_pack(pk, None, nb_total, 1)
+    eng.stream_open_shuffled(nb_total, 1, 0, bk.numel() + 65536, 1, pk.numel() + 65536, 1)
+    eng.stream_append_chunks(0, pool[: used[0] * 256], dirw[: used[0]])
+    eng.stream_append_chunks(1, ppool[: pused[0] * 256], pdirw[: pused[0]])
+    assert eng.stream_finish() == exp0 + 45_000
+    lt = fj.last_timings()
+    assert lt["fell_back"] == 0 and lt["lds_retries"] == 2, lt
 
 
 @pytest.mark.parametrize("nb,npk,hit_bp,fn,hbm", [
