@@ -940,18 +940,22 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
 // A table whose stash overflows marks its item (part_count = FJ_ITEM_RETRY, FJ_STAT_EMIT_RETRY) and
 // the host runs the tagged kernel over the marked items.  Resident workgroups with next-item prefetch as in
 // fj_count_join_persistent; output positions = scanned per-item offsets + an LDS cursor bumped once per wave and 4 key slots.
-struct EkHdr { u32 has_empty, nstash, full, dups, cursor, novf, item_cnt, pad1; u64 empty_val; u64 gbase; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
+struct EkHdr { u32 has_empty, nstash, full, dups, cursor, novf, cur2[2]; u64 empty_val; u64 gb2[2]; u64 pad; u64 stash[CK_STASH]; u64 stash_val[CK_STASH]; };
 
 // DEDUP (the counting pass saw duplicate build keys): the build "values" are original row indices, every copy of a key
 // lowers its slot's index with an LDS atomic minimum, and the winners are turned into values with one gather from the
 // caller's build_values - the reference's first-occurrence rule (hash_join.cpp:125 on a stable partition).
 // SINGLE: the single-pass materialising join - no counting pass ran and nobody knows the items' match counts.  Every probe
-// round (8 keys per thread) first counts: the waves add their hit counts to the LDS cursor (which hands each its offset inside
-// the round), one thread reserves the round's range on the GLOBAL cursor a.out_cursor (one returning atomic per workgroup and
-// round: ~130K per 1B probe rows, far below the 83 M/s one cursor sustains, tools/ubench_atomic_cursor.hip), then the pairs
-// are written there - the keys, values and hit masks of the round wait in registers meanwhile.  Pair order is unspecified
-// (as everywhere); the cursor ends as the match count.  Duplicate build keys are reported exactly (FJ_STAT_DUPS, the sweep of
-// the counting kernels) and the host then discards the output and runs the two-pass first-occurrence path.
+// round (8 keys per thread) counts first: the waves add their hit counts to an LDS cursor (which hands each its offset inside
+// the round), after ONE barrier thread 0 reserves the round's range on the GLOBAL cursor a.out_cursor (one returning atomic
+// per workgroup and round: ~130K per 1B probe rows, far below the 83 M/s one cursor sustains, tools/ubench_atomic_cursor.hip)
+// and does not wait for it: the round's keys, hit bits and 16-bit slot codes stay in registers as the PENDING round while the
+// next round is loaded and probed; the range is published behind the next round's barrier and the pending pairs are written
+// then (values fetched from the table by slot code).  An item's last round is written behind the table reset for the next
+// item (tvals, stash_val and empty_val survive that reset).  So a round costs one barrier and the atomic's ~1-2 us round trip
+// hides under a whole round of LDS lookups.  Pair order is unspecified (as everywhere); the cursor ends as the match count.
+// Duplicate build keys are reported exactly (FJ_STAT_DUPS, the sweep of the counting kernels) and the host then discards the
+// output and runs the two-pass first-occurrence path.
 template <int NT, bool DEDUP, bool SINGLE = false>
 __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a, u32* __restrict__ next_item) {
     static_assert(!(SINGLE && DEDUP), "the single-pass form serves unique build keys");
@@ -1010,7 +1014,10 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
         for (u32 i = tid; i < S; i += NT) { tkeys[i] = FJ_EMPTY_KEY; if (DEDUP) tvals[i] = ~0ull; }
         if (DEDUP && tid < CK_STASH) hdr->stash_val[tid] = ~0ull;
         if (tid < S / 32) bits[tid] = 0;
-        if (tid == 0) { hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->novf = 0; hdr->item_cnt = 0; hdr->empty_val = DEDUP ? ~0ull : 0ull; }
+        if (tid == 0) {
+            hdr->has_empty = 0; hdr->nstash = 0; hdr->full = 0; hdr->dups = 0; hdr->cursor = 0; hdr->novf = 0; hdr->cur2[0] = 0; hdr->cur2[1] = 0;
+            if (!SINGLE) hdr->empty_val = DEDUP ? ~0ull : 0ull;    // (SINGLE: a pending round may still need the old one; read only under has_empty)
+        }
     };
     // step 2: the value of build row (key, val) goes where the key lives now (table before stash, first location before the
     // second: the order the probe uses).  DEDUP: val is the row index, the smallest one stays.
@@ -1055,7 +1062,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
         u32 nrounds = (nbatch + CPR - 1) / CPR;
         if (lv) {
             load_round(pm, 0, nbatch, ka, oka);
-            if (nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
+            if (!SINGLE && nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
             // ---- build, step 1: keys ----
             u32 nbb = d.nbc < JB_META ? d.nbc : JB_META;
             for (u32 bb = 0; bb < d.nbc; bb += JB_META) {
@@ -1094,6 +1101,39 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
             if (tid < nbbn) bmn[tid] = mb;
             if (tid == 0) s_next[buf ^ 1] = atomicAdd(next_item, 1u) + gridDim.x;
             parked = true;
+        };
+
+        // SINGLE: the pending round (counted, range requested, pairs not written yet)
+        u64 kp[8];
+        u32 scp[4] = {0u, 0u, 0u, 0u}, hbp = 0, wbp = 0, par = 0;
+        bool pend = false;
+        u64 gbv = 0; u32 totp = 0, icnt = 0;                 // thread 0: the range request in flight, its size, the item's matches so far
+        auto settle = [&]() {                                 // thread 0 publishes the pending round's range (waits for the atomic here)
+            if (tid == 0 && pend) {
+                u64 gb = gbv;
+                if (totp && gb + totp > a.out_capacity) { atomicOr(a.err, FJ_ERR_OUTCAP); gb = ~0ull; }
+                hdr->gb2[par ^ 1] = gb;
+            }
+        };
+        auto flush = [&]() {                                  // behind the barrier that follows settle(): write the pending pairs
+            const u64 gb = hdr->gb2[par ^ 1];
+            u32 pre = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool bit = (hbp >> i) & 1u;
+                const u64 m = __ballot(bit);
+                if (bit && gb != ~0ull) {
+                    const u32 code = (scp[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+                    u64 val;
+                    if (code < S) val = tvals[code];
+                    else if (code == 0xFFFFu) val = hdr->empty_val;
+                    else val = hdr->stash_val[code - S];
+                    const u64 o = gb + wbp + pre + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                    a.out_keys[o] = kp[i];
+                    a.out_vals[o] = val;
+                }
+                pre += (u32)__popcll(m);
+            }
         };
 
         bool full = false;
@@ -1164,120 +1204,151 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
             const u64 he = hdr->has_empty ? ~0ull : 0ull;
             const u32 nstash = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
             const u64 obase = SINGLE ? 0ull : a.out_off[d.item];
-            // ---- probe + emit ----
-            for (u32 pb = d.s_lo; pb < d.s_hi; pb += JP_META) {
-                if (pb != d.s_lo) {
-                    nbatch = (d.s_hi - pb) < JP_META ? (d.s_hi - pb) : JP_META;
-                    __syncthreads();
-                    if (tid < nbatch) pm[tid] = a.probe.list[pb + tid];
-                    __syncthreads();
-                    nrounds = (nbatch + CPR - 1) / CPR;
-                    load_round(pm, 0, nbatch, ka, oka);
-                    if (nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
-                }
-                for (u32 r = 0; r < nrounds; ++r) {
-                    u64 k[8];
+            if constexpr (SINGLE) {
+                // ---- probe; count; request the range; write the round before ----
+                for (u32 pb = d.s_lo; pb < d.s_hi; pb += JP_META) {
+                    if (pb != d.s_lo) {
+                        nbatch = (d.s_hi - pb) < JP_META ? (d.s_hi - pb) : JP_META;
+                        __syncthreads();
+                        if (tid < nbatch) pm[tid] = a.probe.list[pb + tid];
+                        __syncthreads();
+                        nrounds = (nbatch + CPR - 1) / CPR;
+                        load_round(pm, 0, nbatch, ka, oka);
+                    }
+                    for (u32 r = 0; r < nrounds; ++r) {
+                        u64 k[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { k[i] = ka[i]; ka[i] = kb[i]; }
-                    const u32 okm = oka;
-                    oka = okb;
-                    if (!SINGLE && r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);      // (SINGLE issues it under the reservation's latency, below)
-                    u64 hit8[8], val8[8];                          // SINGLE: the round's hit masks (wave-uniform) and values wait for the reservation
+                        for (int i = 0; i < 8; ++i) k[i] = ka[i];
+                        const u32 okm = oka;
+                        if (r + 1 < nrounds) load_round(pm, r + 1, nbatch, ka, oka);   // a whole round ahead of its use
+                        u32 hb = 0, sc[4] = {0u, 0u, 0u, 0u}, nw = 0;
 #pragma unroll
-                    for (int h = 0; h < 8; h += 4) {              // two halves of 4 keys: 8 LDS reads in flight per lane
-                        u64 c1[4], c2[4];
-                        u32 l1[4], l2[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const u32 w = fj_hash_w2(k[h + i]);
-                            l1[i] = w & (S - 1); l2[i] = (w >> 13) & (S - 1);
-                            c1[i] = tkeys[l1[i]];
-                            c2[i] = tkeys[l2[i]];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        u64 hitm[4];
-                        u64 val[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const u64 key = k[h + i];
-                            const bool h1 = c1[i] == key, h2 = c2[i] == key;
-                            bool hit = h1 | h2;
-                            val[i] = tvals[h1 ? l1[i] : l2[i]];          // (unconditional read: independent of the compare, harmless on a miss)
-                            if (nstash) {                                // (table before stash: the order step 2 used)
-                                for (u32 si = 0; si < nstash; ++si) if (!hit && hdr->stash[si] == key) { hit = true; val[i] = hdr->stash_val[si]; }
-                            }
-                            const bool ise = key == FJ_EMPTY_KEY;        // the empty marker is never stored in the table
-                            if (ise) { hit = he != 0; val[i] = hdr->empty_val; }
-                            hitm[i] = __ballot(hit && ((okm >> (h + i)) & 1u));
-                        }
-                        if constexpr (SINGLE) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { hit8[h + i] = hitm[i]; val8[h + i] = val[i]; }
-                            continue;
-                        }
-                        // ONE LDS cursor bump per wave for the four key slots; lanes ranked inside the ballots
-                        const u32 n0 = (u32)__popcll(hitm[0]), n1 = (u32)__popcll(hitm[1]), n2 = (u32)__popcll(hitm[2]), n3 = (u32)__popcll(hitm[3]);
-                        if (n0 + n1 + n2 + n3) {
-                            u32 wb = 0;
-                            if (lane == 0) wb = atomicAdd(&hdr->cursor, n0 + n1 + n2 + n3);
-                            wb = (u32)__builtin_amdgcn_readfirstlane((int)wb);
-                            const u32 off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+                        for (int h = 0; h < 8; h += 4) {          // two halves of 4 keys: 8 LDS reads in flight per lane
+                            u64 c1[4], c2[4];
+                            u32 l1[4], l2[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const u64 m = hitm[i];
-                                if ((m >> lane) & 1ull) {
-                                    const u64 o = obase + wb + off[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                                    a.out_keys[o] = k[h + i];
-                                    a.out_vals[o] = val[i];
+                                const u32 w = fj_hash_w2(k[h + i]);
+                                l1[i] = w & (S - 1); l2[i] = (w >> 13) & (S - 1);
+                                c1[i] = tkeys[l1[i]];
+                                c2[i] = tkeys[l2[i]];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const u64 key = k[h + i];
+                                const bool h1 = c1[i] == key, h2 = c2[i] == key;
+                                bool hit = h1 | h2;
+                                u32 code = h1 ? l1[i] : l2[i];
+                                if (nstash) {                            // (table before stash: the order step 2 used)
+                                    for (u32 si = 0; si < nstash; ++si) if (!hit && hdr->stash[si] == key) { hit = true; code = S + si; }
                                 }
+                                if (key == FJ_EMPTY_KEY) { hit = he != 0; code = 0xFFFFu; }   // the empty marker is never stored in the table
+                                hit = hit && ((okm >> (h + i)) & 1u);
+                                nw += (u32)__popcll(__ballot(hit));
+                                hb |= (hit ? 1u : 0u) << (h + i);
+                                sc[(h + i) >> 1] |= code << (((h + i) & 1) * 16);
                             }
                         }
-                    }
-                    if constexpr (SINGLE) {
-                        // the round's pairs: wave offsets from the LDS cursor, the round's range from the global cursor
-                        u32 nw = 0, pre[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { pre[i] = nw; nw += (u32)__popcll(hit8[i]); }
                         u32 wb = 0;
-                        if (lane == 0 && nw) wb = atomicAdd(&hdr->cursor, nw);
+                        if (lane == 0 && nw) wb = atomicAdd(&hdr->cur2[par], nw);
                         wb = (u32)__builtin_amdgcn_readfirstlane((int)wb);
-                        __syncthreads();                              // every wave of the round has counted
+                        settle();                                 // the round before: its range must have arrived by now
+                        __syncthreads();                          // every wave has counted this round; the round before has its range
                         if (tid == 0) {
-                            const u32 tot = hdr->cursor;
-                            u64 gb = 0;
-                            if (tot) {
-                                gb = atomicAdd(a.out_cursor, (unsigned long long)tot);
-                                if (gb + tot > a.out_capacity) { atomicOr(a.err, FJ_ERR_OUTCAP); gb = ~0ull; }
-                            }
-                            hdr->gbase = gb; hdr->cursor = 0; hdr->item_cnt += tot;
+                            totp = hdr->cur2[par]; hdr->cur2[par] = 0;      // (next used two rounds on, behind another barrier)
+                            icnt += totp;
+                            gbv = totp ? atomicAdd(a.out_cursor, (unsigned long long)totp) : 0ull;   // not waited for here
                         }
-                        if (r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);          // ~1-2 us of returning-atomic latency to fill
-                        if (!parked) park();
-                        __syncthreads();
-                        const u64 gb = hdr->gbase;
-                        if (nw && gb != ~0ull) {
+                        if (pend) flush();
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const u64 m = hit8[i];
-                                if ((m >> lane) & 1ull) {
-                                    const u64 o = gb + wb + pre[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                                    a.out_keys[o] = k[i];
-                                    a.out_vals[o] = val8[i];
+                        for (int i = 0; i < 8; ++i) kp[i] = k[i];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) scp[i] = sc[i];
+                        hbp = hb; wbp = wb; pend = true; par ^= 1u;
+                        if (!parked) park();                      // after the first round: the entries have long arrived
+                    }
+                }
+            } else {
+                // ---- probe + emit ----
+                for (u32 pb = d.s_lo; pb < d.s_hi; pb += JP_META) {
+                    if (pb != d.s_lo) {
+                        nbatch = (d.s_hi - pb) < JP_META ? (d.s_hi - pb) : JP_META;
+                        __syncthreads();
+                        if (tid < nbatch) pm[tid] = a.probe.list[pb + tid];
+                        __syncthreads();
+                        nrounds = (nbatch + CPR - 1) / CPR;
+                        load_round(pm, 0, nbatch, ka, oka);
+                        if (nrounds > 1) load_round(pm, 1, nbatch, kb, okb);
+                    }
+                    for (u32 r = 0; r < nrounds; ++r) {
+                        u64 k[8];
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) { k[i] = ka[i]; ka[i] = kb[i]; }
+                        const u32 okm = oka;
+                        oka = okb;
+                        if (r + 2 < nrounds) load_round(pm, r + 2, nbatch, kb, okb);
+    #pragma unroll
+                        for (int h = 0; h < 8; h += 4) {              // two halves of 4 keys: 8 LDS reads in flight per lane
+                            u64 c1[4], c2[4];
+                            u32 l1[4], l2[4];
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const u32 w = fj_hash_w2(k[h + i]);
+                                l1[i] = w & (S - 1); l2[i] = (w >> 13) & (S - 1);
+                                c1[i] = tkeys[l1[i]];
+                                c2[i] = tkeys[l2[i]];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            u64 hitm[4];
+                            u64 val[4];
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const u64 key = k[h + i];
+                                const bool h1 = c1[i] == key, h2 = c2[i] == key;
+                                bool hit = h1 | h2;
+                                val[i] = tvals[h1 ? l1[i] : l2[i]];          // (unconditional read: independent of the compare, harmless on a miss)
+                                if (nstash) {                                // (table before stash: the order step 2 used)
+                                    for (u32 si = 0; si < nstash; ++si) if (!hit && hdr->stash[si] == key) { hit = true; val[i] = hdr->stash_val[si]; }
+                                }
+                                const bool ise = key == FJ_EMPTY_KEY;        // the empty marker is never stored in the table
+                                if (ise) { hit = he != 0; val[i] = hdr->empty_val; }
+                                hitm[i] = __ballot(hit && ((okm >> (h + i)) & 1u));
+                            }
+                            // ONE LDS cursor bump per wave for the four key slots; lanes ranked inside the ballots
+                            const u32 n0 = (u32)__popcll(hitm[0]), n1 = (u32)__popcll(hitm[1]), n2 = (u32)__popcll(hitm[2]), n3 = (u32)__popcll(hitm[3]);
+                            if (n0 + n1 + n2 + n3) {
+                                u32 wb = 0;
+                                if (lane == 0) wb = atomicAdd(&hdr->cursor, n0 + n1 + n2 + n3);
+                                wb = (u32)__builtin_amdgcn_readfirstlane((int)wb);
+                                const u32 off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+    #pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const u64 m = hitm[i];
+                                    if ((m >> lane) & 1ull) {
+                                        const u64 o = obase + wb + off[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                                        a.out_keys[o] = k[h + i];
+                                        a.out_vals[o] = val[i];
+                                    }
                                 }
                             }
                         }
+                        if (!parked) park();                      // after the first round: the entries have long arrived
                     }
-                    if (!parked) park();                      // after the first round: the entries have long arrived
                 }
             }
-        }
+            }
         if (!parked) park();                                  // skipped probe loop
         __syncthreads();                                      // every wave is done with the table; the parked entries are visible
-        if (SINGLE && tid == 0 && d.item < nitems && !(lv && full)) a.part_count[d.item] = lv ? hdr->item_cnt : 0u;
+        if (SINGLE && tid == 0 && d.item < nitems && !(lv && full)) a.part_count[d.item] = lv ? icnt : 0u;
         if (lvn) load_build(bmn, 0, nbbn); else bok = 0;      // the next item's build rows fly during the reset
-        if (dn.item >= nitems) break;
-        reset_table();
+        const bool last = dn.item >= nitems;
+        if (!SINGLE && last) break;
+        if (!last) reset_table();
+        if (SINGLE) settle();                                 // the item's last round: its range arrives under the reset
         __syncthreads();
+        if (SINGLE && pend) flush();
+        if (last) break;
         d = dn; buf ^= 1;
     }
 }
