@@ -317,11 +317,14 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
         it.Gmax = std::min(it.Gmax, pass_groups((it.piece_rows + FJ_CHUNK - 1) / FJ_CHUNK, it.piece_rows, it.tile_chunks, it.F));
     const u32 F = it.F, G = it.Gmax, parents = it.parents;
     const u64 nb_out = (u64)parents * F;
-    const u64 cap64 = it.n / FJ_CHUNK + 1 + (2ull * (G + parents) * F + (u64)(G + 1) * fj_slab_for(F)) * it.appends;
+    // chunk ids: the rows' own + per (segment, bucket) one partial chunk and the unused rest of its last run + per workgroup
+    // and launch what is left of its last slab
+    const u64 cap64 = (it.n / FJ_CHUNK + 1 + (((u64)(G + parents) * F << FJ_RUN_LOG) + (u64)(G + 1) * fj_slab_for(F)) * it.appends + 3) & ~3ull;
     if (cap64 >= (1ull << 24) || nb_out >= (1u << 22))
         return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
     FjChunkSet cs{};
     cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0; cs.fan_mask = F - 1; cs.max_segs = (G + parents + 2) * it.appends;
+    cs.run_log = FJ_RUN_LOG;
     const int base = it.side * W_SIDE_STRIDE + (it.slot & 1) * W_KINDS;
     it.cs_base = base;
     void* p;

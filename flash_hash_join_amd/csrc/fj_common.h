@@ -22,9 +22,16 @@ typedef uint16_t u16;
 // chunk-list entry = ((count - 1) << 24) | chunk id   (ids < 2^24), so a consumer needs no directory lookup
 #define FJ_LIST_ID(e) ((e) & 0xFFFFFFu)
 #define FJ_LIST_CNT(e) (((e) >> 24) + 1u)
-#define FJ_SLAB 512u                            // chunks handed to a workgroup per allocator hit (fan-out <= 256)
 #define FJ_MAX_FAN_LOG 9                         // widest pass: 512 buckets
-static inline unsigned fj_slab_for(unsigned fan) { return fan > 256u ? 2u * FJ_SLAB : FJ_SLAB; }   // one tile starts <= (T + 15 fan)/256 + fan chunks
+// A bucket takes its chunk ids in aligned runs of 2^FJ_RUN_LOG consecutive ids (fj_partition_kernel), so that the level
+// bookkeeping places a run's chunk-list entries with one set of gathers (fj_level_lists, FjChunkSet::run_log).
+#ifndef FJ_RUN_LOG
+#define FJ_RUN_LOG 2
+#endif
+// chunk ids a workgroup takes from the pool's allocator at a time (it takes several slabs in one piece when a tile opens more
+// chunks than that: the first tile of a segment opens a run per bucket); what is left of a workgroup's last slab stays unused
+#define FJ_SLAB 256u
+static inline unsigned fj_slab_for(unsigned fan) { (void)fan; return FJ_SLAB; }
 #define FJ_MAX_FANOUT 256u                      // buckets per partition pass (8 bits, as RADIX_BITS)
 
 // LDS-resident join table (per final partition): 8192 slots, 8-B keys (+ 8-B values when

@@ -68,6 +68,8 @@ struct FjChunkSet {
     u32* bchunks;            // [nb]   chunks per bucket
     u32* boff;               // [nb+1] chunk-list offsets; boff[nb] = list length
     u32* list;               // [cap]  chunk ids grouped by bucket
+    u32 run_log;             // chunk ids were handed out in aligned runs of 2^run_log ids per (segment, bucket), used in order, the unused rest
+                             // marked FJ_DIR_INVALID (the partition pass: FJ_RUN_LOG); 0: every id stands alone (bloom stage, owner shuffle)
 };
 
 u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log);

@@ -51,7 +51,7 @@ __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool 
     return L;
 }
 
-enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG };
+enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG, M_NEW_UNITS };
 
 // The kernel is instruction-issue bound (not HBM bound) on gfx950, so the inner phases are written
 // to minimise issued instructions per key: 32-bit-multiply hash, invalid lanes routed to a dummy
@@ -66,6 +66,11 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
     static_assert(!OWN || FLAT, "the owner-grouped form reads a flat relation");
+    // RUNS: a bucket takes its chunk ids in aligned runs of RU consecutive ids (used in order; what a segment leaves unused of
+    // its last run is marked FJ_DIR_INVALID), so that fj_level_lists places RU list entries per step (FjChunkSet::run_log).
+    // The allocator then counts in units of one run.  The owner-grouped form keeps single ids (its regions are sized tightly).
+    constexpr bool RUNS = !OWN;
+    constexpr u32 RL = RUNS ? FJ_RUN_LOG : 0u, RU = 1u << RL;
     const u32 F = 1u << a.fan_log, FM = F - 1;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         }
     };
 
-    if (tid == 0) { misc[M_SLAB_CUR] = 0; misc[M_SLAB_REM] = 0; misc[M_NEW_BASE] = 0; misc[M_SEG] = 0; }
+    if (tid == 0) { misc[M_SLAB_CUR] = 0; misc[M_SLAB_REM] = 0; misc[M_NEW_BASE] = 0; misc[M_SEG] = 0; misc[M_NEW_UNITS] = 0; }
     if (OWN && tid < OWN_MAX) { own_cur[tid] = 0; own_rem[tid] = 0; own_new[tid] = 0; own_fl[tid] = 0; own_kb0[tid] = 0; if (tid == 0) own_kb0[OWN_MAX] = 0; }
     // per-bucket state lives in the registers of thread b (b < F)
     u32 st_left = 0, st_fill = FJ_CHUNK, st_cur = FJ_DIR_INVALID, st_nch = 0;
@@ -188,8 +193,37 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u32 o = owner_of(b), jr = j - own_kb0[o], rem = own_rem[o];
             return jr < rem ? own_cur[o] + jr : own_new[o] + (jr - rem);
         }
+        const u32 rem = misc[M_SLAB_REM];                   // (in allocation units: runs)
+        return j < rem ? misc[M_SLAB_CUR] + (j << RL) : misc[M_NEW_BASE] + ((j - rem) << RL);
+    };
+    // A bucket uses the ids of a run in ROTATED order, starting at rot(b): all workgroups start together and fill their chunks
+    // at the same rate, so with every bucket on its run's first id at the same time the lines in flight would sit in one
+    // quarter of every 8-KiB stretch of the pool (measured: the c3 passes 4-10 % slower).
+    auto rot = [&](u32 b) -> u32 { return ((b * 2654435761u + blockIdx.x * 40503u) >> 13) & (RU - 1u); };   // (not a function of b's low bits alone: those also place the run)
+    // ids left in the run that chunk c0 (bucket b's open chunk) belongs to
+    auto run_left = [&](u32 c0, u32 b) -> u32 { return (RUNS && c0 != FJ_DIR_INVALID) ? (RU - 1u) - ((c0 - rot(b)) & (RU - 1u)) : 0u; };
+    auto run_step = [&](u32 c0, u32 k) -> u32 { return (c0 & ~(RU - 1u)) | ((c0 + k) & (RU - 1u)); };    // k ids further in c0's run
+    // id of the kk-th (1-based) chunk a bucket opens in the current tile: first the rest of its run, then the runs it was
+    // given (ukb = the bucket's prefix over the tile's new allocation units)
+    auto chunk_id = [&](u32 kk, u32 c0, u32 ukb, u32 b) -> u32 {
+        if constexpr (!RUNS) return alloc_id(ukb + kk - 1, b);
+        const u32 rl = run_left(c0, b);
+        if (kk <= rl) return run_step(c0, kk);
+        const u32 q = kk - rl - 1u;
+        return alloc_id(ukb + (q >> RL), b) + ((q + rot(b)) & (RU - 1u));
+    };
+    // (not OWN; one thread) the open slab cannot cover `need` allocation units: take as many fresh slabs as the rest needs, in
+    // one piece - alloc_id() hands out the open slab's remainder first, so nothing is abandoned
+    auto take_slabs = [&](u32 need) {
+        const u32 su = a.slab >> RL, k = (need - misc[M_SLAB_REM] + su - 1) / su;
+        const u32 nb = atomicAdd(a.alloc, k * a.slab);
+        if (nb + k * a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
+        misc[M_NEW_BASE] = nb; misc[M_NEW_UNITS] = k * su;
+    };
+    auto commit_units = [&](u32 need) {                       // (one thread, after the ids were used)
         const u32 rem = misc[M_SLAB_REM];
-        return j < rem ? misc[M_SLAB_CUR] + j : misc[M_NEW_BASE] + (j - rem);
+        if (need <= rem) { misc[M_SLAB_CUR] += need << RL; misc[M_SLAB_REM] = rem - need; }
+        else { const u32 used = need - rem; misc[M_SLAB_CUR] = misc[M_NEW_BASE] + (used << RL); misc[M_SLAB_REM] = misc[M_NEW_UNITS] - used; }
     };
     // OWN: a fresh slab out of owner o's region (thread o)
     auto own_take_slab = [&](u32 o) -> u32 {
@@ -213,19 +247,14 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 own_fl[tid] = 0;
             }
         } else {
-            {   // a slab remainder too small for the flush is abandoned below: its ids stay unlisted (the directory has no memset)
-                const u32 rem0 = misc[M_SLAB_REM], cur0 = misc[M_SLAB_CUR];
-                if (rem0 < F && tid < rem0 && cur0 + tid < cap) a.out_dir[cur0 + tid] = FJ_DIR_INVALID;
-                __syncthreads();
-            }
-            if (tid == 0) {
-                if (misc[M_SLAB_REM] < F) {
-                    const u32 nb = atomicAdd(a.alloc, a.slab);
-                    if (nb + a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
-                    misc[M_SLAB_CUR] = nb; misc[M_SLAB_REM] = a.slab;
-                }
-                misc[M_FLUSH] = 0;
-            }
+            if (tid == 0) misc[M_FLUSH] = 0;
+        }
+        __syncthreads();
+        u32 fresh = 0xFFFFFFFFu;                              // not OWN: index of the fresh allocation unit this bucket's remainder needs
+        if constexpr (!OWN) {
+            if (tid < F && st_left > 0 && st_fill == FJ_CHUNK && !run_left(st_cur, tid)) fresh = atomicAdd(&misc[M_FLUSH], 1u);
+            __syncthreads();
+            if (tid == 0 && misc[M_FLUSH] > misc[M_SLAB_REM]) take_slabs(misc[M_FLUSH]);
         }
         __syncthreads();
         if (tid < F) {
@@ -234,7 +263,8 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u32 outb = parent * F + b;
             if (l > 0 && f0 == FJ_CHUNK) {
                 if constexpr (OWN) { const u32 o = owner_of(b); c = own_cur[o] + atomicAdd(&own_fl[o], 1u); }
-                else c = misc[M_SLAB_CUR] + atomicAdd(&misc[M_FLUSH], 1u);
+                else if (fresh == 0xFFFFFFFFu) c = run_step(c, 1);
+                else c = alloc_id(fresh, b) + rot(b);
                 f0 = 0;
                 if (c < cap) a.out_rel[c] = ((u64)seg << 32) | n;
                 ++n;
@@ -246,6 +276,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                     if (HAS_VALS) a.out_vals[base + j] = lo_v[b * LINE + j];
                 }
                 a.out_dir[c] = (outb << FJ_DIR_CNT_BITS) | (f0 + l);
+                if constexpr (RUNS) { for (u32 k = 1; k <= run_left(c, b); ++k) { const u32 id = run_step(c, k); if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; } }   // rest of the run
             }
             if (n > 0) {
                 const u32 off = atomicAdd(&a.bchunks[outb], n);
@@ -255,7 +286,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         }
         __syncthreads();
         if constexpr (OWN) { if (tid < NR) { const u32 n = own_fl[tid]; own_cur[tid] += n; own_rem[tid] -= n; } }
-        else if (tid == 0) { const u32 n = misc[M_FLUSH]; misc[M_SLAB_CUR] += n; misc[M_SLAB_REM] -= n; }
+        else if (tid == 0) commit_units(misc[M_FLUSH]);
         __syncthreads();
     };
 
@@ -356,7 +387,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         // ---- packed exclusive scan over the buckets (only the waves that own buckets) -----------
         //      fields: tile offset | line offset | new chunks.   A bucket's *virtual run* is its
         //      carried remainder (lo_*, st_left keys) followed by its new keys (tile region).
-        u32 cnt = 0, tot = 0, nf = 0, km = 0, kb = 0, l0 = 0;
+        u32 cnt = 0, tot = 0, nf = 0, km = 0, kr = 0, kb = 0, l0 = 0;       // km new chunks, kr new allocation units, kb = prefix of kr
         if (wave * 64 < F) {
             u64 x = 0;
             if (tid < F) {
@@ -364,7 +395,9 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 tot = st_left + cnt;
                 nf = tot & ~(LINE - 1);
                 km = nf ? ((st_fill + nf - 1) >> FJ_CHUNK_LOG) : 0;
-                x = (u64)cnt | ((u64)(nf >> LINE_LOG) << 20) | ((u64)km << 40);
+                const u32 rl = run_left(st_cur, tid);
+                kr = RUNS ? (km > rl ? (km - rl + RU - 1u) >> RL : 0u) : km;
+                x = (u64)cnt | ((u64)(nf >> LINE_LOG) << 20) | ((u64)kr << 40);
             }
             u64 inc = x;
 #pragma unroll
@@ -388,18 +421,14 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 if constexpr (OWN) {                       // the tile's chunk prefix at each owner's first bucket
                     const u32 o = owner_of(tid);
                     if (tid == 0 || owner_of(tid - 1) != o) own_kb0[o] = kb;
-                    if (tid == F - 1) own_kb0[NR] = kb + km;
+                    if (tid == F - 1) own_kb0[NR] = kb + kr;
                 }
                 if (tid == F - 1) {
                     toff[F] = to + cnt;                    // dummy bucket goes behind everything
-                    const u32 need = kb + km;
+                    const u32 need = kb + kr;
                     misc[M_NLINES] = l0 + (nf >> LINE_LOG);
                     misc[M_NEED] = need;
-                    if (!OWN && need > misc[M_SLAB_REM]) {
-                        const u32 nb = atomicAdd(a.alloc, a.slab);
-                        if (nb + a.slab > cap) atomicOr(a.err, FJ_ERR_POOL);
-                        misc[M_NEW_BASE] = nb;
-                    }
+                    if (!OWN && need > misc[M_SLAB_REM]) take_slabs(need);
                 }
             }
         }
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u32 nl = own ? (nf >> LINE_LOG) : 0u;
             auto put = [&](u32 pb, u32 pf0, u32 pc0, u32 pkb, u32 ptb, u32 pleft, u32 pl0, u32 j) {
                 const u32 q = j << LINE_LOG, pq = pf0 + q, kk = pq >> FJ_CHUNK_LOG, off = pq & (FJ_CHUNK - 1);
-                const u32 id = kk == 0 ? pc0 : alloc_id(pkb + kk - 1, pb);
+                const u32 id = kk == 0 ? pc0 : chunk_id(kk, pc0, pkb, pb);
                 const u32 dst = id < cap ? id * FJ_CHUNK + off : FJ_DIR_INVALID;
                 const u32 lc = j == 0 ? pleft : 0u;
                 const u32 sidx = ptb + q + 32u - pleft;             // tile index of virtual key q (may precede the run for line 0)
@@ -451,12 +480,12 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u32 outb = (parent * F + b) << FJ_DIR_CNT_BITS;
             const u64 segw = (u64)misc[M_SEG] << 32;
             for (u32 kk = 1; kk <= km; ++kk) {
-                const u32 id = alloc_id(kb + kk - 1, b);
+                const u32 id = chunk_id(kk, c0, kb, b);
                 if (id < cap) { a.out_dir[id] = outb | FJ_CHUNK; a.out_rel[id] = segw | (n0 + kk - 1); }
             }
             // remember what the carry step needs (it runs at the top of the next iteration)
             pend_cnt = cnt; pend_nf = nf; pend_tb = tb;
-            st_cur = km ? alloc_id(kb + km - 1, b) : c0;
+            st_cur = km ? chunk_id(km, c0, kb, b) : c0;
             st_fill = f0 + nf - (km << FJ_CHUNK_LOG);
             st_nch = n0 + km;
         }
@@ -497,9 +526,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 else { const u32 used = need - rem; own_cur[tid] = own_new[tid] + used; own_rem[tid] = a.slab - used; }
             }
         } else if (tid == 0) {
-            const u32 need = misc[M_NEED], rem = misc[M_SLAB_REM];
-            if (need <= rem) { misc[M_SLAB_CUR] += need; misc[M_SLAB_REM] = rem - need; }
-            else { const u32 used = need - rem; misc[M_SLAB_CUR] = misc[M_NEW_BASE] + used; misc[M_SLAB_REM] = a.slab - used; }
+            commit_units(misc[M_NEED]);
         }
         __syncthreads();
     }
@@ -511,7 +538,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         for (u32 o = 0; o < NR; ++o)
             for (u32 j = tid; j < own_rem[o]; j += NT) { const u32 id = own_cur[o] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
     } else {
-        for (u32 j = tid; j < misc[M_SLAB_REM]; j += NT) { const u32 id = misc[M_SLAB_CUR] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
+        for (u32 j = tid; j < (misc[M_SLAB_REM] << RL); j += NT) { const u32 id = misc[M_SLAB_CUR] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
     }
 }
 
@@ -640,13 +667,16 @@ __global__ __launch_bounds__(1024) void fj_scan_u32_to_u64(const u32* __restrict
 // chunk lists without atomics: list[boff[bucket] + span offset of the producing segment + rank] = chunk.  The same launch
 // expands the consumer's tile table (independent work on the scan's outputs) and clears the tail of an optional per-tile
 // array (the join's per-item counts: entries past the device-side item count must read 0).
+template <u32 RL>
 __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
                                u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
                                u32 max_segs, u32* __restrict__ list,
                                u32 nb, u32 tc, const u32* __restrict__ toff, uint4* __restrict__ tiles, u32 max_tiles,
                                u32* __restrict__ zero_tail) {
-    // a chain of dependent loads per chunk (dir/rel -> boff/seg_off -> store): four chunks per thread and step keep
-    // four chains in flight (the kernel is latency-bound: ~4M chunks at c3), and the grid fills the chip's thread slots
+    // a chain of dependent loads per chunk (dir/rel -> boff/seg_off -> store): four chains per thread and step are kept in
+    // flight (the kernel is latency-bound: ~4M chunks at c3), and the grid fills the chip's thread slots.
+    // RL > 0: the ids came in aligned runs of 2^RL per (segment, bucket), used in order with consecutive ranks - one chain
+    // places a whole run (a 16-B directory load, one rel word, one pair of gathers, neighbouring list entries).
     u32 n = *nalloc; if (n > cap) n = cap;
     const u32 stride = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tc) {
@@ -657,24 +687,71 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
             else if (zero_tail) zero_tail[t] = 0;
         }
     }
-    for (u32 i0 = gtid; i0 < n; i0 += 4 * stride) {
-        u32 e[4]; u64 r[4];
+    if constexpr (RL > 0) {
+        constexpr u32 R = 1u << RL;
+        const u32 nr = n >> RL;                               // (the allocator moves in whole slabs: n % R == 0)
+        for (u32 i0 = gtid; i0 < nr; i0 += 2 * stride) {
+            u32 ev[2][R]; u64 r[2][R];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const u32 i = i0 + u * stride;
-            e[u] = i < n ? dir[i] : FJ_DIR_INVALID;
-            r[u] = i < n ? rel[i] : 0;
+            for (int u = 0; u < 2; ++u) {
+                const u32 i = i0 + u * stride;
+#pragma unroll
+                for (u32 j = 0; j < R; ++j) { ev[u][j] = FJ_DIR_INVALID; r[u][j] = 0; }
+                if (i < nr) {
+                    if constexpr (RL == 2) {
+                        const uint4 e = reinterpret_cast<const uint4*>(dir)[i];
+                        ev[u][0] = e.x; ev[u][1] = e.y; ev[u][2] = e.z; ev[u][3] = e.w;
+                    } else {
+                        const uint2 e = reinterpret_cast<const uint2*>(dir)[i];
+                        ev[u][0] = e.x; ev[u][1] = e.y;
+                    }
+#pragma unroll
+                    for (u32 j = 0; j < R; j += 2) {
+                        const ulonglong2 q = reinterpret_cast<const ulonglong2*>(rel)[((u64)i * R + j) >> 1];
+                        r[u][j] = q.x; r[u][j + 1] = q.y;
+                    }
+                }
+            }
+            u32 base[2]; bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // the (bucket, segment) of the run from any used id (the ids of a run are used in a rotated order)
+                u32 e0 = FJ_DIR_INVALID; u64 r0 = 0;
+#pragma unroll
+                for (int j = (int)R - 1; j >= 0; --j) if (ev[u][j] != FJ_DIR_INVALID) { e0 = ev[u][j]; r0 = r[u][j]; }
+                const u32 b = e0 >> FJ_DIR_CNT_BITS, seg = (u32)(r0 >> 32);
+                ok[u] = e0 != FJ_DIR_INVALID && seg < max_segs;
+                base[u] = ok[u] ? boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!ok[u]) continue;
+                const u32 id = R * (i0 + u * stride);
+#pragma unroll
+                for (u32 j = 0; j < R; ++j)
+                    if (ev[u][j] != FJ_DIR_INVALID) list[base[u] + (u32)r[u][j]] = (((ev[u][j] & FJ_DIR_CNT_MASK) - 1u) << 24) | (id + j);
+            }
         }
-        u32 pos[4]; bool ok[4];
+    } else {
+        for (u32 i0 = gtid; i0 < n; i0 += 4 * stride) {
+            u32 e[4]; u64 r[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const u32 b = e[u] >> FJ_DIR_CNT_BITS, seg = (u32)(r[u] >> 32);
-            ok[u] = e[u] != FJ_DIR_INVALID && seg < max_segs;
-            pos[u] = ok[u] ? boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r[u] : 0;
+            for (int u = 0; u < 4; ++u) {
+                const u32 i = i0 + u * stride;
+                e[u] = i < n ? dir[i] : FJ_DIR_INVALID;
+                r[u] = i < n ? rel[i] : 0;
+            }
+            u32 pos[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u32 b = e[u] >> FJ_DIR_CNT_BITS, seg = (u32)(r[u] >> 32);
+                ok[u] = e[u] != FJ_DIR_INVALID && seg < max_segs;
+                pos[u] = ok[u] ? boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r[u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) list[pos[u]] = (((e[u] & FJ_DIR_CNT_MASK) - 1u) << 24) | (i0 + u * stride);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (ok[u]) list[pos[u]] = (((e[u] & FJ_DIR_CNT_MASK) - 1u) << 24) | (i0 + u * stride);
     }
 }
 
@@ -787,7 +864,7 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
         if (line_log != 4) return hipErrorInvalidValue;
         return a.side == 0 ? launch_part1<1024, 8, 4, false, true, false, true>(a, g, s) : launch_part1<1024, 8, 4, false, true, true, true>(a, g, s);
     }
-    if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < 48 + (1u << a.fan_log)) return hipErrorInvalidValue;
+    if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < (1u << FJ_RUN_LOG) || (a.slab & ((1u << FJ_RUN_LOG) - 1u))) return hipErrorInvalidValue;
     if (a.fan_log == 9) {
         // 512 buckets: one bucket per thread needs >= 512 threads and the open lines take 64 KiB (keys) -- one
         // 1024-thread workgroup per CU; with values the lines shrink to 64 B so that both payloads still fit
@@ -809,7 +886,10 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
 hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s) {
     if (cs.nb & 3u) return hipErrorInvalidValue;           // fj_level_scan works in 16-B pieces
     hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
-    hipLaunchKernelGGL(fj_level_lists, dim3(2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
+    static_assert(FJ_RUN_LOG == 1 || FJ_RUN_LOG == 2, "fj_level_lists reads a run's directory words with one 8-B or 16-B load");
+    if (cs.run_log != 0 && cs.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
+    auto kern = cs.run_log ? fj_level_lists<FJ_RUN_LOG> : fj_level_lists<0>;
+    hipLaunchKernelGGL(kern, dim3(cs.run_log ? 1024 : 2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
                        cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
     return hipGetLastError();
 }
