@@ -319,7 +319,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     const u64 nb_out = (u64)parents * F;
     // chunk ids: the rows' own + per (segment, bucket) one partial chunk and the unused rest of its last run + per workgroup
     // and launch what is left of its last slab
-    const u64 cap64 = (it.n / FJ_CHUNK + 1 + (((u64)(G + parents) * F << FJ_RUN_LOG) + (u64)(G + 1) * fj_slab_for(F)) * it.appends + 3) & ~3ull;
+    const u64 cap64 = (it.n / FJ_CHUNK + 1 + (((u64)(G + parents) * F << FJ_RUN_LOG) + (u64)(G + 1) * fj_slab_for(it.appends)) * it.appends + 3) & ~3ull;
     if (cap64 >= (1ull << 24) || nb_out >= (1u << 22))
         return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
     FjChunkSet cs{};
@@ -362,7 +362,7 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     a.bchunks = cs.bchunks; a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + it.i];
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
     a.err = &c->d_sc->err;
-    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.F); a.side = (u32)it.side;
+    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.appends); a.side = (u32)it.side;
     // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter); only a 512-bucket pass that
     // also carries values has to fall back to them (LDS)
     const int line_log = (it.has_vals && it.F > 256) ? 3 : 4;

@@ -46,6 +46,13 @@ constexpr u32 BF_NW = BF_NT / 64;
 constexpr u32 BF_KPT = 8;                   // probe keys per thread and tile
 constexpr u32 BF_T = BF_NT * BF_KPT;        // 8192 keys = 32 chunks per tile
 constexpr u32 BF_STG = 128;                 // staging row of a wave: keys
+#ifndef FJ_BLOOM_SNAP16
+#define FJ_BLOOM_SNAP16 3
+#endif
+// a workgroup boundary this close to a bucket boundary (in 16ths of the bucket's tiles) moves onto it: one filter build less on
+// each side (a build costs what ~5-10 % of a bucket's probe tiles cost); with equal buckets the tile-balanced boundaries drift
+// from the bucket boundaries like a random walk (c4: up to ~9 % of a bucket in the middle of the range)
+constexpr u32 BF_SNAP16 = FJ_BLOOM_SNAP16;
 // output chunks a wave takes per allocator hit.  The hit is a returning global atomic: its wait drains the wave's whole load
 // pipeline, so it must be rare - 128 chunks = 32768 survivors cover a wave's share of a 1B-row probe side at 13 % survivors
 constexpr u32 BF_SLAB = 128;
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(BF_NT, 1) void fj_bloom_filter_kernel(FjBloomArgs a
             if (gg == 0 || gg >= G || ntiles == 0) return gg >= G ? ntiles : t;
             u32 lo = 0, hi = nb;                                 // last bucket p with toff[p] <= t
             while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
-            const u32 b0 = toff[lo], b1 = toff[lo + 1], slack = (b1 - b0) >> 4;
+            const u32 b0 = toff[lo], b1 = toff[lo + 1], slack = ((b1 - b0) * BF_SNAP16) >> 4;
             if (t - b0 <= slack) t = b0; else if (b1 - t <= slack) t = b1;
             return t;
         };

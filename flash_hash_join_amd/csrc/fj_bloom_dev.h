@@ -82,26 +82,38 @@ __device__ __forceinline__ void bf_build_filter(unsigned char* filt, const u64* 
             e[i] = blist[b0 + (j < nbc ? j : (nbc ? nbc - 1 : 0u))];
         }
     };
+    // software pipeline: the keys of step s+1 and the entries of step s+2 are requested before the keys of step s are inserted
+    // (a filter of ~195K keys is 24 steps: with the key loads issued only after the previous step's inserts every step paid
+    // a full memory latency while the CU's only workgroup did nothing else)
     u32 be[4];
-    if (nbc) bentries(0, be);
-    for (u32 c0 = 0; c0 < nbc; c0 += 32) {
-        u64x2 q[4]; u32 cn[4];
+    u64x2 q[4]; u32 cn[4];
+    auto bkeys_of = [&](u32 c0, const u32 (&e)[4], u64x2 (&qq)[4], u32 (&cc)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const u32 eu = bf_uni(be[i]);
-            cn[i] = (c0 + (u32)i * 8u + jb) < nbc ? FJ_LIST_CNT(eu) : 0u;
+            const u32 eu = bf_uni(e[i]);
+            cc[i] = (c0 + (u32)i * 8u + jb) < nbc ? FJ_LIST_CNT(eu) : 0u;
             const unsigned char* base = reinterpret_cast<const unsigned char*>(bkeys + (u64)FJ_LIST_ID(eu) * FJ_CHUNK);
-            q[i] = *reinterpret_cast<const u64x2*>(base + off16);
+            qq[i] = *reinterpret_cast<const u64x2*>(base + off16);
         }
+    };
+    if (nbc) {
+        bentries(0, be);
+        bkeys_of(0, be, q, cn);
+        bentries(32 < nbc ? 32 : 0, be);
+    }
+    for (u32 c0 = 0; c0 < nbc; c0 += 32) {
+        u64x2 qn[4]; u32 cnn[4] = {0u, 0u, 0u, 0u};
+        const bool more = c0 + 32 < nbc;
+        if (more) bkeys_of(c0 + 32, be, qn, cnn);
         u32 bn[4];
-        bentries(c0 + 32 < nbc ? c0 + 32 : c0, bn);
+        bentries(c0 + 64 < nbc ? c0 + 64 : c0, bn);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (off < cn[i]) bf_insert<VAR>(filt, q[i].x);
             if (off + 1 < cn[i]) bf_insert<VAR>(filt, q[i].y);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) be[i] = bn[i];
+        for (int i = 0; i < 4; ++i) { be[i] = bn[i]; cn[i] = cnn[i]; if (more) q[i] = qn[i]; }
     }
     __syncthreads();
 }

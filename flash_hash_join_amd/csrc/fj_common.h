@@ -29,9 +29,10 @@ typedef uint16_t u16;
 #define FJ_RUN_LOG 2
 #endif
 // chunk ids a workgroup takes from the pool's allocator at a time (it takes several slabs in one piece when a tile opens more
-// chunks than that: the first tile of a segment opens a run per bucket); what is left of a workgroup's last slab stays unused
-#define FJ_SLAB 256u
-static inline unsigned fj_slab_for(unsigned fan) { (void)fan; return FJ_SLAB; }
+// chunks than that: the first tile of a segment opens a run per bucket); what is left of a workgroup's last slab stays unused,
+// so a level that is appended to by many launches (streamed pieces) takes small slabs.  1024 against 256 at c3: the passes
+// ~0.5 % faster (longer contiguous stretches per producer), 64: the chunk-list pass 2 % slower.
+static inline unsigned fj_slab_for(unsigned appends) { return appends > 1u ? 256u : 1024u; }
 #define FJ_MAX_FANOUT 256u                      // buckets per partition pass (8 bits, as RADIX_BITS)
 
 // LDS-resident join table (per final partition): 8192 slots, 8-B keys (+ 8-B values when

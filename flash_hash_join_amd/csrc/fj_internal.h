@@ -42,7 +42,7 @@ struct FjPartArgs {
     u32 shift;
     u32 fan_log;
     u32 side;                // 0 = build relation, 1 = probe relation (selects the kernel's name only)
-    u32 slab;                // chunks a workgroup takes per allocator hit: >= tile chunks + fan-out (fj_slab_for)
+    u32 slab;                // chunk ids a workgroup takes per allocator hit (fj_slab_for; a multiple of the run length)
     // owner-grouped form (multi-GPU sender, flat input only): bucket b belongs to owner GPU (b * own_nranks) >> fan_log, and
     // the chunks of owner r's buckets are allocated from region r of the output pool, ids [r * own_region, (r + 1) * own_region),
     // through own_alloc[r] - so that what goes to one peer is ONE contiguous piece of the pool (the first radix
