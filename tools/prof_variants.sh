@@ -17,7 +17,7 @@ for r in csv.DictReader(open(f)):
 print("==", sys.argv[1])
 for (n, g), v in acc.items():
     if len(v) >= 10: v = sorted(v)[1:-1]
-    if sum(v) / len(v) > 30: print("  %-60s grid %-8s n=%-4d mean %9.1f us" % (n, g, len(v), sum(v) / len(v)))
+    if sum(v) / len(v) > 15: print("  %-60s grid %-8s n=%-4d mean %9.1f us" % (n, g, len(v), sum(v) / len(v)))
 PY
 done; done
 cp /tmp/cur.so flash_hash_join_amd/lib/libflashjoin_hip.so
