@@ -324,7 +324,10 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
         return set_err("relation of %zu rows is too large for one GPU's chunk directory", it.n);
     FjChunkSet cs{};
     cs.cap = (u32)cap64; cs.nb = (u32)nb_out; cs.n_flat = 0; cs.fan_mask = F - 1; cs.max_segs = (G + parents + 2) * it.appends;
-    cs.run_log = FJ_RUN_LOG;
+    // Chunk ids in runs of 4 make the level's bookkeeping cheaper (fj_level_lists: 70 -> 40 us per 1B-row level), but a flat
+    // pass of <= 256 buckets writes ~2 % slower with them than with ids handed out densely in the order its tiles open chunks
+    // (3.13 -> 3.21 ms per 1B rows; chunk-list passes and the 512-bucket flat pass do not care or gain: EXPERIMENTS.md)
+    cs.run_log = (!it.have_prev && it.i == 0 && F <= 256) ? 0u : (u32)FJ_RUN_LOG;      // (i > 0 without a previous level yet: a shuffled stream, whose pieces arrive as chunk lists)
     const int base = it.side * W_SIDE_STRIDE + (it.slot & 1) * W_KINDS;
     it.cs_base = base;
     void* p;
@@ -362,7 +365,7 @@ int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_
     a.bchunks = cs.bchunks; a.alloc = cs.alloc; a.seg_counter = &c->d_sc->seg_counter[it.side * 4 + it.i];
     a.cap_chunks = cs.cap; a.max_segs = cs.max_segs;
     a.err = &c->d_sc->err;
-    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.appends); a.side = (u32)it.side;
+    a.shift = (u32)it.used; a.fan_log = (u32)it.plan.fan_log[it.i]; a.slab = fj_slab_for(it.appends); a.run_log = cs.run_log; a.side = (u32)it.side;
     // 128-B lines: 64-B pieces cost ~27 % of scatter bandwidth (tools/ubench_scatter); only a 512-bucket pass that
     // also carries values has to fall back to them (LDS)
     const int line_log = (it.has_vals && it.F > 256) ? 3 : 4;

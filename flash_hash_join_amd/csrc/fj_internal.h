@@ -43,6 +43,7 @@ struct FjPartArgs {
     u32 fan_log;
     u32 side;                // 0 = build relation, 1 = probe relation (selects the kernel's name only)
     u32 slab;                // chunk ids a workgroup takes per allocator hit (fj_slab_for; a multiple of the run length)
+    u32 run_log;             // chunk ids per (segment, bucket) in aligned runs of 2^run_log (0 or FJ_RUN_LOG; FjChunkSet::run_log of the output)
     // owner-grouped form (multi-GPU sender, flat input only): bucket b belongs to owner GPU (b * own_nranks) >> fan_log, and
     // the chunks of owner r's buckets are allocated from region r of the output pool, ids [r * own_region, (r + 1) * own_region),
     // through own_alloc[r] - so that what goes to one peer is ONE contiguous piece of the pool (the first radix

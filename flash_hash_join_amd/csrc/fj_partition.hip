@@ -61,16 +61,19 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG,
 // relations, and per-kernel profiler statistics should not average 100M-row and 1B-row launches together.
 // OWN: the owner-grouped form (see FjPartArgs): every workgroup keeps one open slab PER OWNER GPU, taken from that owner's
 // region of the output pool; everything else is the same pass.
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false>
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG>
 __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
     static_assert(!OWN || FLAT, "the owner-grouped form reads a flat relation");
-    // RUNS: a bucket takes its chunk ids in aligned runs of RU consecutive ids (used in order; what a segment leaves unused of
-    // its last run is marked FJ_DIR_INVALID), so that fj_level_lists places RU list entries per step (FjChunkSet::run_log).
-    // The allocator then counts in units of one run.  The owner-grouped form keeps single ids (its regions are sized tightly).
-    constexpr bool RUNS = !OWN;
-    constexpr u32 RL = RUNS ? FJ_RUN_LOG : 0u, RU = 1u << RL;
+    // RUNS (RLOG > 0): a bucket takes its chunk ids in aligned runs of RU = 2^RLOG ids (used in a rotated order; what a segment
+    // leaves unused of its last run is marked FJ_DIR_INVALID), so that fj_level_lists places RU list entries per step
+    // (FjChunkSet::run_log).  The allocator then counts in units of one run.  RLOG == 0: ids one by one in the order the tiles
+    // open chunks (the owner-grouped form, whose regions are sized tightly; flat passes of <= 256 buckets, see fj_api.hip).
+    // (A compile-time choice: with the run length as a kernel argument every pass ran 6 % slower.)
+    static_assert(!OWN || RLOG == 0, "the owner-grouped form hands out single ids");
+    constexpr bool RUNS = RLOG > 0;
+    constexpr u32 RL = (u32)RLOG, RU = 1u << RL;
     const u32 F = 1u << a.fan_log, FM = F - 1;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only
@@ -789,15 +792,26 @@ __global__ __launch_bounds__(1024) void fj_dir_rank_kernel(u32* __restrict__ dir
     if (blockIdx.x == 0 && tid == 0) *nalloc = n;
 }
 
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false>
-hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG>
+hipError_t launch_part0(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
     const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64, OWN);
-    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, OWN>;
+    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, OWN, OWN ? 0 : RLOG>;
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, s, a);
     return hipGetLastError();
+}
+
+// run length of the output's chunk ids (a.run_log): single ids exist for flat inputs only
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false>
+hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
+    if constexpr (OWN) return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, true, 0>(a, grid, s);
+    else {
+        if constexpr (FLAT) { if (a.run_log == 0) return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, false, 0>(a, grid, s); }
+        if (a.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
+        return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, false, FJ_RUN_LOG>(a, grid, s);
+    }
 }
 
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
