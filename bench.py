@@ -185,8 +185,8 @@ def host_entry(device) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c3 (BASELINE configs[2]) at --gpus 1, c5 (configs[4], 125M x 1.25B rows per GPU) at --gpus > 1")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (debugging)")
