@@ -37,22 +37,21 @@ __global__ __launch_bounds__(NT) void packed_scatter(const u64x2* __restrict__ i
     if (tid < F) { fill[tid] = 0; chunk[tid] = tid; }
     if (tid == 0) next_chunk = F;
     __syncthreads();
-    u64x2 k[4], kn[4];
+    // two key buffers that rotate by NAME (the loop body is written twice): a register copy of a buffer whose load is still in
+    // flight would make the wave wait for it, i.e. no prefetch at all
+    u64x2 ka[4], kb[4];
     auto load = [&](u64 t, u64x2 (&kk)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) kk[i] = in[t * (T / 2) + (u64)i * NT + tid];
     };
-    if (t0 < t1) load(t0, kn);
     u32 rng = blockIdx.x * 2654435761u + 12345u;
-    for (u64 t = t0; t < t1; ++t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) k[i] = kn[i];
+    auto tile = [&](u64 t, const u64x2 (&k)[4], u64x2 (&kn)[4]) {
         if (t + 1 < t1) load(t + 1, kn);
         // line l of the tile -> bucket (uniform pseudo-random, the same sequence for every variant) -> destination
         if (tid < LINES) {
             const u32 h = (rng + tid * 0x9E3779B1u) * 0x85EBCA77u;
             const u32 b = (h >> 7) & (F - 1);
-            const u32 f = atomicAdd(&fill[b], 1u);                    // (slots 16.. belong to the bucket's next chunk)
+            const u32 f = atomicAdd(&fill[b], 1u);                    // (slots LPC.. belong to the bucket's next chunk)
             line_dst[tid] = b | (f << 16);
         }
         __syncthreads();
@@ -80,6 +79,11 @@ __global__ __launch_bounds__(NT) void packed_scatter(const u64x2* __restrict__ i
         }
         rng = rng * 1664525u + 1013904223u;
         __syncthreads();
+    };
+    if (t0 < t1) load(t0, ka);
+    for (u64 t = t0; t < t1; t += 2) {
+        tile(t, ka, kb);
+        if (t + 1 < t1) tile(t + 1, kb, ka);
     }
 }
 
