@@ -191,7 +191,7 @@ struct Options {
     Options() {
         mat_single_pass = getenv("FJ_MAT_SINGLE_PASS") ? atoi(getenv("FJ_MAT_SINGLE_PASS")) : 1;
         bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
-        bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2500;     // measured break-even at c4 sizes: 28 % hits (profiles/r02_bloom_threshold.csv)
+        bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2300;     // measured break-even at c4 sizes: 24 % hits (profiles/r03_bloom_threshold.csv; round 2: 28 % - the plain plan gained more since)
         const char* bvr = getenv("FJ_BLOOM_VARIANT");
         bloom_variant = bvr ? std::min(2, std::max(0, atoi(bvr))) : 0;
         const char* pt = getenv("FJ_PLAN_TARGET_KEYS");

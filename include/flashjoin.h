@@ -84,7 +84,7 @@ const char* fj_version(void);
  *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
  *   "bloom_auto"       - 1 (default): the adaptive_* functions decide on the bloom precheck of the partitioned plan from a
  *                        sample of the probe side (4096 rows looked up in the partitioned build side): on when at most
- *                        "bloom_auto_max_hit_bp" (default 2500 = 25 %; measured break-even 28 %) of them hit; 0: adaptive_*_bloom filter, adaptive_* do
+ *                        "bloom_auto_max_hit_bp" (default 2300 = 23 %; measured break-even 24 %) of them hit; 0: adaptive_*_bloom filter, adaptive_* do
  *                        not, as named (env FJ_BLOOM_AUTO, FJ_BLOOM_AUTO_MAX_HIT_BP).  The explicit hash_join*_bloom
  *                        functions always run the precheck when the plan has two or more passes; hash_join* never do.
  *   "bloom_variant"    - hash / bit layout of the filter, 0..2 (csrc/fj_bloom_dev.h; default 2; env FJ_BLOOM_VARIANT).  Must be

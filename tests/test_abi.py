@@ -128,7 +128,7 @@ def test_dispatch_options_round_trip(lib):
     from flash_hash_join_amd import api
     assert api.get_option("radix_threshold") == 0 and api.get_option("scalar_hbm_table") == 0
     assert api.get_option("persistent_min_items") == 8192
-    assert api.get_option("bloom_auto") == 1 and api.get_option("bloom_auto_max_hit_bp") == 2500 and api.get_option("plan_target_keys") == 4096
+    assert api.get_option("bloom_auto") == 1 and api.get_option("bloom_auto_max_hit_bp") == 2300 and api.get_option("plan_target_keys") == 4096
     try:
         api.set_option("radix_threshold", 123456); assert api.get_option("radix_threshold") == 123456
         api.set_option("scalar_hbm_table", 7); assert api.get_option("scalar_hbm_table") == 1

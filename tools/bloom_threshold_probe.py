@@ -8,7 +8,7 @@ from flash_hash_join_amd import datagen
 nb, npk = 100_000_000, 1_000_000_000
 bk, bv = datagen.build_device(nb, "cuda:0")
 print("hit_bp,plain_ms,bloom_ms,survivors")
-for hit_bp in (500, 1000, 2000, 3000, 4000, 5000):
+for hit_bp in (500, 1000, 2000, 2500, 3000, 3500, 4000, 5000):
     pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=1, hit_bp=hit_bp)
     out = []
     for fn in ("hash_join_count_radix", "hash_join_count_radix_bloom"):
