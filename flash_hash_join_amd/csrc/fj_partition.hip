@@ -758,6 +758,80 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
     }
 }
 
+// The same lists for a level of few buckets (<= 512) whose ids stand alone (flat passes of <= 256 buckets, the bloom stage,
+// chunks received from other GPUs).  There the scattered 4-byte stores are what fj_level_lists<0> spends its time on (68 us per
+// 1B-row level; 19 us without the stores, 21 us with linear ones), and a block of consecutive ids holds many chunks per
+// bucket whose list positions are neighbours (consecutive ranks of one producer segment).  A 1024-thread workgroup takes 4096
+// consecutive ids, bins their (position, entry) pairs by bucket in LDS (counting sort: LDS atomics, one scan) and writes the
+// bins out in order: a wave's 64 stores then fall into a few 16-64-byte pieces instead of 64 sectors.  Positions and entries are
+// exactly those of fj_level_lists<0>.
+__global__ __launch_bounds__(1024) void fj_level_lists_binned(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
+                               u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
+                               u32 max_segs, u32* __restrict__ list,
+                               u32 nb, u32 tc, const u32* __restrict__ toff, uint4* __restrict__ tiles, u32 max_tiles,
+                               u32* __restrict__ zero_tail) {
+    constexpr u32 NT = 1024, BLK = 4096, NBMAX = 512;
+    __shared__ u32 hist[NBMAX + 1];
+    __shared__ u32 wsum[NBMAX / 64];
+    __shared__ uint2 ent[BLK];
+    u32 n = *nalloc; if (n > cap) n = cap;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 stride = gridDim.x * NT, gtid = blockIdx.x * NT + tid;
+    if (tc) {
+        u32 total = toff[nb];
+        if (total > max_tiles) total = max_tiles;
+        for (u32 t = gtid; t < max_tiles; t += stride) {
+            if (t < total) { if (zero_tail) fj_tile_expand_one<true>(boff, toff, nb, tc, tiles, t); else fj_tile_expand_one<false>(boff, toff, nb, tc, tiles, t); }
+            else if (zero_tail) zero_tail[t] = 0;
+        }
+    }
+    for (u32 base = blockIdx.x * BLK; base < n; base += gridDim.x * BLK) {
+        if (tid < NBMAX) hist[tid] = 0;
+        __syncthreads();
+        u32 e[4]; u64 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 i = base + (u32)u * NT + tid;
+            e[u] = i < n ? dir[i] : FJ_DIR_INVALID;
+            r[u] = i < n ? rel[i] : 0;
+        }
+        u32 pos[4], slot[4], bk[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 b = e[u] >> FJ_DIR_CNT_BITS, seg = (u32)(r[u] >> 32);
+            ok[u] = e[u] != FJ_DIR_INVALID && seg < max_segs && b < nb;
+            bk[u] = ok[u] ? b : 0u;
+            pos[u] = ok[u] ? boff[b] + seg_off[(u64)seg * (fan_mask + 1) + (b & fan_mask)] + (u32)r[u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) slot[u] = ok[u] ? atomicAdd(&hist[bk[u]], 1u) : 0u;
+        __syncthreads();
+        // exclusive scan of the bin sizes (the first NBMAX threads: whole waves)
+        u32 v = 0, inc = 0;
+        if (tid < NBMAX) {
+            v = hist[tid]; inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
+            if (lane == 63) wsum[wave] = inc;
+        }
+        __syncthreads();
+        if (tid < NBMAX) {
+            u32 woff = 0;
+            for (u32 w = 0; w < wave; ++w) woff += wsum[w];
+            hist[tid] = woff + inc - v;
+            if (tid == NBMAX - 1) hist[NBMAX] = woff + inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) ent[hist[bk[u]] + slot[u]] = make_uint2(pos[u], (((e[u] & FJ_DIR_CNT_MASK) - 1u) << 24) | (base + (u32)u * NT + tid));
+        __syncthreads();
+        const u32 total = hist[NBMAX];
+        for (u32 j = tid; j < total; j += NT) { const uint2 x = ent[j]; list[x.x] = x.y; }
+        __syncthreads();
+    }
+}
+
 // Chunks that arrived from other GPUs (owner shuffle: every sender's region for this owner, concatenated) -> a chunk set the
 // level bookkeeping understands.  Per chunk only its directory word came over the wire; this kernel gives every chunk its
 // rank inside (block of 4096 chunks, bucket) with LDS atomics and every (block, bucket) a span of the bucket's chunk list with
@@ -902,6 +976,12 @@ hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles
     hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
     static_assert(FJ_RUN_LOG == 1 || FJ_RUN_LOG == 2, "fj_level_lists reads a run's directory words with one 8-B or 16-B load");
     if (cs.run_log != 0 && cs.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
+    if (cs.run_log == 0 && cs.nb <= 512 && cs.cap >= 4096) {       // few buckets, single ids: bin the list entries by bucket before storing them
+        const u32 blocks = (cs.cap + 4095u) / 4096u;
+        hipLaunchKernelGGL(fj_level_lists_binned, dim3(blocks < 4096u ? blocks : 4096u), dim3(1024), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff,
+                           cs.seg_off, cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
+        return hipGetLastError();
+    }
     auto kern = cs.run_log ? fj_level_lists<FJ_RUN_LOG> : fj_level_lists<0>;
     hipLaunchKernelGGL(kern, dim3(2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
                        cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
