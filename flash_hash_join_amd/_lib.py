@@ -15,7 +15,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 # every symbol include/flashjoin.h declares
 SYMBOLS = [
-    "fj_initialize", "fj_last_error", "fj_device_count", "fj_version",
+    "fj_initialize", "fj_last_error", "fj_device_count", "fj_version", "fj_key_mix64", "fj_key_unmix64",
     "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes", "fj_ctx_trim", "fj_stream_abort",
     "fj_join_host", "fj_free_host", "fj_last_timings",
     "fj_join_device", "fj_emit_pairs", "fj_owner_split", "fj_owner_hist", "fj_owner_scatter",
@@ -92,6 +92,8 @@ def load() -> ctypes.CDLL:
     L.fj_last_error.restype = ctypes.c_char_p
     L.fj_device_count.restype = i32
     L.fj_version.restype = ctypes.c_char_p
+    L.fj_key_mix64.restype = u64; L.fj_key_mix64.argtypes = [u64]
+    L.fj_key_unmix64.restype = u64; L.fj_key_unmix64.argtypes = [u64]
     L.fj_ctx_create.restype = vp; L.fj_ctx_create.argtypes = [i32]
     L.fj_ctx_destroy.restype = None; L.fj_ctx_destroy.argtypes = [vp]
     L.fj_ctx_workspace_bytes.restype = sz; L.fj_ctx_workspace_bytes.argtypes = [vp]

@@ -989,6 +989,9 @@ long long fj_get_option(const char* name) {
     return -1;
 }
 
+uint64_t fj_key_mix64(uint64_t key) { return fj_key_mix(key); }
+uint64_t fj_key_unmix64(uint64_t mixed) { return fj_key_unmix(mixed); }
+
 int fj_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1715,7 +1718,7 @@ int fj_debug_partition(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals
             if (cnt == 0 || cnt > FJ_CHUNK || cnt != FJ_LIST_CNT(list[i])) return set_err("fj_debug_partition: chunk %u has count %u (list says %u)", id, cnt, FJ_LIST_CNT(list[i]));
             if (w + cnt > n) return set_err("fj_debug_partition: more than %zu rows in the chunk lists", n);
             HIPCHK(hipMemcpy(ck.data(), cs.keys + (size_t)id * FJ_CHUNK, cnt * 8, hipMemcpyDeviceToHost));
-            memcpy(h_out_keys + w, ck.data(), cnt * 8);
+            for (u32 j = 0; j < cnt; ++j) h_out_keys[w + j] = fj_key_unmix(ck[j]);       // chunk pools hold mixed keys (fj_common.h)
             if (d_vals && h_out_vals) {
                 HIPCHK(hipMemcpy(cv.data(), cs.vals + (size_t)id * FJ_CHUNK, cnt * 8, hipMemcpyDeviceToHost));
                 memcpy(h_out_vals + w, cv.data(), cnt * 8);

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void fj_flatten_kernel(FjChunkSet cs, const un
                 const u32 ee = s_ent[j], cc = FJ_LIST_CNT(ee);
                 const u64* src = cs.keys + (u64)FJ_LIST_ID(ee) * FJ_CHUNK;
                 u64* dst = out + run + s_off[j];
-                for (u32 k = lane; k < cc; k += 64) dst[k] = src[k];
+                for (u32 k = lane; k < cc; k += 64) dst[k] = fj_key_unmix(src[k]);      // chunk pools hold mixed keys, the dense array goes to a peer as raw keys
             }
             run += s_off[256];
             __syncthreads();

@@ -14,7 +14,7 @@ constexpr u32 BF_NT = 1024;                 // threads per workgroup of every ke
 __device__ __forceinline__ u32 bf_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 
 // Filter position of a key: byte offset of its LDS word / block and the mask to test or set.
-//   VAR 0 (default): the join's hash word 2 (six 32-bit multiplies in all), 4 bits in one 64-bit block.
+//   VAR 0 (default): the join's hash word 2 = the low word of the mixed key as stored (round 4: no multiply of its own), 4 bits in one 64-bit block.
 //   VAR 1: two-multiply mixer over a fold of the key, 2 bits in one 32-bit word.
 //   VAR 2: the two-multiply mixer, 4 bits in one 64-bit block (2 per half): three multiplies fewer per key than VAR 0 and
 //          the same false-positive rate on the generator's keys - and the same kernel time (round 3, 2.26 ms either way at
@@ -24,10 +24,12 @@ __device__ __forceinline__ u32 bf_uni(u32 v) { return (u32)__builtin_amdgcn_read
 template <int VAR>
 __device__ __forceinline__ void bf_bits(u64 key, u32& byte_off, u32& mlo, u32& mhi) {
     if (VAR == 0) {
-        const u32 w = fj_hash_w2(key), h = w * 0x9E3779B1u;
+        // hash word 2 of the MIXED key as it is stored (no multiply besides the block index): block from the top ~14 bits,
+        // bit positions from bits 0..17 (positions taken from bits the block half-determines cost false positives: VAR 2's note)
+        const u32 w = FJ_HW2(key);
         byte_off = __umulhi(w, FJ_BLOOM_WORDS / 2u) * 8u;
-        mlo = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
-        mhi = (1u << ((h >> 10) & 31u)) | (1u << ((h >> 15) & 31u));
+        mlo = (1u << (w & 31u)) | (1u << ((w >> 5) & 31u));
+        mhi = (1u << ((w >> 9) & 31u)) | (1u << ((w >> 13) & 31u));
         return;
     }
     u32 x = (u32)key ^ __builtin_rotateleft32((u32)(key >> 32), 15);

@@ -23,6 +23,13 @@ typedef uint16_t u16;
 #define FJ_LIST_ID(e) ((e) & 0xFFFFFFu)
 #define FJ_LIST_CNT(e) (((e) >> 24) + 1u)
 #define FJ_MAX_FAN_LOG 9                         // widest pass: 512 buckets
+// Wire format of the owner shuffle (multi-GPU; csrc/fj_pack.hip): a chunk of a first-pass bucket need not carry the hash bits
+// the bucket implies.  First passes of >= 256 buckets ship 7 bytes per key - three planes per 256-key chunk: the low words
+// (1024 B), bits 32..47 (512 B), bits 48..55 (256 B); bits 56..63 = bucket >> (fan_log - 8) - and narrower first passes whole
+// 8-byte words.
+#define FJ_WIRE7_BYTES 1792u
+#define FJ_WIRE7_MID 1024u
+#define FJ_WIRE7_HI 1536u
 // A bucket takes its chunk ids in aligned runs of 2^FJ_RUN_LOG consecutive ids (fj_partition_kernel), so that the level
 // bookkeeping places a run's chunk-list entries with one set of gathers (fj_level_lists, FjChunkSet::run_log).
 #ifndef FJ_RUN_LOG
@@ -62,29 +69,49 @@ static inline unsigned fj_slab_for(unsigned appends) { return appends > 1u ? 256
 // to FJ_EMPTY_KEY is never stored in a table; a per-table flag + value records it instead.
 #define FJ_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
-// Device hash.  The reference hashes with CRC32C*const (hash_join.cpp:40-44), 32 bits of entropy;
-// join results are hash-independent, so the device uses its own mixer.  Both hot kernels are
-// instruction-issue bound on gfx950 (PMC: profiles/r01_v2_c3_pmc_summary.txt), and a 64-bit
-// multiply costs 4+ VALU issues, so the hash is built from 32-bit multiplies only:
-//   a = lo*K1, b = hi*K2
-//   w1 = fmix32(a ^ b)                  -> owner GPU (top 16 bits) and radix digits, taken from the top
-//   w2 = fmix32(a + rotl(b,16) + K3)    -> slot inside a partition's table (low bits)
-// A kernel that needs only one word gets the other one dead-code-eliminated.
+// Device hash = a BIJECTION of the 64-bit key.  The reference hashes with CRC32C*const (hash_join.cpp:40-44), 32 bits of
+// entropy; join results are hash-independent, so the device uses its own mixer - and because equality is all a join needs,
+// every chunk pool holds the MIXED key H = fj_key_mix(k) instead of k (flat caller arrays hold raw keys: a kernel mixes a key
+// once, when it reads it from a flat array, and un-mixes it where a materialising join writes a probe key out):
+//   a = lo*K1, b = hi*K2                      (32-bit multiplies only: a 64-bit multiply costs 4+ VALU issues on gfx950)
+//   w1 = H >> 32  = fmix32(a ^ b)             -> owner GPU (top 16 bits) and radix digits, taken from the top
+//   w2 = (u32)H   = fmix32(a + w1)            -> slot inside a partition's table, tag and bloom bits (low bits)
+// (a, b) <-> (w1, w2) is one-to-one: fmix32 is a bijection of 32-bit words, x = a ^ b gives b from a, and a = fmix32^-1(w2) - w1.
+// What that buys: later passes, the join and the filter kernel take digits, slots and bits straight from the stored word (no
+// multiplies after the first read), and a chunk of a radix bucket need not store the digits the bucket implies - the owner
+// shuffle ships 7 bytes per key (csrc/fj_pack.hip).
 __host__ __device__ __forceinline__ u32 fj_fmix32(u32 x) {
     x ^= x >> 16; x *= 0x85ebca6bu;
     x ^= x >> 13; x *= 0xc2b2ae35u;
     x ^= x >> 16;
     return x;
 }
+__host__ __device__ __forceinline__ u32 fj_fmix32_inv(u32 x) {
+    x ^= x >> 16; x *= 0x7ed1b41du;                 // 0xc2b2ae35^-1 mod 2^32
+    x ^= (x >> 13) ^ (x >> 26); x *= 0xa5cb9243u;   // 0x85ebca6b^-1
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ u64 fj_key_mix(u64 k) {
+    const u32 a = (u32)k * 0x9E3779B1u, b = (u32)(k >> 32) * 0x85EBCA77u;
+    const u32 w1 = fj_fmix32(a ^ b);
+    const u32 w2 = fj_fmix32(a + w1);
+    return ((u64)w1 << 32) | w2;
+}
+__host__ __device__ __forceinline__ u64 fj_key_unmix(u64 h) {
+    const u32 w1 = (u32)(h >> 32), w2 = (u32)h;
+    const u32 a = fj_fmix32_inv(w2) - w1, b = fj_fmix32_inv(w1) ^ a;
+    return ((u64)(b * 0xb6c92f47u) << 32) | (a * 0x0e8b2f51u);      // K2^-1, K1^-1
+}
+// the two hash words of a MIXED key (what chunk pools hold)
+#define FJ_HW1(h) ((u32)((h) >> 32))
+#define FJ_HW2(h) ((u32)(h))
+// ... and of a raw key (flat arrays: the owner split, the HBM-table path); the unused word is dead-code-eliminated
 __host__ __device__ __forceinline__ u32 fj_hash_w1(u64 k) {
     const u32 a = (u32)k * 0x9E3779B1u, b = (u32)(k >> 32) * 0x85EBCA77u;
     return fj_fmix32(a ^ b);
 }
-__host__ __device__ __forceinline__ u32 fj_hash_w2(u64 k) {
-    const u32 a = (u32)k * 0x9E3779B1u, b = (u32)(k >> 32) * 0x85EBCA77u;
-    return fj_fmix32(a + ((b << 16) | (b >> 16)) + 0x27D4EB2Fu);
-}
-__host__ __device__ __forceinline__ u64 fj_hash64(u64 k) { return ((u64)fj_hash_w1(k) << 32) | fj_hash_w2(k); }
+__host__ __device__ __forceinline__ u64 fj_hash64(u64 k) { return fj_key_mix(k); }
 
 // splitmix64-style counter hash used by the synthetic generators; identical in
 // NumPy (flash_hash_join_amd/datagen.py), C and HIP.

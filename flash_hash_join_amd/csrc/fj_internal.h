@@ -51,6 +51,9 @@ struct FjPartArgs {
     u32 own_nranks;
     u32 own_region;          // chunks per region
     u32* own_alloc;          // [own_nranks] device words, zeroed before the pass: chunks allocated in each region
+    // chunk-list input in the owner shuffle's 7-byte wire format (chunks received from other GPUs, csrc/fj_pack.hip): chunk id i
+    // lives at byte i * FJ_WIRE7_BYTES of in_keys; bits 56..63 of its keys = (in_b0 + the tile's parent bucket) >> in_top_shift
+    u32 in_pk7, in_b0, in_top_shift;
 };
 
 // a chunk pool plus its per-bucket chunk lists (output of one pass, input of the next)
@@ -115,6 +118,20 @@ hipError_t fj_launch_bloom_filter(const FjBloomArgs& a, u32 grid, int variant, h
 // all bucket filters of a build-side level -> HBM; chunk set -> dense array (base[nb+1] receives the buckets' offsets, base[nb] the total)
 hipError_t fj_launch_bloom_export(const FjChunkSet& build, u32* out, u32 grid, int variant, hipStream_t s);
 hipError_t fj_launch_flatten(const FjChunkSet& cs, const unsigned long long* bucket_keys, unsigned long long* base, u64* out, hipStream_t s);
+
+// ---- owner shuffle, sender side (csrc/fj_pack.hip): level-1 chunk set -> dense wire-format chunks grouped by owner GPU ----------
+struct FjPackArgs {
+    const u64* keys; const u64* vals;            // the packing pass's chunk pool (vals: nullptr for keys-only relations)
+    const u32* list; const u32* boff;            // its chunk lists
+    u32 nb, fan_log, nranks, wire7;              // nb = 2^fan_log first-pass buckets; wire7: 7-byte chunks (fan_log >= 8), else 8-byte
+    uint2* fi;                                   // [chunks] per bucket b and output chunk c, at boff[b] + c: (input chunk holding key 256 c, keys before that chunk)
+    u32* bkeys;                                  // [nb] keys per bucket
+    u32* obase;                                  // [nb + 1] output chunks before bucket b
+    unsigned long long* used;                    // [nranks] output chunks per owner
+    unsigned char* dst_k[64]; u64* dst_v[64]; u32* dst_d[64];   // per owner: where its chunks, values and directory words go
+};
+hipError_t fj_launch_pack_plan(const FjPackArgs& a, hipStream_t s);       // fills fi, bkeys, obase, used
+hipError_t fj_launch_pack_squeeze(const FjPackArgs& a, u32 grid, hipStream_t s);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
 hipError_t fj_set_max_lds_once(const void* fn, u32 bytes);

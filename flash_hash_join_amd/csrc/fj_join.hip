@@ -44,7 +44,7 @@ struct JoinHdr {              // small scalars at the front of the dynamic LDS b
 // host's plan keeps the load at ~0.4, where a double-full pair is a ~1e-4 event per key).
 constexpr u32 NGRP = S / FJ_LDS_GROUP;
 __device__ __forceinline__ void lds_groups(u64 key, u32& g1, u32& g2) {
-    const u32 w = fj_hash_w2(key);
+    const u32 w = FJ_HW2(key);
     g1 = (w & (NGRP - 1)) * FJ_LDS_GROUP;
     g2 = ((w >> 11) & (NGRP - 1)) * FJ_LDS_GROUP;
 }
@@ -69,7 +69,7 @@ __device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restr
     // the tags (hash_join.cpp:125); two racing copies of one key may both be stored, which no lookup
     // can observe (a lookup only asks whether ANY slot matches).
     unsigned char* ttag8 = reinterpret_cast<unsigned char*>(ttags);
-    const u32 w = fj_hash_w2(key);
+    const u32 w = FJ_HW2(key);
     const u32 g1 = w & (NGRP - 1), g2 = (w >> 11) & (NGRP - 1);            // group indices
     const u32 tag = lds_tag(w), pat = tag * 0x01010101u;
     const u32 t1 = ttags[g1], t2 = ttags[g2];
@@ -121,7 +121,7 @@ __device__ __forceinline__ void lds_probe(const u64* __restrict__ tkeys, const u
     u32 g1[NK], g2[NK], z1[NK], z2[NK];
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-        const u32 w = fj_hash_w2(k[i]);
+        const u32 w = FJ_HW2(k[i]);
         g1[i] = (w & (NGRP - 1)) * FJ_LDS_GROUP;
         g2[i] = ((w >> 11) & (NGRP - 1)) * FJ_LDS_GROUP;
         const u32 pat = lds_tag(w) * 0x01010101u;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void lds_probe(const u64* __restrict__ tkeys, const u
                 for (u32 step = 0; step < NGRP; ++step) {    // an overflow key sits in the first non-full group after g1
                     g = (g + 1) & (NGRP - 1);
                     const u32 t = ttags[g];
-                    u32 m = tag_matches(t, lds_tag(fj_hash_w2(k[i])) * 0x01010101u);
+                    u32 m = tag_matches(t, lds_tag(FJ_HW2(k[i])) * 0x01010101u);
                     while (m) {
                         const u32 c = g * FJ_LDS_GROUP + ((u32)__builtin_ctz(m) >> 3);
                         if (tkeys[c] == k[i]) { found = true; if (MAT) where[i] = c; break; }
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                 const u64 base = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
                 if (off + 1 < cnt) {
                     const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + base);
-                    kk[2 * u] = q.x; kk[2 * u + 1] = q.y; okm |= 3u << (2 * u);
+                    kk[2 * u] = a.probe.list ? q.x : fj_key_mix(q.x); kk[2 * u + 1] = a.probe.list ? q.y : fj_key_mix(q.y); okm |= 3u << (2 * u);     // flat arrays hold raw keys
                 } else if (off < cnt) {
-                    kk[2 * u] = a.probe.keys[base]; okm |= 1u << (2 * u);
+                    kk[2 * u] = a.probe.list ? a.probe.keys[base] : fj_key_mix(a.probe.keys[base]); okm |= 1u << (2 * u);
                 }
             }
         }
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                 const u32 e = bm[c];
                 if (off < FJ_LIST_CNT(e)) {
                     const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
-                    bk[j] = a.build.keys[src];
+                    bk[j] = a.build.list ? a.build.keys[src] : fj_key_mix(a.build.keys[src]);
                     if (MAT) bv[j] = a.build.vals[src];
                     bok |= 1u << j;
                 }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
         for (u32 sl = tid; sl < S; sl += NT) {
             if (reinterpret_cast<const unsigned char*>(ttags)[sl] == 0) continue;
             const u64 key = tkeys[sl];
-            const u32 w = fj_hash_w2(key), pat = lds_tag(w) * 0x01010101u;
+            const u32 w = FJ_HW2(key), pat = lds_tag(w) * 0x01010101u;
             u32 g = w & (NGRP - 1);
             const u32 g2 = (w >> 11) & (NGRP - 1);
             u64 best = tvals[sl];
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(NT, 4) void fj_lds_join_kernel(FjLdsJoinArgs a) {
                             if ((m >> lane) & 1ull) {
                                 const u64 o = obase + wb + off[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
                                 if (a.dbg_flags & 4u) continue;             // (ablation: no output stores)
-                                a.out_keys[o] = k2[i];
+                                a.out_keys[o] = fj_key_unmix(k2[i]);          // (tables and chunk pools hold mixed keys)
                                 a.out_vals[o] = k2[i] == FJ_EMPTY_KEY ? hdr->empty_val : tvals[where[i]];
                             }
                         }
@@ -474,7 +474,7 @@ struct CkHdr { u32 cnt, has_empty, nstash, full, dups, empties, novf, pad1; u64 
 
 template <typename Hdr>
 __device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, Hdr* hdr, u64 key) {
-    u32 w = fj_hash_w2(key);
+    u32 w = FJ_HW2(key);
     u32 l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
     if (tkeys[l1] == key || tkeys[l2] == key) { hdr->dups = 1; return; }   // duplicate build key already stored (hash_join.cpp:125)
     u32 loc = l1;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, Hdr* hdr,
         if (old == key) hdr->dups = 1;
         if (old == FJ_EMPTY_KEY || old == key) return;            // free slot, or displaced a copy of the same key
         key = old;                                                // carry the evicted key to its other location
-        w = fj_hash_w2(key);
+        w = FJ_HW2(key);
         l1 = w & (S - 1); l2 = (w >> 13) & (S - 1);
         loc = loc == l1 ? l2 : l1;
     }
@@ -502,7 +502,7 @@ __device__ __forceinline__ void cuckoo_insert(u64* __restrict__ tkeys, Hdr* hdr,
 constexpr u32 CK_OVF = 1024;
 template <typename Hdr>
 __device__ __forceinline__ void cuckoo_claim(u64* __restrict__ tkeys, u32* __restrict__ bits, u64* __restrict__ ovf, Hdr* hdr, u64 key) {
-    const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+    const u32 w = FJ_HW2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
     const u32 o1 = atomicOr(&bits[l1 >> 5], 1u << (l1 & 31));
     if (!((o1 >> (l1 & 31)) & 1u)) { tkeys[l1] = key; return; }
     const u32 o2 = atomicOr(&bits[l2 >> 5], 1u << (l2 & 31));
@@ -569,9 +569,9 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
                 const u64 base = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
                 if (off + 1 < cnt) {
                     const u64x2 q = *reinterpret_cast<const u64x2*>(a.probe.keys + base);
-                    kk[2 * u] = q.x; kk[2 * u + 1] = q.y; okm |= 3u << (2 * u);
+                    kk[2 * u] = a.probe.list ? q.x : fj_key_mix(q.x); kk[2 * u + 1] = a.probe.list ? q.y : fj_key_mix(q.y); okm |= 3u << (2 * u);     // flat arrays hold raw keys
                 } else if (off < cnt) {
-                    kk[2 * u] = a.probe.keys[base]; okm |= 1u << (2 * u);
+                    kk[2 * u] = a.probe.list ? a.probe.keys[base] : fj_key_mix(a.probe.keys[base]); okm |= 1u << (2 * u);
                 }
             }
         }
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
             bk[j] = 0;
             if (c < nbb) {
                 const u32 e = bm[c];
-                if (off < FJ_LIST_CNT(e)) { bk[j] = a.build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off]; bok |= 1u << j; }
+                if (off < FJ_LIST_CNT(e)) { const u64 raw = a.build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off]; bk[j] = a.build.list ? raw : fj_key_mix(raw); bok |= 1u << j; }
             }
         }
     };
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
         for (u32 sl = tid; sl < S; sl += NT) {
             const u64 key = tkeys[sl];
             if (key == FJ_EMPTY_KEY) continue;
-            const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+            const u32 w = FJ_HW2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
             const u32 other = sl == l1 ? l2 : l1;
             if (other != sl && tkeys[other] == key) hdr->dups = 1;
             for (u32 si = 0; si < nstash; ++si) if (hdr->stash[si] == key) hdr->dups = 1;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_kernel(FjLdsJoinArgs a) {
             u64 c1[8], c2[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {                    // 16 independent LDS reads in flight
-                const u32 w = fj_hash_w2(k[i]);
+                const u32 w = FJ_HW2(k[i]);
                 c1[i] = tkeys[w & (S - 1)];
                 c2[i] = tkeys[(w >> 13) & (S - 1)];
             }
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
                 for (u32 sl = tid; sl < S; sl += NT) {
                     const u64 key = tkeys[sl];
                     if (key == FJ_EMPTY_KEY) continue;
-                    const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+                    const u32 w = FJ_HW2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
                     const u32 other = sl == l1 ? l2 : l1;
                     if (other != sl && tkeys[other] == key) hdr->dups = 1;
                     for (u32 si = 0; si < nstash; ++si) if (hdr->stash[si] == key) hdr->dups = 1;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(NT, 4) void fj_count_join_persistent(FjLdsJoinArgs 
                         u64 c1[4], c2[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const u32 w = fj_hash_w2(k[h + i]);
+                            const u32 w = FJ_HW2(k[h + i]);
                             c1[i] = tkeys[w & (S - 1)];
                             c2[i] = tkeys[(w >> 13) & (S - 1)];
                         }
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
     };
     auto place = [&](u64 key, u64 val) {
         if (key == FJ_EMPTY_KEY) { put(&hdr->empty_val, val); return; }
-        const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+        const u32 w = FJ_HW2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
         if (tkeys[l1] == key) { put(&tvals[l1], val); return; }
         if (tkeys[l2] == key) { put(&tvals[l2], val); return; }
         const u32 ns = hdr->nstash < CK_STASH ? hdr->nstash : CK_STASH;
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                     else if (code == 0xFFFFu) val = hdr->empty_val;
                     else val = hdr->stash_val[code - S];
                     const u64 o = gb + wbp + pre + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                    a.out_keys[o] = kp[i];
+                    a.out_keys[o] = fj_key_unmix(kp[i]);
                     a.out_vals[o] = val;
                 }
                 pre += (u32)__popcll(m);
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
             for (u32 sl = tid; sl < S; sl += NT) {
                 const u64 key = tkeys[sl];
                 if (key == FJ_EMPTY_KEY) continue;
-                const u32 w = fj_hash_w2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
+                const u32 w = FJ_HW2(key), l1 = w & (S - 1), l2 = (w >> 13) & (S - 1);
                 const u32 other = sl == l1 ? l2 : l1;
                 if (other != sl && tkeys[other] == key) hdr->dups = 1;
                 for (u32 si = 0; si < nst; ++si) if (hdr->stash[si] == key) hdr->dups = 1;
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                             u32 l1[4], l2[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const u32 w = fj_hash_w2(k[h + i]);
+                                const u32 w = FJ_HW2(k[h + i]);
                                 l1[i] = w & (S - 1); l2[i] = (w >> 13) & (S - 1);
                                 c1[i] = tkeys[l1[i]];
                                 c2[i] = tkeys[l2[i]];
@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                             u32 l1[4], l2[4];
     #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const u32 w = fj_hash_w2(k[h + i]);
+                                const u32 w = FJ_HW2(k[h + i]);
                                 l1[i] = w & (S - 1); l2[i] = (w >> 13) & (S - 1);
                                 c1[i] = tkeys[l1[i]];
                                 c2[i] = tkeys[l2[i]];
@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                                     const u64 m = hitm[i];
                                     if ((m >> lane) & 1ull) {
                                         const u64 o = obase + wb + off[i] + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                                        a.out_keys[o] = k[h + i];
+                                        a.out_keys[o] = fj_key_unmix(k[h + i]);
                                         a.out_vals[o] = val[i];
                                     }
                                 }
@@ -1358,8 +1358,8 @@ __global__ __launch_bounds__(256) void fj_sample_hits_kernel(FjChunkSet build, c
                                                              u32 shift32, u32 pmask, unsigned long long* __restrict__ hits) {
     const u32 lane = threadIdx.x & 63, widx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (widx >= nsamples) return;
-    const u64 key = pk[(u64)widx * (np / nsamples)];            // wave-uniform
-    const u32 p = (fj_hash_w1(key) >> shift32) & pmask;
+    const u64 key = fj_key_mix(pk[(u64)widx * (np / nsamples)]);   // wave-uniform; the build side's chunks hold mixed keys
+    const u32 p = (FJ_HW1(key) >> shift32) & pmask;
     const u32 b0 = build.boff[p], nbc = build.boff[p + 1] - b0;
     bool found = false;
     for (u32 c = 0; c < nbc; ++c) {

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(MM_NT, 1) void fj_mm_join_kernel(FjLdsJoinArgs a) {
             const u32 e = mm_entry(a.build, b0 + c);
             if (off < FJ_LIST_CNT(e)) {
                 const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + off;
-                const u64 key = a.build.keys[src];
+                const u64 key = a.build.list ? a.build.keys[src] : fj_key_mix(a.build.keys[src]);     // chunk pools hold mixed keys, flat arrays raw ones (fj_common.h)
                 const u32 r = atomicAdd(&hdr->nrows, 1u);
                 if (r >= MM_ROWS) hdr->full = 1;
                 else {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(MM_NT, 1) void fj_mm_join_kernel(FjLdsJoinArgs a) {
                     u32* h;
                     if (key == FJ_EMPTY_KEY) h = &hdr->empty_head;        // the empty marker is never stored in the table
                     else {
-                        u32 pos = fj_hash_w2(key) & (MM_S - 1);
+                        u32 pos = FJ_HW2(key) & (MM_S - 1);
                         for (;;) {                                          // <= 4096 distinct keys in 8192 slots: always terminates
                             const u64 old = atomicCAS((unsigned long long*)&tkeys[pos], (unsigned long long)FJ_EMPTY_KEY, (unsigned long long)key);
                             if (old == FJ_EMPTY_KEY || old == key) break;
@@ -99,13 +99,13 @@ __global__ __launch_bounds__(MM_NT, 1) void fj_mm_join_kernel(FjLdsJoinArgs a) {
         u64 key = 0; bool ok = false;
         if (c < s_hi) {
             const u32 e = mm_entry(a.probe, c);
-            if (off < FJ_LIST_CNT(e)) { key = a.probe.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off]; ok = true; }
+            if (off < FJ_LIST_CNT(e)) { key = a.probe.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + off]; if (!a.probe.list) key = fj_key_mix(key); ok = true; }
         }
         u32 h = MM_NONE;
         if (ok) {
             if (key == FJ_EMPTY_KEY) h = hdr->empty_head;
             else {
-                u32 pos = fj_hash_w2(key) & (MM_S - 1);
+                u32 pos = FJ_HW2(key) & (MM_S - 1);
                 for (;;) {
                     const u64 t = tkeys[pos];
                     if (t == key) { h = head[pos]; break; }
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(MM_NT, 1) void fj_mm_join_kernel(FjLdsJoinArgs a) {
             if (lane == 63) wb = atomicAdd(&hdr->cursor, wave_total);
             wb = __shfl(wb, 63, 64);
             u64 o = obase + wb + (inc - cnt);
-            for (u32 r = h; r != MM_NONE; r = rnext[r]) { a.out_keys[o] = key; a.out_vals[o] = rvals[r]; ++o; }
+            const u64 raw = fj_key_unmix(key);
+            for (u32 r = h; r != MM_NONE; r = rnext[r]) { a.out_keys[o] = raw; a.out_vals[o] = rvals[r]; ++o; }
         }
     }
     if (!MAT) {

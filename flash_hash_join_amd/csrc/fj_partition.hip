@@ -61,11 +61,15 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG,
 // relations, and per-kernel profiler statistics should not average 100M-row and 1B-row launches together.
 // OWN: the owner-grouped form (see FjPartArgs): every workgroup keeps one open slab PER OWNER GPU, taken from that owner's
 // region of the output pool; everything else is the same pass.
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG>
+// PK7: the input chunks are in the owner shuffle's 7-byte wire format (FJ_WIRE7_BYTES per chunk: the low words, the middle 16
+// bits and bits 48..55 of the mixed keys as three planes; bits 56..63 are the top bits of the chunk's first-pass bucket) - the
+// pass that reads what other GPUs sent unpacks it in registers (csrc/fj_pack.hip writes the format).
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG, bool PK7 = false>
 __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64;
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
     static_assert(!OWN || FLAT, "the owner-grouped form reads a flat relation");
+    static_assert(!PK7 || (!FLAT && KPT % 4 == 0), "wire-format chunks come through chunk lists, four keys per load group");
     // RUNS (RLOG > 0): a bucket takes its chunk ids in aligned runs of RU = 2^RLOG ids (used in a rotated order; what a segment
     // leaves unused of its last run is marked FJ_DIR_INVALID), so that fj_level_lists places RU list entries per step
     // (FjChunkSet::run_log).  The allocator then counts in units of one run.  RLOG == 0: ids one by one in the order the tiles
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     constexpr u32 RL = (u32)RLOG, RU = 1u << RL;
     const u32 F = 1u << a.fan_log, FM = F - 1;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only
+    const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only = the high word of the mixed key
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const PartLds Lo = part_lds_layout(T, F, LINE, HAS_VALS, NW, OWN);
@@ -123,6 +127,30 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     // then wait for the older chunk-list load with a counted vmcnt instead of draining these too.
     const bool tiny = FLAT && a.n_flat < 2;
     const u64 last_pair = FLAT ? ((a.n_flat - 2) & ~1ull) : 0;
+    // PK7: the raw planes of a tile (7 words per 4 keys) stay in registers until the keys are needed - assembling them right
+    // after the loads would make the prefetch wait for them
+    struct Pk7Raw { uint4 lo; uint2 mid; u32 hi; };
+    auto key_load7 = [&](u32 tt, Pk7Raw (&rr)[KPT / 4 ? KPT / 4 : 1], u64 (&vv)[KPT], u32& vmask) {
+        (void)tt;
+        vmask = 0;
+#pragma unroll
+        for (int i = 0; i < KPT / 4; ++i) {
+            const u32 kidx = ((u32)i * NT + tid) * 4;
+            const u32 j = kidx >> FJ_CHUNK_LOG, off = kidx & (FJ_CHUNK - 1);
+            const u32 cnt = t_cnt[j];
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(a.in_keys) + (u64)t_chunk[j] * FJ_WIRE7_BYTES;   // whole chunks were received: every offset is readable
+            rr[i].lo = *reinterpret_cast<const uint4*>(base + off * 4u);
+            rr[i].mid = *reinterpret_cast<const uint2*>(base + FJ_WIRE7_MID + off * 2u);
+            rr[i].hi = *reinterpret_cast<const u32*>(base + FJ_WIRE7_HI + off);
+            if (HAS_VALS) {
+                const u64x2 w0 = *reinterpret_cast<const u64x2*>(a.in_vals + (u64)t_chunk[j] * FJ_CHUNK + off);
+                const u64x2 w1 = *reinterpret_cast<const u64x2*>(a.in_vals + (u64)t_chunk[j] * FJ_CHUNK + off + 2);
+                vv[4 * i] = w0.x; vv[4 * i + 1] = w0.y; vv[4 * i + 2] = w1.x; vv[4 * i + 3] = w1.y;
+            }
+            const u32 nv = off < cnt ? (cnt - off < 4u ? cnt - off : 4u) : 0u;
+            vmask |= ((1u << nv) - 1u) << (4 * i);
+        }
+    };
     auto key_load = [&](u32 tt, u64 (&kk)[KPT], u64 (&vv)[KPT], u32& vmask) {
         vmask = 0;
 #pragma unroll
@@ -296,6 +324,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     // ---- prologue: keys of the first tile into registers, metadata of the second into LDS,
     //      descriptor of the third into registers (every dependent load is issued a tile early) ----
     u64 kn[KPT], vn[KPT];
+    Pk7Raw rn[KPT / 4 ? KPT / 4 : 1];
     u32 validn = 0, par_next = a.parent0, par_n2 = a.parent0, mid = 0, mcnt = 0;
     u32 d3_pos = 0, d3_len = 0, d3_par = 0;              // descriptor of tile t+2 at the top of iteration t
     if (FLAT) {
@@ -306,7 +335,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         meta_fetch(p, l, mid, mcnt);
         if (tid < TC) { t_chunk[tid] = mid; t_cnt[tid] = mcnt; }
         __syncthreads();
-        key_load(t, kn, vn, validn);
+        if constexpr (PK7) key_load7(t, rn, vn, validn); else key_load(t, kn, vn, validn);
         mid = 0; mcnt = 0;
         if (t + 1 < thi) { get_desc(t + 1, p, l, par_n2); meta_fetch(p, l, mid, mcnt); }
         if (t + 2 < thi) get_desc(t + 2, d3_pos, d3_len, d3_par);
@@ -320,8 +349,22 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     for (; t < thi; ++t) {
         u64 k[KPT], v[KPT];
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) { k[i] = kn[i]; if (HAS_VALS) v[i] = vn[i]; }
+        for (int i = 0; i < KPT; ++i) { k[i] = FLAT ? fj_key_mix(kn[i]) : kn[i]; if (HAS_VALS) v[i] = vn[i]; }   // flat arrays hold raw keys, chunk pools mixed ones (fj_common.h)
         const u32 valid = validn, parent = par_next;
+        if constexpr (PK7) {
+            // bits 56..63 of every key of this tile: the top bits of the first-pass bucket its chunks belong to
+            const u64 top = (u64)((a.in_b0 + parent) >> a.in_top_shift) << 56;
+#pragma unroll
+            for (int i = 0; i < KPT / 4; ++i) {
+                const u32 lo[4] = {rn[i].lo.x, rn[i].lo.y, rn[i].lo.z, rn[i].lo.w};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const u32 md = ((m & 2) ? rn[i].mid.y : rn[i].mid.x) >> ((m & 1) * 16) & 0xFFFFu;
+                    const u32 hb = (rn[i].hi >> (8 * m)) & 0xFFu;
+                    k[4 * i + m] = top | ((u64)((hb << 16) | md) << 32) | lo[m];
+                }
+            }
+        }
         // keep HBM busy: tile t+2's chunk-list entries first (so that waiting for them later does not
         // wait for the younger key loads), then tile t+1's keys
         const u32 par_t1 = par_n2;
@@ -330,7 +373,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             if (t + 2 < thi) { par_n2 = d3_par; meta_fetch(d3_pos, d3_len, mid, mcnt); }
             if (t + 3 < thi) get_desc(t + 3, d3_pos, d3_len, d3_par);
         }
-        if (t + 1 < thi) { key_load(t + 1, kn, vn, validn); par_next = par_t1; }
+        if (t + 1 < thi) { if constexpr (PK7) key_load7(t + 1, rn, vn, validn); else key_load(t + 1, kn, vn, validn); par_next = par_t1; }
 
         carry();
         if (parent != cur_parent) {
@@ -355,7 +398,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         if (hotb == 0xFFFFFFFFu) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                const u32 b = (valid & (1u << i)) ? ((fj_hash_w1(k[i]) >> sh32) & FM) : F;
+                const u32 b = (valid & (1u << i)) ? ((FJ_HW1(k[i]) >> sh32) & FM) : F;
                 br[i] = (b << 16) | atomicAdd(&hist[b], 1u);
             }
             // detection, for the tiles that follow: is lane 0's last digit shared by >= 8 lanes of this wave?
@@ -366,7 +409,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             u32 seen = 0;
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                const u32 b = (valid & (1u << i)) ? ((fj_hash_w1(k[i]) >> sh32) & FM) : F;
+                const u32 b = (valid & (1u << i)) ? ((FJ_HW1(k[i]) >> sh32) & FM) : F;
                 const u64 m = __ballot(b == hotb);
                 const u32 n = (u32)__popcll(m);
                 seen += n;
@@ -866,11 +909,11 @@ __global__ __launch_bounds__(1024) void fj_dir_rank_kernel(u32* __restrict__ dir
     if (blockIdx.x == 0 && tid == 0) *nalloc = n;
 }
 
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG>
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG, bool PK7 = false>
 hipError_t launch_part0(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
     const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64, OWN);
-    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, OWN, OWN ? 0 : RLOG>;
+    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, OWN, OWN ? 0 : RLOG, PK7>;
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, s, a);
@@ -953,6 +996,19 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
         return a.side == 0 ? launch_part1<1024, 8, 4, false, true, false, true>(a, g, s) : launch_part1<1024, 8, 4, false, true, true, true>(a, g, s);
     }
     if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < (1u << FJ_RUN_LOG) || (a.slab & ((1u << FJ_RUN_LOG) - 1u))) return hipErrorInvalidValue;
+    if (a.in_pk7) {
+        // input chunks in the owner shuffle's 7-byte wire format (what other GPUs sent): same pass, keys unpacked in registers
+        if (!a.in_list || a.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
+        if (vals) {
+            if (a.fan_log == 9 && line_log != 3) return hipErrorInvalidValue;
+            return line_log == 3 ? launch_part0<1024, 4, 3, true, false, true, false, FJ_RUN_LOG, true>(a, grid, s)
+                                 : launch_part0<1024, 4, 4, true, false, true, false, FJ_RUN_LOG, true>(a, grid, s);
+        }
+        if (line_log != 4) return hipErrorInvalidValue;
+        const u32 g = a.fan_log == 9 ? grid : (grid < 256 ? grid : 256);
+        return a.side == 0 ? launch_part0<1024, 8, 4, false, false, false, false, FJ_RUN_LOG, true>(a, g, s)
+                           : launch_part0<1024, 8, 4, false, false, true, false, FJ_RUN_LOG, true>(a, g, s);
+    }
     if (a.fan_log == 9) {
         // 512 buckets: one bucket per thread needs >= 512 threads and the open lines take 64 KiB (keys) -- one
         // 1024-thread workgroup per CU; with values the lines shrink to 64 B so that both payloads still fit

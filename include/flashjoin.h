@@ -98,6 +98,15 @@ const char* fj_version(void);
 int fj_set_option(const char* name, long long value);
 long long fj_get_option(const char* name);
 
+/* The device's key mixer (no reference counterpart; the reference hashes with CRC32C * const, hash_join.cpp:40-44, and
+ * join results are hash-independent): a BIJECTION of 64-bit words.  Chunk pools, LDS tables and the owner shuffle's wire
+ * format hold fj_key_mix64(key) instead of key - equality is preserved, radix digits are its top bits, table slots its low
+ * bits, and a chunk of one radix bucket need not store the digits the bucket implies (7 bytes per key on the wire).
+ * Host functions, no GPU needed: for tests and for hosts that want to predict the owner GPU of a key
+ * (owner = ((mix >> 48) * nranks) >> 16 in the owner-scatter form; first-pass bucket * nranks >> fan_log0 in the chunk form). */
+uint64_t fj_key_mix64(uint64_t key);
+uint64_t fj_key_unmix64(uint64_t mixed);
+
 /* One context per (process, device): owns the grow-only workspace, events and scratch words. */
 fj_ctx* fj_ctx_create(int device);
 void fj_ctx_destroy(fj_ctx* ctx);
