@@ -35,8 +35,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide
-HBM_SCATTER_GBS = 5038.0       # this pool's MI355X: best stream-in / scatter-out rate in >= 128-B pieces, tools/ubench_scatter.hip
-                               # (profiles/r01_ubench_scatter.csv: 4.6-5.0 TB/s by grid) - the access pattern of a radix pass
+HBM_POOL_COPY_GBS = 5621.0     # this pool's MI355X boxes: best plain read-one-write-one copy, tools/ubench_copy.hip (profiles/r01_ubench_copy.csv).
+                               # A radix pass streams 8 B in and 8 B out per key: a copy is its ceiling.  (Rounds 1-3 also quoted a
+                               # "scatter ceiling" of 5038 GB/s from one grid size of tools/ubench_scatter.hip; the same benchmark reaches
+                               # 5.2-5.5 TB/s with other grids - profiles/r02_ubench_scatter_by_grid.csv - and the pass ran at 1.008 of
+                               # it: not a ceiling, dropped.)
 
 WORKLOADS = {
     # name: (build rows per GPU, probe rows per GPU, hit rate in basis points, function)
@@ -114,7 +117,24 @@ def _host_cpu_facts() -> dict:
             j += 1
         ranges.append(str(aff[i]) if i == j else f"{aff[i]}-{aff[j]}")
         i = j + 1
-    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cpus": len(aff), "affinity_mask": ",".join(ranges)}
+    # physical cores and sockets (north_star asks for the core count; os_cpu_count counts hardware threads)
+    cores, sockets = set(), set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core)); sockets.add(phys)
+                    phys = core = None
+    except OSError:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "physical_cores": len(cores) or None, "sockets": len(sockets) or None,
+            "affinity_cpus": len(aff), "affinity_mask": ",".join(ranges)}
 
 
 def cpu_baseline(device, sample_b: int, sample_p: int, hit_bp: int, algo: str = "adaptive", budget_s: float = 25.0) -> dict:
@@ -313,7 +333,7 @@ def main() -> None:
         threading.Thread(target=watchdog, daemon=True).start()
         # the default protocol first (chunk-form shuffle through the native entry); a form that fails its check - the ranks agree
         # on that - is replaced by the next simpler one, and the line says which one was timed
-        forms = [("chunks (native fj_dist_join_count)", {}), ("chunks (torch.distributed)", {"FJ_DIST_NATIVE": "0"}),
+        forms = [("chunks (fj_dist_join_count over RCCL)", {}), ("chunks (fj_dist_join_count over torch.distributed callbacks)", {"FJ_DIST_NATIVE": "0"}),
                  ("owner-scatter", {"FJ_DIST_NATIVE": "0", "FJ_DIST_CHUNK_SHUFFLE": "0"})]
         tried = []
         for name, env in forms:
@@ -461,7 +481,7 @@ def main() -> None:
                 traffic = None
         roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
                 "frac_of_copy_ceiling": round(d["achieved"] / HBM_COPY_GBS, 4),
-                "frac_of_measured_scatter_ceiling": round(d["achieved"] / HBM_SCATTER_GBS, 4),
+                "frac_of_this_pools_copy_rate": round(d["achieved"] / HBM_POOL_COPY_GBS, 4),
                 "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
                 "launches_timed": int(round(d["launches_per_step"] * args.steps)), "traffic": traffic}
     elif part_ms:
@@ -472,7 +492,7 @@ def main() -> None:
         roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
-                "frac_of_measured_scatter_ceiling": round(achieved / HBM_SCATTER_GBS, 4),
+                "frac_of_this_pools_copy_rate": round(achieved / HBM_POOL_COPY_GBS, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 16, "units_per_launch": units_per_launch[0],
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": None}
     else:
@@ -512,7 +532,10 @@ def main() -> None:
                                                                  ("local_join_ms", dtimes["join_s"]))})
         phases.update({"shuffle_prefilter": dlast.get("prefilter"), "shuffle_prefilter_mode": dlast.get("prefilter_mode"),
                        "shuffle_prefilter_sampled_survivors": dlast.get("prefilter_sampled_survivors"),
-                       "probe_rows_sent_rank0": dlast.get("probe_rows_sent"), "shuffle_form": dlast.get("shuffle_form")})
+                       "probe_rows_sent_rank0": dlast.get("probe_rows_sent"), "shuffle_form": dlast.get("shuffle_form"),
+                       # what rank 0 put on its links per step (chunks + directory words; its own share never travels) and per key sent
+                       "wire_chunk_bytes": dlast.get("wire_chunk_bytes"), "wire_bytes_sent_rank0": dlast.get("wire_bytes_sent"),
+                       "chunk_form_error": dlast.get("chunk_form_error")})
 
     out = {
         "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",

@@ -23,12 +23,12 @@ SYMBOLS = [
     "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe",
     "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
     "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
-    "fj_shuffle_plan", "fj_shuffle_region_chunks", "fj_shuffle_pack", "fj_stream_open_shuffled",
+    "fj_shuffle_plan", "fj_shuffle_chunk_bytes", "fj_shuffle_pack_begin", "fj_shuffle_pack_counts", "fj_shuffle_pack_finish", "fj_stream_open_shuffled",
     "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
-    "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
+    "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_from_transport", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
     "fj_dist_join_count",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
-    "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h",
+    "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h", "fj_memcpy_d2d",
 ]
 
 
@@ -52,9 +52,41 @@ class FjDistTimings(ctypes.Structure):
     _fields_ = [
         ("total_ms", ctypes.c_double), ("split_ms", ctypes.c_double), ("exchange_ms", ctypes.c_double), ("join_ms", ctypes.c_double),
         ("local_count", ctypes.c_uint64), ("local_build_chunks", ctypes.c_uint64), ("local_probe_chunks", ctypes.c_uint64),
-        ("pieces", ctypes.c_int), ("nranks", ctypes.c_int), ("fan_log0", ctypes.c_int), ("reserved", ctypes.c_int),
+        ("sent_chunks", ctypes.c_uint64),
+        ("pieces", ctypes.c_int), ("nranks", ctypes.c_int), ("fan_log0", ctypes.c_int), ("wire_chunk_bytes", ctypes.c_int),
         ("local", FjTimings),
     ]
+
+
+# fj_dist_transport / fj_dist_engine_ops (include/flashjoin.h): callback tables of fj_dist_comm_from_transport
+_vp, _pu64, _pvp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_void_p)
+AllGatherFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pu64, ctypes.c_int, _pu64)
+AllReduceFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pu64, ctypes.c_int)
+AllToAllFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _pvp, _pu64, _pvp, _pu64)
+
+
+class FjDistTransport(ctypes.Structure):
+    _fields_ = [("user", _vp), ("nranks", ctypes.c_int), ("rank", ctypes.c_int),
+                ("all_gather_u64", AllGatherFn), ("all_reduce_sum_u64", AllReduceFn), ("all_to_all_bytes", AllToAllFn)]
+
+
+EngErrorFn = ctypes.CFUNCTYPE(ctypes.c_char_p, _vp)
+EngPlanFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint64, ctypes.c_int)
+EngAllocFn = ctypes.CFUNCTYPE(_vp, _vp, ctypes.c_size_t)
+EngReleaseFn = ctypes.CFUNCTYPE(None, _vp, _vp)
+EngPackBeginFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int)
+EngPackCountsFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pu64)
+EngPackFinishFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pvp, _pvp)
+EngOpenFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int)
+EngAppendFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, ctypes.c_uint64)
+EngFinishFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pu64)
+EngAbortFn = ctypes.CFUNCTYPE(None, _vp)
+
+
+class FjDistEngineOps(ctypes.Structure):
+    _fields_ = [("user", _vp), ("chunk_bytes", ctypes.c_size_t), ("error", EngErrorFn), ("plan", EngPlanFn), ("alloc", EngAllocFn),
+                ("release", EngReleaseFn), ("pack_begin", EngPackBeginFn), ("pack_counts", EngPackCountsFn), ("pack_finish", EngPackFinishFn),
+                ("open", EngOpenFn), ("append", EngAppendFn), ("finish", EngFinishFn), ("abort", EngAbortFn)]
 
 
 def build_native(force: bool = False) -> str:
@@ -125,11 +157,15 @@ def load() -> ctypes.CDLL:
     L.fj_bloom_export.restype = i32; L.fj_bloom_export.argtypes = [vp, vp, sz, i32, vp, vp]
     L.fj_bloom_prefilter.restype = i32; L.fj_bloom_prefilter.argtypes = [vp, vp, sz, i32, vp, vp, sz, pu64, vp]
     L.fj_shuffle_plan.restype = i32; L.fj_shuffle_plan.argtypes = [sz, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
-    L.fj_shuffle_region_chunks.restype = sz; L.fj_shuffle_region_chunks.argtypes = [sz, sz, i32, i32]
-    L.fj_shuffle_pack.restype = i32; L.fj_shuffle_pack.argtypes = [vp, vp, vp, sz, sz, i32, vp, vp, vp, sz, pu64, vp]
+    L.fj_shuffle_chunk_bytes.restype = sz; L.fj_shuffle_chunk_bytes.argtypes = [sz, i32]
+    L.fj_shuffle_pack_begin.restype = i32; L.fj_shuffle_pack_begin.argtypes = [vp, vp, vp, sz, sz, i32, vp]
+    L.fj_shuffle_pack_counts.restype = i32; L.fj_shuffle_pack_counts.argtypes = [vp, pu64]
+    L.fj_shuffle_pack_finish.restype = i32; L.fj_shuffle_pack_finish.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
     L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, vp]
     L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, sz, vp]
     L.fj_stream_append_probe_chunks.restype = i32; L.fj_stream_append_probe_chunks.argtypes = [vp, vp, vp, sz, vp]
+    L.fj_dist_comm_from_transport.restype = vp
+    L.fj_dist_comm_from_transport.argtypes = [vp, ctypes.POINTER(FjDistTransport), ctypes.POINTER(FjDistEngineOps)]
     L.fj_dist_unique_id.restype = i32; L.fj_dist_unique_id.argtypes = [ctypes.c_char_p]
     L.fj_dist_comm_create.restype = vp; L.fj_dist_comm_create.argtypes = [vp, ctypes.c_char_p, i32, i32]
     L.fj_dist_comm_from_nccl.restype = vp; L.fj_dist_comm_from_nccl.argtypes = [vp, vp]
@@ -146,6 +182,7 @@ def load() -> ctypes.CDLL:
     L.fj_device_free.restype = i32; L.fj_device_free.argtypes = [vp]
     L.fj_memcpy_h2d.restype = i32; L.fj_memcpy_h2d.argtypes = [vp, vp, sz]
     L.fj_memcpy_d2h.restype = i32; L.fj_memcpy_d2h.argtypes = [vp, vp, sz]
+    L.fj_memcpy_d2d.restype = i32; L.fj_memcpy_d2d.argtypes = [vp, vp, sz]
     _lib = L
     return L
 

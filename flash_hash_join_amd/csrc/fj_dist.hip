@@ -1,54 +1,70 @@
-// fj_dist.hip -- native multi-GPU entry behind the C ABI: the counting radix join of relations that are block-distributed
-// over the ranks of an RCCL communicator (BASELINE configs[4]: 1B x 10B rows over 8 MI355X).
+// fj_dist.hip -- the multi-GPU counting radix join behind the C ABI: relations block-distributed over the ranks of a
+// communicator (BASELINE configs[4]: 1B x 10B rows over 8 MI355X), ONE driver for every transport.
 //
 // No reference counterpart: the reference is one process (hash_join.cpp:318).  What is exploited is that radix partitions
 // are independent join units (hash_join.cpp:340-356, :515-525): the first radix pass of the plan for the TOTAL build side is
-// the owner split, the exchange is an all-to-all of whole 2-KiB chunks over xGMI, and every owner runs the
-// rest of the plan on what it received.  This file is the protocol of flash_hash_join_amd/distributed.py
-// (_chunk_shuffle_count) for a host that has nothing but include/flashjoin.h and an ncclComm_t:
+// the owner split, the exchange is an all-to-all of dense wire-format chunks (7 bytes per key, fj_pack.hip),
+// and every owner runs the rest of the plan on what it received.
 //
-//   sizes all-gathered -> plan -> build side: fj_shuffle_pack, counts all-gathered, grouped ncclSend / ncclRecv of every
-//   owner's region (keys + directory words), fj_stream_open_shuffled + fj_stream_append_build_chunks -> probe side in
-//   `pieces` rounds: piece c is packed (join stream) and put on the wire (exchange stream) while piece c-1 arrives and gets
-//   its second radix pass -> fj_stream_finish -> ncclAllReduce of (count, failure flag).
+//   sizes all-gathered -> plan -> build side as one piece -> probe side in `pieces` pieces; per piece:
+//     pack_begin (first pass, pack stream)  ->  counts to the host, all-gathered (control channel)  ->  buffers, agreed on  ->
+//     pack_finish (the copy into the wire format: own share straight into the receive buffer, the rest into a send pool)  ->
+//     exchange (exchange stream)  ->  append (second pass, join stream)
+//   piece c+1's first pass is queued behind piece c's copy, piece c's append is enqueued before the host waits for piece
+//   c+1's counts: the three streams stay busy and the host blocks once per piece.
+//   -> finish -> all-reduce of (count, failure flag).
 //
-// A failure of one rank's local work never takes it out of step: the rank keeps taking part in the collectives, and the
-// ranks agree on the outcome in the final all-reduce (a packing failure travels in the counts vector).  RCCL is bound at
-// run time (dlopen of librccl.so.1 - in a PyTorch process that is the copy torch already loaded), so the library has no
-// link-time dependency on it and single-GPU users never touch it.  RCCL moves wrong data when one point-to-point message
-// exceeds 4 GiB (tools/rccl_large_message_check.py): messages are cut into rounds of <= 1 GiB.
+// Two seams, so that the same state machine runs everywhere:
+//   Net    - RCCL (grouped ncclSend / ncclRecv on an exchange stream, control collectives on a second communicator so that a
+//            count exchange does not queue behind the previous piece's sends), or a caller's blocking callbacks (gloo, MPI,
+//            a test harness: fj_dist_transport);
+//   Engine - the HIP engine (fj_shuffle_pack_* / fj_stream_*_chunks of include/flashjoin.h), or a caller's stand-in
+//            (fj_dist_engine_ops: the CPU test-suite drives this file over gloo without a GPU).
+// A failure of one rank's packing or allocation is agreed on before anybody posts an exchange; a failure of its local join
+// never takes it out of step (the rank keeps taking part, the ranks agree in the final all-reduce).  RCCL is bound at run
+// time (dlopen of librccl.so.1 - in a PyTorch process that is the copy torch already loaded) through locally declared
+// prototypes: the library neither links against RCCL nor needs its headers.  RCCL moves wrong data when one point-to-point
+// message exceeds 4 GiB (tools/rccl_large_message_check.py): messages are cut into rounds of <= 1 GiB.
 #include "fj_internal.h"
 #include "../../include/flashjoin.h"
 
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
-void fj_set_error_string(const char* msg);       // fj_api.hip: the thread-local string fj_last_error() returns
+void fj_set_error_string(const char* msg);       // fj_plan.hip: the thread-local string fj_last_error() returns
 
 namespace {
+
+// ---- the few RCCL declarations this file needs (rccl.h: stable ABI since NCCL 2.7) ----
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;                         // ncclSuccess == 0
+constexpr int ncclUint8 = 1, ncclUint64 = 5, ncclSum = 0;
 
 struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;      // optional (NCCL >= 2.18)
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -62,9 +78,10 @@ Rccl* rccl() {
             if (r.lib) break;
         }
         if (!r.lib) { r.err = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"); return; }
-        auto sym = [&](const char* n) -> void* { void* p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("librccl has no ") + n; return p; };
+        auto sym = [&](const char* n, bool optional = false) -> void* { void* p = dlsym(r.lib, n); if (!p && !optional && r.err.empty()) r.err = std::string("librccl has no ") + n; return p; };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommSplit = (decltype(r.CommSplit))sym("ncclCommSplit", true);
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
         r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
@@ -86,92 +103,236 @@ int derr(const char* fmt, ...) {
     return 1;
 }
 #define DHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return derr("%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
-#define DNCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return derr("%s:%d: %s failed: %s", __FILE__, __LINE__, #x, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "?"); } while (0)
-
-struct DBuf { void* p = nullptr; size_t bytes = 0; };
-int grow(DBuf& b, size_t bytes) {
-    if (bytes == 0) bytes = 16;
-    if (b.bytes >= bytes) return 0;
-    if (b.p) { DHIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
-    const size_t want = (bytes + 4095) & ~(size_t)4095;
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) return derr("fj_dist: hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-    b.bytes = want;
-    return 0;
-}
+#define DNCCL(x) do { ncclResult_t r_ = (x); if (r_ != 0) return derr("%s:%d: %s failed: %s", __FILE__, __LINE__, #x, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "?"); } while (0)
 
 constexpr int MAX_PIECES = 16;
-constexpr size_t MAX_MSG_ELEMS = (size_t)1 << 27;         // 1 GiB of int64 per point-to-point message and round
+constexpr size_t MAX_MSG_BYTES = (size_t)1 << 30;          // 1 GiB per point-to-point message and round
 constexpr unsigned long long FAIL = 1ull << 60;            // in a counts vector: this rank could not pack the piece
+typedef void* Token;                                       // a hipEvent_t (work ordered on a stream) or null (already done)
+
+// ---- Engine: what a rank does to its own rows ---------------------------------------------------------------------------
+struct Engine {
+    virtual ~Engine() {}
+    virtual int plan(size_t nb_total, int nranks, size_t* chunk_bytes) = 0;     // same verdict on every rank (same arguments)
+    virtual void* alloc(size_t bytes) = 0;
+    virtual void release(void* p) = 0;
+    virtual int pack_begin(const void* rows, size_t n, size_t nb_total, int nranks) = 0;                // asynchronous (ordered behind the previous pack_finish)
+    virtual int pack_counts(unsigned long long* used) = 0;                      // blocks until the counts are known
+    virtual int pack_finish(void* const* dst_chunks, uint32_t* const* dst_dir, Token after, Token* done) = 0;
+    virtual int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces) = 0;
+    virtual int append(int side, const void* chunks, uint32_t* dir, size_t nchunks, Token after) = 0;
+    virtual int finish(uint64_t* count, fj_timings* lt) = 0;
+    virtual void abort() = 0;
+    virtual int drain() = 0;                                                    // everything this engine enqueued has finished
+};
+
+struct HipEngine : Engine {
+    fj_ctx* ctx; hipStream_t js = nullptr, ps = nullptr;                        // join stream (the caller's), pack stream
+    hipEvent_t ev_pack[2] = {nullptr, nullptr}; int evi = 0;
+    explicit HipEngine(fj_ctx* c) : ctx(c) {}
+    int setup() {
+        DHIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+        for (auto& e : ev_pack) DHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return 0;
+    }
+    ~HipEngine() override { for (auto& e : ev_pack) if (e) (void)hipEventDestroy(e); if (ps) (void)hipStreamDestroy(ps); }
+    int plan(size_t nb_total, int nranks, size_t* cb) override {
+        int f0 = 0, np = 0;
+        if (fj_shuffle_plan(nb_total, nranks, &f0, &np)) return 1;
+        *cb = fj_shuffle_chunk_bytes(nb_total, nranks);
+        return 0;
+    }
+    void* alloc(size_t bytes) override { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+    void release(void* p) override { if (p) (void)hipFree(p); }
+    int pack_begin(const void* rows, size_t n, size_t nb_total, int nranks) override {
+        return fj_shuffle_pack_begin(ctx, (const uint64_t*)rows, nullptr, n, nb_total, nranks, ps);
+    }
+    int pack_counts(unsigned long long* used) override { return fj_shuffle_pack_counts(ctx, (uint64_t*)used); }
+    int pack_finish(void* const* dk, uint32_t* const* dd, Token after, Token* done) override {
+        if (after) DHIP(hipStreamWaitEvent(ps, (hipEvent_t)after, 0));
+        if (fj_shuffle_pack_finish(ctx, dk, nullptr, dd, ps)) return 1;
+        hipEvent_t e = ev_pack[evi ^= 1];
+        DHIP(hipEventRecord(e, ps));
+        *done = e;
+        return 0;
+    }
+    int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces) override {
+        return fj_stream_open_shuffled(ctx, nb_total, nranks, rank, nb_bound, 1, np_bound, pieces, js);
+    }
+    int append(int side, const void* chunks, uint32_t* dir, size_t n, Token after) override {
+        if (side && getenv("FJ_DIST_INJECT_FAIL")) return derr("injected failure of a local append (test hook FJ_DIST_INJECT_FAIL)");
+        if (after) DHIP(hipStreamWaitEvent(js, (hipEvent_t)after, 0));
+        return side ? fj_stream_append_probe_chunks(ctx, chunks, dir, n, js) : fj_stream_append_build_chunks(ctx, chunks, dir, n, js);
+    }
+    int finish(uint64_t* count, fj_timings* lt) override { return fj_stream_finish(ctx, js, count, lt); }
+    void abort() override { (void)fj_stream_abort(ctx); }
+    int drain() override { DHIP(hipStreamSynchronize(ps)); DHIP(hipStreamSynchronize(js)); return 0; }
+};
+
+struct CallbackEngine : Engine {                             // a caller's stand-in (tests): everything is synchronous, tokens are null
+    fj_dist_engine_ops o;
+    explicit CallbackEngine(const fj_dist_engine_ops& ops) : o(ops) {}
+    int fail(const char* what) { return derr("%s: %s", what, o.error ? o.error(o.user) : "engine callback failed"); }
+    int plan(size_t nb_total, int nranks, size_t* cb) override { if (o.plan(o.user, nb_total, nranks)) return fail("plan"); *cb = o.chunk_bytes; return 0; }
+    void* alloc(size_t bytes) override { return o.alloc(o.user, bytes); }
+    void release(void* p) override { if (p) o.release(o.user, p); }
+    int pack_begin(const void* rows, size_t n, size_t nb_total, int nranks) override { return o.pack_begin(o.user, rows, n, nb_total, nranks) ? fail("pack_begin") : 0; }
+    int pack_counts(unsigned long long* used) override { return o.pack_counts(o.user, (uint64_t*)used) ? fail("pack_counts") : 0; }
+    int pack_finish(void* const* dk, uint32_t* const* dd, Token, Token* done) override { *done = nullptr; return o.pack_finish(o.user, dk, dd) ? fail("pack_finish") : 0; }
+    int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces) override { return o.open(o.user, nb_total, nranks, rank, nb_bound, np_bound, pieces) ? fail("open") : 0; }
+    int append(int side, const void* chunks, uint32_t* dir, size_t n, Token) override { return o.append(o.user, side, chunks, dir, n) ? fail("append") : 0; }
+    int finish(uint64_t* count, fj_timings* lt) override { memset(lt, 0, sizeof *lt); return o.finish(o.user, count) ? fail("finish") : 0; }
+    void abort() override { if (o.abort) o.abort(o.user); }
+    int drain() override { return 0; }
+};
+
+// ---- Net: what moves between ranks --------------------------------------------------------------------------------------
+struct Net {
+    int nranks = 1, rank = 0;
+    virtual ~Net() {}
+    virtual int all_gather(const unsigned long long* v, int n, unsigned long long* out) = 0;     // blocking
+    virtual int all_reduce(unsigned long long* v, int n) = 0;                                    // blocking, sum
+    // two parts (chunks, directory words): sp[p * nranks + r] / sb[...] = what goes to rank r, rp / rb = what arrives from it.
+    // Starts after `after`; *done = the data have landed (null: they have when the call returns).
+    // `largest` = the largest single message anywhere in the group (every rank passes the same value: both ends of a message
+    // must cut it into the same rounds).
+    virtual int exchange(const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) = 0;
+    virtual int drain() = 0;
+    virtual bool loopback() const { return false; }          // test hook: a rank's own share travels through the transport too
+    virtual void begin_step() {}
+};
+
+struct RcclNet : Net {
+    ncclComm_t data = nullptr, ctl = nullptr;
+    bool own_data = false, own_ctl = false, loop = false;
+    hipStream_t xs = nullptr, cs = nullptr;                  // exchange stream, control stream
+    hipEvent_t ev_x[MAX_PIECES + 1];
+    unsigned long long* d_w = nullptr; unsigned long long* h_w = nullptr;     // scratch words of the control collectives (+ pinned mirror)
+    static constexpr size_t WORDS = 72 + 64 * 65 + 16;
+    int setup() {
+        for (auto& e : ev_x) e = nullptr;
+        DHIP(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking));
+        DHIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        for (auto& e : ev_x) DHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DHIP(hipMalloc((void**)&d_w, WORDS * 8));
+        DHIP(hipHostMalloc((void**)&h_w, WORDS * 8, hipHostMallocDefault));
+        // control collectives on a communicator of their own: on ONE communicator RCCL runs operations in the order they were
+        // issued whatever their streams, and a count exchange must not wait for the previous piece's sends
+        Rccl* R = rccl();
+        if (R->CommSplit && nranks > 1 && !getenv("FJ_DIST_ONE_COMM")) {
+            ncclComm_t c2 = nullptr;
+            if (R->CommSplit(data, 0, rank, &c2, nullptr) == 0 && c2) { ctl = c2; own_ctl = true; }
+        }
+        if (!ctl) ctl = data;
+        return 0;
+    }
+    ~RcclNet() override {
+        (void)hipDeviceSynchronize();
+        if (d_w) (void)hipFree(d_w);
+        if (h_w) (void)hipHostFree(h_w);
+        for (auto& e : ev_x) if (e) (void)hipEventDestroy(e);
+        if (xs) (void)hipStreamDestroy(xs);
+        if (cs) (void)hipStreamDestroy(cs);
+        Rccl* R = rccl();
+        if (own_ctl && ctl && R->CommDestroy) (void)R->CommDestroy(ctl);
+        if (own_data && data && R->CommDestroy) (void)R->CommDestroy(data);
+    }
+    int all_gather(const unsigned long long* v, int n, unsigned long long* out) override {
+        if (n > 65) return derr("fj_dist: control vector of %d words", n);
+        Rccl* R = rccl();
+        memcpy(h_w, v, 8 * (size_t)n);
+        DHIP(hipMemcpyAsync(d_w, h_w, 8 * (size_t)n, hipMemcpyHostToDevice, cs));
+        DNCCL(R->AllGather(d_w, d_w + 72, (size_t)n, ncclUint64, ctl, cs));
+        DHIP(hipMemcpyAsync(h_w + 72, d_w + 72, 8 * (size_t)n * nranks, hipMemcpyDeviceToHost, cs));
+        DHIP(hipStreamSynchronize(cs));
+        memcpy(out, h_w + 72, 8 * (size_t)n * nranks);
+        return 0;
+    }
+    int all_reduce(unsigned long long* v, int n) override {
+        if (n > 8) return derr("fj_dist: control vector of %d words", n);
+        Rccl* R = rccl();
+        unsigned long long* d = d_w + 72 + 64 * 65;
+        memcpy(h_w, v, 8 * (size_t)n);
+        DHIP(hipMemcpyAsync(d, h_w, 8 * (size_t)n, hipMemcpyHostToDevice, cs));
+        DNCCL(R->AllReduce(d, d + 8, (size_t)n, ncclUint64, ncclSum, ctl, cs));
+        DHIP(hipMemcpyAsync(h_w + 8, d + 8, 8 * (size_t)n, hipMemcpyDeviceToHost, cs));
+        DHIP(hipStreamSynchronize(cs));
+        memcpy(v, h_w + 8, 8 * (size_t)n);
+        return 0;
+    }
+    bool loopback() const override { return loop; }
+    void begin_step() override { const char* e = getenv("FJ_DIST_LOOPBACK"); loop = e && atoi(e) != 0; }      // test hook: a rank's own share travels through ncclSend / ncclRecv too
+    bool is_peer(int r) const { return r != rank || loop; }
+    int exchange(const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) override {
+        Rccl* R = rccl();
+        if (after) DHIP(hipStreamWaitEvent(xs, (hipEvent_t)after, 0));
+        bool any = false;
+        for (int i = 0; i < 2 * nranks; ++i) if (is_peer(i % nranks)) any = any || sb[i] || rb[i];
+        const size_t rounds = std::max<size_t>(1, (largest + MAX_MSG_BYTES - 1) / MAX_MSG_BYTES);
+        auto cut = [&](size_t bytes, size_t r) { return bytes / rounds * r + std::min(r, bytes % rounds); };     // round r of a message = [cut(r), cut(r + 1))
+        for (size_t r = 0; any && r < rounds; ++r) {
+            DNCCL(R->GroupStart());
+            for (int i = 0; i < 2 * nranks; ++i) {
+                const int d = i % nranks;
+                if (is_peer(d) && cut(sb[i], r + 1) > cut(sb[i], r)) DNCCL(R->Send((const char*)sp[i] + cut(sb[i], r), cut(sb[i], r + 1) - cut(sb[i], r), ncclUint8, d, data, xs));
+            }
+            for (int i = 0; i < 2 * nranks; ++i) {
+                const int q = i % nranks;
+                if (is_peer(q) && cut(rb[i], r + 1) > cut(rb[i], r)) DNCCL(R->Recv((char*)rp[i] + cut(rb[i], r), cut(rb[i], r + 1) - cut(rb[i], r), ncclUint8, q, data, xs));
+            }
+            DNCCL(R->GroupEnd());
+        }
+        hipEvent_t e = ev_x[slot % (MAX_PIECES + 1)];
+        DHIP(hipEventRecord(e, xs));
+        *done = e;
+        return 0;
+    }
+    int drain() override { DHIP(hipStreamSynchronize(xs)); return 0; }
+};
+
+struct CallbackNet : Net {                                   // a caller's blocking transport
+    fj_dist_transport t;
+    explicit CallbackNet(const fj_dist_transport& tr) : t(tr) { nranks = tr.nranks; rank = tr.rank; }
+    int all_gather(const unsigned long long* v, int n, unsigned long long* out) override {
+        return t.all_gather_u64(t.user, (const uint64_t*)v, n, (uint64_t*)out) ? derr("fj_dist: the transport's all_gather_u64 failed") : 0;
+    }
+    int all_reduce(unsigned long long* v, int n) override {
+        return t.all_reduce_sum_u64(t.user, (uint64_t*)v, n) ? derr("fj_dist: the transport's all_reduce_sum_u64 failed") : 0;
+    }
+    int exchange(const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t, Token after, Token* done, int) override {
+        if (after) DHIP(hipEventSynchronize((hipEvent_t)after));          // the transport reads the buffers from the host side
+        std::vector<uint64_t> s64(sb, sb + 2 * nranks), r64(rb, rb + 2 * nranks);
+        *done = nullptr;
+        return t.all_to_all_bytes(t.user, 2, sp, s64.data(), rp, r64.data()) ? derr("fj_dist: the transport's all_to_all_bytes failed") : 0;
+    }
+    int drain() override { return 0; }
+};
+
+struct DBuf { void* p = nullptr; size_t bytes = 0; };
 
 }  // namespace
 
 struct fj_dist_comm {
-    fj_ctx* ctx = nullptr;
-    ncclComm_t nccl = nullptr;
-    bool own_comm = false;
-    int nranks = 1, rank = 0, device = 0;
-    hipStream_t xs = nullptr;                              // exchange stream: the sends / receives of a piece
-    hipEvent_t ev_x[MAX_PIECES + 1];                       // piece c's exchange has finished
-    unsigned long long* d_cnt = nullptr;                   // scratch words for the small collectives (comm_setup)
-    unsigned long long* h_cnt = nullptr;                   // pinned mirror
-    DBuf pool_k[2], pool_d[2];                             // what fj_shuffle_pack writes (alternating per piece)
-    DBuf recv_k[MAX_PIECES + 1], recv_d[MAX_PIECES + 1];   // what arrives: [0] build side, [1 + c] probe piece c
+    std::unique_ptr<Net> net;
+    std::unique_ptr<Engine> eng;
+    HipEngine* hip = nullptr;                               // == eng.get() when the engine is the HIP one
+    DBuf pool_k[2], pool_d[2];                              // send pools (alternating per piece)
+    DBuf recv_k[MAX_PIECES + 1], recv_d[MAX_PIECES + 1];    // what arrives: [0] build side, [1 + c] probe piece c
+    int grow(DBuf& b, size_t bytes) {
+        if (bytes == 0) bytes = 16;
+        if (b.bytes >= bytes) return 0;
+        if (b.p) { eng->release(b.p); b.p = nullptr; b.bytes = 0; }
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        b.p = eng->alloc(want);
+        if (!b.p) return derr("fj_dist: allocating %zu bytes of device memory failed", want);
+        b.bytes = want;
+        return 0;
+    }
+    void free_all() {
+        for (auto* arr : {pool_k, pool_d}) for (int i = 0; i < 2; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
+        for (auto* arr : {recv_k, recv_d}) for (int i = 0; i <= MAX_PIECES; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
+    }
 };
-
-namespace {
-
-// every rank's vector v[0 .. n) -> matrix m[rank][0 .. n) on every rank (device round trip through the comm's scratch words)
-int all_gather_u64(fj_dist_comm* dc, const unsigned long long* v, int n, unsigned long long* m, hipStream_t s) {
-    Rccl* R = rccl();
-    unsigned long long* d_send = dc->d_cnt, *d_recv = dc->d_cnt + 72;
-    memcpy(dc->h_cnt, v, sizeof(unsigned long long) * n);
-    DHIP(hipMemcpyAsync(d_send, dc->h_cnt, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, s));
-    DNCCL(R->AllGather(d_send, d_recv, (size_t)n, ncclUint64, dc->nccl, s));
-    DHIP(hipMemcpyAsync(dc->h_cnt + 72, d_recv, sizeof(unsigned long long) * n * dc->nranks, hipMemcpyDeviceToHost, s));
-    DHIP(hipStreamSynchronize(s));
-    memcpy(m, dc->h_cnt + 72, sizeof(unsigned long long) * n * dc->nranks);
-    return 0;
-}
-
-// the sends and receives of one packed piece, grouped, on the exchange stream: owner r gets chunks [r * region, r * region + used[r])
-// of the pool; what source q sends lands at chunk offset roff[q] of the receive buffers
-int exchange_piece(fj_dist_comm* dc, const u64* pool_k, const u32* pool_d, size_t region, const unsigned long long* used,
-                   u64* recv_k, u32* recv_d, const unsigned long long* recv_n, size_t largest_chunks) {
-    Rccl* R = rccl();
-    const int N = dc->nranks;
-    const size_t rounds = std::max<size_t>(1, (largest_chunks * FJ_CHUNK + MAX_MSG_ELEMS - 1) / MAX_MSG_ELEMS);
-    std::vector<size_t> roff(N + 1, 0);
-    for (int q = 0; q < N; ++q) roff[q + 1] = roff[q] + (size_t)recv_n[q];
-    // this rank's own region never touches the network: a device-to-device copy on the exchange stream (RCCL would move it
-    // through its channel kernels at a fraction of the copy rate)
-    if (used[dc->rank]) {
-        DHIP(hipMemcpyAsync(recv_k + roff[dc->rank] * FJ_CHUNK, pool_k + (size_t)dc->rank * region * FJ_CHUNK, (size_t)used[dc->rank] * FJ_CHUNK * 8, hipMemcpyDeviceToDevice, dc->xs));
-        DHIP(hipMemcpyAsync(recv_d + roff[dc->rank], pool_d + (size_t)dc->rank * region, (size_t)used[dc->rank] * 4, hipMemcpyDeviceToDevice, dc->xs));
-    }
-    if (N == 1) return 0;
-    for (size_t r = 0; r < rounds; ++r) {
-        DNCCL(R->GroupStart());
-        for (int d = 0; d < N; ++d) {
-            const size_t lo = (size_t)used[d] * r / rounds, hi = (size_t)used[d] * (r + 1) / rounds;
-            if (hi > lo && d != dc->rank) {
-                DNCCL(R->Send(pool_k + ((size_t)d * region + lo) * FJ_CHUNK, (hi - lo) * FJ_CHUNK, ncclUint64, d, dc->nccl, dc->xs));
-                DNCCL(R->Send(pool_d + (size_t)d * region + lo, hi - lo, ncclUint32, d, dc->nccl, dc->xs));
-            }
-        }
-        for (int q = 0; q < N; ++q) {
-            const size_t lo = (size_t)recv_n[q] * r / rounds, hi = (size_t)recv_n[q] * (r + 1) / rounds;
-            if (hi > lo && q != dc->rank) {
-                DNCCL(R->Recv(recv_k + (roff[q] + lo) * FJ_CHUNK, (hi - lo) * FJ_CHUNK, ncclUint64, q, dc->nccl, dc->xs));
-                DNCCL(R->Recv(recv_d + roff[q] + lo, hi - lo, ncclUint32, q, dc->nccl, dc->xs));
-            }
-        }
-        DNCCL(R->GroupEnd());
-    }
-    return 0;
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -181,176 +342,204 @@ int fj_dist_unique_id(char* out128) {
     if (!out128) return derr("fj_dist_unique_id: null buffer");
     ncclUniqueId id;
     DNCCL(R->GetUniqueId(&id));
-    static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
     memcpy(out128, &id, sizeof id);
     return 0;
 }
 
-static int comm_setup(fj_dist_comm* dc) {
-    DHIP(hipGetDevice(&dc->device));
-    DHIP(hipStreamCreateWithFlags(&dc->xs, hipStreamNonBlocking));
-    for (auto& e : dc->ev_x) DHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    const size_t words = 72 + (size_t)64 * 65 + 16;          // send vector (<= 65 words) | gathered matrix (<= 64 x 65) | result words
-    DHIP(hipMalloc((void**)&dc->d_cnt, words * 8));
-    DHIP(hipHostMalloc((void**)&dc->h_cnt, words * 8, hipHostMallocDefault));
-    return 0;
+static fj_dist_comm* comm_over_rccl(fj_ctx* ctx, ncclComm_t nccl, bool own, int nranks, int rank) {
+    fj_dist_comm* dc = new fj_dist_comm();
+    RcclNet* net = new RcclNet();
+    dc->net.reset(net);
+    net->data = nccl; net->own_data = own; net->nranks = nranks; net->rank = rank;
+    HipEngine* he = new HipEngine(ctx);
+    dc->eng.reset(he); dc->hip = he;
+    if (net->setup() || he->setup()) { delete dc; return nullptr; }
+    return dc;
 }
 
 fj_dist_comm* fj_dist_comm_create(fj_ctx* ctx, const char* unique_id128, int nranks, int rank) {
     Rccl* R = rccl();
     if (!R->err.empty()) { derr("fj_dist_comm_create: %s", R->err.c_str()); return nullptr; }
     if (!ctx || !unique_id128 || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) { derr("fj_dist_comm_create: bad arguments (1..64 ranks)"); return nullptr; }
-    fj_dist_comm* dc = new fj_dist_comm();
-    dc->ctx = ctx; dc->nranks = nranks; dc->rank = rank; dc->own_comm = true;
     ncclUniqueId id; memcpy(&id, unique_id128, sizeof id);
-    ncclResult_t r = R->CommInitRank(&dc->nccl, nranks, id, rank);       // (the caller has selected this rank's device)
-    if (r != ncclSuccess) { derr("fj_dist_comm_create: ncclCommInitRank failed: %s", R->GetErrorString(r)); delete dc; return nullptr; }
-    if (comm_setup(dc)) { fj_dist_comm_destroy(dc); return nullptr; }
-    return dc;
+    ncclComm_t nccl = nullptr;
+    ncclResult_t r = R->CommInitRank(&nccl, nranks, id, rank);          // (the caller has selected this rank's device)
+    if (r != 0) { derr("fj_dist_comm_create: ncclCommInitRank failed: %s", R->GetErrorString(r)); return nullptr; }
+    return comm_over_rccl(ctx, nccl, true, nranks, rank);
 }
 
 fj_dist_comm* fj_dist_comm_from_nccl(fj_ctx* ctx, void* nccl_comm) {
     Rccl* R = rccl();
     if (!R->err.empty()) { derr("fj_dist_comm_from_nccl: %s", R->err.c_str()); return nullptr; }
     if (!ctx || !nccl_comm) { derr("fj_dist_comm_from_nccl: null argument"); return nullptr; }
-    fj_dist_comm* dc = new fj_dist_comm();
-    dc->ctx = ctx; dc->nccl = (ncclComm_t)nccl_comm; dc->own_comm = false;
-    if (R->CommCount(dc->nccl, &dc->nranks) != ncclSuccess || R->CommUserRank(dc->nccl, &dc->rank) != ncclSuccess || dc->nranks > 64) {
-        derr("fj_dist_comm_from_nccl: not a usable communicator (1..64 ranks)"); delete dc; return nullptr;
+    int nranks = 0, rank = 0;
+    if (R->CommCount((ncclComm_t)nccl_comm, &nranks) != 0 || R->CommUserRank((ncclComm_t)nccl_comm, &rank) != 0 || nranks < 1 || nranks > 64) {
+        derr("fj_dist_comm_from_nccl: not a usable communicator (1..64 ranks)"); return nullptr;
     }
-    if (comm_setup(dc)) { fj_dist_comm_destroy(dc); return nullptr; }
+    return comm_over_rccl(ctx, (ncclComm_t)nccl_comm, false, nranks, rank);
+}
+
+fj_dist_comm* fj_dist_comm_from_transport(fj_ctx* ctx, const fj_dist_transport* transport, const fj_dist_engine_ops* engine) {
+    if (!transport || !transport->all_gather_u64 || !transport->all_reduce_sum_u64 || !transport->all_to_all_bytes ||
+        transport->nranks < 1 || transport->nranks > 64 || transport->rank < 0 || transport->rank >= transport->nranks) {
+        derr("fj_dist_comm_from_transport: incomplete transport (three callbacks, 1..64 ranks)"); return nullptr;
+    }
+    if (!ctx && !engine) { derr("fj_dist_comm_from_transport: a context or a stand-in engine is needed"); return nullptr; }
+    if (engine && (!engine->plan || !engine->alloc || !engine->release || !engine->pack_begin || !engine->pack_counts || !engine->pack_finish || !engine->open ||
+                   !engine->append || !engine->finish || engine->chunk_bytes == 0)) { derr("fj_dist_comm_from_transport: incomplete engine"); return nullptr; }
+    fj_dist_comm* dc = new fj_dist_comm();
+    dc->net.reset(new CallbackNet(*transport));
+    if (engine) dc->eng.reset(new CallbackEngine(*engine));
+    else { HipEngine* he = new HipEngine(ctx); dc->eng.reset(he); dc->hip = he; if (he->setup()) { delete dc; return nullptr; } }
     return dc;
 }
 
 void fj_dist_comm_destroy(fj_dist_comm* dc) {
     if (!dc) return;
-    (void)hipDeviceSynchronize();
-    for (auto* arr : {dc->pool_k, dc->pool_d}) for (int i = 0; i < 2; ++i) if (arr[i].p) (void)hipFree(arr[i].p);
-    for (auto* arr : {dc->recv_k, dc->recv_d}) for (int i = 0; i <= MAX_PIECES; ++i) if (arr[i].p) (void)hipFree(arr[i].p);
-    if (dc->d_cnt) (void)hipFree(dc->d_cnt);
-    if (dc->h_cnt) (void)hipHostFree(dc->h_cnt);
-    for (auto& e : dc->ev_x) if (e) (void)hipEventDestroy(e);
-    if (dc->xs) (void)hipStreamDestroy(dc->xs);
-    if (dc->own_comm && dc->nccl && rccl()->CommDestroy) (void)rccl()->CommDestroy(dc->nccl);
+    if (dc->hip) (void)hipDeviceSynchronize();
+    dc->free_all();
     delete dc;
 }
 
-int fj_dist_comm_rank(const fj_dist_comm* dc) { return dc ? dc->rank : -1; }
-int fj_dist_comm_size(const fj_dist_comm* dc) { return dc ? dc->nranks : 0; }
+int fj_dist_comm_rank(const fj_dist_comm* dc) { return dc ? dc->net->rank : -1; }
+int fj_dist_comm_size(const fj_dist_comm* dc) { return dc ? dc->net->nranks : 0; }
 
 int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                        void* stream, uint64_t* out_global_count, fj_dist_timings* timings) {
     if (!dc) return derr("fj_dist_join_count: null communicator");
     if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: pieces must be 1..%d", MAX_PIECES);
     if ((nb && !d_build_keys) || (np && !d_probe_keys) || (((uintptr_t)d_build_keys | (uintptr_t)d_probe_keys) & 15)) return derr("fj_dist_join_count: null or misaligned input");
-    Rccl* R = rccl();
-    const int N = dc->nranks, me = dc->rank;
-    hipStream_t s = (hipStream_t)stream;
+    Net& net = *dc->net; Engine& eng = *dc->eng;
+    const int N = net.nranks, me = net.rank;
+    if (dc->hip) dc->hip->js = (hipStream_t)stream;
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     double split_ms = 0;
 
     // relation sizes of every rank: one plan for everybody
     std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 2));
-    { const unsigned long long v[2] = {nb, np}; if (all_gather_u64(dc, v, 2, m.data(), s)) return 1; }
+    { const unsigned long long v[2] = {nb, np}; if (net.all_gather(v, 2, m.data())) return 1; }
     unsigned long long nb_total = 0, np_global = 0, np_min = ~0ull;
     for (int r = 0; r < N; ++r) { nb_total += m[2 * r]; np_global += m[2 * r + 1]; np_min = std::min(np_min, m[2 * r + 1]); }
-    int fan_log0 = 0, npass = 0;
-    if (fj_shuffle_plan(nb_total, N, &fan_log0, &npass)) return 1;          // (same verdict on every rank: same arguments)
+    size_t CB = 0;
+    if (eng.plan(nb_total, N, &CB)) return 1;                 // (same verdict on every rank: same arguments)
     if (np_min < 2ull * pieces) pieces = 1;
+    net.begin_step();
+    const bool loop = net.loopback();
 
-    std::string failed;                                // this rank's first local failure: later engine calls are skipped, collectives go on
+    std::string failed;                                       // this rank's first local join failure: later engine calls are skipped, collectives go on
     auto guarded = [&](int rc) { if (rc && failed.empty()) failed = fj_last_error(); return rc; };
+    bool opened = false;
+    // every exit after the first enqueue drains this rank's streams and drops an open stream join
+    auto bail = [&](const std::string& why) { (void)net.drain(); (void)eng.drain(); if (opened) eng.abort(); return derr("%s", why.c_str()); };
 
-    // pack one piece, agree on its counts; *largest = the largest message of the piece anywhere, in chunks
+    struct Piece { void* rk = nullptr; uint32_t* rd = nullptr; size_t chunks = 0; Token done = nullptr; };
     std::vector<unsigned long long> used(N), recv_n(N);
-    auto pack_and_count = [&](const u64* rows, size_t n, int slot, size_t* region, size_t* largest) -> int {
+    size_t sent_chunks = 0;                                   // chunks this rank put on the links (all pieces)
+    Token pool_free[2] = {nullptr, nullptr};                  // the exchange that last read send pool [slot]
+    // counts -> agreement -> buffers -> agreement -> copy into the wire format -> exchange   (pack_begin has been issued)
+    auto finish_piece = [&](bool begun_ok, int pslot, int rslot, Piece* out) -> int {
         const auto tp = std::chrono::steady_clock::now();
-        *region = fj_shuffle_region_chunks(n, nb_total, N, 0);
-        bool ok = *region != 0 && !grow(dc->pool_k[slot], (size_t)N * *region * FJ_CHUNK * 8) && !grow(dc->pool_d[slot], (size_t)N * *region * 4);
-        if (ok) ok = fj_shuffle_pack(dc->ctx, rows, nullptr, n, nb_total, N, (uint64_t*)dc->pool_k[slot].p, nullptr, (uint32_t*)dc->pool_d[slot].p, *region,
-                                     (uint64_t*)used.data(), s) == 0;
+        bool ok = begun_ok && eng.pack_counts(used.data()) == 0;
         const std::string why = ok ? "" : fj_last_error();
         split_ms += ms_since(tp);
         std::vector<unsigned long long> v(N + 1);
         for (int r = 0; r < N; ++r) v[r] = ok ? used[r] : 0;
         v[N] = ok ? 0 : FAIL;
-        if (all_gather_u64(dc, v.data(), N + 1, m.data(), s)) return 1;
-        *largest = 0;
+        if (net.all_gather(v.data(), N + 1, m.data())) return bail(fj_last_error());
         int nfail = 0;
+        size_t total = 0, out_chunks = 0, largest = 0;
         for (int q = 0; q < N; ++q) {
             if (m[(size_t)q * (N + 1) + N] >= FAIL) ++nfail;
             recv_n[q] = m[(size_t)q * (N + 1) + me];
-            for (int d = 0; d < N; ++d) *largest = std::max<size_t>(*largest, (size_t)m[(size_t)q * (N + 1) + d]);
+            total += (size_t)recv_n[q];
+            for (int d = 0; d < N; ++d) if (m[(size_t)q * (N + 1) + d] < FAIL) largest = std::max<size_t>(largest, (size_t)m[(size_t)q * (N + 1) + d] * CB);
         }
-        if (nfail) return derr("fj_dist_join_count: packing a piece failed on %d rank(s)%s%s", nfail, ok ? "" : "; this rank: ", why.c_str());   // every rank returns here
+        if (nfail) { char b[1200]; snprintf(b, sizeof b, "fj_dist_join_count: packing a piece failed on %d rank(s)%s%s", nfail, ok ? "" : "; this rank: ", why.c_str()); return bail(b); }
+        for (int d = 0; d < N; ++d) if (d != me || loop) out_chunks += (size_t)used[d];
+        sent_chunks += out_chunks;
+        unsigned long long bad = (dc->grow(dc->recv_k[rslot], total * CB) || dc->grow(dc->recv_d[rslot], total * 4) ||
+                                  dc->grow(dc->pool_k[pslot], out_chunks * CB) || dc->grow(dc->pool_d[pslot], out_chunks * 4)) ? 1 : 0;
+        const std::string why2 = bad ? fj_last_error() : "";
+        const bool mine_bad = bad != 0;
+        if (net.all_reduce(&bad, 1)) return bail(fj_last_error());
+        if (bad) { char b[1200]; snprintf(b, sizeof b, "fj_dist_join_count: buffers for a piece could not be allocated on %llu rank(s)%s%s", bad, mine_bad ? "; this rank: " : "", why2.c_str()); return bail(b); }
+        // where every owner's share goes: this rank's own straight into its receive buffer, the others' into the send pool
+        std::vector<void*> dk(N), sp(2 * N), rp(2 * N);
+        std::vector<uint32_t*> dd(N);
+        std::vector<size_t> sb(2 * N, 0), rb(2 * N, 0);
+        std::vector<size_t> roff(N + 1, 0);
+        for (int q = 0; q < N; ++q) roff[q + 1] = roff[q] + (size_t)recv_n[q];
+        char* rk = (char*)dc->recv_k[rslot].p; uint32_t* rd = (uint32_t*)dc->recv_d[rslot].p;
+        size_t po = 0;
+        for (int d = 0; d < N; ++d) {
+            if (d == me && !loop) { dk[d] = rk + roff[me] * CB; dd[d] = rd + roff[me]; sp[d] = sp[N + d] = nullptr; }
+            else {
+                dk[d] = (char*)dc->pool_k[pslot].p + po * CB; dd[d] = (uint32_t*)dc->pool_d[pslot].p + po;
+                sp[d] = dk[d]; sb[d] = (size_t)used[d] * CB; sp[N + d] = dd[d]; sb[N + d] = (size_t)used[d] * 4;
+                po += (size_t)used[d];
+            }
+            rp[d] = rk + roff[d] * CB; rp[N + d] = rd + roff[d];
+            if (d != me || loop) { rb[d] = (size_t)recv_n[d] * CB; rb[N + d] = (size_t)recv_n[d] * 4; }
+        }
+        Token packed = nullptr, done = nullptr;
+        if (eng.pack_finish(dk.data(), dd.data(), pool_free[pslot], &packed)) return bail(fj_last_error());
+        if (net.exchange(sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, rslot)) return bail(fj_last_error());
+        pool_free[pslot] = done;
+        out->rk = rk; out->rd = rd; out->chunks = total; out->done = done ? done : packed;
         return 0;
     };
-    auto recv_total = [&]() { size_t t = 0; for (int q = 0; q < N; ++q) t += (size_t)recv_n[q]; return t; };
 
     // ---- build side: one piece ----
-    size_t region = 0, largest = 0;
-    if (pack_and_count((const u64*)d_build_keys, nb, 0, &region, &largest)) return 1;
-    const size_t nbc = recv_total();
-    if (grow(dc->recv_k[0], nbc * FJ_CHUNK * 8) || grow(dc->recv_d[0], nbc * 4)) return 1;
-    if (exchange_piece(dc, (const u64*)dc->pool_k[0].p, (const u32*)dc->pool_d[0].p, region, used.data(), (u64*)dc->recv_k[0].p, (u32*)dc->recv_d[0].p,
-                       recv_n.data(), largest)) return 1;
-    DHIP(hipEventRecord(dc->ev_x[0], dc->xs));
-    DHIP(hipStreamWaitEvent(s, dc->ev_x[0], 0));
-    const size_t np_bound = (size_t)(1.5 * (double)np_global / N) + ((size_t)1 << 22) + (size_t)2 * FJ_CHUNK * 512 * N * pieces;
-    guarded(fj_stream_open_shuffled(dc->ctx, nb_total, N, me, nbc * FJ_CHUNK, 1, np_bound, pieces, s));
-    if (failed.empty()) guarded(fj_stream_append_build_chunks(dc->ctx, (const uint64_t*)dc->recv_k[0].p, (uint32_t*)dc->recv_d[0].p, nbc, s));
-
-    // ---- probe side: piece c is packed and put on the wire while piece c-1 arrives and gets its second pass ----
-    size_t chunks_in[MAX_PIECES + 1] = {0};
-    size_t rows_recv_chunks = 0;
-    int rc = 0;
-    for (int c = 0; c <= pieces && !rc; ++c) {
-        if (c < pieces) {
-            const size_t lo = (np * (size_t)c / pieces) & ~(size_t)1, hi = c + 1 == pieces ? np : ((np * (size_t)(c + 1) / pieces) & ~(size_t)1);
-            const int slot = c & 1;
-            if (c >= 2) DHIP(hipStreamWaitEvent(s, dc->ev_x[c - 1], 0));      // the pool this piece is packed into was last read by piece c-2's sends
-            if ((rc = pack_and_count((const u64*)d_probe_keys + lo, hi - lo, slot, &region, &largest))) break;
-            chunks_in[c + 1] = recv_total();
-            if ((rc = grow(dc->recv_k[c + 1], chunks_in[c + 1] * FJ_CHUNK * 8) || grow(dc->recv_d[c + 1], chunks_in[c + 1] * 4))) break;
-            if ((rc = exchange_piece(dc, (const u64*)dc->pool_k[slot].p, (const u32*)dc->pool_d[slot].p, region, used.data(), (u64*)dc->recv_k[c + 1].p,
-                                     (u32*)dc->recv_d[c + 1].p, recv_n.data(), largest))) break;
-            DHIP(hipEventRecord(dc->ev_x[c + 1], dc->xs));
-        }
-        if (c >= 1) {
-            DHIP(hipStreamWaitEvent(s, dc->ev_x[c], 0));
-            rows_recv_chunks += chunks_in[c];
-            if (failed.empty()) guarded(fj_stream_append_probe_chunks(dc->ctx, (const uint64_t*)dc->recv_k[c].p, (uint32_t*)dc->recv_d[c].p, chunks_in[c], s));
-        }
+    Piece B;
+    {
+        const auto tp = std::chrono::steady_clock::now();
+        const bool ok = eng.pack_begin(d_build_keys, nb, nb_total, N) == 0;
+        split_ms += ms_since(tp);
+        if (finish_piece(ok, 0, 0, &B)) return 1;
     }
-    if (rc) {                                          // a failure every rank has seen at the same point (or one nobody recovers from)
-        const std::string why = fj_last_error();
-        (void)hipStreamSynchronize(dc->xs);
-        (void)fj_stream_abort(dc->ctx);
-        return derr("%s", why.c_str());
+    const size_t np_bound = (size_t)(1.5 * (double)np_global / N) + ((size_t)1 << 22) + (size_t)FJ_CHUNK * 512 * N * pieces;
+    // ---- probe side: piece c+1's first pass is queued behind piece c's copy; piece c is appended before the host waits for c+1 ----
+    std::vector<Piece> P(pieces);
+    auto bounds = [&](int c, size_t* lo, size_t* hi) { *lo = (np * (size_t)c / pieces) & ~(size_t)1; *hi = c + 1 == pieces ? np : ((np * (size_t)(c + 1) / pieces) & ~(size_t)1); };
+    size_t lo, hi;
+    bounds(0, &lo, &hi);
+    auto tp0 = std::chrono::steady_clock::now();
+    bool begun = eng.pack_begin(d_probe_keys + lo, hi - lo, nb_total, N) == 0;
+    split_ms += ms_since(tp0);
+    opened = guarded(eng.open(nb_total, N, me, B.chunks * FJ_CHUNK, np_bound, pieces)) == 0;
+    if (failed.empty()) guarded(eng.append(0, B.rk, B.rd, B.chunks, B.done));
+    size_t rows_recv_chunks = 0;
+    for (int c = 0; c < pieces; ++c) {
+        if (finish_piece(begun, c & 1, c + 1, &P[c])) return 1;
+        if (c + 1 < pieces) {
+            bounds(c + 1, &lo, &hi);
+            const auto tp = std::chrono::steady_clock::now();
+            begun = eng.pack_begin(d_probe_keys + lo, hi - lo, nb_total, N) == 0;
+            split_ms += ms_since(tp);
+        }
+        rows_recv_chunks += P[c].chunks;
+        if (failed.empty()) guarded(eng.append(1, P[c].rk, P[c].rd, P[c].chunks, P[c].done));
     }
     const auto t2 = std::chrono::steady_clock::now();
     uint64_t local = 0;
     fj_timings lt; memset(&lt, 0, sizeof lt);
-    if (failed.empty()) guarded(fj_stream_finish(dc->ctx, s, &local, &lt));
-    if (!failed.empty()) { local = 0; (void)fj_stream_abort(dc->ctx); }
+    if (failed.empty()) { guarded(eng.finish(&local, &lt)); if (failed.empty()) opened = false; }
+    if (!failed.empty()) { local = 0; if (opened) eng.abort(); opened = false; }
 
     // ---- global count + agreement ----
-    unsigned long long* d_res = dc->d_cnt + 72 + 64 * 65;
-    dc->h_cnt[0] = local; dc->h_cnt[1] = failed.empty() ? 0 : 1;
-    DHIP(hipMemcpyAsync(d_res, dc->h_cnt, 16, hipMemcpyHostToDevice, s));
-    DNCCL(R->AllReduce(d_res, d_res + 2, 2, ncclUint64, ncclSum, dc->nccl, s));
-    DHIP(hipMemcpyAsync(dc->h_cnt + 2, d_res + 2, 16, hipMemcpyDeviceToHost, s));
-    DHIP(hipStreamSynchronize(s));
-    DHIP(hipStreamSynchronize(dc->xs));
-    if (dc->h_cnt[3]) return derr("fj_dist_join_count: the local join failed on %llu rank(s)%s%s", dc->h_cnt[3], failed.empty() ? "" : "; this rank: ", failed.c_str());
-    if (out_global_count) *out_global_count = dc->h_cnt[2];
+    unsigned long long res[2] = {local, failed.empty() ? 0ull : 1ull};
+    if (net.all_reduce(res, 2)) return bail(fj_last_error());
+    if (net.drain() || eng.drain()) return 1;
+    if (res[1]) return derr("fj_dist_join_count: the local join failed on %llu rank(s)%s%s", res[1], failed.empty() ? "" : "; this rank: ", failed.c_str());
+    if (out_global_count) *out_global_count = res[0];
     if (timings) {
         memset(timings, 0, sizeof *timings);
         timings->total_ms = ms_since(t0); timings->split_ms = split_ms; timings->join_ms = ms_since(t2);
         timings->exchange_ms = std::max(0.0, timings->total_ms - timings->join_ms - split_ms);
-        timings->local_count = local; timings->local_build_chunks = nbc; timings->local_probe_chunks = rows_recv_chunks;
-        timings->pieces = pieces; timings->nranks = N; timings->fan_log0 = fan_log0; timings->local = lt;
+        timings->local_count = local; timings->local_build_chunks = B.chunks; timings->local_probe_chunks = rows_recv_chunks;
+        timings->pieces = pieces; timings->nranks = N; timings->fan_log0 = 0; timings->local = lt;
+        timings->wire_chunk_bytes = (int)CB; timings->sent_chunks = sent_chunks;
     }
     return 0;
 }

@@ -124,7 +124,8 @@ struct FjPackArgs {
     const u64* keys; const u64* vals;            // the packing pass's chunk pool (vals: nullptr for keys-only relations)
     const u32* list; const u32* boff;            // its chunk lists
     u32 nb, fan_log, nranks, wire7;              // nb = 2^fan_log first-pass buckets; wire7: 7-byte chunks (fan_log >= 8), else 8-byte
-    uint2* fi;                                   // [chunks] per bucket b and output chunk c, at boff[b] + c: (input chunk holding key 256 c, keys before that chunk)
+    uint4* fi;                                   // [chunks] per bucket b and output chunk c, at boff[b] + c: {list entry of the input chunk holding key 256 c, the next
+                                                 // entry, keys of the bucket before that chunk, its index in the bucket's list}
     u32* bkeys;                                  // [nb] keys per bucket
     u32* obase;                                  // [nb + 1] output chunks before bucket b
     unsigned long long* used;                    // [nranks] output chunks per owner

@@ -18,7 +18,7 @@
 namespace {
 
 constexpr u32 PK_NT = 256;             // threads of the scan and squeeze workgroups = keys per chunk
-constexpr u32 PK_CPW = 4;              // output chunks a squeeze workgroup handles per step (independent load chains in flight)
+constexpr u32 PK_CPW = 8;              // output chunks a squeeze workgroup handles per step (independent load chains in flight)
 
 // one workgroup per first-pass bucket: walk its chunk list, prefix-sum the chunks' key counts
 __global__ __launch_bounds__(PK_NT) void fj_pack_scan(FjPackArgs a) {
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(PK_NT) void fj_pack_scan(FjPackArgs a) {
     u32 run = 0;
     for (u32 c0 = 0; c0 < n; c0 += PK_NT) {
         const u32 j = c0 + tid;
-        const u32 cnt = j < n ? FJ_LIST_CNT(a.list[l0 + j]) : 0u;
+        const u32 e = j < n ? a.list[l0 + j] : 0u, e1 = j + 1 < n ? a.list[l0 + j + 1] : e;
+        const u32 cnt = j < n ? FJ_LIST_CNT(e) : 0u;
         u32 inc = cnt;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
@@ -37,9 +38,10 @@ __global__ __launch_bounds__(PK_NT) void fj_pack_scan(FjPackArgs a) {
         u32 pre = run + inc - cnt, tot = 0;
         for (u32 w = 0; w < PK_NT / 64; ++w) { if (w < wave) pre += wsum[w]; tot += wsum[w]; }
         // the input chunk that holds key 256 * c of the bucket's stream starts output chunk c (a chunk has <= 256 keys: at most
-        // one such c per input chunk, exactly one input chunk per c)
+        // one such c per input chunk, exactly one input chunk per c).  The descriptor carries that chunk's list entry and the
+        // next one, so that the copy reaches its keys with ONE dependent load (full chunks make a third input chunk rare).
         const u32 c = (pre + FJ_CHUNK - 1) >> FJ_CHUNK_LOG;
-        if (cnt && (c << FJ_CHUNK_LOG) < pre + cnt) a.fi[l0 + c] = make_uint2(j, pre);
+        if (cnt && (c << FJ_CHUNK_LOG) < pre + cnt) a.fi[l0 + c] = make_uint4(e, e1, pre, j);
         run += tot;
         __syncthreads();
     }
@@ -68,47 +70,50 @@ __global__ __launch_bounds__(512) void fj_pack_offsets(FjPackArgs a) {
     }
 }
 
-// the copy.  A workgroup takes PK_CPW consecutive output chunks per step; thread t owns key t of each: it finds the key in the
-// bucket's input chunks (the first two candidates are read unconditionally: full chunks make a third one rare), and the
-// workgroup writes every chunk's 1792 (2048) bytes as whole 16-byte pieces.
+// the copy.  A resident workgroup takes PK_CPW consecutive output chunks per step; thread t owns key t of each.  It is written
+// against latency: the per-bucket tables live in LDS, an output chunk's descriptor (one 16-byte load) names the two input chunks
+// its keys can sit in (a third one is rare: only after a run of tiny partial chunks), the descriptors of the NEXT step are
+// requested before this step's keys, and a chunk's 1792 (2048) bytes leave as whole 16-byte pieces.
 template <bool W7, bool VALS>
 __global__ __launch_bounds__(PK_NT) void fj_pack_squeeze(FjPackArgs a) {
-    __shared__ u32 s_ob[(1u << FJ_MAX_FAN_LOG) + 1];
+    constexpr u32 NB1 = (1u << FJ_MAX_FAN_LOG) + 1;
+    __shared__ u32 s_ob[NB1], s_bo[NB1], s_nk[NB1];
     __shared__ __attribute__((aligned(16))) unsigned char s_pk[PK_CPW][W7 ? FJ_WIRE7_BYTES : 16];
     __shared__ unsigned char* s_dst[PK_CPW];          // W7: where chunk u of the step goes (null: past the end)
     const u32 tid = threadIdx.x, F = a.nb, N = a.nranks;
-    for (u32 i = tid; i <= F; i += PK_NT) s_ob[i] = a.obase[i];
+    for (u32 i = tid; i <= F; i += PK_NT) { s_ob[i] = a.obase[i]; s_bo[i] = a.boff[i]; s_nk[i] = i < F ? a.bkeys[i] : 0u; }
     __syncthreads();
     const u32 total = s_ob[F];
-    for (u32 g0 = blockIdx.x * PK_CPW; g0 < total; g0 += gridDim.x * PK_CPW) {
-        u32 bb[PK_CPW], cc[PK_CPW], l0[PK_CPW], nl[PK_CPW], nk[PK_CPW];
-        uint2 f[PK_CPW];
+    u32 bb[PK_CPW], cc[PK_CPW];
+    uint4 f[PK_CPW];
+    auto describe = [&](u32 g0, u32 (&b_)[PK_CPW], u32 (&c_)[PK_CPW], uint4 (&f_)[PK_CPW]) {
 #pragma unroll
         for (u32 u = 0; u < PK_CPW; ++u) {
             const u32 g = g0 + u < total ? g0 + u : total - 1;            // (clamped: the loads stay unconditional)
             u32 lo = 0, hi = F;                                            // last b with s_ob[b] <= g (buckets without keys repeat an offset)
             while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_ob[mid] <= g) lo = mid; else hi = mid; }
-            bb[u] = lo; cc[u] = g - s_ob[lo];
-            l0[u] = a.boff[lo]; nl[u] = a.boff[lo + 1] - l0[u]; nk[u] = a.bkeys[lo];
-            f[u] = a.fi[l0[u] + cc[u]];
+            b_[u] = lo; c_[u] = g - s_ob[lo];
+            f_[u] = a.fi[s_bo[lo] + c_[u]];
         }
-        u32 e0[PK_CPW], e1[PK_CPW];
-#pragma unroll
-        for (u32 u = 0; u < PK_CPW; ++u) {
-            e0[u] = a.list[l0[u] + f[u].x];
-            e1[u] = a.list[l0[u] + (f[u].x + 1 < nl[u] ? f[u].x + 1 : f[u].x)];
-        }
+    };
+    u32 g0 = blockIdx.x * PK_CPW;
+    if (g0 < total) describe(g0, bb, cc, f);
+    for (; g0 < total; g0 += gridDim.x * PK_CPW) {
+        u32 bn[PK_CPW], cn[PK_CPW];
+        uint4 fn[PK_CPW];
+        const u32 gn = g0 + gridDim.x * PK_CPW;
+        if (gn < total) describe(gn, bn, cn, fn);                          // next step's descriptors fly under this step's keys
         u64 key[PK_CPW], val[PK_CPW];
         bool ok[PK_CPW];
 #pragma unroll
         for (u32 u = 0; u < PK_CPW; ++u) {
-            const u32 pos = (cc[u] << FJ_CHUNK_LOG) + tid;
-            ok[u] = g0 + u < total && pos < nk[u];
-            u32 rel = pos - f[u].y, e = e0[u];
+            const u32 pos = (cc[u] << FJ_CHUNK_LOG) + tid, nk = s_nk[bb[u]];
+            ok[u] = g0 + u < total && pos < nk;
+            u32 rel = pos - f[u].z, e = f[u].x;
             if (ok[u] && rel >= FJ_LIST_CNT(e)) {
-                rel -= FJ_LIST_CNT(e); e = e1[u];
-                u32 j = f[u].x + 1;
-                while (rel >= FJ_LIST_CNT(e)) { rel -= FJ_LIST_CNT(e); ++j; e = a.list[l0[u] + j]; }      // (pos < nk: the walk ends inside the list)
+                rel -= FJ_LIST_CNT(e); e = f[u].y;
+                u32 j = f[u].w + 1;
+                while (rel >= FJ_LIST_CNT(e)) { rel -= FJ_LIST_CNT(e); ++j; e = a.list[s_bo[bb[u]] + j]; }      // (pos < nk: the walk ends inside the list)
             }
             const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + (ok[u] ? rel : 0u);
             key[u] = a.keys[src];
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(PK_NT) void fj_pack_squeeze(FjPackArgs a) {
             }
             if (VALS) a.dst_v[r][(u64)idx * FJ_CHUNK + tid] = ok[u] ? val[u] : 0ull;
             if (tid == 0) {
-                const u32 left = nk[u] - (cc[u] << FJ_CHUNK_LOG);
+                const u32 left = s_nk[b] - (cc[u] << FJ_CHUNK_LOG);
                 a.dst_d[r][idx] = (b << FJ_DIR_CNT_BITS) | (left < FJ_CHUNK ? left : FJ_CHUNK);
                 if (W7) s_dst[u] = a.dst_k[r] + (u64)idx * FJ_WIRE7_BYTES;
             }
@@ -142,6 +147,8 @@ __global__ __launch_bounds__(PK_NT) void fj_pack_squeeze(FjPackArgs a) {
             }
             __syncthreads();
         }
+#pragma unroll
+        for (u32 u = 0; u < PK_CPW; ++u) { bb[u] = bn[u]; cc[u] = cn[u]; f[u] = fn[u]; }
     }
 }
 

@@ -895,8 +895,22 @@ __global__ __launch_bounds__(1024) void fj_dir_rank_kernel(u32* __restrict__ dir
         if (i < n) {
             const u32 e = dir[i], b = (e >> FJ_DIR_CNT_BITS) - b_lo, cnt = e & FJ_DIR_CNT_MASK;
             const bool ok = e != FJ_DIR_INVALID && b < nbk && cnt >= 1u && cnt <= FJ_CHUNK;
-            if (ok) { rr[u] = atomicAdd(&h[b], 1u); bb[u] = b; }
+            if (ok) bb[u] = b;
             dir[i] = ok ? ((b << FJ_DIR_CNT_BITS) | cnt) : FJ_DIR_INVALID;
+        }
+        // rank inside (block, bucket).  What a sender packs is dense and bucket-ordered (fj_pack.hip): the lanes of a wave nearly
+        // always share ONE bucket, and 64 LDS atomics on one word are served one after the other (0.6 ms per 1.2M-chunk piece) -
+        // such a wave takes its ranks with one atomic and a ballot prefix.
+        const bool ok = bb[u] != FJ_DIR_INVALID;
+        const u64 m = __ballot(ok);
+        if (m) {
+            const u32 b0 = (u32)__builtin_amdgcn_readlane((int)bb[u], __builtin_ctzll(m));
+            if (__ballot(ok && bb[u] != b0) == 0) {
+                u32 wb = 0;
+                if ((threadIdx.x & 63u) == (u32)__builtin_ctzll(m)) wb = atomicAdd(&h[b0], (u32)__popcll(m));
+                wb = (u32)__builtin_amdgcn_readlane((int)wb, __builtin_ctzll(m));
+                if (ok) rr[u] = wb + (u32)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            } else if (ok) rr[u] = atomicAdd(&h[bb[u]], 1u);
         }
     }
     __syncthreads();

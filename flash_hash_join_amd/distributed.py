@@ -176,24 +176,30 @@ class HipEngine:
             return None
         return int(f0.value)
 
+    def shuffle_chunk_bytes(self, nb_total: int, world: int) -> int:
+        return int(self.L.fj_shuffle_chunk_bytes(nb_total, world))
+
     def shuffle_pack(self, keys, vals, nb_total: int, world: int):
-        """First pass of the global plan over local rows, chunks grouped by owner GPU.  Returns (pool_keys, pool_vals, dir,
-        region_chunks, used): owner r's chunks are [r * region_chunks, r * region_chunks + used[r]) of the pool (256 keys
-        each), with one directory word per chunk."""
+        """First pass of the global plan over local rows, rewritten for the wire (fj_shuffle_pack_begin / _counts / _finish).
+        Returns (chunks, dir, used): per owner r a uint8 tensor of used[r] * shuffle_chunk_bytes() bytes (dense 256-key chunks
+        in the 7-byte wire format when the first pass has >= 256 buckets) and an int32 tensor of used[r] directory words."""
         t = self.torch
         keys = self._aligned(keys)
-        n = keys.numel()
-        region = int(self.L.fj_shuffle_region_chunks(n, nb_total, world, int(vals is not None)))
-        if region == 0:
+        stream = t.cuda.current_stream(self.index).cuda_stream
+        cb = self.shuffle_chunk_bytes(nb_total, world)
+        if cb == 0:
             raise RuntimeError(self._lib.last_error())
-        pool_k = self.empty(world * region * 256)
-        pool_v = self.empty(world * region * 256) if vals is not None else None
-        dirw = self.empty_i32(world * region)
+        self._lib.check(self.L.fj_shuffle_pack_begin(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, world, stream))
         used = (ctypes.c_uint64 * 64)()
-        self._lib.check(self.L.fj_shuffle_pack(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, n, nb_total, world,
-                                               pool_k.data_ptr(), pool_v.data_ptr() if pool_v is not None else None, dirw.data_ptr(), region,
-                                               used, t.cuda.current_stream(self.index).cuda_stream))
-        return pool_k, pool_v, dirw, region, [int(used[r]) for r in range(world)]
+        self._lib.check(self.L.fj_shuffle_pack_counts(self.ctx, used))
+        used = [int(used[r]) for r in range(world)]
+        chunks = [t.empty(max(16, u * cb), dtype=t.uint8, device=self.device) for u in used]
+        dirs = [self.empty_i32(max(4, u)) for u in used]
+        vp = ctypes.c_void_p
+        dk = (vp * 64)(*[c.data_ptr() for c in chunks])
+        dd = (vp * 64)(*[d.data_ptr() for d in dirs])
+        self._lib.check(self.L.fj_shuffle_pack_finish(self.ctx, dk, None, dd, stream))
+        return [c[: u * cb] for c, u in zip(chunks, used)], [d[:u] for d, u in zip(dirs, used)], used
 
     def stream_open_shuffled(self, nb_total: int, world: int, rank: int, nb_bound: int, build_appends: int, np_bound: int, probe_appends: int):
         self._keep = []
@@ -201,7 +207,7 @@ class HipEngine:
                                                        self.torch.cuda.current_stream(self.index).cuda_stream))
 
     def stream_append_chunks(self, side: int, chunks, dirw):
-        """A received piece: whole 256-key chunks + their directory words (rewritten in place)."""
+        """A received piece: wire-format chunks (uint8 tensor) + their directory words (rewritten in place)."""
         self._keep += [chunks, dirw]
         fn = self.L.fj_stream_append_probe_chunks if side else self.L.fj_stream_append_build_chunks
         self._lib.check(fn(self.ctx, chunks.data_ptr(), dirw.data_ptr(), dirw.numel(), self.torch.cuda.current_stream(self.index).cuda_stream))
@@ -213,14 +219,15 @@ class HipEngine:
         cnt = dirw & 0x1FF
         return int(cnt[dirw != -1].sum().item())
 
-    # ---- the native multi-GPU entry (csrc/fj_dist.hip): the same chunk-form protocol, driven from C++ over an RCCL communicator
-    #      of the library's own (torch does not hand out its ncclComm_t) ----
+    # ---- the multi-GPU driver (csrc/fj_dist.hip): fj_dist_join_count over an RCCL communicator of the library's own (torch does
+    #      not hand out its ncclComm_t) ----
     _native_comms: dict = {}
 
     def native_comm(self, dist, group):
-        """fj_dist_comm for (this device, group): rank 0's unique id travels by a torch.distributed broadcast, every rank then
-        joins ncclCommInitRank inside fj_dist_comm_create.  Cached for the life of the process."""
-        key = (self.index, id(group) if group is not None else 0)
+        """fj_dist_comm for (this device, the group's ranks): rank 0's unique id travels by a torch.distributed broadcast, every
+        rank then joins ncclCommInitRank inside fj_dist_comm_create.  Cached for the life of the process (closed at exit)."""
+        ranks = tuple(dist.get_process_group_ranks(group)) if group is not None else tuple(range(dist.get_world_size()))
+        key = (self.index, ranks)
         comm = HipEngine._native_comms.get(key)
         if comm:
             return comm
@@ -237,28 +244,22 @@ class HipEngine:
             comm = self.L.fj_dist_comm_create(self.ctx, raw, world, rank)
         if not comm:
             raise RuntimeError(self._lib.last_error())
+        if not HipEngine._native_comms:
+            import atexit
+            atexit.register(HipEngine.close_native_comms)
         HipEngine._native_comms[key] = comm
         return comm
 
-    def native_count(self, dist, group, build_keys, probe_keys, pieces: int, timings: Optional[dict]):
-        """fj_dist_join_count: the global match count of the block-distributed relations (collective)."""
-        t = self.torch
-        comm = self.native_comm(dist, group)
-        bk, pk = self._aligned(build_keys), self._aligned(probe_keys)
-        cnt = ctypes.c_uint64(0)
-        dt = self._lib.FjDistTimings()
-        t0 = time.perf_counter()
-        with t.cuda.device(self.index):
-            self._lib.check(self.L.fj_dist_join_count(comm, bk.data_ptr(), bk.numel(), pk.data_ptr(), pk.numel(), pieces,
-                                                      t.cuda.current_stream(self.index).cuda_stream, ctypes.byref(cnt), ctypes.byref(dt)))
-        sec = time.perf_counter() - t0
-        self.api._last = dt.local
-        if timings is not None:
-            timings.update(strategy="shuffle", shuffle_form="chunks (native fj_dist_join_count)", split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
-                           join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces), local_build_rows=int(dt.local_build_chunks) * 256,
-                           local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=False, prefilter_mode="off",
-                           prefilter_sampled_survivors=None, probe_rows_sent=pk.numel(), rows_are_chunk_capacity=True)
-        return int(cnt.value), sec
+    @staticmethod
+    def close_native_comms():
+        """Destroy the cached RCCL communicators (before torch.distributed.destroy_process_group, or at exit)."""
+        from . import _lib
+        comms, HipEngine._native_comms = HipEngine._native_comms, {}
+        for comm in comms.values():
+            try:
+                _lib.load().fj_dist_comm_destroy(comm)
+            except Exception:                    # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def stream_abort(self):
         """Error recovery: drop a stream join that will not be finished, so that the context serves other joins again."""
@@ -503,136 +504,198 @@ def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe
     return int(tot.item()), t3 - t0
 
 
-def _chunk_shuffle_count(dist, group, engine, world, build_keys, probe_keys, nb_total: int, np_global: int, pieces: int,
-                         timings: Optional[dict]):
-    """Counting join, owner shuffle in CHUNK form: the first radix pass of the plan for the TOTAL build side is
-    the owner split.  A sender runs that pass over its local rows with the chunks grouped by owner GPU (engine.shuffle_pack:
-    no owner histogram, no owner scatter), ships every owner its chunks and their directory words, and the owner starts at
-    the plan's SECOND pass (engine.stream_append_chunks).  The probe side travels in `pieces` rounds: piece c is packed while
-    piece c-1 is on the wire and the second pass runs over piece c-2.  Per rank: two passes over every probe row instead of
-    three (owner scatter + two passes).  A failure on any rank (a skewed key set overflowing an owner's region, a pool
-    error) is agreed on by all ranks before anybody raises."""
-    t0 = time.perf_counter()
-    rank = dist.get_rank(group)
-    CH = 256
-    FAIL = 1 << 60
-    split_s = 0.0
+class _CallbackTransport:
+    """fj_dist_transport over torch.distributed (or an object with its functions): three blocking callbacks for the C++ driver
+    (csrc/fj_dist.hip) - the transport of gloo jobs, of FJ_DIST_NATIVE=0 and of the test-suite; by default the driver talks to
+    RCCL itself under the nccl backend.  memory: "device" - the driver's pointers are HIP device pointers, payload is staged
+    through host tensors (gloo) or device tensors (nccl); "host" - plain host pointers (a stand-in engine)."""
 
-    def pack(rows):
-        nonlocal split_s
-        t = time.perf_counter()
+    def __init__(self, dist, group, memory: str, device=None):
+        import numpy as np
+        import torch
+        from . import _lib
+        self.np, self.torch, self._lib, self.dist, self.group = np, torch, _lib, dist, group
+        self.L = _lib.load() if memory == "device" else None
+        self.memory = memory
+        # tensors handed to the collectives: device tensors under nccl, host tensors otherwise
+        self.tdev = device if (memory == "device" and device is not None and getattr(dist, "get_backend", lambda g: "gloo")(group) == "nccl") else None
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.error = None
+        self.bytes_sent = 0
+        self.struct = _lib.FjDistTransport(None, self.world, self.rank, _lib.AllGatherFn(self._all_gather), _lib.AllReduceFn(self._all_reduce),
+                                           _lib.AllToAllFn(self._all_to_all))
+
+    def _guard(self, fn):
         try:
-            out = engine.shuffle_pack(rows, None, nb_total, world)
-        except RuntimeError as ex:               # agreed on below (largest_message), then raised everywhere
-            out = ex
-        split_s += time.perf_counter() - t
-        return out
+            fn()
+            return 0
+        except BaseException as ex:              # noqa: BLE001  (an exception must not cross the C frames)
+            self.error = ex
+            return 1
 
-    def counts_and_rounds(packed):
-        """chunks per source for this piece; rounds such that no message exceeds the RCCL-safe size; raises on every rank
-        when any rank failed to pack."""
-        used = [0] * world if isinstance(packed, Exception) else packed[4]
-        send_c = engine.counts_tensor(used)
-        recv_c = engine.counts_tensor([0] * world)
-        dist.all_to_all_single(recv_c, send_c, group=group)
-        mx = engine.counts_tensor([FAIL if isinstance(packed, Exception) else max(used) * CH])
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-        if int(mx.item()) >= FAIL:
-            raise _PackFailed("owner shuffle (chunk form) failed on a rank: " + (str(packed) if isinstance(packed, Exception) else
-                               "see that rank's error") + "; FJ_DIST_CHUNK_SHUFFLE=0 selects the owner-scatter form")
-        return [int(x) for x in recv_c.tolist()], max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
+    def _all_gather(self, _user, v, n, out):
+        def run():
+            t = self.torch
+            mine = t.tensor([int(v[i]) for i in range(n)], dtype=t.int64, device=self.tdev)
+            allv = t.zeros(n * self.world, dtype=t.int64, device=self.tdev)
+            self.dist.all_gather_into_tensor(allv, mine, group=self.group)
+            for i, x in enumerate(allv.tolist()):
+                out[i] = x
+        return self._guard(run)
 
-    def put_on_the_wire(packed, recv_n, rounds, async_op):
-        pool_k, _, dirw, region, used = packed
-        rk, rd = engine.empty(sum(recv_n) * CH), engine.empty_i32(sum(recv_n))
-        works = []
-        roff = [0]
-        for c in recv_n:
-            roff.append(roff[-1] + c)
-        for r in range(rounds):                  # round r moves slice r of every (source, destination) message
-            lo = lambda n_: n_ * r // rounds
-            hi = lambda n_: n_ * (r + 1) // rounds
-            ins_k = [pool_k[(d * region + lo(used[d])) * CH: (d * region + hi(used[d])) * CH] for d in range(world)]
-            outs_k = [rk[(roff[q] + lo(recv_n[q])) * CH: (roff[q] + hi(recv_n[q])) * CH] for q in range(world)]
-            ins_d = [dirw[d * region + lo(used[d]): d * region + hi(used[d])] for d in range(world)]
-            outs_d = [rd[roff[q] + lo(recv_n[q]): roff[q] + hi(recv_n[q])] for q in range(world)]
-            works += _views_all_to_all(dist, group, ins_k, outs_k)
-            works += _views_all_to_all(dist, group, ins_d, outs_d)
-        if not async_op:
-            for w in works:
+    def _all_reduce(self, _user, v, n):
+        def run():
+            t = self.torch
+            x = t.tensor([int(v[i]) for i in range(n)], dtype=t.int64, device=self.tdev)
+            self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)
+            for i, y in enumerate(x.tolist()):
+                v[i] = y
+        return self._guard(run)
+
+    def _read(self, ptr, nbytes):
+        t = self.torch
+        if self.tdev is not None:
+            buf = t.empty(nbytes, dtype=t.uint8, device=self.tdev)
+            self._lib.check(self.L.fj_memcpy_d2d(buf.data_ptr(), ptr, nbytes))
+            return buf
+        buf = self.np.empty(nbytes, dtype=self.np.uint8)
+        if self.memory == "device":
+            self._lib.check(self.L.fj_memcpy_d2h(buf.ctypes.data, ptr, nbytes))
+        else:
+            ctypes.memmove(buf.ctypes.data, ptr, nbytes)
+        return t.from_numpy(buf)
+
+    def _write(self, ptr, t):
+        if self.tdev is not None:
+            self.torch.cuda.synchronize(self.tdev)
+            self._lib.check(self.L.fj_memcpy_d2d(ptr, t.data_ptr(), t.numel()))
+            return
+        a = t.numpy()
+        if self.memory == "device":
+            self._lib.check(self.L.fj_memcpy_h2d(ptr, a.ctypes.data, a.size))
+        else:
+            ctypes.memmove(ptr, a.ctypes.data, a.size)
+
+    def _all_to_all(self, _user, nparts, sp, sb, rp, rb):
+        def run():
+            dist, t = self.dist, self.torch
+            peer = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+            ops, landed = [], []
+            for p in range(nparts):
+                for r in range(self.world):
+                    i = p * self.world + r
+                    ns, nr = int(sb[i]), int(rb[i])
+                    if r == self.rank:           # (only the loop-back test hook routes a rank's own share through the transport)
+                        if ns:
+                            self._write(rp[i], self._read(sp[i], ns))
+                        continue
+                    if ns:
+                        ops.append(dist.P2POp(dist.isend, self._read(sp[i], ns), peer(r), self.group))
+                        self.bytes_sent += ns
+                    if nr:
+                        buf = t.empty(nr, dtype=t.uint8, device=self.tdev)
+                        landed.append((rp[i], buf))
+                        ops.append(dist.P2POp(dist.irecv, buf, peer(r), self.group))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
                 w.wait()
-            works = []
-        return rk, rd, works, packed             # (the packed pool stays alive until the wait)
+            for ptr, buf in landed:
+                self._write(ptr, buf)
+        return self._guard(run)
 
-    def wait(sent):
-        for w in sent[2]:
-            w.wait()
-        return sent[0], sent[1]
 
-    class _PackFailed(RuntimeError):
-        pass
+def _engine_ops_struct(ops, keep: list):
+    """fj_dist_engine_ops for a stand-in engine object (tests): methods plan / alloc / release / pack_begin / pack_counts /
+    pack_finish / open / append / finish / abort and the attribute chunk_bytes.  Exceptions become error returns."""
+    from . import _lib
+    state = {"err": b""}
 
-    # A failure of this rank's ENGINE calls (open / append / finish) must not take it out of step with its peers: the first
-    # one is remembered, later engine calls are skipped, every collective still runs, and the ranks agree at the end.
-    failed: List[Exception] = []
-
-    def guarded(fn, *a):
-        if failed:
-            return None
-        try:
-            return fn(*a)
-        except RuntimeError as ex:
-            failed.append(ex)
-            return None
-
-    inflight = []
-    try:
-        # build side: one piece
-        pb = pack(build_keys)
-        recv_b, rounds_b = counts_and_rounds(pb)
-        rkb, rdb = wait(put_on_the_wire(pb, recv_b, rounds_b, False))
-        del pb
-        n = probe_keys.numel()
-        bounds = [(n * c // pieces) & ~1 for c in range(pieces)] + [n]      # even row offsets: every piece stays 16-byte aligned
-        np_bound = int(1.5 * np_global / world) + (1 << 22) + 2 * CH * 512 * world * pieces   # an even share + 50 % + the partial chunks
-        rows_recv = 0
-        guarded(engine.stream_open_shuffled, nb_total, world, rank, sum(recv_b) * CH, 1, np_bound, pieces)
-        guarded(engine.stream_append_chunks, 0, rkb, rdb)
-        for c in range(pieces + 1):              # piece c is packed and sent while piece c-1 arrives and is appended
-            if c < pieces:
-                pp = pack(probe_keys[bounds[c]: bounds[c + 1]])
-                recv_p, rounds_p = counts_and_rounds(pp)
-                inflight.append(put_on_the_wire(pp, recv_p, rounds_p, True))
-                del pp
-            if c >= 1:
-                rk, rd = wait(inflight.pop(0))
-                guarded(engine.stream_append_chunks, 1, rk, rd)
-                if timings is not None:
-                    rows_recv += engine.chunk_rows(rd)
-        t2 = time.perf_counter()
-        local_count = guarded(engine.stream_finish) or 0
-    except BaseException:                        # a failure every rank has seen (packing), or one no rank can recover from
-        for sent in inflight:
+    def guard(fn, fail=1):
+        def wrapped(_user, *a):
             try:
-                wait(sent)
-            except Exception:                    # noqa: BLE001
-                pass
-        _abort_stream(engine)
-        raise
-    tot = engine.counts_tensor([local_count, 1 if failed else 0])
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
-    engine.synchronize()
-    t3 = time.perf_counter()
-    total, nfailed = (int(x) for x in tot.tolist())
-    if nfailed:
-        _abort_stream(engine)
-        raise RuntimeError(f"owner shuffle (chunk form): the local join failed on {nfailed} rank(s)" + (f"; this rank: {failed[0]}" if failed else ""))
+                r = fn(*a)
+                return 0 if r is None else r
+            except BaseException as ex:          # noqa: BLE001
+                state["err"] = repr(ex).encode()
+                return fail
+        return wrapped
+
+    def pack_counts(used):
+        for r, u in enumerate(ops.pack_counts()):
+            used[r] = int(u)
+
+    def finish(out):
+        out[0] = int(ops.finish())
+
+    world = ops.world
+    cbs = dict(
+        error=_lib.EngErrorFn(lambda _u: state["err"]),
+        plan=_lib.EngPlanFn(guard(lambda nb_total, nranks: 0 if ops.plan(nb_total, nranks) else 1)),
+        alloc=_lib.EngAllocFn(guard(ops.alloc, fail=None)),
+        release=_lib.EngReleaseFn(guard(ops.release, fail=None)),
+        pack_begin=_lib.EngPackBeginFn(guard(ops.pack_begin)),
+        pack_counts=_lib.EngPackCountsFn(guard(pack_counts)),
+        pack_finish=_lib.EngPackFinishFn(guard(lambda dk, dd: ops.pack_finish([dk[r] for r in range(world)], [dd[r] for r in range(world)]))),
+        open=_lib.EngOpenFn(guard(ops.open)),
+        append=_lib.EngAppendFn(guard(ops.append)),
+        finish=_lib.EngFinishFn(guard(finish)),
+        abort=_lib.EngAbortFn(guard(ops.abort, fail=None)),
+    )
+    keep.append(cbs)
+    return _lib.FjDistEngineOps(None, int(ops.chunk_bytes), cbs["error"], cbs["plan"], cbs["alloc"], cbs["release"], cbs["pack_begin"],
+                                cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"])
+
+
+def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport):
+    """The counting owner shuffle in chunk form through the ONE driver, csrc/fj_dist.hip (fj_dist_join_count): natively over RCCL
+    under the nccl backend; over a callback transport (torch.distributed with host staging: gloo, a transport object) otherwise;
+    with a stand-in engine's callbacks in the CPU test-suite.  Collective; a failure on any rank raises on every rank."""
+    from . import _lib
+    L = _lib.load()
+    t0 = time.perf_counter()
+    cnt = ctypes.c_uint64(0)
+    dt = _lib.FjDistTimings()
+    keep: list = []
+    standin = hasattr(engine, "dist_engine_ops")
+    native = (not standin and transport is None and os.environ.get("FJ_DIST_NATIVE", "1") != "0" and dist.get_backend(group) == "nccl")
+    if native:
+        comm, own = engine.native_comm(dist, group), False
+        form = "chunks (fj_dist_join_count over RCCL)"
+    else:
+        tr = _CallbackTransport(dist, group, "host" if standin else "device", None if standin else engine.device)
+        ops = _engine_ops_struct(engine.dist_engine_ops(tr.world), keep) if standin else None
+        comm = L.fj_dist_comm_from_transport(None if standin else engine.ctx, ctypes.byref(tr.struct), ctypes.byref(ops) if ops is not None else None)
+        if not comm:
+            raise RuntimeError(_lib.last_error())
+        own = True
+        form = "chunks (fj_dist_join_count over a callback transport)"
+    try:
+        if standin:
+            rc = L.fj_dist_join_count(comm, build_keys.data_ptr(), build_keys.numel(), probe_keys.data_ptr(), probe_keys.numel(), pieces, None,
+                                      ctypes.byref(cnt), ctypes.byref(dt))
+        else:
+            tt = engine.torch
+            bk, pk = engine._aligned(build_keys), engine._aligned(probe_keys)
+            with tt.cuda.device(engine.index):
+                rc = L.fj_dist_join_count(comm, bk.data_ptr(), bk.numel(), pk.data_ptr(), pk.numel(), pieces,
+                                          tt.cuda.current_stream(engine.index).cuda_stream, ctypes.byref(cnt), ctypes.byref(dt))
+        if rc:
+            msg = _lib.last_error()
+            if not native and tr.error is not None:
+                raise RuntimeError(f"{msg} ({tr.error!r})")
+            raise RuntimeError(msg)
+    finally:
+        if own:
+            L.fj_dist_comm_destroy(comm)
+    sec = time.perf_counter() - t0
+    if not standin:
+        engine.api._last = dt.local
     if timings is not None:
-        timings.update(split_s=split_s, exchange_s=max(0.0, (t2 - t0) - split_s), join_s=t3 - t2, exchange_rounds=rounds_b, pieces=pieces,
-                       local_build_rows=engine.chunk_rows(rdb), local_probe_rows=rows_recv, local_count=local_count,
-                       prefilter=False, prefilter_mode="off", prefilter_sampled_survivors=None, probe_rows_sent=n,
-                       shuffle_form="chunks")
-    return total, t3 - t0
+        timings.update(strategy="shuffle", shuffle_form=form, split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
+                       join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces), local_build_rows=int(dt.local_build_chunks) * 256,
+                       local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=False, prefilter_mode="off",
+                       prefilter_sampled_survivors=None, probe_rows_sent=probe_keys.numel(), rows_are_chunk_capacity=True,
+                       wire_chunk_bytes=int(dt.wire_chunk_bytes), wire_bytes_sent=int(dt.sent_chunks) * (int(dt.wire_chunk_bytes) + 4))
+    return int(cnt.value), sec
 
 
 # ---- strategy 2: replicate the build side ------------------------------------------------------------------
@@ -893,12 +956,19 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
         # global plan has two or more passes; the owner-scatter form below the small ones and the sender-side precheck
         if (mode == "off" and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
                 and min(int(x[1]) for x in allsz) >= 2 * pieces and engine.shuffle_plan(nb_total, world) is not None):
-            # under RCCL the protocol runs natively (csrc/fj_dist.hip, fj_dist_join_count); _chunk_shuffle_count is the same
-            # protocol over torch.distributed - what gloo, a transport object and the stand-in engines of the CPU tests use
-            if (transport is None and hasattr(engine, "native_count") and os.environ.get("FJ_DIST_NATIVE", "1") != "0"
-                    and dist.get_backend(group) == "nccl"):
-                return engine.native_count(dist, group, build_keys, probe_keys, pieces, timings)
-            return _chunk_shuffle_count(dist, group, engine, world, build_keys, probe_keys, nb_total, np_global, pieces, timings)
+            # ONE driver for every transport: csrc/fj_dist.hip (fj_dist_join_count) - over RCCL under the nccl backend, over
+            # callbacks into torch.distributed under gloo / a transport object, with a stand-in engine in the CPU tests.  A step
+            # that fails on any rank fails on every rank (the driver agrees on it), so all of them fall back together to the
+            # owner-scatter form, whose segments are sized from an owner histogram: the answer to heavily skewed keys (an owner
+            # that receives far more than 1.5x its share overflows the chunk form's pools).
+            try:
+                return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport)
+            except RuntimeError as ex:
+                if os.environ.get("FJ_DIST_NO_FALLBACK"):
+                    raise
+                _abort_stream(engine)
+                if timings is not None:
+                    timings["chunk_form_error"] = str(ex)
         if timings is not None:
             timings["shuffle_form"] = "owner-scatter"
         return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings, prefilter=mode)

@@ -173,33 +173,41 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
 /*
  * Owner shuffle in the shape of SURVEY.md 8(e) (no reference counterpart; radix partitions are independent join units,
  * hash_join.cpp:340-356, :515-525): the FIRST radix pass of the plan for the TOTAL build side is the owner split.
- * Every rank plans for nb_total = all ranks' build rows; pass 1 of that plan has 2^fan_log0 buckets (256 or 512) and bucket
- * b belongs to rank (b * nranks) >> fan_log0.
- *   fj_shuffle_plan          - 0 if the chunk form applies (a plan of two or more passes, at least nranks first-pass buckets:
- *                              build sides above ~2M rows in all); else an error (use fj_owner_split + fj_stream_begin).
- *   fj_shuffle_region_chunks - capacity to give each owner's region when packing n local rows (an even share + 25 % + the
- *                              partial chunks); the output pool is nranks regions of that many 2-KiB chunks.
- *   fj_shuffle_pack          - runs that first pass over n local rows (values too when d_vals != NULL): the chunks of rank r's
- *                              buckets are chunks [r * region_chunks, r * region_chunks + h_used[r]) of d_out_keys (d_out_vals),
- *                              one directory word per chunk in d_out_dir (same indexing).  Synchronous (h_used is valid on
- *                              return); may run while a stream join is open on the context.  A region that overflows
- *                              (skewed keys) is an error: fall back to fj_owner_split.
- * The caller sends rank r its region's used prefix (keys and directory words; RCCL all-to-all) and the owner appends what it
- * received - every sender's piece concatenated, in any order - as level-1 chunk sets:
+ * Every rank plans for nb_total = all ranks' build rows; pass 1 of that plan has 2^fan_log0 buckets and bucket b belongs to
+ * rank (b * nranks) >> fan_log0.  A sender runs that pass over its local rows and rewrites the result for the wire: dense
+ * 256-key chunks, bucket after bucket - so an owner's share is one contiguous range - of fj_shuffle_chunk_bytes() bytes each:
+ * 1792 = 7 bytes per key when the first pass has >= 256 buckets (chunk pools hold a bijective mix of the key, fj_key_mix64,
+ * and a chunk need not carry the 8 top bits its bucket implies: three planes - low words, bits 32..47, bits 48..55), else
+ * 2048; plus one directory word (bucket << 9 | keys) per chunk.
+ *   fj_shuffle_plan        - 0 if the chunk form applies (a plan of two or more passes, at least nranks first-pass buckets:
+ *                            build sides above ~2M rows in all); else an error (use fj_owner_split + fj_stream_begin).
+ *   fj_shuffle_chunk_bytes - bytes per wire chunk under that plan (0: the chunk form does not apply).
+ *   fj_shuffle_pack_begin  - asynchronous on `stream`: the first pass over n local rows (values too when d_vals != NULL), its
+ *                            bookkeeping, and the per-owner chunk counts on their way to the host.  May run while a stream
+ *                            join is open on the context, on another stream.  One piece at a time per context.
+ *   fj_shuffle_pack_counts - waits for those counts: h_used[r] = wire chunks for rank r (exact: skewed keys just make a share
+ *                            larger).  The caller sizes its buffers and tells the receivers.
+ *   fj_shuffle_pack_finish - asynchronous on `stream` (the same stream, or one ordered behind it): writes rank r's chunks to
+ *                            d_dst_chunks[r] (h_used[r] * chunk_bytes bytes, 16-byte aligned), their directory words to
+ *                            d_dst_dir[r] and - pieces with values - 256 values per chunk to d_dst_vals[r].  The pointers may
+ *                            point anywhere: a rank's own share can go straight into its receive buffer.
+ * The owner appends what it received - every sender's share concatenated, in any order - as level-1 chunk sets:
  *   fj_stream_open_shuffled        - as fj_stream_open, for the rows this rank will OWN (bounds; appends = pieces per side)
  *   fj_stream_append_build_chunks /
  *   fj_stream_append_probe_chunks  - chunk lists from the directory words (rewritten in place), then the plan's second pass
- *                                    over the piece; asynchronous on `stream`, the piece stays allocated until the finish
+ *                                    over the piece (it unpacks the wire format in registers); asynchronous on `stream`, the
+ *                                    piece stays allocated until the finish
  *   fj_stream_finish               - remaining passes, join, count (counting joins only).
  */
 int fj_shuffle_plan(size_t nb_total, int nranks, int* fan_log0, int* npass);
-size_t fj_shuffle_region_chunks(size_t n, size_t nb_total, int nranks, int with_vals);
-int fj_shuffle_pack(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks,
-                    uint64_t* d_out_keys, uint64_t* d_out_vals, uint32_t* d_out_dir, size_t region_chunks, uint64_t* h_used, void* stream);
+size_t fj_shuffle_chunk_bytes(size_t nb_total, int nranks);
+int fj_shuffle_pack_begin(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks, void* stream);
+int fj_shuffle_pack_counts(fj_ctx* ctx, uint64_t* h_used);
+int fj_shuffle_pack_finish(fj_ctx* ctx, void* const* d_dst_chunks, uint64_t* const* d_dst_vals, uint32_t* const* d_dst_dir, void* stream);
 int fj_stream_open_shuffled(fj_ctx* ctx, size_t nb_total, int nranks, int rank, size_t nb_bound, int build_appends,
                             size_t np_bound, int probe_appends, void* stream);
-int fj_stream_append_build_chunks(fj_ctx* ctx, const uint64_t* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
-int fj_stream_append_probe_chunks(fj_ctx* ctx, const uint64_t* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
+int fj_stream_append_build_chunks(fj_ctx* ctx, const void* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
+int fj_stream_append_probe_chunks(fj_ctx* ctx, const void* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
 
 /*
  * Sender-side bloom precheck of the owner shuffle (no reference counterpart).  fj_bloom_export: an owner partitions the
@@ -242,30 +250,64 @@ int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error
 /*
  * Native multi-GPU entry (no reference counterpart: the reference is one process, hash_join.cpp:318; SURVEY.md 5 row
  * "Distributed communication backend", 7.1 dist/alltoall): the counting radix join of relations whose rows are block-distributed
- * over the ranks of an RCCL communicator - BASELINE configs[4].  One process per GPU; every rank calls fj_dist_join_count
- * with its LOCAL rows and gets the GLOBAL match count.  The owner shuffle runs in chunk form (above): sizes and per-piece
- * chunk counts travel by ncclAllGather, every owner's region by grouped ncclSend / ncclRecv on a second stream while the
- * next piece is packed and the previous one gets its second radix pass, the count by ncclAllReduce.  RCCL is bound at run
- * time (dlopen of librccl.so.1): a host that never calls these functions does not need it.
- *   fj_dist_unique_id      - rank 0: 128 bytes for the other ranks (any out-of-band channel), as ncclGetUniqueId
- *   fj_dist_comm_create    - every rank, after selecting its device and creating its fj_ctx: ncclCommInitRank inside
- *   fj_dist_comm_from_nccl - or wrap an ncclComm_t the host already has (not destroyed by fj_dist_comm_destroy)
- *   fj_dist_join_count     - collective.  pieces: rounds of the probe exchange (4 is the measured default).  A build side of
- *                            less than ~2M rows in all is refused (one-pass plan: join it on one GPU).  A failure on any rank
- *                            is reported by every rank (non-zero return, fj_last_error()).
+ * over the ranks of a communicator - BASELINE configs[4].  One process per GPU; every rank calls fj_dist_join_count with its
+ * LOCAL rows and gets the GLOBAL match count.  ONE driver (csrc/fj_dist.hip) runs the owner shuffle in chunk form (above) over
+ * whatever moves the bytes: per piece the first radix pass, the per-owner chunk counts all-gathered on a control channel, the
+ * copy into the 7-byte wire format (a rank's own share straight into its receive buffer), the exchange, the owner's second
+ * pass - on three streams, the host blocking once per piece; a failure on any rank is reported by every rank.
+ *   fj_dist_unique_id           - rank 0: 128 bytes for the other ranks (any out-of-band channel), as ncclGetUniqueId
+ *   fj_dist_comm_create         - every rank, after selecting its device and creating its fj_ctx: ncclCommInitRank inside.
+ *                                 RCCL is bound at run time (dlopen of librccl.so.1): a host that never calls this needs neither
+ *                                 the library nor its headers.  Payload: grouped ncclSend / ncclRecv on an exchange stream;
+ *                                 control collectives on a second communicator (ncclCommSplit) so that they do not queue behind
+ *                                 the previous piece's sends.
+ *   fj_dist_comm_from_nccl      - or wrap an ncclComm_t the host already has (not destroyed by fj_dist_comm_destroy)
+ *   fj_dist_comm_from_transport - or bring your own transport: three blocking callbacks (gloo, MPI, a test harness).  With
+ *                                 engine == NULL the rank's work runs on ctx's GPU; a stand-in engine (tests) replaces it,
+ *                                 then ctx may be NULL and "device" pointers are whatever the stand-in's alloc returns.
+ *   fj_dist_join_count          - collective.  pieces: rounds of the probe exchange (4 is the measured default).  A build side
+ *                                 of less than ~2M rows in all is refused (one-pass plan: join it on one GPU).
  */
 typedef struct fj_dist_comm fj_dist_comm;
 typedef struct fj_dist_timings {
-    double total_ms, split_ms, exchange_ms, join_ms;   /* host wall clock of this rank: whole step; packing (first radix pass);
-                                                          the rest up to the local join's finish; finish + all-reduce */
+    double total_ms, split_ms, exchange_ms, join_ms;   /* host wall clock of this rank: whole step; waiting for the packing passes'
+                                                          counts; the rest up to the local join's finish; finish + all-reduce */
     uint64_t local_count;                              /* matches this rank found in what it owns                 */
-    uint64_t local_build_chunks, local_probe_chunks;   /* 256-key chunks this rank received                        */
-    int pieces, nranks, fan_log0, reserved;
+    uint64_t local_build_chunks, local_probe_chunks;   /* 256-key wire chunks this rank received (own share included) */
+    uint64_t sent_chunks;                              /* ... and put on the links (own share excluded)            */
+    int pieces, nranks, fan_log0, wire_chunk_bytes;    /* wire_chunk_bytes: 1792 (7 bytes per key) or 2048         */
     fj_timings local;                                  /* device timings of this rank's local join (fj_stream_finish) */
 } fj_dist_timings;
+typedef struct fj_dist_transport {
+    void* user;
+    int nranks, rank;
+    int (*all_gather_u64)(void* user, const uint64_t* v, int n, uint64_t* out /* [nranks][n], rank-major */);
+    int (*all_reduce_sum_u64)(void* user, uint64_t* v, int n);
+    /* all-to-all of byte ranges that live in device memory (the driver has finished writing them): for part p < nparts and
+     * peer r, send_bytes[p * nranks + r] bytes at send_ptr[...] go to r, recv_bytes[...] bytes from r land at recv_ptr[...];
+     * returns once everything has landed.  Zero-byte entries (null pointers) are skipped on both sides. */
+    int (*all_to_all_bytes)(void* user, int nparts, const void* const* send_ptr, const uint64_t* send_bytes,
+                            void* const* recv_ptr, const uint64_t* recv_bytes);
+} fj_dist_transport;
+typedef struct fj_dist_engine_ops {   /* a stand-in for the rank's own work (the CPU test-suite); 0 = success everywhere */
+    void* user;
+    size_t chunk_bytes;                                /* bytes per wire chunk the stand-in produces and consumes */
+    const char* (*error)(void* user);
+    int (*plan)(void* user, uint64_t nb_total, int nranks);
+    void* (*alloc)(void* user, size_t bytes);
+    void (*release)(void* user, void* p);
+    int (*pack_begin)(void* user, const void* rows, uint64_t n, uint64_t nb_total, int nranks);
+    int (*pack_counts)(void* user, uint64_t* used);
+    int (*pack_finish)(void* user, void* const* dst_chunks, uint32_t* const* dst_dir);
+    int (*open)(void* user, uint64_t nb_total, int nranks, int rank, uint64_t nb_bound, uint64_t np_bound, int pieces);
+    int (*append)(void* user, int side, const void* chunks, uint32_t* dir, uint64_t nchunks);
+    int (*finish)(void* user, uint64_t* count);
+    void (*abort)(void* user);
+} fj_dist_engine_ops;
 int fj_dist_unique_id(char* out128);
 fj_dist_comm* fj_dist_comm_create(fj_ctx* ctx, const char* unique_id128, int nranks, int rank);
 fj_dist_comm* fj_dist_comm_from_nccl(fj_ctx* ctx, void* nccl_comm);
+fj_dist_comm* fj_dist_comm_from_transport(fj_ctx* ctx, const fj_dist_transport* transport, const fj_dist_engine_ops* engine);
 void fj_dist_comm_destroy(fj_dist_comm* comm);
 int fj_dist_comm_rank(const fj_dist_comm* comm);
 int fj_dist_comm_size(const fj_dist_comm* comm);
@@ -296,6 +338,7 @@ int fj_device_malloc(void** p, size_t bytes);
 int fj_device_free(void* p);
 int fj_memcpy_h2d(void* d, const void* h, size_t bytes);
 int fj_memcpy_d2h(void* h, const void* d, size_t bytes);
+int fj_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 
 #ifdef __cplusplus
 }

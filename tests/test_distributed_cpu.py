@@ -77,52 +77,15 @@ class OracleEngine:
         assert c == list(counts)
         return out
 
-    # stand-ins for the chunk form of the owner shuffle (fj_shuffle_pack / fj_stream_open_shuffled / fj_stream_append_*_chunks):
-    # 32 first-pass buckets from the top hash bits, bucket b belongs to rank (b * world) >> 5; chunks of up to 256 keys with a
-    # directory word (bucket << 9 | count) each, deliberately ragged (200-key chunks, an unused id per owner)
-    _F0LOG = 5
-
-    def empty_i32(self, n):
-        return torch.empty(n, dtype=torch.int32)
+    # stand-in for the chunk form of the owner shuffle: the rank's own work behind the C++ driver (csrc/fj_dist.hip runs the
+    # protocol; fj_dist_engine_ops callbacks do what fj_shuffle_pack_* / fj_stream_open_shuffled / fj_stream_append_*_chunks do
+    # on a GPU).  32 first-pass buckets from the top hash bits, bucket b belongs to rank (b * world) >> 5; wire chunks = 2048
+    # bytes = 256 raw int64 keys, deliberately ragged (200-key chunks) with a directory word (bucket << 9 | count) each.
+    def dist_engine_ops(self, world):
+        return _StandInOps(self, world)
 
     def shuffle_plan(self, nb_total, world):
-        return self._F0LOG if nb_total >= 10000 and world <= 32 else None
-
-    def shuffle_pack(self, keys, vals, nb_total, world):
-        assert vals is None
-        k = keys.numpy().view(np.uint64)
-        b = (_fmix64(k.copy()) >> np.uint64(64 - self._F0LOG)).astype(np.int64)
-        region = k.size // 200 + 2 * 32 + 4
-        pool = np.zeros(world * region * 256, dtype=np.int64)
-        dirw = np.full(world * region, -1, dtype=np.int32)
-        used = [1] * world                                  # id 0 of every region stays unused (directory word: all ones)
-        for bb in range(32):
-            rows, o = k[b == bb].view(np.int64), (bb * world) >> self._F0LOG
-            for i in range(0, rows.size, 200):
-                ch = rows[i: i + 200]
-                cid = o * region + used[o]
-                pool[cid * 256: cid * 256 + ch.size] = ch
-                dirw[cid] = (bb << 9) | ch.size
-                used[o] += 1
-        return torch.from_numpy(pool), None, torch.from_numpy(dirw), region, used
-
-    def stream_open_shuffled(self, nb_total, world, rank, nb_bound, build_appends, np_bound, probe_appends):
-        self._b = None; self._bp = []; self._pieces = []; self._closed = False
-        self._chunks = {0: [], 1: []}; self._left = {0: build_appends, 1: probe_appends}; self._cbound = {0: nb_bound, 1: np_bound}
-        self._mine = [bb for bb in range(32) if (bb * world) >> self._F0LOG == rank]
-
-    def stream_append_chunks(self, side, chunks, dirw):
-        assert self._left[side] > 0 and chunks.numel() == dirw.numel() * 256
-        self._left[side] -= 1
-        d, c = dirw.numpy(), chunks.numpy().reshape(-1, 256)
-        for i in np.nonzero(d != -1)[0]:
-            assert (int(d[i]) >> 9) in self._mine and 1 <= (int(d[i]) & 0x1FF) <= 256
-            self._chunks[side].append(c[i, : int(d[i]) & 0x1FF].copy())
-        assert sum(x.size for x in self._chunks[side]) <= self._cbound[side]
-
-    def chunk_rows(self, dirw):
-        d = dirw.numpy()
-        return int((d[d != -1] & 0x1FF).sum())
+        return 5 if nb_total >= 10000 and world <= 32 else None
 
     def stream_begin(self, bk, bv, np_bound, max_appends, hash_top_bits):
         self._b = (bk, bv); self._pieces = []; self._bound = np_bound; self._max = max_appends; self._closed = False
@@ -145,11 +108,6 @@ class OracleEngine:
         assert len(self._pieces) <= self._max and sum(p.numel() for p in self._pieces) <= self._bound
 
     def stream_finish(self):
-        if getattr(self, "_chunks", None) is not None and (self._chunks[0] or self._chunks[1]):
-            cat = lambda xs: np.concatenate(xs) if xs else np.empty(0, dtype=np.int64)
-            bk, pk = cat(self._chunks[0]), cat(self._chunks[1])
-            self._chunks = None
-            return self.O.c_join(bk, np.zeros_like(bk), pk, algo="radix", threads=2)[0]
         pk = torch.cat(self._pieces) if self._pieces else torch.empty(0, dtype=torch.int64)
         assert pk.numel() == self._bound
         if self._b is None:                     # replicate strategy: build keys arrived in pieces, no values
@@ -169,6 +127,96 @@ class OracleEngine:
         pass
 
 
+class _StandInOps:
+    """fj_dist_engine_ops of the CPU tests: "device memory" is host memory, rows and chunks are NumPy views of raw pointers."""
+    chunk_bytes = 2048
+    F0LOG = 5
+
+    def __init__(self, eng, world):
+        import ctypes
+        self.ct, self.O, self.world = ctypes, eng.O, world
+        self.bufs = {}
+        self.packed = None
+        self.npacks = 0
+        # test hook FJ_TEST_FAIL = "pack:<rank>" / "append:<rank>": that rank's third packing pass / second probe append fails
+        what, _, who = os.environ.get("FJ_TEST_FAIL", ":").partition(":")
+        self.fail = what if who != "" and int(who) == dist.get_rank() else ""
+
+    def _view(self, ptr, n, dtype):
+        if n == 0:
+            return np.empty(0, dtype=dtype)
+        return np.frombuffer((self.ct.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype)
+
+    def plan(self, nb_total, nranks):
+        return nb_total >= 10000 and nranks <= 32
+
+    def alloc(self, nbytes):
+        a = np.zeros(nbytes + 64, dtype=np.uint8)
+        addr = (a.ctypes.data + 63) & ~63
+        self.bufs[addr] = a
+        return addr
+
+    def release(self, ptr):
+        self.bufs.pop(ptr, None)
+
+    def pack_begin(self, rows, n, nb_total, nranks):
+        assert nranks == self.world and self.packed is None
+        self.npacks += 1
+        if self.fail == "pack" and self.npacks == 3:
+            raise RuntimeError("injected packing failure")
+        k = self._view(rows, n, np.uint64).copy()
+        b = (_fmix64(k.copy()) >> np.uint64(64 - self.F0LOG)).astype(np.int64)
+        per = [[] for _ in range(nranks)]                      # per owner: (bucket, keys of one chunk)
+        for bb in range(32):
+            rws, o = k[b == bb].view(np.int64), (bb * nranks) >> self.F0LOG
+            for i in range(0, rws.size, 200):
+                per[o].append((bb, rws[i: i + 200]))
+        self.packed = per
+
+    def pack_counts(self):
+        return [len(x) for x in self.packed]
+
+    def pack_finish(self, dst_chunks, dst_dir):
+        for o, chunks in enumerate(self.packed):
+            if not chunks:
+                continue
+            ck = self._view(dst_chunks[o], len(chunks) * 256, np.int64).reshape(-1, 256)
+            dw = self._view(dst_dir[o], len(chunks), np.int32)
+            for i, (bb, rws) in enumerate(chunks):
+                ck[i, : rws.size] = rws
+                ck[i, rws.size:] = -1
+                dw[i] = (bb << 9) | rws.size
+        self.packed = None
+
+    def open(self, nb_total, nranks, rank, nb_bound, np_bound, pieces):
+        self.mine = [bb for bb in range(32) if (bb * nranks) >> self.F0LOG == rank]
+        self.chunks = {0: [], 1: []}
+        self.left = {0: 1, 1: pieces}
+        self.bound = {0: nb_bound, 1: np_bound}
+
+    def append(self, side, chunks, dirw, nchunks):
+        assert self.left[side] > 0
+        self.left[side] -= 1
+        if self.fail == "append" and side == 1 and self.left[1] == 2:
+            raise RuntimeError("injected append failure")
+        d, c = self._view(dirw, nchunks, np.int32), self._view(chunks, nchunks * 256, np.int64).reshape(-1, 256)
+        for i in range(nchunks):
+            assert (int(d[i]) >> 9) in self.mine and 1 <= (int(d[i]) & 0x1FF) <= 256
+            self.chunks[side].append(c[i, : int(d[i]) & 0x1FF].copy())
+        assert sum(x.size for x in self.chunks[side]) <= self.bound[side]
+
+    def finish(self):
+        cat = lambda xs: np.concatenate(xs) if xs else np.empty(0, dtype=np.int64)
+        bk, pk = cat(self.chunks[0]), cat(self.chunks[1])
+        self.chunks = None
+        if bk.size == 0 or pk.size == 0:
+            return 0
+        return self.O.c_join(bk, np.zeros_like(bk), pk, algo="radix", threads=2)[0]
+
+    def abort(self):
+        self.chunks = None
+
+
 def _worker(rank, world, port, nb, npk, q, strategy):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -180,6 +228,8 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     os.environ["FJ_DIST_PREFILTER"] = {"prefilter": "1", "prefilterauto": "auto", "prefilterdeclined": "auto"}.get(variant, "0")
     os.environ["FJ_DIST_STRATEGY"] = strategy
     os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if variant == "scatter" else "1"
+    if variant in ("packfail", "appendfail"):    # one rank's packing pass / local join fails inside the C++ driver: EVERY rank sees the failure
+        os.environ["FJ_TEST_FAIL"] = variant[:-4] + ":" + str(world - 1)
     if strategy == "replicate":
         os.environ["FJ_REPLICATE_PIECES"] = "3"
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -215,8 +265,16 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         res = distributed_join(tb, tv, tp, materialize=True, return_arrays=True, engine=OracleEngine(), timings=t)
         exp = torch.tensor([exp_local]); dist.all_reduce(exp)
         tc = {}
+        if variant in ("packfail", "appendfail"):
+            os.environ["FJ_DIST_NO_FALLBACK"] = "1"
+            with pytest.raises(RuntimeError, match="packing a piece failed on 1 rank" if variant == "packfail" else "the local join failed on 1 rank") as ei:
+                distributed_join(tb, tv, tp, engine=OracleEngine())
+            assert ("injected" in str(ei.value)) == (rank == world - 1)       # the failing rank says why, the others that somebody failed
+            del os.environ["FJ_DIST_NO_FALLBACK"]
         cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)        # counting: pipelined exchange
         assert cnt == int(exp.item()) and tc["strategy"] == t["strategy"] == strategy
+        if variant in ("packfail", "appendfail"):    # ... and without FJ_DIST_NO_FALLBACK all ranks rerun in the owner-scatter form together
+            assert "failed on 1 rank" in tc["chunk_form_error"] and tc["shuffle_form"] == "owner-scatter"
         keys = res[2].numpy().view(np.uint64)
         assert tc.get("prefilter", False) == prefilter
         if variant.startswith("prefilter"):
@@ -233,9 +291,11 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         elif strategy == "shuffle" and variant == "":
             # the counting join took the chunk form (its owners are whole first-pass buckets: another split of the hash range than
             # the owner-scatter form the materialising join uses, so only the totals agree)
-            assert tc["shuffle_form"] == "chunks" and tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
-            glob = torch.tensor([tc["local_probe_rows"], tc["local_build_rows"]]); dist.all_reduce(glob)
-            assert glob.tolist() == [npk, nb]
+            assert tc["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport") and tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
+            assert tc["wire_chunk_bytes"] == 2048 and "chunk_form_error" not in tc
+            # (the driver reports received CHUNKS x 256: the stand-in's ragged 200-key chunks count as whole ones)
+            glob = torch.tensor([tc["local_probe_rows"], tc["local_build_rows"], tc["local_count"]]); dist.all_reduce(glob)
+            assert npk <= glob[0] <= 2.5 * npk and nb <= glob[1] <= 2.5 * nb and int(glob[2]) == int(exp.item())
         else:
             assert tc["local_probe_rows"] == t["local_probe_rows"]
             if strategy == "shuffle":
@@ -259,7 +319,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
+@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_appendfail", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
                                       "replicate_small_messages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):
