@@ -487,13 +487,16 @@ def main() -> None:
     elif part_ms:
         # multi-GPU: the first probe-side pass over what this rank received (one launch per piece / per step)
         avg_ms = mean(part_ms)
-        alg_bytes = 16.0 * units_per_launch[0]
+        # chunk form: the owner's pass reads the wire format (7 bytes per key when wire_chunk_bytes == 1792) and writes 8
+        bpu = 8.0 + (float(dlast["wire_chunk_bytes"]) / 256.0 if dlast.get("wire_chunk_bytes") else 8.0)
+        alg_bytes = bpu * units_per_launch[0]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (probe-side radix pass)",
+        roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (the owner's radix pass over a received piece)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
                 "frac_of_this_pools_copy_rate": round(achieved / HBM_POOL_COPY_GBS, 4),
-                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": 16, "units_per_launch": units_per_launch[0],
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": bpu, "units_per_launch": units_per_launch[0],
+                "note": "launch time by HIP events on the join stream: at N > 1 the pass shares the GPU with the next piece's packing kernels (other streams), so this is an upper bound of the kernel's own time",
                 "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": None}
     else:
         # non-partitioned workloads (one table in HBM): the probe kernel dominates; 8 B per probe key

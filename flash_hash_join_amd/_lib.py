@@ -26,7 +26,7 @@ SYMBOLS = [
     "fj_shuffle_plan", "fj_shuffle_chunk_bytes", "fj_shuffle_pack_begin", "fj_shuffle_pack_counts", "fj_shuffle_pack_finish", "fj_stream_open_shuffled",
     "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
     "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_from_transport", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
-    "fj_dist_join_count",
+    "fj_dist_join_count", "fj_dist_join",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
     "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h", "fj_memcpy_d2d",
 ]
@@ -161,8 +161,8 @@ def load() -> ctypes.CDLL:
     L.fj_shuffle_pack_begin.restype = i32; L.fj_shuffle_pack_begin.argtypes = [vp, vp, vp, sz, sz, i32, vp]
     L.fj_shuffle_pack_counts.restype = i32; L.fj_shuffle_pack_counts.argtypes = [vp, pu64]
     L.fj_shuffle_pack_finish.restype = i32; L.fj_shuffle_pack_finish.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
-    L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, vp]
-    L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, sz, vp]
+    L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, i32, vp]
+    L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, vp, sz, vp]
     L.fj_stream_append_probe_chunks.restype = i32; L.fj_stream_append_probe_chunks.argtypes = [vp, vp, vp, sz, vp]
     L.fj_dist_comm_from_transport.restype = vp
     L.fj_dist_comm_from_transport.argtypes = [vp, ctypes.POINTER(FjDistTransport), ctypes.POINTER(FjDistEngineOps)]
@@ -173,6 +173,7 @@ def load() -> ctypes.CDLL:
     L.fj_dist_comm_rank.restype = i32; L.fj_dist_comm_rank.argtypes = [vp]
     L.fj_dist_comm_size.restype = i32; L.fj_dist_comm_size.argtypes = [vp]
     L.fj_dist_join_count.restype = i32; L.fj_dist_join_count.argtypes = [vp, vp, sz, vp, sz, i32, vp, pu64, ctypes.POINTER(FjDistTimings)]
+    L.fj_dist_join.restype = i32; L.fj_dist_join.argtypes = [vp, vp, vp, sz, vp, sz, i32, i32, vp, pu64, pu64, ctypes.POINTER(FjDistTimings)]
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]
     L.fj_generate_probe.restype = i32
     L.fj_generate_probe.argtypes = [vp, vp, u64, sz, u64, u64, ctypes.c_uint32, pu64, vp]

@@ -184,7 +184,14 @@ def join_device(algo: int, bloom: int, materialize: int, bk, bv, pk, return_arra
             n = int(cnt.value)
             _last = t
             if return_arrays:
-                return n, t.total_ms * 1e-3, ok[:n], ov[:n]
+                # the buffers hold room for ANY result; a view of their first n rows would keep 16 bytes per PROBE row alive for as
+                # long as the caller keeps the pairs (16 GB at config 3 for 8 GB of pairs).  Unless the result fills most of them,
+                # hand back exact-size copies (one device-to-device copy of n rows) and let the big buffers go.
+                if n * 4 < pk.numel() * 3:
+                    ok, ov = ok[:n].clone(), ov[:n].clone()
+                else:
+                    ok, ov = ok[:n], ov[:n]
+                return n, t.total_ms * 1e-3, ok, ov
             return n, t.total_ms * 1e-3
         check(L.fj_join_device(ctx, algo, bloom, materialize, bk.data_ptr(), bv.data_ptr(), bk.numel(), pk.data_ptr(),
                                pk.numel(), stream, hash_top_bits, ctypes.byref(cnt), None, None, 0, ctypes.byref(t)))

@@ -116,11 +116,11 @@ struct Engine {
     virtual int plan(size_t nb_total, int nranks, size_t* chunk_bytes) = 0;     // same verdict on every rank (same arguments)
     virtual void* alloc(size_t bytes) = 0;
     virtual void release(void* p) = 0;
-    virtual int pack_begin(const void* rows, size_t n, size_t nb_total, int nranks) = 0;                // asynchronous (ordered behind the previous pack_finish)
+    virtual int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks) = 0;   // asynchronous (ordered behind the previous pack_finish); vals: null = keys only
     virtual int pack_counts(unsigned long long* used) = 0;                      // blocks until the counts are known
-    virtual int pack_finish(void* const* dst_chunks, uint32_t* const* dst_dir, Token after, Token* done) = 0;
-    virtual int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces) = 0;
-    virtual int append(int side, const void* chunks, uint32_t* dir, size_t nchunks, Token after) = 0;
+    virtual int pack_finish(void* const* dst_chunks, uint64_t* const* dst_vals, uint32_t* const* dst_dir, Token after, Token* done) = 0;
+    virtual int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces, bool with_vals) = 0;
+    virtual int append(int side, const void* chunks, const uint64_t* vals, uint32_t* dir, size_t nchunks, Token after) = 0;
     virtual int finish(uint64_t* count, fj_timings* lt) = 0;
     virtual void abort() = 0;
     virtual int drain() = 0;                                                    // everything this engine enqueued has finished
@@ -144,25 +144,25 @@ struct HipEngine : Engine {
     }
     void* alloc(size_t bytes) override { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
     void release(void* p) override { if (p) (void)hipFree(p); }
-    int pack_begin(const void* rows, size_t n, size_t nb_total, int nranks) override {
-        return fj_shuffle_pack_begin(ctx, (const uint64_t*)rows, nullptr, n, nb_total, nranks, ps);
+    int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks) override {
+        return fj_shuffle_pack_begin(ctx, (const uint64_t*)rows, (const uint64_t*)vals, n, nb_total, nranks, ps);
     }
     int pack_counts(unsigned long long* used) override { return fj_shuffle_pack_counts(ctx, (uint64_t*)used); }
-    int pack_finish(void* const* dk, uint32_t* const* dd, Token after, Token* done) override {
+    int pack_finish(void* const* dk, uint64_t* const* dv, uint32_t* const* dd, Token after, Token* done) override {
         if (after) DHIP(hipStreamWaitEvent(ps, (hipEvent_t)after, 0));
-        if (fj_shuffle_pack_finish(ctx, dk, nullptr, dd, ps)) return 1;
+        if (fj_shuffle_pack_finish(ctx, dk, dv, dd, ps)) return 1;
         hipEvent_t e = ev_pack[evi ^= 1];
         DHIP(hipEventRecord(e, ps));
         *done = e;
         return 0;
     }
-    int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces) override {
-        return fj_stream_open_shuffled(ctx, nb_total, nranks, rank, nb_bound, 1, np_bound, pieces, js);
+    int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces, bool with_vals) override {
+        return fj_stream_open_shuffled(ctx, nb_total, nranks, rank, nb_bound, 1, np_bound, pieces, with_vals ? 1 : 0, js);
     }
-    int append(int side, const void* chunks, uint32_t* dir, size_t n, Token after) override {
+    int append(int side, const void* chunks, const uint64_t* vals, uint32_t* dir, size_t n, Token after) override {
         if (side && getenv("FJ_DIST_INJECT_FAIL")) return derr("injected failure of a local append (test hook FJ_DIST_INJECT_FAIL)");
         if (after) DHIP(hipStreamWaitEvent(js, (hipEvent_t)after, 0));
-        return side ? fj_stream_append_probe_chunks(ctx, chunks, dir, n, js) : fj_stream_append_build_chunks(ctx, chunks, dir, n, js);
+        return side ? fj_stream_append_probe_chunks(ctx, chunks, dir, n, js) : fj_stream_append_build_chunks(ctx, chunks, vals, dir, n, js);
     }
     int finish(uint64_t* count, fj_timings* lt) override { return fj_stream_finish(ctx, js, count, lt); }
     void abort() override { (void)fj_stream_abort(ctx); }
@@ -176,11 +176,14 @@ struct CallbackEngine : Engine {                             // a caller's stand
     int plan(size_t nb_total, int nranks, size_t* cb) override { if (o.plan(o.user, nb_total, nranks)) return fail("plan"); *cb = o.chunk_bytes; return 0; }
     void* alloc(size_t bytes) override { return o.alloc(o.user, bytes); }
     void release(void* p) override { if (p) o.release(o.user, p); }
-    int pack_begin(const void* rows, size_t n, size_t nb_total, int nranks) override { return o.pack_begin(o.user, rows, n, nb_total, nranks) ? fail("pack_begin") : 0; }
+    int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks) override {
+        if (vals) return derr("fj_dist: the stand-in engine carries no values");
+        return o.pack_begin(o.user, rows, n, nb_total, nranks) ? fail("pack_begin") : 0;
+    }
     int pack_counts(unsigned long long* used) override { return o.pack_counts(o.user, (uint64_t*)used) ? fail("pack_counts") : 0; }
-    int pack_finish(void* const* dk, uint32_t* const* dd, Token, Token* done) override { *done = nullptr; return o.pack_finish(o.user, dk, dd) ? fail("pack_finish") : 0; }
-    int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces) override { return o.open(o.user, nb_total, nranks, rank, nb_bound, np_bound, pieces) ? fail("open") : 0; }
-    int append(int side, const void* chunks, uint32_t* dir, size_t n, Token) override { return o.append(o.user, side, chunks, dir, n) ? fail("append") : 0; }
+    int pack_finish(void* const* dk, uint64_t* const*, uint32_t* const* dd, Token, Token* done) override { *done = nullptr; return o.pack_finish(o.user, dk, dd) ? fail("pack_finish") : 0; }
+    int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces, bool) override { return o.open(o.user, nb_total, nranks, rank, nb_bound, np_bound, pieces) ? fail("open") : 0; }
+    int append(int side, const void* chunks, const uint64_t*, uint32_t* dir, size_t n, Token) override { return o.append(o.user, side, chunks, dir, n) ? fail("append") : 0; }
     int finish(uint64_t* count, fj_timings* lt) override { memset(lt, 0, sizeof *lt); return o.finish(o.user, count) ? fail("finish") : 0; }
     void abort() override { if (o.abort) o.abort(o.user); }
     int drain() override { return 0; }
@@ -192,11 +195,11 @@ struct Net {
     virtual ~Net() {}
     virtual int all_gather(const unsigned long long* v, int n, unsigned long long* out) = 0;     // blocking
     virtual int all_reduce(unsigned long long* v, int n) = 0;                                    // blocking, sum
-    // two parts (chunks, directory words): sp[p * nranks + r] / sb[...] = what goes to rank r, rp / rb = what arrives from it.
+    // nparts parts (chunks, directory words[, values]): sp[p * nranks + r] / sb[...] = what goes to rank r, rp / rb = what arrives from it.
     // Starts after `after`; *done = the data have landed (null: they have when the call returns).
     // `largest` = the largest single message anywhere in the group (every rank passes the same value: both ends of a message
     // must cut it into the same rounds).
-    virtual int exchange(const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) = 0;
+    virtual int exchange(int nparts, const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) = 0;
     virtual int drain() = 0;
     virtual bool loopback() const { return false; }          // test hook: a rank's own share travels through the transport too
     virtual void begin_step() {}
@@ -263,20 +266,20 @@ struct RcclNet : Net {
     bool loopback() const override { return loop; }
     void begin_step() override { const char* e = getenv("FJ_DIST_LOOPBACK"); loop = e && atoi(e) != 0; }      // test hook: a rank's own share travels through ncclSend / ncclRecv too
     bool is_peer(int r) const { return r != rank || loop; }
-    int exchange(const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) override {
+    int exchange(int nparts, const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) override {
         Rccl* R = rccl();
         if (after) DHIP(hipStreamWaitEvent(xs, (hipEvent_t)after, 0));
         bool any = false;
-        for (int i = 0; i < 2 * nranks; ++i) if (is_peer(i % nranks)) any = any || sb[i] || rb[i];
+        for (int i = 0; i < nparts * nranks; ++i) if (is_peer(i % nranks)) any = any || sb[i] || rb[i];
         const size_t rounds = std::max<size_t>(1, (largest + MAX_MSG_BYTES - 1) / MAX_MSG_BYTES);
         auto cut = [&](size_t bytes, size_t r) { return bytes / rounds * r + std::min(r, bytes % rounds); };     // round r of a message = [cut(r), cut(r + 1))
         for (size_t r = 0; any && r < rounds; ++r) {
             DNCCL(R->GroupStart());
-            for (int i = 0; i < 2 * nranks; ++i) {
+            for (int i = 0; i < nparts * nranks; ++i) {
                 const int d = i % nranks;
                 if (is_peer(d) && cut(sb[i], r + 1) > cut(sb[i], r)) DNCCL(R->Send((const char*)sp[i] + cut(sb[i], r), cut(sb[i], r + 1) - cut(sb[i], r), ncclUint8, d, data, xs));
             }
-            for (int i = 0; i < 2 * nranks; ++i) {
+            for (int i = 0; i < nparts * nranks; ++i) {
                 const int q = i % nranks;
                 if (is_peer(q) && cut(rb[i], r + 1) > cut(rb[i], r)) DNCCL(R->Recv((char*)rp[i] + cut(rb[i], r), cut(rb[i], r + 1) - cut(rb[i], r), ncclUint8, q, data, xs));
             }
@@ -299,11 +302,11 @@ struct CallbackNet : Net {                                   // a caller's block
     int all_reduce(unsigned long long* v, int n) override {
         return t.all_reduce_sum_u64(t.user, (uint64_t*)v, n) ? derr("fj_dist: the transport's all_reduce_sum_u64 failed") : 0;
     }
-    int exchange(const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t, Token after, Token* done, int) override {
+    int exchange(int nparts, const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t, Token after, Token* done, int) override {
         if (after) DHIP(hipEventSynchronize((hipEvent_t)after));          // the transport reads the buffers from the host side
-        std::vector<uint64_t> s64(sb, sb + 2 * nranks), r64(rb, rb + 2 * nranks);
+        std::vector<uint64_t> s64(sb, sb + nparts * nranks), r64(rb, rb + nparts * nranks);
         *done = nullptr;
-        return t.all_to_all_bytes(t.user, 2, sp, s64.data(), rp, r64.data()) ? derr("fj_dist: the transport's all_to_all_bytes failed") : 0;
+        return t.all_to_all_bytes(t.user, nparts, sp, s64.data(), rp, r64.data()) ? derr("fj_dist: the transport's all_to_all_bytes failed") : 0;
     }
     int drain() override { return 0; }
 };
@@ -316,8 +319,8 @@ struct fj_dist_comm {
     std::unique_ptr<Net> net;
     std::unique_ptr<Engine> eng;
     HipEngine* hip = nullptr;                               // == eng.get() when the engine is the HIP one
-    DBuf pool_k[2], pool_d[2];                              // send pools (alternating per piece)
-    DBuf recv_k[MAX_PIECES + 1], recv_d[MAX_PIECES + 1];    // what arrives: [0] build side, [1 + c] probe piece c
+    DBuf pool_k[2], pool_d[2], pool_v;                      // send pools (alternating per piece; values: the build piece only)
+    DBuf recv_k[MAX_PIECES + 1], recv_d[MAX_PIECES + 1], recv_v;   // what arrives: [0] build side, [1 + c] probe piece c
     int grow(DBuf& b, size_t bytes) {
         if (bytes == 0) bytes = 16;
         if (b.bytes >= bytes) return 0;
@@ -331,6 +334,7 @@ struct fj_dist_comm {
     void free_all() {
         for (auto* arr : {pool_k, pool_d}) for (int i = 0; i < 2; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
         for (auto* arr : {recv_k, recv_d}) for (int i = 0; i <= MAX_PIECES; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
+        for (DBuf* b : {&pool_v, &recv_v}) if (b->p) { eng->release(b->p); *b = DBuf(); }
     }
 };
 
@@ -406,7 +410,14 @@ int fj_dist_comm_size(const fj_dist_comm* dc) { return dc ? dc->net->nranks : 0;
 
 int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                        void* stream, uint64_t* out_global_count, fj_dist_timings* timings) {
+    return fj_dist_join(dc, d_build_keys, nullptr, nb, d_probe_keys, np, pieces, 0, stream, out_global_count, nullptr, timings);
+}
+
+int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
+                 int materialize, void* stream, uint64_t* out_global_count, uint64_t* out_local_count, fj_dist_timings* timings) {
     if (!dc) return derr("fj_dist_join_count: null communicator");
+    if (materialize && (!dc->hip || (nb && !d_build_vals) || ((uintptr_t)d_build_vals & 15))) return derr("fj_dist_join: a materialising join needs the HIP engine and 16-byte aligned build values");
+    const bool mat = materialize != 0;
     if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: pieces must be 1..%d", MAX_PIECES);
     if ((nb && !d_build_keys) || (np && !d_probe_keys) || (((uintptr_t)d_build_keys | (uintptr_t)d_probe_keys) & 15)) return derr("fj_dist_join_count: null or misaligned input");
     Net& net = *dc->net; Engine& eng = *dc->eng;
@@ -415,6 +426,10 @@ int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     double split_ms = 0;
+    // FJ_DIST_TRACE=1: host-side time stamps of this rank's step on stderr (where does the host spend its time between the launches)
+    const bool trace = getenv("FJ_DIST_TRACE") != nullptr;
+    std::vector<std::pair<const char*, double>> marks;
+    auto mark = [&](const char* what) { if (trace) marks.emplace_back(what, ms_since(t0)); };
 
     // relation sizes of every rank: one plan for everybody
     std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 2));
@@ -433,20 +448,23 @@ int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb
     // every exit after the first enqueue drains this rank's streams and drops an open stream join
     auto bail = [&](const std::string& why) { (void)net.drain(); (void)eng.drain(); if (opened) eng.abort(); return derr("%s", why.c_str()); };
 
-    struct Piece { void* rk = nullptr; uint32_t* rd = nullptr; size_t chunks = 0; Token done = nullptr; };
+    struct Piece { void* rk = nullptr; uint32_t* rd = nullptr; uint64_t* rv = nullptr; size_t chunks = 0; Token done = nullptr; };
     std::vector<unsigned long long> used(N), recv_n(N);
     size_t sent_chunks = 0;                                   // chunks this rank put on the links (all pieces)
     Token pool_free[2] = {nullptr, nullptr};                  // the exchange that last read send pool [slot]
     // counts -> agreement -> buffers -> agreement -> copy into the wire format -> exchange   (pack_begin has been issued)
-    auto finish_piece = [&](bool begun_ok, int pslot, int rslot, Piece* out) -> int {
+    auto finish_piece = [&](bool begun_ok, int pslot, int rslot, bool vals, Piece* out) -> int {
         const auto tp = std::chrono::steady_clock::now();
+        mark("finish_piece");
         bool ok = begun_ok && eng.pack_counts(used.data()) == 0;
         const std::string why = ok ? "" : fj_last_error();
         split_ms += ms_since(tp);
+        mark(" counts known");
         std::vector<unsigned long long> v(N + 1);
         for (int r = 0; r < N; ++r) v[r] = ok ? used[r] : 0;
         v[N] = ok ? 0 : FAIL;
         if (net.all_gather(v.data(), N + 1, m.data())) return bail(fj_last_error());
+        mark(" all-gathered");
         int nfail = 0;
         size_t total = 0, out_chunks = 0, largest = 0;
         for (int q = 0; q < N; ++q) {
@@ -459,34 +477,45 @@ int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb
         for (int d = 0; d < N; ++d) if (d != me || loop) out_chunks += (size_t)used[d];
         sent_chunks += out_chunks;
         unsigned long long bad = (dc->grow(dc->recv_k[rslot], total * CB) || dc->grow(dc->recv_d[rslot], total * 4) ||
-                                  dc->grow(dc->pool_k[pslot], out_chunks * CB) || dc->grow(dc->pool_d[pslot], out_chunks * 4)) ? 1 : 0;
+                                  dc->grow(dc->pool_k[pslot], out_chunks * CB) || dc->grow(dc->pool_d[pslot], out_chunks * 4) ||
+                                  (vals && (dc->grow(dc->recv_v, total * FJ_CHUNK * 8) || dc->grow(dc->pool_v, out_chunks * FJ_CHUNK * 8)))) ? 1 : 0;
         const std::string why2 = bad ? fj_last_error() : "";
         const bool mine_bad = bad != 0;
+        mark(" buffers");
         if (net.all_reduce(&bad, 1)) return bail(fj_last_error());
+        mark(" agreed");
         if (bad) { char b[1200]; snprintf(b, sizeof b, "fj_dist_join_count: buffers for a piece could not be allocated on %llu rank(s)%s%s", bad, mine_bad ? "; this rank: " : "", why2.c_str()); return bail(b); }
         // where every owner's share goes: this rank's own straight into its receive buffer, the others' into the send pool
-        std::vector<void*> dk(N), sp(2 * N), rp(2 * N);
+        const int nparts = vals ? 3 : 2;                       // chunks, directory words, values
+        std::vector<void*> dk(N), sp(3 * N, nullptr), rp(3 * N, nullptr);
         std::vector<uint32_t*> dd(N);
-        std::vector<size_t> sb(2 * N, 0), rb(2 * N, 0);
+        std::vector<uint64_t*> dv(N, nullptr);
+        std::vector<size_t> sb(3 * N, 0), rb(3 * N, 0);
         std::vector<size_t> roff(N + 1, 0);
         for (int q = 0; q < N; ++q) roff[q + 1] = roff[q] + (size_t)recv_n[q];
         char* rk = (char*)dc->recv_k[rslot].p; uint32_t* rd = (uint32_t*)dc->recv_d[rslot].p;
+        uint64_t* rv = vals ? (uint64_t*)dc->recv_v.p : nullptr;
         size_t po = 0;
         for (int d = 0; d < N; ++d) {
-            if (d == me && !loop) { dk[d] = rk + roff[me] * CB; dd[d] = rd + roff[me]; sp[d] = sp[N + d] = nullptr; }
+            if (d == me && !loop) { dk[d] = rk + roff[me] * CB; dd[d] = rd + roff[me]; if (vals) dv[d] = rv + roff[me] * FJ_CHUNK; }
             else {
                 dk[d] = (char*)dc->pool_k[pslot].p + po * CB; dd[d] = (uint32_t*)dc->pool_d[pslot].p + po;
                 sp[d] = dk[d]; sb[d] = (size_t)used[d] * CB; sp[N + d] = dd[d]; sb[N + d] = (size_t)used[d] * 4;
+                if (vals) { dv[d] = (uint64_t*)dc->pool_v.p + po * FJ_CHUNK; sp[2 * N + d] = dv[d]; sb[2 * N + d] = (size_t)used[d] * FJ_CHUNK * 8; }
                 po += (size_t)used[d];
             }
             rp[d] = rk + roff[d] * CB; rp[N + d] = rd + roff[d];
-            if (d != me || loop) { rb[d] = (size_t)recv_n[d] * CB; rb[N + d] = (size_t)recv_n[d] * 4; }
+            if (vals) rp[2 * N + d] = rv + roff[d] * FJ_CHUNK;
+            if (d != me || loop) { rb[d] = (size_t)recv_n[d] * CB; rb[N + d] = (size_t)recv_n[d] * 4; if (vals) rb[2 * N + d] = (size_t)recv_n[d] * FJ_CHUNK * 8; }
         }
+        if (vals) largest = largest / CB * (FJ_CHUNK * 8);     // (the value part of a message is its largest: 2048 bytes per chunk)
         Token packed = nullptr, done = nullptr;
-        if (eng.pack_finish(dk.data(), dd.data(), pool_free[pslot], &packed)) return bail(fj_last_error());
-        if (net.exchange(sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, rslot)) return bail(fj_last_error());
+        if (eng.pack_finish(dk.data(), vals ? dv.data() : nullptr, dd.data(), pool_free[pslot], &packed)) return bail(fj_last_error());
+        mark(" copy enqueued");
+        if (net.exchange(nparts, sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, rslot)) return bail(fj_last_error());
+        mark(" exchange enqueued");
         pool_free[pslot] = done;
-        out->rk = rk; out->rd = rd; out->chunks = total; out->done = done ? done : packed;
+        out->rk = rk; out->rd = rd; out->rv = rv; out->chunks = total; out->done = done ? done : packed;
         return 0;
     };
 
@@ -494,9 +523,9 @@ int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb
     Piece B;
     {
         const auto tp = std::chrono::steady_clock::now();
-        const bool ok = eng.pack_begin(d_build_keys, nb, nb_total, N) == 0;
+        const bool ok = eng.pack_begin(d_build_keys, mat ? d_build_vals : nullptr, nb, nb_total, N) == 0;
         split_ms += ms_since(tp);
-        if (finish_piece(ok, 0, 0, &B)) return 1;
+        if (finish_piece(ok, 0, 0, mat, &B)) return 1;
     }
     const size_t np_bound = (size_t)(1.5 * (double)np_global / N) + ((size_t)1 << 22) + (size_t)FJ_CHUNK * 512 * N * pieces;
     // ---- probe side: piece c+1's first pass is queued behind piece c's copy; piece c is appended before the host waits for c+1 ----
@@ -505,34 +534,41 @@ int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb
     size_t lo, hi;
     bounds(0, &lo, &hi);
     auto tp0 = std::chrono::steady_clock::now();
-    bool begun = eng.pack_begin(d_probe_keys + lo, hi - lo, nb_total, N) == 0;
+    bool begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N) == 0;
     split_ms += ms_since(tp0);
-    opened = guarded(eng.open(nb_total, N, me, B.chunks * FJ_CHUNK, np_bound, pieces)) == 0;
-    if (failed.empty()) guarded(eng.append(0, B.rk, B.rd, B.chunks, B.done));
+    opened = guarded(eng.open(nb_total, N, me, B.chunks * FJ_CHUNK, np_bound, pieces, mat)) == 0;
+    if (failed.empty()) guarded(eng.append(0, B.rk, B.rv, B.rd, B.chunks, B.done));
     size_t rows_recv_chunks = 0;
     for (int c = 0; c < pieces; ++c) {
-        if (finish_piece(begun, c & 1, c + 1, &P[c])) return 1;
+        if (finish_piece(begun, c & 1, c + 1, false, &P[c])) return 1;
         if (c + 1 < pieces) {
             bounds(c + 1, &lo, &hi);
             const auto tp = std::chrono::steady_clock::now();
-            begun = eng.pack_begin(d_probe_keys + lo, hi - lo, nb_total, N) == 0;
+            begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N) == 0;
             split_ms += ms_since(tp);
         }
+        mark(" next pass enqueued");
         rows_recv_chunks += P[c].chunks;
-        if (failed.empty()) guarded(eng.append(1, P[c].rk, P[c].rd, P[c].chunks, P[c].done));
+        if (failed.empty()) guarded(eng.append(1, P[c].rk, nullptr, P[c].rd, P[c].chunks, P[c].done));
+        mark(" append enqueued");
     }
     const auto t2 = std::chrono::steady_clock::now();
     uint64_t local = 0;
     fj_timings lt; memset(&lt, 0, sizeof lt);
+    mark("finish");
     if (failed.empty()) { guarded(eng.finish(&local, &lt)); if (failed.empty()) opened = false; }
+    mark(" finished");
     if (!failed.empty()) { local = 0; if (opened) eng.abort(); opened = false; }
 
     // ---- global count + agreement ----
     unsigned long long res[2] = {local, failed.empty() ? 0ull : 1ull};
     if (net.all_reduce(res, 2)) return bail(fj_last_error());
     if (net.drain() || eng.drain()) return 1;
+    mark("done");
+    if (trace) { for (auto& mk : marks) fprintf(stderr, "[fj_dist rank %d] %9.3f ms  %s\n", me, mk.second, mk.first); }
     if (res[1]) return derr("fj_dist_join_count: the local join failed on %llu rank(s)%s%s", res[1], failed.empty() ? "" : "; this rank: ", failed.c_str());
     if (out_global_count) *out_global_count = res[0];
+    if (out_local_count) *out_local_count = local;          // materialising: fj_emit_pairs(ctx, ...) then writes this rank's `local` pairs (they stay with the owner)
     if (timings) {
         memset(timings, 0, sizeof *timings);
         timings->total_ms = ms_since(t0); timings->split_ms = split_ms; timings->join_ms = ms_since(t2);

@@ -155,6 +155,7 @@ struct StreamState {            // fj_stream_*: a counting join whose relations 
     // owner shuffle, receiver side (fj_stream_open_shuffled): the pieces are chunk pools that peers filled with the FIRST pass of
     // the global plan; this rank owns level-1 buckets [b_lo, b_lo + nbk) and runs the plan from its second pass on
     bool shuffled = false; u32 b_lo = 0, nbk = 0, nbk_pad = 0;
+    bool with_vals = false;         // ... and the build side carries values: a materialising join (pairs stay with the owner: fj_emit_pairs after the finish)
 };
 
 struct fj_ctx {

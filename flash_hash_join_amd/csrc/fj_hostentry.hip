@@ -127,9 +127,10 @@ public:
 int copy_bind_mode() { static const int m = getenv("FJ_HOST_COPY_BIND") ? atoi(getenv("FJ_HOST_COPY_BIND")) : 2; return m; }
 unsigned copy_threads_for(size_t ncpus) {
     if (const char* e = getenv("FJ_HOST_COPY_THREADS")) return (unsigned)std::max(1, atoi(e));
-    // from the CPUs the threads may actually use (the affinity mask, or one node's share of it), not a constant: a sixth of them,
-    // 4..16 - a pageable -> pinned memcpy saturates a socket's memory controllers well before all of its cores copy
-    return (unsigned)std::min<size_t>(16, std::max<size_t>(4, ncpus / 6));
+    // from the CPUs the threads may actually use (the affinity mask, or one node's share of it): a quarter of them, at most 6.  One
+    // core copies pageable -> pinned memory at ~14 GB/s and PCIe Gen5 x16 takes ~57: four to six threads keep up, and MORE is worse
+    // (profiles/r04_host_entry_probe.txt: 1.11-1.15x a pinned copy with 4-16 threads, 1.37-1.41x with 24-32)
+    return (unsigned)std::min<size_t>(6, std::max<size_t>(2, ncpus / 4));
 }
 // the pool that copies a piece whose source starts at `src`, for the context's device
 CopyPool& copy_pool_for(const void* src, int device) {

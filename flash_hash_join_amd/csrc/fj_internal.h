@@ -44,13 +44,6 @@ struct FjPartArgs {
     u32 side;                // 0 = build relation, 1 = probe relation (selects the kernel's name only)
     u32 slab;                // chunk ids a workgroup takes per allocator hit (fj_slab_for; a multiple of the run length)
     u32 run_log;             // chunk ids per (segment, bucket) in aligned runs of 2^run_log (0 or FJ_RUN_LOG; FjChunkSet::run_log of the output)
-    // owner-grouped form (multi-GPU sender, flat input only): bucket b belongs to owner GPU (b * own_nranks) >> fan_log, and
-    // the chunks of owner r's buckets are allocated from region r of the output pool, ids [r * own_region, (r + 1) * own_region),
-    // through own_alloc[r] - so that what goes to one peer is ONE contiguous piece of the pool (the first radix
-    // pass IS the owner split).  own_nranks == 0: one allocator for the whole pool (a.alloc).
-    u32 own_nranks;
-    u32 own_region;          // chunks per region
-    u32* own_alloc;          // [own_nranks] device words, zeroed before the pass: chunks allocated in each region
     // chunk-list input in the owner shuffle's 7-byte wire format (chunks received from other GPUs, csrc/fj_pack.hip): chunk id i
     // lives at byte i * FJ_WIRE7_BYTES of in_keys; bits 56..63 of its keys = (in_b0 + the tile's parent bucket) >> in_top_shift
     u32 in_pk7, in_b0, in_top_shift;
@@ -80,8 +73,6 @@ u32 fj_partition_lds_bytes(u32 fan_log, bool vals, int line_log);
 // chunks (of 256 rows) per input tile of the pass kernel chosen for this fan-out and payload
 u32 fj_partition_tile_chunks(u32 fan_log, bool vals);
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s);
-// chunks a workgroup takes per allocator hit in the owner-grouped form (per owner: tile chunks + the owner's buckets + slack)
-u32 fj_own_slab(u32 fan_log, bool vals, u32 nranks);
 // level bookkeeping after a pass: chunk-list offsets (clears cs.bchunks for the next join), chunk lists, and the tile table
 // of the level's consumer (tc chunks per tile; 0 = none); zero_tail: optional [max_tiles] array whose entries past the
 // number of tiles are cleared
@@ -124,10 +115,11 @@ struct FjPackArgs {
     const u64* keys; const u64* vals;            // the packing pass's chunk pool (vals: nullptr for keys-only relations)
     const u32* list; const u32* boff;            // its chunk lists
     u32 nb, fan_log, nranks, wire7;              // nb = 2^fan_log first-pass buckets; wire7: 7-byte chunks (fan_log >= 8), else 8-byte
-    uint4* fi;                                   // [chunks] per bucket b and output chunk c, at boff[b] + c: {list entry of the input chunk holding key 256 c, the next
-                                                 // entry, keys of the bucket before that chunk, its index in the bucket's list}
+    uint4* fi;                                   // [output chunks] descriptor: {list entry of the input chunk holding the chunk's key 0, the next entry,
+                                                 //  position of key 0 inside that input chunk, index of that entry in the chunk list}
+    u32* fb;                                     // [output chunks] the chunk's directory word (bucket << 9 | keys)
     u32* bkeys;                                  // [nb] keys per bucket
-    u32* obase;                                  // [nb + 1] output chunks before bucket b
+    u32* obase;                                  // [nb + 1] output chunks before bucket b; [nb + 1 + r]: first output chunk of owner r
     unsigned long long* used;                    // [nranks] output chunks per owner
     unsigned char* dst_k[64]; u64* dst_v[64]; u32* dst_d[64];   // per owner: where its chunks, values and directory words go
 };

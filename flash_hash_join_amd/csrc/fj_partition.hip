@@ -25,20 +25,23 @@
 
 namespace {
 
+// u64 of padding per carry row (0: round 3's layout; an A/B knob: -DFJ_LO_PAD=0)
+#ifndef FJ_LO_PAD
+#define FJ_LO_PAD 1u
+#endif
 // dynamic-LDS layout, shared by kernel and host-side size computation
 struct PartLds {
-    u32 sorted_k, sorted_v, lo_k, lo_v, hist, toff, line_desc, t_chunk, t_cnt, wsum, misc, own, total;
+    u32 sorted_k, sorted_v, lo_k, lo_v, hist, toff, line_desc, t_chunk, t_cnt, wsum, misc, total;
 };
-constexpr u32 OWN_MAX = 64;            // owner GPUs of the owner-grouped form
-__host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool vals, u32 nwaves, bool own = false) {
+__host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool vals, u32 nwaves) {
     PartLds L;
     const u32 nsorted = T + 2;                             // bucket-sorted tile (remainders stay in lo_*)
     const u32 maxl = (T + (line - 1) * F) / line + 2;
     u32 o = 0;
     L.sorted_k = o; o += nsorted * 8;
     L.sorted_v = o; if (vals) o += nsorted * 8;
-    L.lo_k = o; o += F * line * 8;
-    L.lo_v = o; if (vals) o += F * line * 8;
+    L.lo_k = o; o += F * (line + FJ_LO_PAD) * 8;              // per-bucket carry rows, padded: a row stride of `line` u64 (128 B) puts
+    L.lo_v = o; if (vals) o += F * (line + FJ_LO_PAD) * 8;   // row j of every bucket on ONE bank pair (the carry copy: 64-way conflicts)
     L.line_desc = o; o += maxl * 8;
     L.wsum = o; o += nwaves * 8;
     L.hist = o; o += (F + 4) * 4;
@@ -46,7 +49,6 @@ __host__ __device__ inline PartLds part_lds_layout(u32 T, u32 F, u32 line, bool 
     L.t_chunk = o; o += (T / FJ_CHUNK) * 4;
     L.t_cnt = o; o += (T / FJ_CHUNK) * 4;
     L.misc = o; o += 16 * 4;
-    L.own = o; if (own) o += (5 * OWN_MAX + 4) * 4;        // per-owner slab state: cur, rem, new, flush count, kb0[OWN_MAX + 1]
     L.total = (o + 15) & ~15u;
     return L;
 }
@@ -59,23 +61,21 @@ enum { M_SLAB_CUR = 0, M_SLAB_REM, M_NEW_BASE, M_NEED, M_NLINES, M_FLUSH, M_SEG,
 // only by the waves that own buckets, whole contiguous lines per store instruction in the write-out.
 // PROBE_SIDE only names the instantiation (identical code): a counting join runs the keys-only kernel over both
 // relations, and per-kernel profiler statistics should not average 100M-row and 1B-row launches together.
-// OWN: the owner-grouped form (see FjPartArgs): every workgroup keeps one open slab PER OWNER GPU, taken from that owner's
-// region of the output pool; everything else is the same pass.
+// (Round 3's owner-grouped form of this kernel - one open slab per owner GPU - is gone: the multi-GPU sender runs this pass as
+// it is and csrc/fj_pack.hip rewrites its output for the wire.)
 // PK7: the input chunks are in the owner shuffle's 7-byte wire format (FJ_WIRE7_BYTES per chunk: the low words, the middle 16
 // bits and bits 48..55 of the mixed keys as three planes; bits 56..63 are the top bits of the chunk's first-pass bucket) - the
 // pass that reads what other GPUs sent unpacks it in registers (csrc/fj_pack.hip writes the format).
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG, bool PK7 = false>
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, int RLOG = FJ_RUN_LOG, bool PK7 = false>
 __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
-    constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64;
+    constexpr u32 T = NT * KPT, LINE = 1u << LINE_LOG, TC = T / FJ_CHUNK, NW = NT / 64, LOS = LINE + FJ_LO_PAD;     // LOS: stride of a carry row
     static_assert(T % FJ_CHUNK == 0 && TC <= NT && LINE >= 4 && T + 64 < (1u << 17), "tile geometry");
-    static_assert(!OWN || FLAT, "the owner-grouped form reads a flat relation");
     static_assert(!PK7 || (!FLAT && KPT % 4 == 0), "wire-format chunks come through chunk lists, four keys per load group");
     // RUNS (RLOG > 0): a bucket takes its chunk ids in aligned runs of RU = 2^RLOG ids (used in a rotated order; what a segment
     // leaves unused of its last run is marked FJ_DIR_INVALID), so that fj_level_lists places RU list entries per step
     // (FjChunkSet::run_log).  The allocator then counts in units of one run.  RLOG == 0: ids one by one in the order the tiles
-    // open chunks (the owner-grouped form, whose regions are sized tightly; flat passes of <= 256 buckets, see fj_api.hip).
+    // open chunks (flat passes of <= 256 buckets, see fj_plan.hip).
     // (A compile-time choice: with the run length as a kernel argument every pass ran 6 % slower.)
-    static_assert(!OWN || RLOG == 0, "the owner-grouped form hands out single ids");
     constexpr bool RUNS = RLOG > 0;
     constexpr u32 RL = (u32)RLOG, RU = 1u << RL;
     const u32 F = 1u << a.fan_log, FM = F - 1;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     const u32 sh32 = a.shift - 32;                       // digit comes from hash word 1 only = the high word of the mixed key
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const PartLds Lo = part_lds_layout(T, F, LINE, HAS_VALS, NW, OWN);
+    const PartLds Lo = part_lds_layout(T, F, LINE, HAS_VALS, NW);
     u64* tile_k = (u64*)(smem + Lo.sorted_k);
     u64* tile_v = (u64*)(smem + Lo.sorted_v);
     u64* lo_k = (u64*)(smem + Lo.lo_k);
@@ -95,13 +95,6 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     u32* t_chunk = (u32*)(smem + Lo.t_chunk);
     u32* t_cnt = (u32*)(smem + Lo.t_cnt);
     u32* misc = (u32*)(smem + Lo.misc);
-    u32* own_cur = (u32*)(smem + Lo.own);            // OWN: current slab position / ids left / fresh slab / flush count per owner,
-    u32* own_rem = own_cur + OWN_MAX;                //      and the tile's chunk-prefix at each owner's first bucket
-    u32* own_new = own_rem + OWN_MAX;
-    u32* own_fl = own_new + OWN_MAX;
-    u32* own_kb0 = own_fl + OWN_MAX;
-    const u32 NR = OWN ? a.own_nranks : 1u;
-    auto owner_of = [&](u32 b) -> u32 { return (b * NR) >> a.fan_log; };
 
     const u32 Lc = FLAT ? (u32)((a.n_flat + FJ_CHUNK - 1) >> FJ_CHUNK_LOG) : 0u;
     const u32 ntiles = FLAT ? (Lc + TC - 1) / TC : *a.in_ntiles;
@@ -190,7 +183,6 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
     };
 
     if (tid == 0) { misc[M_SLAB_CUR] = 0; misc[M_SLAB_REM] = 0; misc[M_NEW_BASE] = 0; misc[M_SEG] = 0; misc[M_NEW_UNITS] = 0; }
-    if (OWN && tid < OWN_MAX) { own_cur[tid] = 0; own_rem[tid] = 0; own_new[tid] = 0; own_fl[tid] = 0; own_kb0[tid] = 0; if (tid == 0) own_kb0[OWN_MAX] = 0; }
     // per-bucket state lives in the registers of thread b (b < F)
     u32 st_left = 0, st_fill = FJ_CHUNK, st_cur = FJ_DIR_INVALID, st_nch = 0;
     u32 pend_cnt = 0, pend_nf = 0, pend_tb = 0;
@@ -202,14 +194,14 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             const u32 b = tid, tot = st_left + pend_cnt;
             if (pend_nf == 0) {                                   // nothing was written: append the new keys
                 for (u32 j = 0; j < pend_cnt; ++j) {
-                    lo_k[b * LINE + st_left + j] = tile_k[pend_tb + j];
-                    if (HAS_VALS) lo_v[b * LINE + st_left + j] = tile_v[pend_tb + j];
+                    lo_k[b * LOS + st_left + j] = tile_k[pend_tb + j];
+                    if (HAS_VALS) lo_v[b * LOS + st_left + j] = tile_v[pend_tb + j];
                 }
             } else {                                              // the remainder is the tail of the new keys
                 const u32 nl2 = tot - pend_nf, src = pend_tb + (pend_nf - st_left);
                 for (u32 j = 0; j < nl2; ++j) {
-                    lo_k[b * LINE + j] = tile_k[src + j];
-                    if (HAS_VALS) lo_v[b * LINE + j] = tile_v[src + j];
+                    lo_k[b * LOS + j] = tile_k[src + j];
+                    if (HAS_VALS) lo_v[b * LOS + j] = tile_v[src + j];
                 }
             }
             st_left = tot - pend_nf;
@@ -217,13 +209,8 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         }
     };
 
-    // id of the j-th chunk this workgroup allocates in the current tile (j counts over all buckets in bucket order; b = the
-    // bucket the chunk is for: in the owner-grouped form it comes out of the slab of b's owner)
-    auto alloc_id = [&](u32 j, u32 b) -> u32 {
-        if constexpr (OWN) {
-            const u32 o = owner_of(b), jr = j - own_kb0[o], rem = own_rem[o];
-            return jr < rem ? own_cur[o] + jr : own_new[o] + (jr - rem);
-        }
+    // id of the j-th chunk this workgroup allocates in the current tile (j counts over all buckets in bucket order)
+    auto alloc_id = [&](u32 j, u32) -> u32 {
         const u32 rem = misc[M_SLAB_REM];                   // (in allocation units: runs)
         return j < rem ? misc[M_SLAB_CUR] + (j << RL) : misc[M_NEW_BASE] + ((j - rem) << RL);
     };
@@ -243,7 +230,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         const u32 q = kk - rl - 1u;
         return alloc_id(ukb + (q >> RL), b) + ((q + rot(b)) & (RU - 1u));
     };
-    // (not OWN; one thread) the open slab cannot cover `need` allocation units: take as many fresh slabs as the rest needs, in
+    // (one thread) the open slab cannot cover `need` allocation units: take as many fresh slabs as the rest needs, in
     // one piece - alloc_id() hands out the open slab's remainder first, so nothing is abandoned
     auto take_slabs = [&](u32 need) {
         const u32 su = a.slab >> RL, k = (need - misc[M_SLAB_REM] + su - 1) / su;
@@ -256,45 +243,23 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
         if (need <= rem) { misc[M_SLAB_CUR] += need << RL; misc[M_SLAB_REM] = rem - need; }
         else { const u32 used = need - rem; misc[M_SLAB_CUR] = misc[M_NEW_BASE] + (used << RL); misc[M_SLAB_REM] = misc[M_NEW_UNITS] - used; }
     };
-    // OWN: a fresh slab out of owner o's region (thread o)
-    auto own_take_slab = [&](u32 o) -> u32 {
-        u32 nb = atomicAdd(&a.own_alloc[o], a.slab);
-        if (nb + a.slab > a.own_region) { atomicOr(a.err, FJ_ERR_POOL); nb = 0; }     // (stay inside the region: the result is discarded)
-        return o * a.own_region + nb;
-    };
 
     // end of a segment (= this workgroup's share of one parent bucket): write the carried
     // remainders, fix the last chunk's count, reserve the chunk-list spans, reset the state
     auto flush = [&](u32 parent) {
-        if constexpr (OWN) {
-            // every owner's open slab must cover one chunk per bucket of that owner; a remainder too small is abandoned
-            const u32 FO = (F + NR - 1) / NR + 1;
-            if (tid < NR) {
-                const u32 rem0 = own_rem[tid], cur0 = own_cur[tid];
-                if (rem0 < FO) {
-                    for (u32 j = 0; j < rem0; ++j) if (cur0 + j < cap) a.out_dir[cur0 + j] = FJ_DIR_INVALID;
-                    own_cur[tid] = own_take_slab(tid); own_rem[tid] = a.slab;
-                }
-                own_fl[tid] = 0;
-            }
-        } else {
-            if (tid == 0) misc[M_FLUSH] = 0;
-        }
+        if (tid == 0) misc[M_FLUSH] = 0;
         __syncthreads();
-        u32 fresh = 0xFFFFFFFFu;                              // not OWN: index of the fresh allocation unit this bucket's remainder needs
-        if constexpr (!OWN) {
-            if (tid < F && st_left > 0 && st_fill == FJ_CHUNK && !run_left(st_cur, tid)) fresh = atomicAdd(&misc[M_FLUSH], 1u);
-            __syncthreads();
-            if (tid == 0 && misc[M_FLUSH] > misc[M_SLAB_REM]) take_slabs(misc[M_FLUSH]);
-        }
+        u32 fresh = 0xFFFFFFFFu;                              // index of the fresh allocation unit this bucket's remainder needs
+        if (tid < F && st_left > 0 && st_fill == FJ_CHUNK && !run_left(st_cur, tid)) fresh = atomicAdd(&misc[M_FLUSH], 1u);
+        __syncthreads();
+        if (tid == 0 && misc[M_FLUSH] > misc[M_SLAB_REM]) take_slabs(misc[M_FLUSH]);
         __syncthreads();
         if (tid < F) {
             const u32 b = tid, l = st_left, seg = misc[M_SEG];
             u32 f0 = st_fill, c = st_cur, n = st_nch;
             const u32 outb = parent * F + b;
             if (l > 0 && f0 == FJ_CHUNK) {
-                if constexpr (OWN) { const u32 o = owner_of(b); c = own_cur[o] + atomicAdd(&own_fl[o], 1u); }
-                else if (fresh == 0xFFFFFFFFu) c = run_step(c, 1);
+                if (fresh == 0xFFFFFFFFu) c = run_step(c, 1);
                 else c = alloc_id(fresh, b) + rot(b);
                 f0 = 0;
                 if (c < cap) a.out_rel[c] = ((u64)seg << 32) | n;
@@ -303,8 +268,8 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             if (c != FJ_DIR_INVALID && c < cap) {
                 const u64 base = (u64)c * FJ_CHUNK + f0;
                 for (u32 j = 0; j < l; ++j) {
-                    a.out_keys[base + j] = lo_k[b * LINE + j];
-                    if (HAS_VALS) a.out_vals[base + j] = lo_v[b * LINE + j];
+                    a.out_keys[base + j] = lo_k[b * LOS + j];
+                    if (HAS_VALS) a.out_vals[base + j] = lo_v[b * LOS + j];
                 }
                 a.out_dir[c] = (outb << FJ_DIR_CNT_BITS) | (f0 + l);
                 if constexpr (RUNS) { for (u32 k = 1; k <= run_left(c, b); ++k) { const u32 id = run_step(c, k); if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; } }   // rest of the run
@@ -316,8 +281,7 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
             st_left = 0; st_fill = FJ_CHUNK; st_cur = FJ_DIR_INVALID; st_nch = 0;
         }
         __syncthreads();
-        if constexpr (OWN) { if (tid < NR) { const u32 n = own_fl[tid]; own_cur[tid] += n; own_rem[tid] -= n; } }
-        else if (tid == 0) commit_units(misc[M_FLUSH]);
+        if (tid == 0) commit_units(misc[M_FLUSH]);
         __syncthreads();
     };
 
@@ -464,25 +428,16 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 toff[tid] = to;
                 l0 += (u32)((woff >> 20) & 0xFFFFFu);
                 kb += (u32)(woff >> 40);
-                if constexpr (OWN) {                       // the tile's chunk prefix at each owner's first bucket
-                    const u32 o = owner_of(tid);
-                    if (tid == 0 || owner_of(tid - 1) != o) own_kb0[o] = kb;
-                    if (tid == F - 1) own_kb0[NR] = kb + kr;
-                }
                 if (tid == F - 1) {
                     toff[F] = to + cnt;                    // dummy bucket goes behind everything
                     const u32 need = kb + kr;
                     misc[M_NLINES] = l0 + (nf >> LINE_LOG);
                     misc[M_NEED] = need;
-                    if (!OWN && need > misc[M_SLAB_REM]) take_slabs(need);
+                    if (need > misc[M_SLAB_REM]) take_slabs(need);
                 }
             }
         }
         __syncthreads();
-        if constexpr (OWN) {                               // an owner whose slab cannot cover this tile's new chunks gets a fresh one
-            if (tid < NR && own_kb0[tid + 1] - own_kb0[tid] > own_rem[tid]) own_new[tid] = own_take_slab(tid);
-            __syncthreads();
-        }
 
         // ---- bucket-sort the tile's new keys in LDS ---------------------------------------------
 #pragma unroll
@@ -556,36 +511,23 @@ __global__ __launch_bounds__(NT, 4) void fj_partition_kernel(FjPartArgs a) {
                 for (int i = 0; i < (int)WK; ++i) {
                     const u32 vi = q + i;
                     const bool in_lo = vi < lc;
-                    const u64* sk = in_lo ? (lo_k + b * LINE + vi) : (tile_k + (sidx + vi));
+                    const u64* sk = in_lo ? (lo_k + b * LOS + vi) : (tile_k + (sidx + vi));
                     r[i] = *sk;
-                    if (HAS_VALS) { const u64* sv = in_lo ? (lo_v + b * LINE + vi) : (tile_v + (sidx + vi)); rv[i] = *sv; }
+                    if (HAS_VALS) { const u64* sv = in_lo ? (lo_v + b * LOS + vi) : (tile_v + (sidx + vi)); rv[i] = *sv; }
                 }
                 u64x2 r0; r0.x = r[0]; r0.y = r[1];
                 *reinterpret_cast<u64x2*>(a.out_keys + (u64)dst + q) = r0;
                 if (HAS_VALS) { u64x2 w0; w0.x = rv[0]; w0.y = rv[1]; *reinterpret_cast<u64x2*>(a.out_vals + (u64)dst + q) = w0; }
             }
         }
-        if constexpr (OWN) {
-            if (tid < NR) {
-                const u32 need = own_kb0[tid + 1] - own_kb0[tid], rem = own_rem[tid];
-                if (need <= rem) { own_cur[tid] += need; own_rem[tid] = rem - need; }
-                else { const u32 used = need - rem; own_cur[tid] = own_new[tid] + used; own_rem[tid] = a.slab - used; }
-            }
-        } else if (tid == 0) {
-            commit_units(misc[M_NEED]);
-        }
+        if (tid == 0) commit_units(misc[M_NEED]);
         __syncthreads();
     }
     carry();
     flush(cur_parent);
     // The chunk ids this workgroup took from the allocator but never used stay unlisted: their directory words say so.
     // (Every id below the allocator's high-water mark is thus defined by its owner - the directory needs no memset.)
-    if constexpr (OWN) {
-        for (u32 o = 0; o < NR; ++o)
-            for (u32 j = tid; j < own_rem[o]; j += NT) { const u32 id = own_cur[o] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
-    } else {
-        for (u32 j = tid; j < (misc[M_SLAB_REM] << RL); j += NT) { const u32 id = misc[M_SLAB_CUR] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
-    }
+    for (u32 j = tid; j < (misc[M_SLAB_REM] << RL); j += NT) { const u32 id = misc[M_SLAB_CUR] + j; if (id < cap) a.out_dir[id] = FJ_DIR_INVALID; }
 }
 
 // Single-workgroup exclusive scan (bucket counts -> offsets): sweeps of 16384 elements.  A thread takes four groups of four
@@ -923,11 +865,11 @@ __global__ __launch_bounds__(1024) void fj_dir_rank_kernel(u32* __restrict__ dir
     if (blockIdx.x == 0 && tid == 0) *nalloc = n;
 }
 
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false, int RLOG = FJ_RUN_LOG, bool PK7 = false>
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, int RLOG = FJ_RUN_LOG, bool PK7 = false>
 hipError_t launch_part0(const FjPartArgs& a, u32 grid, hipStream_t s) {
     const u32 F = 1u << a.fan_log;
-    const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64, OWN);
-    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, OWN, OWN ? 0 : RLOG, PK7>;
+    const PartLds L = part_lds_layout(NT * KPT, F, 1u << LINE_LOG, HAS_VALS, NT / 64);
+    auto kern = fj_partition_kernel<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, RLOG, PK7>;
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, s, a);
@@ -935,14 +877,11 @@ hipError_t launch_part0(const FjPartArgs& a, u32 grid, hipStream_t s) {
 }
 
 // run length of the output's chunk ids (a.run_log): single ids exist for flat inputs only
-template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE, bool OWN = false>
+template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT, bool PROBE_SIDE>
 hipError_t launch_part1(const FjPartArgs& a, u32 grid, hipStream_t s) {
-    if constexpr (OWN) return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, true, 0>(a, grid, s);
-    else {
-        if constexpr (FLAT) { if (a.run_log == 0) return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, false, 0>(a, grid, s); }
-        if (a.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
-        return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, false, FJ_RUN_LOG>(a, grid, s);
-    }
+    if constexpr (FLAT) { if (a.run_log == 0) return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, 0>(a, grid, s); }
+    if (a.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
+    return launch_part0<NT, KPT, LINE_LOG, HAS_VALS, FLAT, PROBE_SIDE, FJ_RUN_LOG>(a, grid, s);
 }
 
 template <int NT, int KPT, int LINE_LOG, bool HAS_VALS, bool FLAT>
@@ -992,36 +931,22 @@ u32 fj_partition_tile_chunks(u32 fan_log, bool vals) { (void)fan_log; return val
 
 // One partition pass, one 1024-thread workgroup per CU: keys only 8192-key tiles (8 keys per thread; half as many barriers
 // and bucket scans per key as the 4096-key tiles of two 512-thread workgroups), with values 4096-row tiles (4 rows per thread).
-u32 fj_own_slab(u32 fan_log, bool vals, u32 nranks) {
-    const u32 F = 1u << fan_log, need = fj_partition_tile_chunks(fan_log, vals) + (F + nranks - 1) / nranks + 1 + 16;   // per owner and tile: <= tile chunks + its buckets (+ slack)
-    u32 s = 64; while (s < need) s <<= 1;
-    return s;
-}
 
 hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32 grid, hipStream_t s) {
     if (a.shift < 32) return hipErrorInvalidValue;       // radix digits must come from hash word 1
-    if (a.own_nranks) {
-        // owner-grouped form (multi-GPU sender): flat input, one open slab per owner and workgroup
-        if (a.in_list || a.own_nranks > OWN_MAX || (1u << a.fan_log) < a.own_nranks || a.fan_log > FJ_MAX_FAN_LOG || !a.own_alloc ||
-            a.slab < fj_own_slab(a.fan_log, vals, a.own_nranks) || a.parent0 != 0) return hipErrorInvalidValue;
-        const u32 g = grid < 256 ? grid : 256;
-        if (vals) return line_log == 3 ? launch_part1<1024, 4, 3, true, true, true, true>(a, g, s) : launch_part1<1024, 4, 4, true, true, true, true>(a, g, s);
-        if (line_log != 4) return hipErrorInvalidValue;
-        return a.side == 0 ? launch_part1<1024, 8, 4, false, true, false, true>(a, g, s) : launch_part1<1024, 8, 4, false, true, true, true>(a, g, s);
-    }
     if (a.fan_log > FJ_MAX_FAN_LOG || a.slab < (1u << FJ_RUN_LOG) || (a.slab & ((1u << FJ_RUN_LOG) - 1u))) return hipErrorInvalidValue;
     if (a.in_pk7) {
         // input chunks in the owner shuffle's 7-byte wire format (what other GPUs sent): same pass, keys unpacked in registers
         if (!a.in_list || a.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
         if (vals) {
             if (a.fan_log == 9 && line_log != 3) return hipErrorInvalidValue;
-            return line_log == 3 ? launch_part0<1024, 4, 3, true, false, true, false, FJ_RUN_LOG, true>(a, grid, s)
-                                 : launch_part0<1024, 4, 4, true, false, true, false, FJ_RUN_LOG, true>(a, grid, s);
+            return line_log == 3 ? launch_part0<1024, 4, 3, true, false, true, FJ_RUN_LOG, true>(a, grid, s)
+                                 : launch_part0<1024, 4, 4, true, false, true, FJ_RUN_LOG, true>(a, grid, s);
         }
         if (line_log != 4) return hipErrorInvalidValue;
         const u32 g = a.fan_log == 9 ? grid : (grid < 256 ? grid : 256);
-        return a.side == 0 ? launch_part0<1024, 8, 4, false, false, false, false, FJ_RUN_LOG, true>(a, g, s)
-                           : launch_part0<1024, 8, 4, false, false, true, false, FJ_RUN_LOG, true>(a, g, s);
+        return a.side == 0 ? launch_part0<1024, 8, 4, false, false, false, FJ_RUN_LOG, true>(a, g, s)
+                           : launch_part0<1024, 8, 4, false, false, true, FJ_RUN_LOG, true>(a, g, s);
     }
     if (a.fan_log == 9) {
         // 512 buckets: one bucket per thread needs >= 512 threads and the open lines take 64 KiB (keys) -- one

@@ -207,7 +207,14 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         }
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
-        if (radix_join_tail(c, 0, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full, st.top_bits)) return 1;
+        const int mat = st.shuffled && st.with_vals ? 1 : 0;     // counting pass of a materialising join: the pairs follow with fj_emit_pairs
+        if (radix_join_tail(c, mat, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full, st.top_bits)) return 1;
+        if (mat && c->pend.valid && (c->pend.has_dups || c->pend.has_second)) {
+            // first-occurrence semantics for duplicate build keys (and the re-partitioning of an oversized partition) need the
+            // caller's flat build arrays, which a shuffled stream never sees: the caller takes the owner-scatter form instead
+            c->pend.valid = false;
+            return set_err("shuffled materialising join: duplicate build keys or an oversized partition (use the owner-scatter form)");
+        }
         if (lds_full && st.shuffled)
             return set_err("shuffled stream join: a final partition holds more than 8128 distinct build keys (skewed build side); no fallback for chunk pieces");
         if (lds_full) {
@@ -309,9 +316,9 @@ int fj_shuffle_pack_begin(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_v
     void* p;
     a.keys = it.cs.keys; a.vals = it.cs.vals; a.list = it.cs.list; a.boff = it.cs.boff;
     a.nb = F; a.fan_log = fan_log; a.nranks = (u32)nranks; a.wire7 = wire7(plan) ? 1u : 0u;
-    if (get_buf(c, W_PK_FI, (size_t)it.cs.cap * sizeof(uint4), &p)) return 1; a.fi = (uint4*)p;
+    if (get_buf(c, W_PK_FI, (size_t)it.cs.cap * (sizeof(uint4) + 4), &p)) return 1; a.fi = (uint4*)p; a.fb = (u32*)(a.fi + it.cs.cap);
     if (get_buf(c, W_PK_BKEYS, (size_t)F * 4, &p)) return 1; a.bkeys = (u32*)p;
-    if (get_buf(c, W_PK_OBASE, ((size_t)F + 1) * 4, &p)) return 1; a.obase = (u32*)p;
+    if (get_buf(c, W_PK_OBASE, ((size_t)F + 1 + 64) * 4, &p)) return 1; a.obase = (u32*)p;
     a.used = c->d_sc->pack_used;
     HIPCHK(fj_launch_pack_plan(a, s));
     HIPCHK(hipMemcpyAsync(c->pk_h, c->d_sc->pack_used, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -349,13 +356,13 @@ int fj_shuffle_pack_finish(fj_ctx* c, void* const* d_dst_chunks, uint64_t* const
     }
     pk.begun = false;
     if (total == 0) return 0;
-    const u32 grid = (u32)std::min<u64>(8u * c->num_cus, (total + 7) / 8);        // resident 256-thread workgroups, eight chunks per step
+    const u32 grid = (u32)std::min<u64>(16u * c->num_cus, (total + 3) / 4);       // 256-thread workgroups, four chunks per step
     HIPCHK(fj_launch_pack_squeeze(a, grid, (hipStream_t)stream));
     return 0;
 }
 
 int fj_stream_open_shuffled(fj_ctx* c, size_t nb_total, int nranks, int rank, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends,
-                            void* stream) {
+                            int with_vals, void* stream) {
     if (!c) return set_err("fj_stream_open_shuffled: null context");
     if (rank < 0 || rank >= nranks) return set_err("fj_stream_open_shuffled: rank %d of %d", rank, nranks);
     if (build_appends < 1 || build_appends > 64 || probe_appends < 1 || probe_appends > 64) return set_err("fj_stream_open_shuffled: build_appends and probe_appends must be 1..64");
@@ -366,7 +373,7 @@ int fj_stream_open_shuffled(fj_ctx* c, size_t nb_total, int nranks, int rank, si
     StreamState& st = c->st;
     st = StreamState();
     c->pend.valid = false;
-    st.plan = plan; st.top_bits = 64; st.shuffled = true;
+    st.plan = plan; st.top_bits = 64; st.shuffled = true; st.with_vals = with_vals != 0;
     const u32 F0 = 1u << plan.fan_log[0];
     st.b_lo = (u32)(((u64)rank * F0 + nranks - 1) / nranks);                     // first bucket b with (b * nranks) >> log2(F0) == rank
     st.nbk = (u32)(((u64)(rank + 1) * F0 + nranks - 1) / nranks) - st.b_lo;
@@ -377,7 +384,7 @@ int fj_stream_open_shuffled(fj_ctx* c, size_t nb_total, int nranks, int rank, si
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     if (clear_plan_scalars(c, s)) return 1;
     auto init = [&](PassIter& it, int side, size_t n, u32 appends) -> int {
-        pass_init(it, side, false, std::max<size_t>(n, 1), plan, 64);
+        pass_init(it, side, side == 0 && with_vals, std::max<size_t>(n, 1), plan, 64);
         it.i = 1; it.used = 64 - plan.fan_log[0]; it.parents = st.nbk_pad; it.slot = 1;     // pass 1 of the plan ran at the senders
         it.lbound = it.n / FJ_CHUNK + 1 + (u64)appends * ((u64)64 * F0 + 64);               // one partial chunk per (sender, bucket, piece)
         it.in_pk7 = wire7(plan); it.in_b0 = st.b_lo; it.in_top_shift = (u32)std::max(0, plan.fan_log[0] - 8);
@@ -392,17 +399,17 @@ int fj_stream_open_shuffled(fj_ctx* c, size_t nb_total, int nranks, int rank, si
 
 namespace {
 // one received piece (wire-format chunks + their directory words) -> chunk lists + tile table -> the plan's second pass over it
-int stream_append_chunks(fj_ctx* c, int side, const void* d_chunks, u32* d_dir, size_t nchunks, hipStream_t s) {
+int stream_append_chunks(fj_ctx* c, int side, const void* d_chunks, const u64* d_vals, u32* d_dir, size_t nchunks, hipStream_t s) {
     StreamState& st = c->st;
     PassIter& it = side ? st.pit : st.bit;
     if (nchunks >= (1ull << 24)) return set_err("fj_stream_append_*_chunks: a piece of %zu chunks exceeds one chunk directory", nchunks);
     const u32 n = (u32)nchunks, nblocks = (n + 4095u) / 4096u;
     u32 fan = 4; while (fan < st.nbk_pad) fan <<= 1;
-    const u32 tc = fj_partition_tile_chunks((u32)st.plan.fan_log[1], false);
+    const u32 tc = fj_partition_tile_chunks((u32)st.plan.fan_log[1], it.has_vals);
     const u64 max_tiles = n / tc + st.nbk_pad + 1;
     FjChunkSet cs{};
     void* p;
-    cs.keys = (u64*)const_cast<void*>(d_chunks); cs.vals = nullptr; cs.dir = d_dir; cs.cap = n; cs.nb = st.nbk_pad; cs.fan_mask = fan - 1; cs.max_segs = nblocks;
+    cs.keys = (u64*)const_cast<void*>(d_chunks); cs.vals = const_cast<u64*>(d_vals); cs.dir = d_dir; cs.cap = n; cs.nb = st.nbk_pad; cs.fan_mask = fan - 1; cs.max_segs = nblocks;
     if (get_buf(c, W_RX_REL, (size_t)n * 8, &p)) return 1; cs.rel = (u64*)p;
     if (get_buf(c, W_RX_LIST, (size_t)n * 4, &p)) return 1; cs.list = (u32*)p;
     if (get_buf(c, W_RX_SEGOFF, (size_t)nblocks * fan * 4, &p)) return 1; cs.seg_off = (u32*)p;
@@ -418,16 +425,17 @@ int stream_append_chunks(fj_ctx* c, int side, const void* d_chunks, u32* d_dir, 
 }
 }  // namespace
 
-int fj_stream_append_build_chunks(fj_ctx* c, const void* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream) {
+int fj_stream_append_build_chunks(fj_ctx* c, const void* d_chunks, const uint64_t* d_vals, uint32_t* d_dir, size_t nchunks, void* stream) {
     if (!c || !c->st.active || !c->st.shuffled) return set_err("fj_stream_append_build_chunks: no shuffled stream join is open on this context");
     StreamState& st = c->st;
     if (st.build_done) return set_err("fj_stream_append_build_chunks: the build side is already closed");
     if (st.b_appends_left == 0) return set_err("fj_stream_append_build_chunks: more pieces than build_appends");
-    if (nchunks && (!d_chunks || !d_dir || ((uintptr_t)d_chunks & 15))) return set_err("fj_stream_append_build_chunks: null or misaligned piece");
+    if (nchunks && (!d_chunks || !d_dir || ((uintptr_t)d_chunks & 15) || ((uintptr_t)d_vals & 15))) return set_err("fj_stream_append_build_chunks: null or misaligned piece");
+    if (nchunks && st.with_vals != (d_vals != nullptr)) return set_err("fj_stream_append_build_chunks: the stream was opened %s values", st.with_vals ? "with" : "without");
     FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     --st.b_appends_left;
-    if (nchunks) { st.nb_seen += nchunks * FJ_CHUNK; if (stream_append_chunks(c, 0, d_chunks, d_dir, nchunks, s)) return 1; }
+    if (nchunks) { st.nb_seen += nchunks * FJ_CHUNK; if (stream_append_chunks(c, 0, d_chunks, (const u64*)d_vals, d_dir, nchunks, s)) return 1; }
     if (st.b_appends_left == 0) return stream_flush_build(c, st, s);          // the build side is complete: its remaining passes run now
     return 0;
 }
@@ -442,7 +450,7 @@ int fj_stream_append_probe_chunks(fj_ctx* c, const void* d_chunks, uint32_t* d_d
     --st.p_appends_left;
     if (nchunks == 0) return 0;
     st.np_seen += nchunks * FJ_CHUNK;
-    return stream_append_chunks(c, 1, d_chunks, d_dir, nchunks, (hipStream_t)stream);
+    return stream_append_chunks(c, 1, d_chunks, nullptr, d_dir, nchunks, (hipStream_t)stream);
 }
 
 }  // extern "C"

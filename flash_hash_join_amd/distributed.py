@@ -189,6 +189,8 @@ class HipEngine:
         cb = self.shuffle_chunk_bytes(nb_total, world)
         if cb == 0:
             raise RuntimeError(self._lib.last_error())
+        if vals is not None:
+            vals = self._aligned(vals)
         self._lib.check(self.L.fj_shuffle_pack_begin(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, world, stream))
         used = (ctypes.c_uint64 * 64)()
         self._lib.check(self.L.fj_shuffle_pack_counts(self.ctx, used))
@@ -198,19 +200,36 @@ class HipEngine:
         vp = ctypes.c_void_p
         dk = (vp * 64)(*[c.data_ptr() for c in chunks])
         dd = (vp * 64)(*[d.data_ptr() for d in dirs])
-        self._lib.check(self.L.fj_shuffle_pack_finish(self.ctx, dk, None, dd, stream))
-        return [c[: u * cb] for c, u in zip(chunks, used)], [d[:u] for d, u in zip(dirs, used)], used
+        if vals is None:
+            self._lib.check(self.L.fj_shuffle_pack_finish(self.ctx, dk, None, dd, stream))
+            return [c[: u * cb] for c, u in zip(chunks, used)], [d[:u] for d, u in zip(dirs, used)], used
+        vouts = [self.empty(max(2, u * 256)) for u in used]
+        dv = (vp * 64)(*[v.data_ptr() for v in vouts])
+        self._lib.check(self.L.fj_shuffle_pack_finish(self.ctx, dk, dv, dd, stream))
+        return [c[: u * cb] for c, u in zip(chunks, used)], [d[:u] for d, u in zip(dirs, used)], used, [v[: u * 256] for v, u in zip(vouts, used)]
 
-    def stream_open_shuffled(self, nb_total: int, world: int, rank: int, nb_bound: int, build_appends: int, np_bound: int, probe_appends: int):
+    def stream_open_shuffled(self, nb_total: int, world: int, rank: int, nb_bound: int, build_appends: int, np_bound: int, probe_appends: int,
+                             with_vals: bool = False):
         self._keep = []
-        self._lib.check(self.L.fj_stream_open_shuffled(self.ctx, nb_total, world, rank, nb_bound, build_appends, np_bound, probe_appends,
+        self._lib.check(self.L.fj_stream_open_shuffled(self.ctx, nb_total, world, rank, nb_bound, build_appends, np_bound, probe_appends, int(with_vals),
                                                        self.torch.cuda.current_stream(self.index).cuda_stream))
 
-    def stream_append_chunks(self, side: int, chunks, dirw):
-        """A received piece: wire-format chunks (uint8 tensor) + their directory words (rewritten in place)."""
-        self._keep += [chunks, dirw]
-        fn = self.L.fj_stream_append_probe_chunks if side else self.L.fj_stream_append_build_chunks
-        self._lib.check(fn(self.ctx, chunks.data_ptr(), dirw.data_ptr(), dirw.numel(), self.torch.cuda.current_stream(self.index).cuda_stream))
+    def stream_append_chunks(self, side: int, chunks, dirw, vals=None):
+        """A received piece: wire-format chunks (uint8 tensor) + their directory words (rewritten in place) [+ 256 values per build chunk]."""
+        self._keep += [chunks, dirw, vals]
+        stream = self.torch.cuda.current_stream(self.index).cuda_stream
+        if side:
+            self._lib.check(self.L.fj_stream_append_probe_chunks(self.ctx, chunks.data_ptr(), dirw.data_ptr(), dirw.numel(), stream))
+        else:
+            self._lib.check(self.L.fj_stream_append_build_chunks(self.ctx, chunks.data_ptr(), vals.data_ptr() if vals is not None else None, dirw.data_ptr(),
+                                                                 dirw.numel(), stream))
+
+    def emit_pairs(self, n: int):
+        """The pairs of the materialising join that was just counted on this context (fj_emit_pairs): two int64 tensors of n rows."""
+        ok, ov = self.empty(max(n, 2)), self.empty(max(n, 2))
+        t = self._lib.FjTimings()
+        self._lib.check(self.L.fj_emit_pairs(self.ctx, ok.data_ptr(), ov.data_ptr(), n, self.torch.cuda.current_stream(self.index).cuda_stream, ctypes.byref(t)))
+        return ok[:n], ov[:n]
 
     def chunk_rows(self, dirw) -> int:
         """Rows in a set of chunks, from their directory words (bucket << 9 | count; unused ids are all ones)."""
@@ -645,16 +664,18 @@ def _engine_ops_struct(ops, keep: list):
                                 cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"])
 
 
-def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport):
-    """The counting owner shuffle in chunk form through the ONE driver, csrc/fj_dist.hip (fj_dist_join_count): natively over RCCL
-    under the nccl backend; over a callback transport (torch.distributed with host staging: gloo, a transport object) otherwise;
-    with a stand-in engine's callbacks in the CPU test-suite.  Collective; a failure on any rank raises on every rank."""
+def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport, build_values=None, return_arrays=False):
+    """The owner shuffle in chunk form through the ONE driver, csrc/fj_dist.hip (fj_dist_join): natively over RCCL under the nccl
+    backend; over a callback transport (torch.distributed with host staging: gloo, a transport object) otherwise; with a stand-in
+    engine's callbacks in the CPU test-suite.  build_values: a materialising join (the pairs stay with the owner; returned when
+    return_arrays).  Collective; a failure on any rank raises on every rank."""
     from . import _lib
     L = _lib.load()
     t0 = time.perf_counter()
-    cnt = ctypes.c_uint64(0)
+    cnt, local = ctypes.c_uint64(0), ctypes.c_uint64(0)
     dt = _lib.FjDistTimings()
     keep: list = []
+    pairs = None
     standin = hasattr(engine, "dist_engine_ops")
     native = (not standin and transport is None and os.environ.get("FJ_DIST_NATIVE", "1") != "0" and dist.get_backend(group) == "nccl")
     if native:
@@ -675,9 +696,12 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
         else:
             tt = engine.torch
             bk, pk = engine._aligned(build_keys), engine._aligned(probe_keys)
+            bv = engine._aligned(build_values) if build_values is not None else None
             with tt.cuda.device(engine.index):
-                rc = L.fj_dist_join_count(comm, bk.data_ptr(), bk.numel(), pk.data_ptr(), pk.numel(), pieces,
-                                          tt.cuda.current_stream(engine.index).cuda_stream, ctypes.byref(cnt), ctypes.byref(dt))
+                rc = L.fj_dist_join(comm, bk.data_ptr(), bv.data_ptr() if bv is not None else None, bk.numel(), pk.data_ptr(), pk.numel(), pieces,
+                                    int(bv is not None), tt.cuda.current_stream(engine.index).cuda_stream, ctypes.byref(cnt), ctypes.byref(local), ctypes.byref(dt))
+                if rc == 0 and bv is not None and return_arrays:
+                    pairs = engine.emit_pairs(int(local.value))
         if rc:
             msg = _lib.last_error()
             if not native and tr.error is not None:
@@ -695,6 +719,8 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
                        local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=False, prefilter_mode="off",
                        prefilter_sampled_survivors=None, probe_rows_sent=probe_keys.numel(), rows_are_chunk_capacity=True,
                        wire_chunk_bytes=int(dt.wire_chunk_bytes), wire_bytes_sent=int(dt.sent_chunks) * (int(dt.wire_chunk_bytes) + 4))
+    if pairs is not None:
+        return int(cnt.value), sec, pairs[0], pairs[1]
     return int(cnt.value), sec
 
 
@@ -972,6 +998,23 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
         if timings is not None:
             timings["shuffle_form"] = "owner-scatter"
         return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings, prefilter=mode)
+
+    # materialising joins: the chunk form too (the build rows travel with their values, the pairs stay with the owner: SURVEY 8(e)) -
+    # through the same driver; duplicate build keys, the sender-side precheck and small build sides take the owner-scatter form below
+    if (materialize and hasattr(engine, "emit_pairs") and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0"
+            and (_prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off") == "off"
+            and min(int(x[1]) for x in allsz) >= 2 * pieces and engine.shuffle_plan(sum(sizes_b), world) is not None
+            ):
+        try:
+            return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport, build_values=build_values, return_arrays=return_arrays)
+        except RuntimeError as ex:
+            if os.environ.get("FJ_DIST_NO_FALLBACK"):
+                raise
+            _abort_stream(engine)
+            if timings is not None:
+                timings["chunk_form_error"] = str(ex)
+    if timings is not None:
+        timings["shuffle_form"] = "owner-scatter"
 
     # 1. split by owner
     bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)

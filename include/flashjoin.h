@@ -197,7 +197,12 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
  *   fj_stream_append_probe_chunks  - chunk lists from the directory words (rewritten in place), then the plan's second pass
  *                                    over the piece (it unpacks the wire format in registers); asynchronous on `stream`, the
  *                                    piece stays allocated until the finish
- *   fj_stream_finish               - remaining passes, join, count (counting joins only).
+ *   fj_stream_finish               - remaining passes, join, count.
+ * Materialising joins (_hash_join_radix_materialize, hash_join.cpp:315-381, across GPUs): open with with_vals = 1 and append the
+ * build side with its values (256 per chunk, as fj_shuffle_pack_finish wrote them; d_vals == NULL otherwise); fj_stream_finish
+ * then returns the count and leaves the partitions resident, fj_emit_pairs writes this owner's (probe_key, build_value) pairs -
+ * they stay with the owner.  Duplicate build keys are refused there (first-occurrence semantics need the flat
+ * build arrays): the owner-scatter form serves them.
  */
 int fj_shuffle_plan(size_t nb_total, int nranks, int* fan_log0, int* npass);
 size_t fj_shuffle_chunk_bytes(size_t nb_total, int nranks);
@@ -205,8 +210,8 @@ int fj_shuffle_pack_begin(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d
 int fj_shuffle_pack_counts(fj_ctx* ctx, uint64_t* h_used);
 int fj_shuffle_pack_finish(fj_ctx* ctx, void* const* d_dst_chunks, uint64_t* const* d_dst_vals, uint32_t* const* d_dst_dir, void* stream);
 int fj_stream_open_shuffled(fj_ctx* ctx, size_t nb_total, int nranks, int rank, size_t nb_bound, int build_appends,
-                            size_t np_bound, int probe_appends, void* stream);
-int fj_stream_append_build_chunks(fj_ctx* ctx, const void* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
+                            size_t np_bound, int probe_appends, int with_vals, void* stream);
+int fj_stream_append_build_chunks(fj_ctx* ctx, const void* d_chunks, const uint64_t* d_vals, uint32_t* d_dir, size_t nchunks, void* stream);
 int fj_stream_append_probe_chunks(fj_ctx* ctx, const void* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
 
 /*
@@ -267,6 +272,9 @@ int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error
  *                                 then ctx may be NULL and "device" pointers are whatever the stand-in's alloc returns.
  *   fj_dist_join_count          - collective.  pieces: rounds of the probe exchange (4 is the measured default).  A build side
  *                                 of less than ~2M rows in all is refused (one-pass plan: join it on one GPU).
+ *   fj_dist_join                - the same step, optionally materialising (materialize != 0: the build rows travel with their
+ *                                 values, 16 bytes per build row on the wire): *out_local_count = pairs this rank owns; the
+ *                                 caller then allocates them and calls fj_emit_pairs(ctx, ...) - before the next join on ctx.
  */
 typedef struct fj_dist_comm fj_dist_comm;
 typedef struct fj_dist_timings {
@@ -313,6 +321,8 @@ int fj_dist_comm_rank(const fj_dist_comm* comm);
 int fj_dist_comm_size(const fj_dist_comm* comm);
 int fj_dist_join_count(fj_dist_comm* comm, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                        void* stream, uint64_t* out_global_count, fj_dist_timings* timings);
+int fj_dist_join(fj_dist_comm* comm, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, const uint64_t* d_probe_keys, size_t np,
+                 int pieces, int materialize, void* stream, uint64_t* out_global_count, uint64_t* out_local_count, fj_dist_timings* timings);
 
 /*
  * Deterministic synthetic relations, generated in HBM:

@@ -444,6 +444,65 @@ def test_owner_shuffle_in_chunk_form_on_one_gpu(fj, world, nb_total, nb, npk, bp
     assert total == exp
 
 
+@pytest.mark.parametrize("world,nb_total,nb,npk", [(1, 40_000_000, 5_000_000, 30_000_000), (3, 300_000_000, 3_000_000, 20_000_000), (8, 300_000_000, 3_000_000, 20_000_000)])
+def test_materialising_owner_shuffle_in_chunk_form_on_one_gpu(fj, world, nb_total, nb, npk):
+    """_hash_join_radix_materialize (hash_join.cpp:315-381) across GPUs in the chunk form, all ranks played by one GPU: the build
+    rows are packed WITH their values (256 per wire chunk), every owner opens its stream join with values, appends what the
+    senders packed for it, counts (fj_stream_finish) and writes its pairs (fj_emit_pairs) - they stay with the owner.  Every pair
+    is a probe key with its build value, the owners' pair sets add up to the closed-form count, and a pair sits with the owner of
+    its key's first-pass bucket."""
+    import torch
+    import keymix
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    eng = HipEngine("cuda:0")
+    f0 = eng.shuffle_plan(nb_total, world)
+    bk, bv = datagen.build_device(nb, "cuda:0")
+    pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=33, hit_bp=3000)
+    bch, bdir, bused, bvals = eng.shuffle_pack(bk, bv, nb_total, world)
+    pch, pdir, pused = eng.shuffle_pack(pk, None, nb_total, world)
+    torch.cuda.synchronize()
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+    total = 0
+    for r in range(world):
+        assert bvals[r].numel() == bused[r] * 256
+        eng.stream_open_shuffled(nb_total, world, r, bused[r] * 256 + 1024, 1, pused[r] * 256 + 1024, 1, with_vals=True)
+        eng.stream_append_chunks(0, bch[r], bdir[r], bvals[r])
+        eng.stream_append_chunks(1, pch[r], pdir[r])
+        n = eng.stream_finish()
+        k, v = eng.emit_pairs(n)
+        assert k.numel() == n and bool(torch.all((v + 1) * M == k))              # (probe key, value of the build row with that key)
+        if n:
+            b = (keymix.hash_w1(k.cpu().numpy().view(np.uint64)) >> np.uint32(32 - f0)).astype(np.int64)
+            assert np.all((b * world) >> f0 == r)                                 # pairs stay with the owner of their bucket
+        total += n
+    assert total == exp
+    # duplicate build keys are refused in this form (first-occurrence semantics need the flat build arrays): an error, not a wrong pair
+    dk = torch.cat([bk, bk[:1000]]); dv = torch.cat([bv, bv[:1000] + 7])
+    dch, ddir, dused, dvals = eng.shuffle_pack(dk, dv, nb_total, 1)
+    qch, qdir, qused = eng.shuffle_pack(pk, None, nb_total, 1)
+    eng.stream_open_shuffled(nb_total, 1, 0, dused[0] * 256 + 1024, 1, qused[0] * 256 + 1024, 1, with_vals=True)
+    eng.stream_append_chunks(0, dch[0], ddir[0], dvals[0])
+    eng.stream_append_chunks(1, qch[0], qdir[0])
+    with pytest.raises(RuntimeError, match="duplicate build keys"):
+        eng.stream_finish()
+    assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp                         # the context serves other joins again
+
+
+def test_materialised_pairs_do_not_pin_the_probe_sized_buffers(fj):
+    """The single-pass materialising join writes into buffers with room for ANY result (16 bytes per probe row); what it hands
+    back must not keep them alive: at 30 % hits the returned tensors own exactly n rows."""
+    import torch
+    from flash_hash_join_amd import datagen
+    bk, bv = datagen.build_device(2_000_000, "cuda:0")
+    pk, exp = datagen.probe_device(20_000_000, 2_000_000, "cuda:0", seed=5, hit_bp=3000)
+    n, _, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+    assert n == exp and k.numel() == n and v.numel() == n
+    assert k.untyped_storage().nbytes() == n * 8 and v.untyped_storage().nbytes() == n * 8
+    M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+    assert bool(torch.all((v + 1) * M == k))
+
+
 @pytest.mark.parametrize("top_bits", [64, 48])
 @pytest.mark.parametrize("nb,npk,hit_bp", [(1, 1000, 5000), (3000, 200_000, 0), (1_000_000, 5_000_000, 500), (20_000_000, 30_000_000, 2500),
                                             (150_000_000, 40_000_000, 100)])

@@ -95,9 +95,13 @@ def worker(rank, world, port, q):
             assert n == exp, (strategy, n, exp)
             if pieces == "prefilter":                       # half the probe rows miss; the owners' filters stop nearly all of them
                 assert t["prefilter"] and t["probe_rows_sent"] < 0.56 * (p1 - p0), t
-            n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True, transport=shim)
+            tm = {}
+            n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True, transport=shim, timings=tm)
             M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
             assert n2 == exp and bool(torch.all((v + 1) * M == k)), strategy
+            if strategy == "shuffle":                        # materialising joins take the chunk form too (values travel with the build rows)
+                assert tm["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport" if pieces == "1" else "owner-scatter"), tm
+                assert "chunk_form_error" not in tm, tm
             tot = torch.tensor([k.numel()]); dist.all_reduce(tot)
             assert int(tot.item()) == exp                   # the ranks' pair sets add up to the global result
             if strategy == "shuffle":
