@@ -36,6 +36,40 @@ def test_library_exports_every_declared_symbol(lib):
         assert re.search(rf"\bT {name}\b", out), f"{name} is not an exported text symbol"
 
 
+def test_key_mixer_is_a_bijection_and_matches_its_numpy_restatement(lib):
+    """fj_key_mix64 / fj_key_unmix64 (host functions of the C ABI: no GPU needed): chunk pools and wire chunks hold the mixed key,
+    so the mixer must be one-to-one - unmix(mix(k)) == k, mix(unmix(h)) == h - and tests/keymix.py, which the GPU tests check
+    placements and wire chunks against, must be the same function.  Hash word 1 (the high word) is what rounds 1-3 partitioned
+    on: its known answers must not move."""
+    import keymix
+    rng = np.random.default_rng(7)
+    ks = np.concatenate([np.array([0, 1, 2, 42, 2**64 - 1, 0x9E3779B97F4A7C15, 1 << 32, (1 << 32) - 1], dtype=np.uint64),
+                         rng.integers(0, 2**63, 2000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 2000, dtype=np.uint64),
+                         np.arange(500, dtype=np.uint64) << np.uint64(32), np.arange(500, dtype=np.uint64)])
+    m = keymix.mix(ks)
+    for k, h in zip(ks.tolist(), m.tolist()):
+        assert lib.fj_key_mix64(k) == h and lib.fj_key_unmix64(h) == k
+        assert lib.fj_key_mix64(lib.fj_key_unmix64(k)) == k           # onto as well: every 64-bit word is some key's image
+    assert np.array_equal(keymix.unmix(m), ks) and np.unique(m).size == np.unique(ks).size
+
+    def w1_round3(k):                                          # fj_hash_w1 as rounds 1-3 defined it
+        lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            x = (lo * np.uint32(0x9E3779B1)) ^ (hi * np.uint32(0x85EBCA77))
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b)
+            x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35)
+            x ^= x >> np.uint32(16)
+        return x
+    assert np.array_equal(keymix.hash_w1(ks), w1_round3(ks))
+    # quality: sequential keys and keys that differ in their high word only spread like random ones over 1024 partitions
+    for keys in (np.arange(1 << 20, dtype=np.uint64), np.arange(1 << 20, dtype=np.uint64) << np.uint64(32)):
+        h = keymix.mix(keys)
+        cnt = np.bincount((h >> np.uint64(54)).astype(np.int64), minlength=1024)
+        assert cnt.min() > 800 and cnt.max() < 1250               # 1024 +- 4 sigma
+        slots = np.bincount((h & np.uint64(8191)).astype(np.int64), minlength=8192)
+        assert slots.min() > 70 and slots.max() < 190              # 128 +- 5 sigma
+
+
 def test_library_contains_gfx950_code_object(lib):
     from flash_hash_join_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()

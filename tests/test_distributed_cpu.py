@@ -247,6 +247,16 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         p0, p1 = rank * npk // world, (rank + 1) * npk // world
         bk, bv = datagen.build_numpy(b1 - b0, first=b0)
         pk, exp_local = datagen.probe_numpy(p1 - p0, nb, seed=1, hit_bp=5000, first=p0)
+        if variant in ("skew", "lateskew"):
+            # hot probe key: 60 % of every rank's probe rows carry ONE build key, so its owner receives far more than 1.5x an even share.
+            # "skew": spread over all pieces - the driver sizes the owner's pools from the first piece it sees, the chunk form succeeds;
+            # "lateskew": only in the second half of the rows - what the first piece cannot announce
+            hot = np.uint64(12345 * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
+            pk = pk.copy()
+            idx = np.arange(pk.size)
+            sel = (idx % 5 < 3) if variant == "skew" else ((idx >= pk.size // 2) & (idx % 10 < 9))
+            exp_local += int(sel.sum()) - int(np.isin(pk[sel], np.arange(1, nb + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).sum())
+            pk[sel] = hot
         t = {}
         tb, tv, tp = (torch.from_numpy(x.view(np.int64)) for x in (bk, bv, pk))
         if strategy == "shuffle" and variant == "":
@@ -275,6 +285,10 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         assert cnt == int(exp.item()) and tc["strategy"] == t["strategy"] == strategy
         if variant in ("packfail", "appendfail"):    # ... and without FJ_DIST_NO_FALLBACK all ranks rerun in the owner-scatter form together
             assert "failed on 1 rank" in tc["chunk_form_error"] and tc["shuffle_form"] == "owner-scatter"
+        if variant == "skew":
+            assert tc["shuffle_form"].startswith("chunks") and "chunk_form_error" not in tc, tc
+        if variant == "lateskew":                    # (at these sizes the pools' constant slack absorbs it; at scale the ranks would rerun together in the owner-scatter form)
+            assert tc["shuffle_form"].startswith("chunks") or "failed on" in tc["chunk_form_error"], tc
         keys = res[2].numpy().view(np.uint64)
         assert tc.get("prefilter", False) == prefilter
         if variant.startswith("prefilter"):
@@ -288,6 +302,8 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             assert tc["local_probe_rows"] == t["local_probe_rows"] and tc["probe_rows_sent"] == t["probe_rows_sent"] < 0.6 * (p1 - p0)
             glob = torch.tensor([tc["local_probe_rows"]]); dist.all_reduce(glob)
             assert int(exp.item()) <= int(glob.item()) < 0.6 * npk
+        elif strategy == "shuffle" and variant in ("skew", "lateskew"):
+            pass
         elif strategy == "shuffle" and variant == "":
             # the counting join took the chunk form (its owners are whole first-pass buckets: another split of the hash range than
             # the owner-scatter form the materialising join uses, so only the totals agree)
@@ -319,7 +335,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_appendfail", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
+@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_appendfail", "shuffle_skew", "shuffle_lateskew", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
                                       "replicate_small_messages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):
