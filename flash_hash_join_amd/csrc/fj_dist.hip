@@ -539,18 +539,18 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     size_t rows_recv_chunks = 0;
     for (int c = 0; c < pieces; ++c) {
         if (finish_piece(begun, c & 1, c + 1, false, &P[c])) return 1;
+        if (c + 1 < pieces) {
+            bounds(c + 1, &lo, &hi);
+            const auto tp = std::chrono::steady_clock::now();
+            begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N) == 0;
+            split_ms += ms_since(tp);
+        }
         if (c == 0) {
             // the owner's stream join opens once the first probe piece's size is known: an owner of hot probe keys (its share far above
             // np_global / N) sizes its pools from what actually arrives - 1.25x the first piece's rate - instead of failing later
             const size_t seen = (size_t)(1.25 * (double)P[0].chunks * FJ_CHUNK * pieces) + ((size_t)1 << 20);
             opened = guarded(eng.open(nb_total, N, me, B.chunks * FJ_CHUNK, std::max(np_bound, seen), pieces, mat)) == 0;
             if (failed.empty()) guarded(eng.append(0, B.rk, B.rv, B.rd, B.chunks, B.done));
-        }
-        if (c + 1 < pieces) {
-            bounds(c + 1, &lo, &hi);
-            const auto tp = std::chrono::steady_clock::now();
-            begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N) == 0;
-            split_ms += ms_since(tp);
         }
         mark(" next pass enqueued");
         rows_recv_chunks += P[c].chunks;

@@ -18,7 +18,7 @@
 namespace {
 
 constexpr u32 PK_NT = 256;             // threads of the scan and squeeze workgroups = keys per chunk
-constexpr u32 PK_CPW = 4;              // output chunks a squeeze workgroup handles per step (independent load chains in flight)
+constexpr u32 PK_CPW = 8;              // output chunks a squeeze workgroup handles per step (four per half workgroup: independent load chains in flight)
 
 // keys per first-pass bucket: one workgroup per bucket sums its chunk list's counts
 __global__ __launch_bounds__(PK_NT) void fj_pack_count(FjPackArgs a) {
@@ -87,58 +87,72 @@ __global__ __launch_bounds__(PK_NT) void fj_pack_scan(FjPackArgs a) {
     }
 }
 
-// the copy.  A workgroup takes PK_CPW consecutive output chunks per step, thread t owns key t of each; every wave is on its own
-// (no LDS, no barrier): the chunk's descriptor and directory word come through the scalar cache (wave-uniform loads), one
-// dependent vector load reaches the key, and the three planes of the wire format leave straight from registers - every lane
-// stores its low word, even lanes the pair of 16-bit fields they collect from their neighbour, every fourth lane the four bytes
-// of its group: a wave's stores cover 256 / 128 / 64 contiguous bytes.  (Rounds of this kernel with an LDS transpose and with a
-// per-chunk binary search over the bucket offsets ran at 2.7-3.0 TB/s.)
+// the copy.  A workgroup takes PK_CPW consecutive output chunks per step - its lower 128 threads the even ones, its upper 128 the
+// odd ones - and a thread owns keys 2q, 2q + 1 of its chunk; every wave is on its own (no LDS, no barrier): the chunk's
+// descriptor and directory word come through the scalar cache (wave-uniform loads), one dependent 16-byte load reaches the two
+// keys (8-byte aligned: after a partial input chunk the stream's positions are odd as often as even), and the three planes of the
+// wire format leave straight from registers - 8 bytes of low words and 4 bytes of 16-bit fields per lane, even lanes the four
+// bytes of their group: a wave's stores cover 512 / 256 / 128 contiguous bytes.  (Rounds of this kernel: LDS transpose + a
+// per-chunk binary search over the bucket offsets 3.0 TB/s; one key per lane 4.4 TB/s.)
+struct __attribute__((packed, aligned(8))) u64x2u { u64 x, y; };
 template <bool W7, bool VALS>
 __global__ __launch_bounds__(PK_NT) void fj_pack_squeeze(FjPackArgs a, const uint4* __restrict__ fi, const u32* __restrict__ fb, const u32* __restrict__ list,
                                                          const u32* __restrict__ obase, const u64* __restrict__ keys, const u64* __restrict__ vals) {
+    constexpr u32 SLOTS = PK_CPW / 2;
     const u32 tid = threadIdx.x, F = a.nb, N = a.nranks;
+    const u32 half = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 7)), q = tid & 127u;
     const u32 total = obase[F];
+    // the key at position `rel` of the stream that starts in list entry e (index j of the chunk list): walk on while it lies beyond
+    auto resolve = [&](u32 rel, u32 e, u32 e1, u32 j) -> u64 {
+        if (rel >= FJ_LIST_CNT(e)) {
+            rel -= FJ_LIST_CNT(e); e = e1; ++j;
+            while (rel >= FJ_LIST_CNT(e)) { rel -= FJ_LIST_CNT(e); ++j; e = list[j]; }      // (the key exists: the walk ends inside the bucket's list)
+        }
+        return (u64)FJ_LIST_ID(e) * FJ_CHUNK + rel;
+    };
     for (u32 g0 = blockIdx.x * PK_CPW; g0 < total; g0 += gridDim.x * PK_CPW) {
-        uint4 f[PK_CPW]; u32 dw[PK_CPW];
+        uint4 f[SLOTS]; u32 dw[SLOTS];
 #pragma unroll
-        for (u32 u = 0; u < PK_CPW; ++u) {
-            const u32 g = g0 + u < total ? g0 + u : total - 1;            // (clamped: the loads stay unconditional; g is wave-uniform)
+        for (u32 u = 0; u < SLOTS; ++u) {
+            const u32 gg = g0 + 2 * u + half, g = gg < total ? gg : total - 1;     // (clamped: the loads stay unconditional; g is wave-uniform)
             f[u] = fi[g]; dw[u] = fb[g];
         }
-        u64 key[PK_CPW], val[PK_CPW];
-        bool ok[PK_CPW];
+        u64 k0[SLOTS], k1[SLOTS], v0[SLOTS], v1[SLOTS];
 #pragma unroll
-        for (u32 u = 0; u < PK_CPW; ++u) {
-            ok[u] = g0 + u < total && tid < (dw[u] & FJ_DIR_CNT_MASK);
-            u32 rel = f[u].z + tid, e = f[u].x;
-            if (ok[u] && rel >= FJ_LIST_CNT(e)) {
-                rel -= FJ_LIST_CNT(e); e = f[u].y;
-                u32 j = f[u].w + 1;
-                while (rel >= FJ_LIST_CNT(e)) { rel -= FJ_LIST_CNT(e); ++j; e = list[j]; }      // (the key exists: the walk ends inside the bucket's list)
+        for (u32 u = 0; u < SLOTS; ++u) {
+            const u32 cnt = g0 + 2 * u + half < total ? (dw[u] & FJ_DIR_CNT_MASK) : 0u;
+            const bool ok0 = 2 * q < cnt, ok1 = 2 * q + 1 < cnt;
+            const u32 rel = f[u].z + 2 * q;
+            k0[u] = 0; k1[u] = 0; v0[u] = 0; v1[u] = 0;
+            if (ok1 && rel + 1 < FJ_LIST_CNT(f[u].x)) {                           // both keys in the first input chunk: one 16-byte load
+                const u64 src = (u64)FJ_LIST_ID(f[u].x) * FJ_CHUNK + rel;
+                const u64x2u kk = *reinterpret_cast<const u64x2u*>(keys + src);
+                k0[u] = kk.x; k1[u] = kk.y;
+                if (VALS) { const u64x2u vv = *reinterpret_cast<const u64x2u*>(vals + src); v0[u] = vv.x; v1[u] = vv.y; }
+            } else {
+                if (ok0) { const u64 s0 = resolve(rel, f[u].x, f[u].y, f[u].w); k0[u] = keys[s0]; if (VALS) v0[u] = vals[s0]; }
+                if (ok1) { const u64 s1 = resolve(rel + 1, f[u].x, f[u].y, f[u].w); k1[u] = keys[s1]; if (VALS) v1[u] = vals[s1]; }
             }
-            const u64 src = (u64)FJ_LIST_ID(e) * FJ_CHUNK + (ok[u] ? rel : 0u);
-            key[u] = keys[src];
-            if (VALS) val[u] = vals[src];
         }
 #pragma unroll
-        for (u32 u = 0; u < PK_CPW; ++u) {
-            if (g0 + u >= total) continue;                                 // (workgroup-uniform)
-            const u32 b = dw[u] >> FJ_DIR_CNT_BITS, r = (b * N) >> a.fan_log, idx = g0 + u - obase[F + 1 + r];
-            const u64 k = ok[u] ? key[u] : 0ull;
+        for (u32 u = 0; u < SLOTS; ++u) {
+            const u32 g = g0 + 2 * u + half;
+            if (g >= total) continue;                                      // (wave-uniform)
+            const u32 b = dw[u] >> FJ_DIR_CNT_BITS, r = (b * N) >> a.fan_log, idx = g - obase[F + 1 + r];
             if (W7) {
                 unsigned char* d = a.dst_k[r] + (u64)idx * FJ_WIRE7_BYTES;
-                const u32 md = (u32)(k >> 32) & 0xFFFFu, hb = (u32)(k >> 48) & 0xFFu;
-                const u32 md2 = md | (__shfl_down(md, 1, 64) << 16);
-                u32 hb4 = hb | (__shfl_down(hb, 1, 64) << 8);
-                hb4 |= __shfl_down(hb4, 2, 64) << 16;
-                reinterpret_cast<u32*>(d)[tid] = (u32)k;
-                if (!(tid & 1u)) reinterpret_cast<u32*>(d + FJ_WIRE7_MID)[tid >> 1] = md2;
-                if (!(tid & 3u)) reinterpret_cast<u32*>(d + FJ_WIRE7_HI)[tid >> 2] = hb4;
+                const u32 md = ((u32)(k0[u] >> 32) & 0xFFFFu) | ((u32)(k1[u] >> 32) << 16);
+                const u32 hb2 = ((u32)(k0[u] >> 48) & 0xFFu) | (((u32)(k1[u] >> 48) & 0xFFu) << 8);
+                const u32 hb4 = hb2 | (__shfl_down(hb2, 1, 64) << 16);
+                reinterpret_cast<uint2*>(d)[q] = make_uint2((u32)k0[u], (u32)k1[u]);
+                reinterpret_cast<u32*>(d + FJ_WIRE7_MID)[q] = md;
+                if (!(q & 1u)) reinterpret_cast<u32*>(d + FJ_WIRE7_HI)[q >> 1] = hb4;
             } else {
-                reinterpret_cast<u64*>(a.dst_k[r] + (u64)idx * (FJ_CHUNK * 8u))[tid] = k;
+                u64x2 kk; kk.x = k0[u]; kk.y = k1[u];
+                reinterpret_cast<u64x2*>(a.dst_k[r] + (u64)idx * (FJ_CHUNK * 8u))[q] = kk;
             }
-            if (VALS) a.dst_v[r][(u64)idx * FJ_CHUNK + tid] = ok[u] ? val[u] : 0ull;
-            if (tid == 0) a.dst_d[r][idx] = dw[u];
+            if (VALS) { u64x2 vv; vv.x = v0[u]; vv.y = v1[u]; reinterpret_cast<u64x2*>(a.dst_v[r] + (u64)idx * FJ_CHUNK)[q] = vv; }
+            if (q == 0) a.dst_d[r][idx] = dw[u];
         }
     }
 }

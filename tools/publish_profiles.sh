@@ -14,9 +14,13 @@ done
 [ -s $S/traffic_latest.json ] && cp $S/traffic_latest.json profiles/traffic_latest.json
 D=gpurun_out/${TAG}d
 if [ -d $D ]; then
-  cp $D/c5_dist_form1_bench.json profiles/${TAG}_c5_one_rank_shuffle_chunks_bench.json
-  cp $D/c5_dist_form1_kernel_stats.csv profiles/${TAG}_c5_one_rank_shuffle_chunks_kernel_stats.csv
-  cp $D/c5_dist_form0_bench.json profiles/${TAG}_c5_one_rank_shuffle_owner_scatter_bench.json
-  cp $D/c5_dist_form0_kernel_stats.csv profiles/${TAG}_c5_one_rank_shuffle_owner_scatter_kernel_stats.csv
+  if [ -s $D/c5_one_rank_bench.json ]; then          # tools/r4_dist_one_gpu.sh: the step through the C++ driver
+    for f in c5_one_rank_bench.json c5_one_rank_loopback_bench.json c5_plain_join_bench.json c5_one_rank_kernel_stats.csv; do cp $D/$f profiles/${TAG}_$f; done
+  else                                                # tools/r3_dist_one_gpu.sh
+    cp $D/c5_dist_form1_bench.json profiles/${TAG}_c5_one_rank_shuffle_chunks_bench.json
+    cp $D/c5_dist_form1_kernel_stats.csv profiles/${TAG}_c5_one_rank_shuffle_chunks_kernel_stats.csv
+    cp $D/c5_dist_form0_bench.json profiles/${TAG}_c5_one_rank_shuffle_owner_scatter_bench.json
+    cp $D/c5_dist_form0_kernel_stats.csv profiles/${TAG}_c5_one_rank_shuffle_owner_scatter_kernel_stats.csv
+  fi
 fi
 python3 tools/source_hash.py | tail -1; grep source_sha256 profiles/traffic_latest.json

@@ -12,7 +12,7 @@ for line in open(summary):
         continue
     k, c, n, v = m.group(1), m.group(2), int(m.group(3)), float(m.group(4))
     # keys-only passes over the PROBE side (last template argument), flat and chunk-list input
-    if re.search(r"fj_partition_kernel<(512|1024), 8, 4, false, (true|false), true(, false)?(, [02])?>", k):      # (..., PROBE_SIDE = true, OWN = false, RLOG)
+    if re.search(r"fj_partition_kernel<(512|1024), 8, 4, false, (true|false), true(, false)?(, [02])?(, false)?>", k):      # (..., PROBE_SIDE = true, [OWN = false: rounds 1-3,] RLOG, PK7 = false)
         (fetch if c == "FETCH_SIZE" else write).append(v)
 f = sum(fetch) / len(fetch) * 1024 * 2
 w = sum(write) / len(write) * 1024
