@@ -489,6 +489,48 @@ def test_materialising_owner_shuffle_in_chunk_form_on_one_gpu(fj, world, nb_tota
     assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp                         # the context serves other joins again
 
 
+@pytest.mark.parametrize("nb_total,world", [(300_000_000, 8), (40_000_000, 3), (1_000_000_000, 64)])
+def test_wire_format_edge_cases(fj, nb_total, world):
+    """fj_shuffle_pack_* on ragged inputs: empty, one row, 255 / 256 / 257 rows, an odd count, every key equal (one bucket, one
+    owner: exact region sizes mean skew cannot overflow anything), keys 0 and 2^64 - 1, and values riding along - what comes out,
+    unpacked with the NumPy restatement of the wire format, is exactly the multiset that went in, every chunk with its owner."""
+    import torch
+    import keymix
+    from flash_hash_join_amd.distributed import HipEngine
+    eng = HipEngine("cuda:0")
+    f0 = eng.shuffle_plan(nb_total, world)
+    rng = np.random.default_rng(11)
+    cases = [np.empty(0, dtype=np.uint64), np.array([42], dtype=np.uint64), rng.integers(0, 2**63, 255, dtype=np.uint64),
+             rng.integers(0, 2**63, 256, dtype=np.uint64), rng.integers(0, 2**63, 257, dtype=np.uint64),
+             rng.integers(0, 2**63, 100_003, dtype=np.uint64) * np.uint64(2) + np.uint64(1),
+             np.full(70_001, 0xDEADBEEFCAFEF00D, dtype=np.uint64),
+             np.concatenate([np.array([0, 2**64 - 1, 1, 2**63], dtype=np.uint64), np.arange(5000, dtype=np.uint64) << np.uint64(32)])]
+    for keys in cases:
+        for with_vals in (False, True):
+            tk = torch.from_numpy(keys.view(np.int64).copy()).cuda()
+            tv = torch.from_numpy((keys * np.uint64(3) + np.uint64(1)).view(np.int64).copy()).cuda() if with_vals else None
+            out = eng.shuffle_pack(tk, tv, nb_total, world)
+            torch.cuda.synchronize()
+            chunks, dirs, used = out[0], out[1], out[2]
+            got_k, got_v = [], []
+            for r in range(world):
+                if used[r] == 0:
+                    continue
+                k, bucket, cnt = keymix.unpack_wire(chunks[r].cpu().numpy(), dirs[r].cpu().numpy(), f0)
+                assert np.all((bucket * world) >> f0 == r)
+                assert np.array_equal((keymix.hash_w1(k) >> np.uint32(32 - f0)).astype(np.int64), bucket)
+                got_k.append(k)
+                if with_vals:
+                    v = out[3][r].cpu().numpy().view(np.uint64).reshape(-1, 256)
+                    got_v.append(v[np.arange(256)[None, :] < cnt[:, None]])
+            gk = np.concatenate(got_k) if got_k else np.empty(0, dtype=np.uint64)
+            assert sum(used) == sum(-(-int(c) // 256) for c in np.bincount((keymix.hash_w1(keys) >> np.uint32(32 - f0)).astype(np.int64), minlength=1)) if keys.size else sum(used) == 0
+            assert np.array_equal(np.sort(gk), np.sort(keys))
+            if with_vals and keys.size:
+                gv = np.concatenate(got_v)
+                assert np.array_equal(gv, gk * np.uint64(3) + np.uint64(1))          # every value still sits next to its key
+
+
 def test_materialised_pairs_do_not_pin_the_probe_sized_buffers(fj):
     """The single-pass materialising join writes into buffers with room for ANY result (16 bytes per probe row); what it hands
     back must not keep them alive: at 30 % hits the returned tensors own exactly n rows."""
