@@ -209,6 +209,7 @@ struct RcclNet : Net {
     ncclComm_t data = nullptr, ctl = nullptr;
     bool own_data = false, own_ctl = false, loop = false;
     hipStream_t xs = nullptr, cs = nullptr;                  // exchange stream, control stream
+    bool split() const { return own_ctl; }
     hipEvent_t ev_x[MAX_PIECES + 1];
     unsigned long long* d_w = nullptr; unsigned long long* h_w = nullptr;     // scratch words of the control collectives (+ pinned mirror)
     static constexpr size_t WORDS = 72 + 64 * 65 + 16;
@@ -222,7 +223,7 @@ struct RcclNet : Net {
         // control collectives on a communicator of their own: on ONE communicator RCCL runs operations in the order they were
         // issued whatever their streams, and a count exchange must not wait for the previous piece's sends
         Rccl* R = rccl();
-        if (R->CommSplit && nranks > 1 && !getenv("FJ_DIST_ONE_COMM")) {
+        if (R->CommSplit && (nranks > 1 || getenv("FJ_DIST_SPLIT_ALWAYS")) && !getenv("FJ_DIST_ONE_COMM")) {      // (FJ_DIST_SPLIT_ALWAYS: test hook, a 1-rank communicator is split too)
             ncclComm_t c2 = nullptr;
             if (R->CommSplit(data, 0, rank, &c2, nullptr) == 0 && c2) { ctl = c2; own_ctl = true; }
         }

@@ -1032,6 +1032,15 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
             assert t["wire_bytes_sent"] == (sent if loop == "1" else 0), (t["wire_bytes_sent"], sent)
             lt = fj.last_timings()
             assert lt["fell_back"] == 0 and lt["passes"] == 2
+        # the control collectives on a communicator of their own (ncclCommSplit - what every N > 1 job does; a 1-rank communicator
+        # only splits under this test hook): a fresh communicator, the same step, the same count
+        from flash_hash_join_amd.distributed import HipEngine
+        HipEngine.close_native_comms()
+        monkeypatch.setenv("FJ_DIST_SPLIT_ALWAYS", "1"); monkeypatch.setenv("FJ_DIST_LOOPBACK", "1"); monkeypatch.setenv("FJ_DIST_NATIVE", "1")
+        t = {}
+        n, sec = distributed_join(bk[: nb // 10], bv[: nb // 10], pk[: npk // 10], timings=t)
+        assert t["shuffle_form"] == "chunks (fj_dist_join_count over RCCL)" and n == int(torch.isin(pk[: npk // 10], bk[: nb // 10]).sum())
+        HipEngine.close_native_comms()
     finally:
         dist.destroy_process_group()
 
