@@ -541,8 +541,9 @@ class _CallbackTransport:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.error = None
         self.bytes_sent = 0
-        self.struct = _lib.FjDistTransport(None, self.world, self.rank, _lib.AllGatherFn(self._all_gather), _lib.AllReduceFn(self._all_reduce),
-                                           _lib.AllToAllFn(self._all_to_all))
+        # (the C side calls these for as long as the communicator lives: keep the ctypes trampolines referenced here, not only in the struct)
+        self._cbs = (_lib.AllGatherFn(self._all_gather), _lib.AllReduceFn(self._all_reduce), _lib.AllToAllFn(self._all_to_all))
+        self.struct = _lib.FjDistTransport(None, self.world, self.rank, *self._cbs)
 
     def _guard(self, fn):
         try:

@@ -270,6 +270,7 @@ int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error
  *   fj_dist_comm_from_transport - or bring your own transport: three blocking callbacks (gloo, MPI, a test harness).  With
  *                                 engine == NULL the rank's work runs on ctx's GPU; a stand-in engine (tests) replaces it,
  *                                 then ctx may be NULL and "device" pointers are whatever the stand-in's alloc returns.
+ *   (a communicator serves ONE join at a time - it owns the exchange buffers and streams of the step; use one per thread)
  *   fj_dist_join_count          - collective.  pieces: rounds of the probe exchange (4 is the measured default).  A build side
  *                                 of less than ~2M rows in all is refused (one-pass plan: join it on one GPU).
  *   fj_dist_join                - the same step, optionally materialising (materialize != 0: the build rows travel with their

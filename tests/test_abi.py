@@ -70,6 +70,22 @@ def test_key_mixer_is_a_bijection_and_matches_its_numpy_restatement(lib):
         assert slots.min() > 70 and slots.max() < 190              # 128 +- 5 sigma
 
 
+def test_header_is_plain_c_and_the_c_example_links(lib, tmp_path):
+    """include/flashjoin.h must be usable from C (the boundary a cgo / JNI / ctypes binding sees): it compiles as C99 and as
+    C++11 on its own, and examples/host_join.c builds and links against the library (running it needs a GPU)."""
+    from flash_hash_join_amd import _lib
+    hdr = os.path.join(ROOT, "include", "flashjoin.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    exe = str(tmp_path / "host_join")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_join.c"),
+                           "-L" + os.path.dirname(_lib.LIB_PATH), "-lflashjoin_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", exe])
+    assert os.path.exists(exe)
+    if not has_gpu():                                           # no GPU: the example must fail loudly through fj_last_error, not crash
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 1 and "flash_join:" in out.stderr
+
+
 def test_library_contains_gfx950_code_object(lib):
     from flash_hash_join_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()

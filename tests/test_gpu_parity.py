@@ -531,6 +531,18 @@ def test_wire_format_edge_cases(fj, nb_total, world):
                 assert np.array_equal(gv, gk * np.uint64(3) + np.uint64(1))          # every value still sits next to its key
 
 
+def test_c_host_example_runs(fj, tmp_path):
+    """examples/host_join.c - a C99 program with nothing but include/flashjoin.h - joins 1M x 10M rows through fj_join_host."""
+    import subprocess
+    from conftest import ROOT
+    from flash_hash_join_amd import _lib
+    exe = str(tmp_path / "host_join")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_join.c"),
+                           "-L" + os.path.dirname(_lib.LIB_PATH), "-lflashjoin_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "matches (expected" in out.stdout, out.stdout + out.stderr
+
+
 def test_materialised_pairs_do_not_pin_the_probe_sized_buffers(fj):
     """The single-pass materialising join writes into buffers with room for ANY result (16 bytes per probe row); what it hands
     back must not keep them alive: at 30 % hits the returned tensors own exactly n rows."""
