@@ -15,11 +15,14 @@ replicate -- every rank all-gathers the build KEYS (and values when materialisin
 shuffle -- radix partitions are independent join units (hash_join.cpp:340-356, :515-525), so the level-0 digit is
   the owner GPU:   owner(key) = (top 16 bits of hash(key) * world) >> 16
 
-  Counting joins whose GLOBAL plan has two or more passes take the CHUNK form (_chunk_shuffle_count): the first
-  radix pass of the plan for the total build side IS the owner split - bucket b of its 256 / 512 buckets belongs to rank
-  (b * world) >> log2(buckets); a sender runs that pass with the chunks grouped by owner (fj_shuffle_pack), ships whole chunks
-  + directory words (grouped RCCL sends / receives), and the owner starts at the plan's second pass.  Everything else
-  (materialising joins, small build sides, the sender-side precheck) takes the OWNER-SCATTER form:
+  Joins whose GLOBAL plan has two or more passes take the CHUNK form: the first radix pass of the plan for the
+  total build side IS the owner split - bucket b of its 256 / 512 buckets belongs to rank (b * world) >> log2(buckets); a sender
+  runs that pass and rewrites its output for the wire (fj_shuffle_pack_begin / _counts / _finish: dense 256-key chunks, 7 bytes
+  per key, one directory word per chunk), and the owner starts at the plan's second pass.  The protocol lives in ONE place, the
+  C++ driver csrc/fj_dist.hip (fj_dist_join / fj_dist_join_count); this module hands it RCCL (nccl backend), or three callbacks
+  into torch.distributed (_CallbackTransport: gloo, a transport object), or - in the CPU test-suite - also a stand-in for the
+  rank's own work.  Everything else (small build sides, the sender-side precheck, duplicate build keys in a materialising join,
+  and any step the chunk form fails on) takes the OWNER-SCATTER form, driven from here:
   1. every rank splits its local rows of both relations by owner (fj_owner_split: LDS counting
      sort per tile, contiguous per-owner segments);
   2. ONE all-to-all per relation moves each segment to its owner (torch.distributed
@@ -744,7 +747,7 @@ def _npass(bits: int) -> int:
 
 
 def _plan_passes(nb: int) -> int:
-    """Partition passes of the single-GPU plan for a build side of nb rows (csrc/fj_api.hip make_plan)."""
+    """Partition passes of the single-GPU plan for a build side of nb rows (csrc/fj_plan.hip make_plan)."""
     bits = 0
     if nb > 4096:
         bits = (-(-nb // 4096) - 1).bit_length()
