@@ -124,6 +124,7 @@ struct Engine {
     virtual int finish(uint64_t* count, fj_timings* lt) = 0;
     virtual void abort() = 0;
     virtual int drain() = 0;                                                    // everything this engine enqueued has finished
+    virtual void reserve(bool) {}                                               // leave room for the transport's own kernels (HIP engine over RCCL)
 };
 
 struct HipEngine : Engine {
@@ -167,6 +168,15 @@ struct HipEngine : Engine {
     int finish(uint64_t* count, fj_timings* lt) override { return fj_stream_finish(ctx, js, count, lt); }
     void abort() override { (void)fj_stream_abort(ctx); }
     int drain() override { DHIP(hipStreamSynchronize(ps)); DHIP(hipStreamSynchronize(js)); return 0; }
+    // RCCL's kernels are resident for the length of an exchange: the partition passes (one persistent workgroup per CU, static
+    // tile shares) leave them room - see fj_ctx_reserve_cus.  FJ_DIST_RESERVE_CUS (default 32) CUs while a step over RCCL with more
+    // than one rank runs (FJ_DIST_RESERVE_ALWAYS: also on one rank - a test and measurement hook).  Not measured on a multi-GPU box:
+    // a hedge whose price is bounded (the passes run ~14 % slower in a regime where the wire is the bottleneck) against a cliff
+    // (a pass that does not get every CU takes twice as long).
+    void reserve(bool on) override {
+        static const unsigned n = getenv("FJ_DIST_RESERVE_CUS") ? (unsigned)atoi(getenv("FJ_DIST_RESERVE_CUS")) : 32u;
+        fj_ctx_reserve_cus(ctx, on ? n : 0u);
+    }
 };
 
 struct CallbackEngine : Engine {                             // a caller's stand-in (tests): everything is synchronous, tokens are null
@@ -202,6 +212,7 @@ struct Net {
     virtual int exchange(int nparts, const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) = 0;
     virtual int drain() = 0;
     virtual bool loopback() const { return false; }          // test hook: a rank's own share travels through the transport too
+    virtual bool shares_the_gpu() const { return false; }    // the transport runs kernels of its own on this GPU during an exchange (RCCL)
     virtual void begin_step() {}
 };
 
@@ -265,6 +276,7 @@ struct RcclNet : Net {
         return 0;
     }
     bool loopback() const override { return loop; }
+    bool shares_the_gpu() const override { return true; }
     void begin_step() override { const char* e = getenv("FJ_DIST_LOOPBACK"); loop = e && atoi(e) != 0; }      // test hook: a rank's own share travels through ncclSend / ncclRecv too
     bool is_peer(int r) const { return r != rank || loop; }
     int exchange(int nparts, const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) override {
@@ -442,6 +454,9 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     if (np_min < 2ull * pieces) pieces = 1;
     net.begin_step();
     const bool loop = net.loopback();
+    const bool reserve = net.shares_the_gpu() && (N > 1 || getenv("FJ_DIST_RESERVE_ALWAYS"));
+    struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(false); } } reserve_guard{eng, reserve};
+    if (reserve) eng.reserve(true);
 
     std::string failed;                                       // this rank's first local join failure: later engine calls are skipped, collectives go on
     auto guarded = [&](int rc) { if (rc && failed.empty()) failed = fj_last_error(); return rc; };

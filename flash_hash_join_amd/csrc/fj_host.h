@@ -172,6 +172,7 @@ struct fj_ctx {
     unsigned long long* pk_h = nullptr;   // pinned: [64] chunks per owner, [64] = the pass's error word
     size_t ws_bytes = 0;
     u32 num_cus = 256;
+    u32 reserve_cus = 0;               // CUs the partition passes leave free (set by the multi-GPU driver while RCCL's kernels share the GPU: fj_ctx_reserve_cus)
     void* stage[3] = {nullptr, nullptr, nullptr};     // pinned staging ring of the host-buffer entry (fj_join_host)
     size_t stage_bytes = 0;
     bool plan_in_flight = false;       // a plan was begun and has not completed (an error in between leaves chunk counts behind)

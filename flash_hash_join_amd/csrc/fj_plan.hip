@@ -122,6 +122,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     it.appends = appends ? appends : 1;
     it.tile_chunks = fj_partition_tile_chunks((u32)it.plan.fan_log[i], it.has_vals);
     it.Gmax = pass_groups(it.lbound, it.n, it.tile_chunks, it.F);
+    if (c->reserve_cus) it.Gmax = std::min<u32>(it.Gmax, c->reserve_cus < c->num_cus ? c->num_cus - c->reserve_cus : 1u);   // (fj_ctx_reserve_cus)
     if (it.piece_rows && it.appends > 1 && !it.have_prev)      // many small appends: each launch has few workgroups, so little slack per append
         it.Gmax = std::min(it.Gmax, pass_groups((it.piece_rows + FJ_CHUNK - 1) / FJ_CHUNK, it.piece_rows, it.tile_chunks, it.F));
     const u32 F = it.F, G = it.Gmax, parents = it.parents;
@@ -434,6 +435,7 @@ void fj_ctx_destroy(fj_ctx* c) {
 }
 
 size_t fj_ctx_workspace_bytes(const fj_ctx* c) { return c ? c->ws_bytes : 0; }
+void fj_ctx_reserve_cus(fj_ctx* c, unsigned n) { if (c) c->reserve_cus = n; }
 
 // Give the cached workspace (chunk pools, directories, tables: tens of GB after a 1B-row join) back to the device; the
 // context stays usable and grows again on demand.  A pending emit (fj_emit_pairs not yet called) is dropped.
