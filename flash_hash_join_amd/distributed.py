@@ -985,7 +985,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
         # the chunk form (the first radix pass of the global plan is the owner split) serves every counting shuffle whose
         # global plan has two or more passes; the owner-scatter form below the small ones and the sender-side precheck
         if (mode == "off" and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
-                and min(int(x[1]) for x in allsz) >= 2 * pieces and engine.shuffle_plan(nb_total, world) is not None):
+                and engine.shuffle_plan(nb_total, world) is not None):      # (ranks with few or no rows: the driver sends everything as one piece)
             # ONE driver for every transport: csrc/fj_dist.hip (fj_dist_join_count) - over RCCL under the nccl backend, over
             # callbacks into torch.distributed under gloo / a transport object, with a stand-in engine in the CPU tests.  A step
             # that fails on any rank fails on every rank (the driver agrees on it), so all of them fall back together to the
@@ -1007,8 +1007,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     # through the same driver; duplicate build keys, the sender-side precheck and small build sides take the owner-scatter form below
     if (materialize and hasattr(engine, "emit_pairs") and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0"
             and (_prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off") == "off"
-            and min(int(x[1]) for x in allsz) >= 2 * pieces and engine.shuffle_plan(sum(sizes_b), world) is not None
-            ):
+            and engine.shuffle_plan(sum(sizes_b), world) is not None):
         try:
             return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport, build_values=build_values, return_arrays=return_arrays)
         except RuntimeError as ex:

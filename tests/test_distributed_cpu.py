@@ -245,6 +245,9 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         # block distribution of the global relation (GPU g holds rows [g*N/G, (g+1)*N/G))
         b0, b1 = rank * nb // world, (rank + 1) * nb // world
         p0, p1 = rank * npk // world, (rank + 1) * npk // world
+        if variant == "uneven":                 # every probe row on rank 0, every build row on the last rank: empty shards elsewhere
+            b0, b1 = (0, nb) if rank == world - 1 else (0, 0)
+            p0, p1 = (0, npk) if rank == 0 else (0, 0)
         bk, bv = datagen.build_numpy(b1 - b0, first=b0)
         pk, exp_local = datagen.probe_numpy(p1 - p0, nb, seed=1, hit_bp=5000, first=p0)
         if variant in ("skew", "lateskew"):
@@ -285,8 +288,10 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         assert cnt == int(exp.item()) and tc["strategy"] == t["strategy"] == strategy
         if variant in ("packfail", "appendfail"):    # ... and without FJ_DIST_NO_FALLBACK all ranks rerun in the owner-scatter form together
             assert "failed on 1 rank" in tc["chunk_form_error"] and tc["shuffle_form"] == "owner-scatter"
-        if variant == "skew":
+        if variant in ("skew", "uneven"):
             assert tc["shuffle_form"].startswith("chunks") and "chunk_form_error" not in tc, tc
+        if variant == "uneven":
+            assert tc["pieces"] == 1          # a rank without probe rows: the exchange is not cut into pieces
         if variant == "lateskew":                    # (at these sizes the pools' constant slack absorbs it; at scale the ranks would rerun together in the owner-scatter form)
             assert tc["shuffle_form"].startswith("chunks") or "failed on" in tc["chunk_form_error"], tc
         keys = res[2].numpy().view(np.uint64)
@@ -302,7 +307,7 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             assert tc["local_probe_rows"] == t["local_probe_rows"] and tc["probe_rows_sent"] == t["probe_rows_sent"] < 0.6 * (p1 - p0)
             glob = torch.tensor([tc["local_probe_rows"]]); dist.all_reduce(glob)
             assert int(exp.item()) <= int(glob.item()) < 0.6 * npk
-        elif strategy == "shuffle" and variant in ("skew", "lateskew"):
+        elif strategy == "shuffle" and variant in ("skew", "lateskew", "uneven"):
             pass
         elif strategy == "shuffle" and variant == "":
             # the counting join took the chunk form (its owners are whole first-pass buckets: another split of the hash range than
@@ -317,7 +322,7 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             if strategy == "shuffle":
                 assert tc["shuffle_form"] == "owner-scatter" and tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
         if strategy == "shuffle":
-            assert tc["pieces"] == 4
+            assert tc["pieces"] == (1 if variant == "uneven" else 4)
             # every pair this rank owns must hash to this rank
             owner = ((_fmix64(keys.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)
             owned = bool(np.all(owner == rank))
@@ -335,7 +340,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_appendfail", "shuffle_skew", "shuffle_lateskew", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
+@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_appendfail", "shuffle_skew", "shuffle_lateskew", "shuffle_uneven", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
                                       "replicate_small_messages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):

@@ -1057,6 +1057,33 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
         dist.destroy_process_group()
 
 
+def test_driver_with_tiny_and_empty_probe_sides(fj, monkeypatch):
+    """fj_dist_join_count on a 1-rank communicator when the probe side is too small to be cut into pieces (one piece then), one
+    row, or empty; and a materialising step whose probe side is tiny."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import distributed_join
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        monkeypatch.setenv("FJ_FORCE_EXCHANGE", "1"); monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        bk, bv = datagen.build_device(6_000_000, "cuda:0")
+        pk, _ = datagen.probe_device(1000, 6_000_000, "cuda:0", seed=8, hit_bp=5000)
+        for n in (0, 1, 5, 7, 1000):
+            t = {}
+            sub = pk[:n].clone() if n else pk[:0]
+            got, _ = distributed_join(bk, bv, sub, timings=t)
+            assert got == int(torch.isin(sub, bk).sum()) and t["shuffle_form"].startswith("chunks") and t["pieces"] == (4 if n >= 8 else 1), (n, t)
+        n, _, k, v = distributed_join(bk, bv, pk[:7].clone(), materialize=True, return_arrays=True)
+        M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+        assert n == int(torch.isin(pk[:7], bk).sum()) == k.numel() and bool(torch.all((v + 1) * M == k))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_one_oversized_partition_costs_little_at_full_size(fj):
     """Build-side skew at BASELINE configs[2] sizes: 100M x 1B rows plus 27K build keys that all land in ONE of the 32768 final
     partitions (ten times its share: keys picked so that the top 15 bits of their hash word 1 agree), probed 500K times.
