@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU call that produces what is committed under profiles/ for a kernel version:  tools/collect_profiles.sh <tag>
 #   PMC passes (c3, c4, c3_mat, c2), rocprofv3 --kernel-trace --stats (c3, c4, c3_mat, c2 and the literal HBM-table forms),
-#   the default bench line, the other workloads' bench lines, the J1 harness log, traffic_latest.json.
+#   the default bench line, the other workloads' bench lines, the J1 harness log, traffic_latest.json, the one-rank multi-GPU step
+#   (tools/r4_dist_one_gpu.sh <tag>d) and tools/pack_probe.py.  Then: tools/publish_profiles.sh <tag>.
 TAG=${1:-r03}
 cd ${GRAFT_REPO_ROOT:-$PWD}
 O=gpurun_out/$TAG; mkdir -p $O
@@ -25,4 +26,7 @@ done
 FJ_MAT_SINGLE_PASS=0 timeout 300 python bench.py --workload c3_mat --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c3_mat_two_pass_bench.json
 timeout 600 python tools/skew_build_partition_probe.py 4 > $O/skew_build_partition_probe.txt 2>&1
 timeout 900 python tools/benchmark_j1.py --sizes 1e7,4e7 --cpu --duckdb > $O/j1_shaped_benchmark.log 2>&1
+# the multi-GPU step of config 5 on one rank (C++ driver) and the sender side in isolation
+bash tools/r4_dist_one_gpu.sh ${TAG}d > $O/dist_one_gpu.txt 2>&1
+timeout 300 python tools/pack_probe.py > $O/pack_probe.txt 2>&1
 ls -la $O | head -50
