@@ -25,6 +25,7 @@ SYMBOLS = [
     "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
     "fj_shuffle_plan", "fj_shuffle_chunk_bytes", "fj_shuffle_pack_begin", "fj_shuffle_pack_counts", "fj_shuffle_pack_finish", "fj_stream_open_shuffled",
     "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
+    "fj_shuffle_part_filter_bytes", "fj_shuffle_part_filter_range", "fj_stream_export_part_filters", "fj_shuffle_pack_filter", "fj_shuffle_pack_kept", "fj_part_filter_sample",
     "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_from_transport", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
     "fj_dist_join_count", "fj_dist_join",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
@@ -54,6 +55,7 @@ class FjDistTimings(ctypes.Structure):
         ("local_count", ctypes.c_uint64), ("local_build_chunks", ctypes.c_uint64), ("local_probe_chunks", ctypes.c_uint64),
         ("sent_chunks", ctypes.c_uint64),
         ("pieces", ctypes.c_int), ("nranks", ctypes.c_int), ("fan_log0", ctypes.c_int), ("wire_chunk_bytes", ctypes.c_int),
+        ("prefilter", ctypes.c_int), ("prefilter_sampled", ctypes.c_double), ("probe_rows_kept", ctypes.c_uint64), ("filter_bytes", ctypes.c_uint64),
         ("local", FjTimings),
     ]
 
@@ -158,7 +160,13 @@ def load() -> ctypes.CDLL:
     L.fj_bloom_prefilter.restype = i32; L.fj_bloom_prefilter.argtypes = [vp, vp, sz, i32, vp, vp, sz, pu64, vp]
     L.fj_shuffle_plan.restype = i32; L.fj_shuffle_plan.argtypes = [sz, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.fj_shuffle_chunk_bytes.restype = sz; L.fj_shuffle_chunk_bytes.argtypes = [sz, i32]
-    L.fj_shuffle_pack_begin.restype = i32; L.fj_shuffle_pack_begin.argtypes = [vp, vp, vp, sz, sz, i32, vp]
+    L.fj_shuffle_pack_begin.restype = i32; L.fj_shuffle_pack_begin.argtypes = [vp, vp, vp, sz, sz, i32, i32, vp]
+    L.fj_shuffle_part_filter_bytes.restype = sz; L.fj_shuffle_part_filter_bytes.argtypes = []
+    L.fj_shuffle_part_filter_range.restype = i32; L.fj_shuffle_part_filter_range.argtypes = [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    L.fj_stream_export_part_filters.restype = i32; L.fj_stream_export_part_filters.argtypes = [vp, vp, vp]
+    L.fj_shuffle_pack_filter.restype = i32; L.fj_shuffle_pack_filter.argtypes = [vp, vp, vp]
+    L.fj_shuffle_pack_kept.restype = u64; L.fj_shuffle_pack_kept.argtypes = [vp]
+    L.fj_part_filter_sample.restype = i32; L.fj_part_filter_sample.argtypes = [vp, vp, sz, sz, vp, sz, i32, vp, pu64]
     L.fj_shuffle_pack_counts.restype = i32; L.fj_shuffle_pack_counts.argtypes = [vp, pu64]
     L.fj_shuffle_pack_finish.restype = i32; L.fj_shuffle_pack_finish.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
     L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, i32, vp]
@@ -173,7 +181,7 @@ def load() -> ctypes.CDLL:
     L.fj_dist_comm_rank.restype = i32; L.fj_dist_comm_rank.argtypes = [vp]
     L.fj_dist_comm_size.restype = i32; L.fj_dist_comm_size.argtypes = [vp]
     L.fj_dist_join_count.restype = i32; L.fj_dist_join_count.argtypes = [vp, vp, sz, vp, sz, i32, vp, pu64, ctypes.POINTER(FjDistTimings)]
-    L.fj_dist_join.restype = i32; L.fj_dist_join.argtypes = [vp, vp, vp, sz, vp, sz, i32, i32, vp, pu64, pu64, ctypes.POINTER(FjDistTimings)]
+    L.fj_dist_join.restype = i32; L.fj_dist_join.argtypes = [vp, vp, vp, sz, vp, sz, i32, i32, ctypes.c_double, vp, pu64, pu64, ctypes.POINTER(FjDistTimings)]
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]
     L.fj_generate_probe.restype = i32
     L.fj_generate_probe.argtypes = [vp, vp, u64, sz, u64, u64, ctypes.c_uint32, pu64, vp]

@@ -116,7 +116,14 @@ struct Engine {
     virtual int plan(size_t nb_total, int nranks, size_t* chunk_bytes) = 0;     // same verdict on every rank (same arguments)
     virtual void* alloc(size_t bytes) = 0;
     virtual void release(void* p) = 0;
-    virtual int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks) = 0;   // asynchronous (ordered behind the previous pack_finish); vals: null = keys only
+    // asynchronous (ordered behind the previous pack_finish); vals: null = keys only; filters: null, or the partition filters the
+    // piece is prechecked against once `filters_ready` has happened (the first pass does not wait for it)
+    virtual int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks, const void* filters, Token filters_ready) = 0;
+    virtual unsigned long long pack_kept() { return 0; }                        // after pack_counts: rows the precheck kept
+    // sender-side precheck (HIP engine only): where rank r's partition filters sit; this owner's filters; a sample of raw rows
+    virtual int filter_range(size_t, int, int, size_t*, size_t*, size_t*, size_t*) { return derr("fj_dist: this engine has no sender-side precheck"); }
+    virtual int export_filters(void*, Token*) { return derr("fj_dist: this engine has no sender-side precheck"); }
+    virtual int sample(const void*, size_t, size_t, const void*, size_t, int, Token, unsigned long long*) { return derr("fj_dist: this engine has no sender-side precheck"); }
     virtual int pack_counts(unsigned long long* used) = 0;                      // blocks until the counts are known
     virtual int pack_finish(void* const* dst_chunks, uint64_t* const* dst_vals, uint32_t* const* dst_dir, Token after, Token* done) = 0;
     virtual int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces, bool with_vals) = 0;
@@ -129,14 +136,15 @@ struct Engine {
 
 struct HipEngine : Engine {
     fj_ctx* ctx; hipStream_t js = nullptr, ps = nullptr;                        // join stream (the caller's), pack stream
-    hipEvent_t ev_pack[2] = {nullptr, nullptr}; int evi = 0;
+    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_filt = nullptr; int evi = 0;
     explicit HipEngine(fj_ctx* c) : ctx(c) {}
     int setup() {
         DHIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
         for (auto& e : ev_pack) DHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DHIP(hipEventCreateWithFlags(&ev_filt, hipEventDisableTiming));
         return 0;
     }
-    ~HipEngine() override { for (auto& e : ev_pack) if (e) (void)hipEventDestroy(e); if (ps) (void)hipStreamDestroy(ps); }
+    ~HipEngine() override { for (auto& e : ev_pack) if (e) (void)hipEventDestroy(e); if (ev_filt) (void)hipEventDestroy(ev_filt); if (ps) (void)hipStreamDestroy(ps); }
     int plan(size_t nb_total, int nranks, size_t* cb) override {
         int f0 = 0, np = 0;
         if (fj_shuffle_plan(nb_total, nranks, &f0, &np)) return 1;
@@ -145,8 +153,29 @@ struct HipEngine : Engine {
     }
     void* alloc(size_t bytes) override { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
     void release(void* p) override { if (p) (void)hipFree(p); }
-    int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks) override {
-        return fj_shuffle_pack_begin(ctx, (const uint64_t*)rows, (const uint64_t*)vals, n, nb_total, nranks, ps);
+    int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks, const void* filters, Token ready) override {
+        if (fj_shuffle_pack_begin(ctx, (const uint64_t*)rows, (const uint64_t*)vals, n, nb_total, nranks, filters ? 1 : 0, ps)) return 1;
+        if (!filters) return 0;
+        if (ready) DHIP(hipStreamWaitEvent(ps, (hipEvent_t)ready, 0));
+        return fj_shuffle_pack_filter(ctx, filters, ps);
+    }
+    unsigned long long pack_kept() override { return fj_shuffle_pack_kept(ctx); }
+    int filter_range(size_t nb_total, int nranks, int r, size_t* first, size_t* count, size_t* total, size_t* bytes_each) override {
+        *bytes_each = fj_shuffle_part_filter_bytes();
+        return fj_shuffle_part_filter_range(nb_total, nranks, r, first, count, total);
+    }
+    int export_filters(void* dst, Token* done) override {
+        if (fj_stream_export_part_filters(ctx, dst, js)) return 1;
+        DHIP(hipEventRecord(ev_filt, js));
+        *done = ev_filt;
+        return 0;
+    }
+    int sample(const void* rows, size_t n, size_t stride, const void* filters, size_t nb_total, int nranks, Token after, unsigned long long* kept) override {
+        if (after) DHIP(hipStreamWaitEvent(ps, (hipEvent_t)after, 0));
+        uint64_t k = 0;
+        if (fj_part_filter_sample(ctx, (const uint64_t*)rows, n, stride, filters, nb_total, nranks, ps, &k)) return 1;
+        *kept = k;
+        return 0;
     }
     int pack_counts(unsigned long long* used) override { return fj_shuffle_pack_counts(ctx, (uint64_t*)used); }
     int pack_finish(void* const* dk, uint64_t* const* dv, uint32_t* const* dd, Token after, Token* done) override {
@@ -186,8 +215,8 @@ struct CallbackEngine : Engine {                             // a caller's stand
     int plan(size_t nb_total, int nranks, size_t* cb) override { if (o.plan(o.user, nb_total, nranks)) return fail("plan"); *cb = o.chunk_bytes; return 0; }
     void* alloc(size_t bytes) override { return o.alloc(o.user, bytes); }
     void release(void* p) override { if (p) o.release(o.user, p); }
-    int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks) override {
-        if (vals) return derr("fj_dist: the stand-in engine carries no values");
+    int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks, const void* filters, Token) override {
+        if (vals || filters) return derr("fj_dist: the stand-in engine carries no values and has no precheck");
         return o.pack_begin(o.user, rows, n, nb_total, nranks) ? fail("pack_begin") : 0;
     }
     int pack_counts(unsigned long long* used) override { return o.pack_counts(o.user, (uint64_t*)used) ? fail("pack_counts") : 0; }
@@ -221,7 +250,7 @@ struct RcclNet : Net {
     bool own_data = false, own_ctl = false, loop = false;
     hipStream_t xs = nullptr, cs = nullptr;                  // exchange stream, control stream
     bool split() const { return own_ctl; }
-    hipEvent_t ev_x[MAX_PIECES + 1];
+    hipEvent_t ev_x[MAX_PIECES + 2];                          // build piece, probe pieces, partition filters
     unsigned long long* d_w = nullptr; unsigned long long* h_w = nullptr;     // scratch words of the control collectives (+ pinned mirror)
     static constexpr size_t WORDS = 72 + 64 * 65 + 16;
     int setup() {
@@ -298,7 +327,7 @@ struct RcclNet : Net {
             }
             DNCCL(R->GroupEnd());
         }
-        hipEvent_t e = ev_x[slot % (MAX_PIECES + 1)];
+        hipEvent_t e = ev_x[slot % (MAX_PIECES + 2)];
         DHIP(hipEventRecord(e, xs));
         *done = e;
         return 0;
@@ -334,6 +363,7 @@ struct fj_dist_comm {
     HipEngine* hip = nullptr;                               // == eng.get() when the engine is the HIP one
     DBuf pool_k[2], pool_d[2], pool_v;                      // send pools (alternating per piece; values: the build piece only)
     DBuf recv_k[MAX_PIECES + 1], recv_d[MAX_PIECES + 1], recv_v;   // what arrives: [0] build side, [1 + c] probe piece c
+    DBuf filt;                                              // every final partition's Bloom filter (sender-side precheck)
     int grow(DBuf& b, size_t bytes) {
         if (bytes == 0) bytes = 16;
         if (b.bytes >= bytes) return 0;
@@ -347,7 +377,7 @@ struct fj_dist_comm {
     void free_all() {
         for (auto* arr : {pool_k, pool_d}) for (int i = 0; i < 2; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
         for (auto* arr : {recv_k, recv_d}) for (int i = 0; i <= MAX_PIECES; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
-        for (DBuf* b : {&pool_v, &recv_v}) if (b->p) { eng->release(b->p); *b = DBuf(); }
+        for (DBuf* b : {&pool_v, &recv_v, &filt}) if (b->p) { eng->release(b->p); *b = DBuf(); }
     }
 };
 
@@ -423,12 +453,14 @@ int fj_dist_comm_size(const fj_dist_comm* dc) { return dc ? dc->net->nranks : 0;
 
 int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                        void* stream, uint64_t* out_global_count, fj_dist_timings* timings) {
-    return fj_dist_join(dc, d_build_keys, nullptr, nb, d_probe_keys, np, pieces, 0, stream, out_global_count, nullptr, timings);
+    return fj_dist_join(dc, d_build_keys, nullptr, nb, d_probe_keys, np, pieces, 0, 0.0, stream, out_global_count, nullptr, timings);
 }
 
 int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
-                 int materialize, void* stream, uint64_t* out_global_count, uint64_t* out_local_count, fj_dist_timings* timings) {
+                 int materialize, double prefilter_below, void* stream, uint64_t* out_global_count, uint64_t* out_local_count, fj_dist_timings* timings) {
     if (!dc) return derr("fj_dist_join_count: null communicator");
+    const bool want_pf = prefilter_below > 0;
+    if (want_pf && !dc->hip) return derr("fj_dist_join: the sender-side precheck needs the HIP engine");
     if (materialize && (!dc->hip || (nb && !d_build_vals) || ((uintptr_t)d_build_vals & 15))) return derr("fj_dist_join: a materialising join needs the HIP engine and 16-byte aligned build values");
     const bool mat = materialize != 0;
     if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: pieces must be 1..%d", MAX_PIECES);
@@ -539,29 +571,75 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     Piece B;
     {
         const auto tp = std::chrono::steady_clock::now();
-        const bool ok = eng.pack_begin(d_build_keys, mat ? d_build_vals : nullptr, nb, nb_total, N) == 0;
+        const bool ok = eng.pack_begin(d_build_keys, mat ? d_build_vals : nullptr, nb, nb_total, N, nullptr, nullptr) == 0;
         split_ms += ms_since(tp);
         if (finish_piece(ok, 0, 0, mat, &B)) return 1;
     }
     const size_t np_bound = (size_t)(1.5 * (double)np_global / N) + ((size_t)1 << 22) + (size_t)FJ_CHUNK * 512 * N * pieces;
+    // ---- sender-side precheck: the owners' partition filters, all-gathered; a sample decides whether they are used ----
+    bool pf = false;
+    double sampled = -1.0;
+    Token filt_ready = nullptr;
+    size_t filter_bytes = 0;
+    unsigned long long kept_rows = 0;
+    if (want_pf) {
+        opened = guarded(eng.open(nb_total, N, me, B.chunks * FJ_CHUNK, np_bound, pieces, mat)) == 0;
+        if (failed.empty()) guarded(eng.append(0, B.rk, B.rv, B.rd, B.chunks, B.done));
+        std::vector<size_t> first(N), cnt(N);
+        size_t total = 0, FB = 0, largest = 0;
+        for (int r = 0; r < N && failed.empty(); ++r) guarded(eng.filter_range(nb_total, N, r, &first[r], &cnt[r], &total, &FB));
+        if (failed.empty()) guarded(dc->grow(dc->filt, total * FB));
+        Token exported = nullptr;
+        if (failed.empty()) guarded(eng.export_filters((char*)dc->filt.p + first[me] * FB, &exported));
+        unsigned long long bad = failed.empty() ? 0 : 1;
+        if (net.all_reduce(&bad, 1)) return bail(fj_last_error());
+        if (bad) { char b[1200]; snprintf(b, sizeof b, "fj_dist_join: the partition filters could not be prepared on %llu rank(s)%s%s", bad, failed.empty() ? "" : "; this rank: ", failed.c_str()); return bail(b); }
+        std::vector<const void*> sp(N, nullptr); std::vector<void*> rp(N, nullptr);
+        std::vector<size_t> sb(N, 0), rb(N, 0);
+        for (int r = 0; r < N; ++r) {
+            largest = std::max(largest, cnt[r] * FB);
+            if (r == me) continue;                             // (a rank's own filters are where they belong)
+            sp[r] = (char*)dc->filt.p + first[me] * FB; sb[r] = cnt[me] * FB;
+            rp[r] = (char*)dc->filt.p + first[r] * FB; rb[r] = cnt[r] * FB;
+            filter_bytes += rb[r];
+        }
+        if (net.exchange(1, sp.data(), sb.data(), rp.data(), rb.data(), largest, exported, &filt_ready, MAX_PIECES + 1)) return bail(fj_last_error());
+        if (!filt_ready) filt_ready = exported;
+        mark("filters on their way");
+        if (prefilter_below >= 2.0) pf = true;
+        else {
+            const size_t ns = std::min<size_t>(np, (size_t)1 << 20), stride = ns ? np / ns : 1;
+            unsigned long long k = 0;
+            const bool ok = eng.sample(d_probe_keys, ns, stride, dc->filt.p, nb_total, N, filt_ready, &k) == 0;
+            const std::string why = ok ? "" : fj_last_error();
+            unsigned long long v[3] = {k, ns, ok ? 0ull : 1ull};
+            if (net.all_reduce(v, 3)) return bail(fj_last_error());
+            if (v[2]) { char b[1200]; snprintf(b, sizeof b, "fj_dist_join: sampling the probe rows failed on %llu rank(s)%s%s", v[2], ok ? "" : "; this rank: ", why.c_str()); return bail(b); }
+            sampled = v[1] ? (double)v[0] / (double)v[1] : 1.0;
+            pf = sampled < prefilter_below;
+            mark("sampled");
+        }
+    }
+    const void* filters = pf ? dc->filt.p : nullptr;
     // ---- probe side: piece c+1's first pass is queued behind piece c's copy; piece c is appended before the host waits for c+1 ----
     std::vector<Piece> P(pieces);
     auto bounds = [&](int c, size_t* lo, size_t* hi) { *lo = (np * (size_t)c / pieces) & ~(size_t)1; *hi = c + 1 == pieces ? np : ((np * (size_t)(c + 1) / pieces) & ~(size_t)1); };
     size_t lo, hi;
     bounds(0, &lo, &hi);
     auto tp0 = std::chrono::steady_clock::now();
-    bool begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N) == 0;
+    bool begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N, filters, filt_ready) == 0;
     split_ms += ms_since(tp0);
     size_t rows_recv_chunks = 0;
     for (int c = 0; c < pieces; ++c) {
         if (finish_piece(begun, c & 1, c + 1, false, &P[c])) return 1;
+        kept_rows += pf ? eng.pack_kept() : (unsigned long long)(hi - lo);
         if (c + 1 < pieces) {
             bounds(c + 1, &lo, &hi);
             const auto tp = std::chrono::steady_clock::now();
-            begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N) == 0;
+            begun = eng.pack_begin(d_probe_keys + lo, nullptr, hi - lo, nb_total, N, filters, filt_ready) == 0;
             split_ms += ms_since(tp);
         }
-        if (c == 0) {
+        if (c == 0 && !want_pf) {
             // the owner's stream join opens once the first probe piece's size is known: an owner of hot probe keys (its share far above
             // np_global / N) sizes its pools from what actually arrives - 1.25x the first piece's rate - instead of failing later
             const size_t seen = (size_t)(1.25 * (double)P[0].chunks * FJ_CHUNK * pieces) + ((size_t)1 << 20);
@@ -597,6 +675,7 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
         timings->local_count = local; timings->local_build_chunks = B.chunks; timings->local_probe_chunks = rows_recv_chunks;
         timings->pieces = pieces; timings->nranks = N; timings->fan_log0 = 0; timings->local = lt;
         timings->wire_chunk_bytes = (int)CB; timings->sent_chunks = sent_chunks;
+        timings->prefilter = pf ? 1 : 0; timings->prefilter_sampled = sampled; timings->probe_rows_kept = kept_rows; timings->filter_bytes = filter_bytes;
     }
     return 0;
 }

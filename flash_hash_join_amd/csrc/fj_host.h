@@ -69,6 +69,7 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     // its own, outside what clear_plan_scalars and the plan's error handling touch)
     u32 pack_alloc, pack_seg, pack_err, rx_alloc;   // chunk allocator / segment counter / error word of the packing pass; chunk count of a received piece
     unsigned long long pack_used[64];  // wire-format chunks per owner GPU (fj_pack_offsets)
+    unsigned long long pack_kept;      // probe keys a piece kept after the sender-side precheck (fj_part_filter_inplace) / passing keys of a sample
 };
 
 enum Slot {
@@ -134,7 +135,8 @@ struct PassIter {
 }  // namespace fjh
 
 struct PackState {              // fj_shuffle_pack_begin .. _finish: one piece on its way into the wire format
-    bool begun = false;
+    bool begun = false, deferred = false;      // deferred: the first pass is queued, fj_shuffle_pack_filter queues the rest
+    u32 part_shift = 0;                        // mixed key >> part_shift = final partition of the global plan
     fjh::PassIter it;
     FjPackArgs args{};
     int nranks = 0;
@@ -169,7 +171,7 @@ struct fj_ctx {
     StreamState st;
     PackState pk;
     hipEvent_t pk_ev = nullptr;        // the packing pass's counts have landed in pk_h
-    unsigned long long* pk_h = nullptr;   // pinned: [64] chunks per owner, [64] = the pass's error word
+    unsigned long long* pk_h = nullptr;   // pinned: [64] chunks per owner, [64] = the pass's error word, [65] = keys kept by the precheck, [66] = sample result
     size_t ws_bytes = 0;
     u32 num_cus = 256;
     u32 reserve_cus = 0;               // CUs the partition passes leave free (set by the multi-GPU driver while RCCL's kernels share the GPU: fj_ctx_reserve_cus)

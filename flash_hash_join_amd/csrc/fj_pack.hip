@@ -157,6 +157,115 @@ __global__ __launch_bounds__(PK_NT) void fj_pack_squeeze(FjPackArgs a, const uin
     }
 }
 
+// ---- sender-side precheck in chunk form: one small Bloom filter per FINAL partition of the global plan ---------------------------
+// An owner writes, for every final partition it owns, a blocked Bloom filter of the build keys it received (FJ_PFILT_BYTES = 4 KiB
+// for ~3-4K keys: ~8 bits per key, four bits inside one 64-bit block), all owners' filters are all-gathered (1 byte per build key
+// in all), and a sender drops the probe keys that no filter admits BEFORE the copy into the wire format - at 50 % hits ~45 % of
+// what would travel, at 5 % hits ~90 %.  The filters are far too many for LDS (config 5: 1 GB), but a sender works through its
+// level-1 chunk lists bucket after bucket, and the filters of ONE level-1 bucket's partitions are a contiguous 2 MiB: they stay in
+// the XCDs' L2s while that bucket's keys stream by (round 2's microbenchmark: 205-270 G keys/s against an L2-resident filter,
+// profiles/r02_ubench_bloom_probe.csv).  Role of the reference's bloom directory (hash_join.cpp:60-74, :122, :183-189): insert
+// and test use the same bits, so no key of the build side is ever dropped.
+__device__ __forceinline__ void pf_bits(u64 h, u32& block, u64& mask) {
+    const u32 w = FJ_HW2(h);
+    block = __umulhi(w, FJ_PFILT_BYTES / 8u);                                       // top bits of hash word 2
+    mask = (1ull << (w & 63u)) | (1ull << ((w >> 6) & 63u)) | (1ull << ((w >> 12) & 63u)) | (1ull << ((w >> 18) & 63u));
+}
+
+// owner: one 256-thread workgroup per final partition (grid-stride): filter in LDS, written out whole
+__global__ __launch_bounds__(256) void fj_part_filter_export(FjChunkSet build, u64* __restrict__ out) {
+    __shared__ unsigned long long filt[FJ_PFILT_BYTES / 8];
+    const u32 tid = threadIdx.x;
+    for (u32 p = blockIdx.x; p < build.nb; p += gridDim.x) {
+        for (u32 i = tid; i < FJ_PFILT_BYTES / 8; i += 256) filt[i] = 0;
+        __syncthreads();
+        const u32 l0 = build.boff[p], n = build.boff[p + 1] - l0;
+        for (u32 c = 0; c < n; ++c) {
+            const u32 e = build.list[l0 + c];
+            if (tid < FJ_LIST_CNT(e)) {
+                u32 b; u64 m;
+                pf_bits(build.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + tid], b, m);
+                atomicOr(&filt[b], (unsigned long long)m);
+            }
+        }
+        __syncthreads();
+        for (u32 i = tid; i < FJ_PFILT_BYTES / 8; i += 256) out[(u64)p * (FJ_PFILT_BYTES / 8) + i] = filt[i];
+        __syncthreads();
+    }
+}
+
+// sender: the chunks of a level-1 chunk set are compacted IN PLACE to the keys some filter admits, and a chunk's list entry gets its
+// new count.  A WAVE owns a chunk - four keys per lane, two 16-byte loads - and is on its own: four independent filter words in
+// flight per lane, survivor positions from ballots (their order inside the chunk is free), no LDS, no barrier; every key of the
+// chunk is in a register before the first survivor is written back.  A chunk without survivors keeps its first key (a key that
+// matches nothing is harmless on the wire; a list entry cannot say "empty").  Chunks are taken in list order = bucket after bucket
+// (see above).  part_shift: H >> part_shift = final partition.  The launch gives a wave ~9 chunks (strided: the resident waves stay
+// within a few buckets of each other): the kernel shares the CUs with the owner's partition passes on another stream, and a static
+// share per wave of a small grid waits for the slowest CU (16 workgroups per CU: 3.7 ms per 312M keys, ~9 chunks per wave: 2.3 ms).
+// Bound by the texture path: one divergent filter-word load per key (1.5 ms of the 2.3; tools/ubench_bloom_probe.hip: 205 G/s against
+// 1-2 MiB in L2), beside 0.6 ms of key streaming; the survivors' stores are free.  (First version: a workgroup per chunk, one key
+// per thread, two barriers per chunk: 3.9 ms.)
+__global__ __launch_bounds__(256) void fj_part_filter_inplace(u64* keys, u32* list, const u32* __restrict__ boff, u32 nb,
+                                                              const u64* __restrict__ filters, u32 part_shift, unsigned long long* __restrict__ kept) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), nw = gridDim.x * 4;
+    const u32 total = boff[nb];
+    if (w0 >= total) return;
+    const u64 lt = (1ull << lane) - 1ull;
+    unsigned long long mine = 0;
+    // software pipeline: the NEXT chunk's keys and the list entry after it are requested before this chunk's filter words are
+    // waited for (one memory latency per chunk instead of three; indices beyond the end are clamped - loaded, never used)
+    u32 e = list[w0];
+    const uint4* c4 = reinterpret_cast<const uint4*>(keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK);
+    uint4 a = c4[2 * lane], c = c4[2 * lane + 1];                                // keys 4 * lane .. 4 * lane + 3 (slack beyond the count: never counted)
+    u32 e1 = list[w0 + nw < total ? w0 + nw : total - 1];
+    for (u32 i = w0; i < total; i += nw) {
+        const uint4* n4 = reinterpret_cast<const uint4*>(keys + (u64)FJ_LIST_ID(e1) * FJ_CHUNK);
+        const uint4 an = n4[2 * lane], cn = n4[2 * lane + 1];
+        const u32 i2 = i + 2 * nw < total ? i + 2 * nw : total - 1;
+        const u32 e2 = list[i2];
+        const u32 cnt = FJ_LIST_CNT(e), id = FJ_LIST_ID(e);
+        const u64 h[4] = {(u64)a.y << 32 | a.x, (u64)a.w << 32 | a.z, (u64)c.y << 32 | c.x, (u64)c.w << 32 | c.z};
+        u64 word[4], m[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            u32 b;
+            pf_bits(h[j], b, m[j]);
+            const u64 part = 4 * lane + j < cnt ? h[j] >> part_shift : 0ull;     // (slack lanes read partition 0's filter: unconditional loads)
+            const u64* fp = filters + part * (FJ_PFILT_BYTES / 8) + b;
+            word[j] = *fp;
+        }
+        u64* ck = keys + (u64)id * FJ_CHUNK;
+        u32 base = 0;
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            const bool pass = (word[j] & m[j]) == m[j] && 4 * lane + j < cnt;
+            const u64 bal = __ballot(pass);
+            if (pass) ck[base + (u32)__popcll(bal & lt)] = h[j];
+            base += (u32)__popcll(bal);
+        }
+        if (lane == 0) list[i] = ((base ? base - 1u : 0u) << 24) | id;            // (no survivor: key 0 stays - its slot was not written)
+        mine += base;
+        e = e1; e1 = e2; a = an; c = cn;
+    }
+    if (lane == 0 && mine) atomicAdd(kept, mine);
+}
+
+// how many of n raw probe keys (a strided sample) would pass: the "auto" decision
+__global__ __launch_bounds__(256) void fj_part_filter_sample(const u64* __restrict__ raw, u64 n, u64 stride, const u64* __restrict__ filters, u32 part_shift,
+                                                             unsigned long long* __restrict__ kept) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool pass = false;
+    if (i < n) {
+        const u64 h = fj_key_mix(raw[i * stride]);
+        u32 b; u64 m;
+        pf_bits(h, b, m);
+        pass = (filters[(h >> part_shift) * (FJ_PFILT_BYTES / 8) + b] & m) == m;
+    }
+    const u64 bal = __ballot(pass);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(kept, (unsigned long long)__popcll(bal));
+}
+
 }  // namespace
 
 hipError_t fj_launch_pack_plan(const FjPackArgs& a, hipStream_t s) {
@@ -171,5 +280,22 @@ hipError_t fj_launch_pack_squeeze(const FjPackArgs& a, u32 grid, hipStream_t s) 
     if (a.wire7 && a.fan_log < 8) return hipErrorInvalidValue;
     auto kern = a.wire7 ? (a.vals ? fj_pack_squeeze<true, true> : fj_pack_squeeze<true, false>) : (a.vals ? fj_pack_squeeze<false, true> : fj_pack_squeeze<false, false>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PK_NT), 0, s, a, a.fi, a.fb, a.list, a.obase, a.keys, a.vals);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_part_filter_export(const FjChunkSet& build, u64* out, u32 grid, hipStream_t s) {
+    if (!build.list || build.nb == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fj_part_filter_export, dim3(grid < build.nb ? grid : build.nb), dim3(256), 0, s, build, out);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_part_filter_inplace(const FjChunkSet& cs, const u64* filters, u32 part_shift, unsigned long long* kept, u32 grid, hipStream_t s) {
+    hipLaunchKernelGGL(fj_part_filter_inplace, dim3(grid), dim3(256), 0, s, cs.keys, cs.list, cs.boff, cs.nb, filters, part_shift, kept);
+    return hipGetLastError();
+}
+
+hipError_t fj_launch_part_filter_sample(const u64* raw, u64 n, u64 stride, const u64* filters, u32 part_shift, unsigned long long* kept, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fj_part_filter_sample, dim3((u32)((n + 255) / 256)), dim3(256), 0, s, raw, n, stride, filters, part_shift, kept);
     return hipGetLastError();
 }

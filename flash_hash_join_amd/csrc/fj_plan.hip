@@ -415,7 +415,7 @@ fj_ctx* fj_ctx_create(int device) {
               hipMemset(c->d_sc, 0, sizeof(Scalars)) == hipSuccess;
     for (int i = 0; ok && i < E_NEV; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->pk_ev, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void**)&c->pk_h, 65 * 8, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->pk_ev, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void**)&c->pk_h, 67 * 8, hipHostMallocDefault) == hipSuccess;
     if (!ok) { set_err("fj_ctx_create: allocating context scratch failed: %s", hipGetErrorString(hipGetLastError())); delete c; return nullptr; }
     return c;
 }

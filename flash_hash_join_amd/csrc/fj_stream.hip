@@ -290,10 +290,46 @@ size_t fj_shuffle_chunk_bytes(size_t nb_total, int nranks) {
     return wire7(p) ? FJ_WIRE7_BYTES : FJ_CHUNK * 8u;
 }
 
-int fj_shuffle_pack_begin(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks, void* stream) {
+size_t fj_shuffle_part_filter_bytes(void) { return FJ_PFILT_BYTES; }
+
+int fj_shuffle_part_filter_range(size_t nb_total, int nranks, int rank, size_t* first_part, size_t* n_parts, size_t* total_parts) {
+    Plan p;
+    if (shuffle_plan(nb_total, nranks, &p)) return 1;
+    if (rank < 0 || rank >= nranks) return set_err("fj_shuffle_part_filter_range: rank %d of %d", rank, nranks);
+    const u64 F0 = 1ull << p.fan_log[0], rest = 1ull << (p.bits - p.fan_log[0]);
+    const u64 lo = ((u64)rank * F0 + nranks - 1) / nranks, hi = ((u64)(rank + 1) * F0 + nranks - 1) / nranks;
+    if (first_part) *first_part = (size_t)(lo * rest);
+    if (n_parts) *n_parts = (size_t)((hi - lo) * rest);
+    if (total_parts) *total_parts = (size_t)1 << p.bits;
+    return 0;
+}
+
+namespace {
+// second half of a packing pass: (precheck,) keys per bucket, output chunk ranges, descriptors, counts on their way to the host
+int pack_plan_tail(fj_ctx* c, const u64* filters, hipStream_t s) {
+    PackState& pk = c->pk;
+    PassIter& it = pk.it;
+    HIPCHK(hipMemsetAsync(&c->d_sc->pack_kept, 0, sizeof(unsigned long long), s));
+    if (filters) {
+        const u64 chunks = it.n / FJ_CHUNK + pk.args.nb;                                   // (what the piece's first pass can have filled, roughly)
+        const u32 grid = (u32)std::min<u64>(65536, std::max<u64>(c->num_cus, chunks / 36));   // four waves per workgroup, ~9 chunks per wave
+        HIPCHK(fj_launch_part_filter_inplace(it.cs, filters, pk.part_shift, &c->d_sc->pack_kept, grid, s));
+    }
+    HIPCHK(fj_launch_pack_plan(pk.args, s));
+    HIPCHK(hipMemcpyAsync(c->pk_h, c->d_sc->pack_used, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->pk_h + 64, &c->d_sc->pack_err, sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->pk_h + 65, &c->d_sc->pack_kept, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->pk_ev, s));
+    pk.deferred = false; pk.begun = true;
+    return 0;
+}
+}  // namespace
+
+int fj_shuffle_pack_begin(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks, int defer_plan, void* stream) {
     if (!c) return set_err("fj_shuffle_pack_begin: null context");
     if (n && !d_keys) return set_err("fj_shuffle_pack_begin: null pointer");
     if (((uintptr_t)d_keys | (uintptr_t)d_vals) & 15) return set_err("fj_shuffle_pack_begin: pointers must be 16-byte aligned");
+    if (defer_plan && d_vals) return set_err("fj_shuffle_pack_begin: the precheck is for probe pieces (keys only)");
     Plan plan;
     if (shuffle_plan(nb_total, nranks, &plan)) return 1;
     FJ_ENTER(c);
@@ -301,6 +337,7 @@ int fj_shuffle_pack_begin(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_v
     PackState& pk = c->pk;
     pk = PackState();
     pk.nranks = nranks;
+    pk.part_shift = 64u - (u32)plan.bits;
     const bool vals = d_vals != nullptr;
     const u32 fan_log = (u32)plan.fan_log[0], F = 1u << fan_log;
     Plan p1; p1.bits = (int)fan_log; p1.npass = 1; p1.fan_log[0] = (int)fan_log;
@@ -320,11 +357,30 @@ int fj_shuffle_pack_begin(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_v
     if (get_buf(c, W_PK_BKEYS, (size_t)F * 4, &p)) return 1; a.bkeys = (u32*)p;
     if (get_buf(c, W_PK_OBASE, ((size_t)F + 1 + 64) * 4, &p)) return 1; a.obase = (u32*)p;
     a.used = c->d_sc->pack_used;
-    HIPCHK(fj_launch_pack_plan(a, s));
-    HIPCHK(hipMemcpyAsync(c->pk_h, c->d_sc->pack_used, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(c->pk_h + 64, &c->d_sc->pack_err, sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(c->pk_ev, s));
-    pk.args = a; pk.begun = true;
+    pk.args = a;
+    if (defer_plan) { pk.deferred = true; return 0; }
+    return pack_plan_tail(c, nullptr, s);
+}
+
+int fj_shuffle_pack_filter(fj_ctx* c, const void* d_part_filters, void* stream) {
+    if (!c) return set_err("fj_shuffle_pack_filter: null context");
+    if (!c->pk.deferred) return set_err("fj_shuffle_pack_filter: no fj_shuffle_pack_begin(defer_plan = 1) is pending on this context");
+    if ((uintptr_t)d_part_filters & 7) return set_err("fj_shuffle_pack_filter: misaligned filters");
+    FJ_ENTER(c);
+    return pack_plan_tail(c, (const u64*)d_part_filters, (hipStream_t)stream);
+}
+
+int fj_part_filter_sample(fj_ctx* c, const uint64_t* d_raw_keys, size_t n, size_t stride, const void* d_part_filters, size_t nb_total, int nranks, void* stream, uint64_t* kept) {
+    if (!c || !kept || (n && (!d_raw_keys || !d_part_filters)) || stride == 0) return set_err("fj_part_filter_sample: bad argument");
+    Plan plan;
+    if (shuffle_plan(nb_total, nranks, &plan)) return 1;
+    FJ_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(&c->d_sc->pack_kept, 0, sizeof(unsigned long long), s));
+    HIPCHK(fj_launch_part_filter_sample((const u64*)d_raw_keys, n, stride, (const u64*)d_part_filters, 64u - (u32)plan.bits, &c->d_sc->pack_kept, s));
+    HIPCHK(hipMemcpyAsync(c->pk_h + 66, &c->d_sc->pack_kept, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *kept = c->pk_h[66];
     return 0;
 }
 
@@ -337,6 +393,8 @@ int fj_shuffle_pack_counts(fj_ctx* c, uint64_t* h_used) {
     for (int r = 0; r < c->pk.nranks; ++r) h_used[r] = c->pk_h[r];
     return 0;
 }
+
+uint64_t fj_shuffle_pack_kept(fj_ctx* c) { return c && c->pk_h ? c->pk_h[65] : 0; }   // after fj_shuffle_pack_counts: keys the precheck kept
 
 int fj_shuffle_pack_finish(fj_ctx* c, void* const* d_dst_chunks, uint64_t* const* d_dst_vals, uint32_t* const* d_dst_dir, void* stream) {
     if (!c || !d_dst_chunks || !d_dst_dir) return set_err("fj_shuffle_pack_finish: null argument");
@@ -437,6 +495,22 @@ int fj_stream_append_build_chunks(fj_ctx* c, const void* d_chunks, const uint64_
     --st.b_appends_left;
     if (nchunks) { st.nb_seen += nchunks * FJ_CHUNK; if (stream_append_chunks(c, 0, d_chunks, (const u64*)d_vals, d_dir, nchunks, s)) return 1; }
     if (st.b_appends_left == 0) return stream_flush_build(c, st, s);          // the build side is complete: its remaining passes run now
+    return 0;
+}
+
+int fj_stream_export_part_filters(fj_ctx* c, void* d_out, void* stream) {
+    if (!c || !c->st.active || !c->st.shuffled) return set_err("fj_stream_export_part_filters: no shuffled stream join is open on this context");
+    StreamState& st = c->st;
+    if (!st.build_done) return set_err("fj_stream_export_part_filters: the build side is not complete yet");
+    if (!d_out || ((uintptr_t)d_out & 7)) return set_err("fj_stream_export_part_filters: null or misaligned output");
+    FJ_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    const u64 rest = 1ull << (st.plan.bits - st.plan.fan_log[0]);
+    const u64 nparts = (u64)st.nbk * rest;                                     // (the padding buckets of the owner's range have no partitions to speak for)
+    if (st.nb_seen == 0 || !st.ja.build.list) { HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nparts * FJ_PFILT_BYTES, s)); return 0; }
+    FjChunkSet b = st.ja.build;
+    b.nb = (u32)nparts;
+    HIPCHK(fj_launch_part_filter_export(b, (u64*)d_out, 8u * c->num_cus, s));
     return 0;
 }
 

@@ -194,7 +194,7 @@ class HipEngine:
             raise RuntimeError(self._lib.last_error())
         if vals is not None:
             vals = self._aligned(vals)
-        self._lib.check(self.L.fj_shuffle_pack_begin(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, world, stream))
+        self._lib.check(self.L.fj_shuffle_pack_begin(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, world, 0, stream))
         used = (ctypes.c_uint64 * 64)()
         self._lib.check(self.L.fj_shuffle_pack_counts(self.ctx, used))
         used = [int(used[r]) for r in range(world)]
@@ -377,6 +377,52 @@ def _prefilter_break_even(world: int) -> float:
     link = 8.0 / _LINK_BYTES_PER_S
     f = (link - _PREFILTER_S_PER_ROW * world) / (link + _PREFILTER_S_PER_SURVIVOR * world)
     return max(0.0, 0.8 * f)
+
+
+# the precheck in chunk form (fj_dist_join(prefilter_below), csrc/fj_pack.hip: fj_part_filter_inplace): what a config-5 shard costs
+# per local probe row on ONE MI355X through the driver (profiles/r04_prefilter_one_rank.txt: 15.5 ms without it; with it 17.1 ms at
+# 8 % survivors, 21.8 ms at 52 %), as  off = FIXED + REST,  on(f) = FIXED + FILTER + f x REST
+_CHUNK_FIXED_S_PER_ROW = 6.0e-12        # first pass of the global plan over the probe rows + the build side's and the host's share of the step
+_CHUNK_FILTER_S_PER_ROW = 6.9e-12       # the precheck: every row is tested (6.2 ps at 8 % survivors ... 7.5 ps at 52 %)
+_CHUNK_REST_S_PER_ROW = 6.4e-12         # copy into the wire format + the owner's second pass, lists and join: scale with what survives
+_CHUNK_WIRE_BYTES_PER_ROW = 7.02
+
+
+def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> float:
+    """Survivor fraction below which the precheck of the chunk form pays (FJ_DIST_PREFILTER_BELOW overrides the model).  Per local
+    probe row a step costs max(wire, kernels): wire = 7.02 B x f / (world x link rate) on each of the links that work in parallel,
+    kernels as above; the filters cost 1 byte per build key to every rank (~nb_total / world bytes per link) and ~0.5 ms of
+    latency before the first probe piece can be checked.  It never pays where the kernels bound the step (one rank; links faster
+    than ~12 ps per row); on wire-bound steps it does below ~55 % survivors at 8 GPUs and ~45 GB/s per link, below ~85 % at 2-4."""
+    env = os.environ.get("FJ_DIST_PREFILTER_BELOW")
+    if env:
+        return float(env)
+    if np_local <= 0:
+        return 0.0
+    wire = _CHUNK_WIRE_BYTES_PER_ROW / (world * _LINK_BYTES_PER_S) if world > 1 else 0.0
+    head = ((nb_total / world / _LINK_BYTES_PER_S if world > 1 else 0.0) + 0.5e-3) / np_local
+    off = max(wire, _CHUNK_FIXED_S_PER_ROW + _CHUNK_REST_S_PER_ROW)
+
+    def on(f):
+        return max(wire * f, _CHUNK_FIXED_S_PER_ROW + _CHUNK_FILTER_S_PER_ROW + f * _CHUNK_REST_S_PER_ROW) + head
+    if on(0.0) >= off:
+        return 0.0
+    lo, hi = 0.0, 1.0
+    for _ in range(30):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if on(mid) < off else (lo, mid)
+    return 0.9 * lo
+
+
+def _chunk_prefilter_mode(bloom: bool, world: int) -> str:
+    """The chunk form's precheck: FJ_DIST_PREFILTER=1 / 0 / auto decides; unset it is "auto" for every join across more than one
+    rank (the *_bloom functions and the plain ones alike: results are identical, and a step whose links are the bottleneck is
+    shorter by what the owners' filters keep off them - the model above prices it with the measured link rate when bench.py or the
+    host called set_link_rate) and for the *_bloom functions on one rank (where the model declines)."""
+    env = os.environ.get("FJ_DIST_PREFILTER", "")
+    if env in ("0", "1", "auto"):
+        return {"0": "off", "1": "on", "auto": "auto"}[env]
+    return "auto" if (bloom or world > 1) else "off"
 
 
 def _sampled_survivors(dist, group, engine, world, probe_keys, filters) -> float:
@@ -668,11 +714,13 @@ def _engine_ops_struct(ops, keep: list):
                                 cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"])
 
 
-def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport, build_values=None, return_arrays=False):
+def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport, build_values=None, return_arrays=False,
+                  prefilter_below: float = 0.0, prefilter_mode: str = "off"):
     """The owner shuffle in chunk form through the ONE driver, csrc/fj_dist.hip (fj_dist_join): natively over RCCL under the nccl
     backend; over a callback transport (torch.distributed with host staging: gloo, a transport object) otherwise; with a stand-in
     engine's callbacks in the CPU test-suite.  build_values: a materialising join (the pairs stay with the owner; returned when
-    return_arrays).  Collective; a failure on any rank raises on every rank."""
+    return_arrays).  prefilter_below: the sender-side precheck in chunk form (include/flashjoin.h: fj_dist_join) - 0 never, >= 2
+    always, else the survivor share of a sample below which it runs.  Collective; a failure on any rank raises on every rank."""
     from . import _lib
     L = _lib.load()
     t0 = time.perf_counter()
@@ -703,7 +751,7 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
             bv = engine._aligned(build_values) if build_values is not None else None
             with tt.cuda.device(engine.index):
                 rc = L.fj_dist_join(comm, bk.data_ptr(), bv.data_ptr() if bv is not None else None, bk.numel(), pk.data_ptr(), pk.numel(), pieces,
-                                    int(bv is not None), tt.cuda.current_stream(engine.index).cuda_stream, ctypes.byref(cnt), ctypes.byref(local), ctypes.byref(dt))
+                                    int(bv is not None), float(prefilter_below), tt.cuda.current_stream(engine.index).cuda_stream, ctypes.byref(cnt), ctypes.byref(local), ctypes.byref(dt))
                 if rc == 0 and bv is not None and return_arrays:
                     pairs = engine.emit_pairs(int(local.value))
         if rc:
@@ -720,8 +768,10 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
     if timings is not None:
         timings.update(strategy="shuffle", shuffle_form=form, split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
                        join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces), local_build_rows=int(dt.local_build_chunks) * 256,
-                       local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=False, prefilter_mode="off",
-                       prefilter_sampled_survivors=None, probe_rows_sent=probe_keys.numel(), rows_are_chunk_capacity=True,
+                       local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=bool(dt.prefilter), prefilter_mode=prefilter_mode,
+                       prefilter_sampled_survivors=(float(dt.prefilter_sampled) if dt.prefilter_sampled >= 0 else None), prefilter_below=float(prefilter_below),
+                       probe_rows_sent=int(dt.probe_rows_kept) if not standin else probe_keys.numel(), filter_bytes_received=int(dt.filter_bytes),
+                       rows_are_chunk_capacity=True,
                        wire_chunk_bytes=int(dt.wire_chunk_bytes), wire_bytes_sent=int(dt.sent_chunks) * (int(dt.wire_chunk_bytes) + 4))
     if pairs is not None:
         return int(cnt.value), sec, pairs[0], pairs[1]
@@ -849,7 +899,34 @@ def self_check(dist, group, engine, small_inputs, expected_small: int, message_e
         flag = engine.counts_tensor([1 if err else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
         nbad = int(flag.item())
-    return {"ok": nbad == 0, "error": err, "failed_ranks": nbad, "message_bytes": n * 8, "seconds": round(time.perf_counter() - t0, 3)}
+    # (3) the same join with the sender-side precheck forced on (what "auto" may choose in the timed steps: filters exported,
+    #     all-gathered, probe pieces compacted).  A failure does not fail the check: the precheck is switched off for this process
+    #     (FJ_DIST_PREFILTER=0, the ranks agree) and the verdict says so.
+    precheck = None
+    if nbad == 0 and os.environ.get("FJ_DIST_PREFILTER", "") != "0" and hasattr(engine, "shuffle_plan") and not hasattr(engine, "dist_engine_ops"):
+        perr = None
+        saved = os.environ.get("FJ_DIST_PREFILTER")
+        os.environ["FJ_DIST_PREFILTER"] = "1"
+        try:
+            tt: dict = {}
+            got = distributed_join(bk, bv, pk, group=group, engine=engine, transport=transport, timings=tt)[0]
+            if int(got) != int(expected_small):
+                perr = f"count {got} != closed form {expected_small}"
+            precheck = {"ok": perr is None, "ran": bool(tt.get("prefilter")), "rows_sent": tt.get("probe_rows_sent"), "form": tt.get("shuffle_form")}
+        except Exception as ex:                                    # noqa: BLE001
+            perr = f"raised {ex!r}"
+            precheck = {"ok": False}
+        finally:
+            if saved is None:
+                os.environ.pop("FJ_DIST_PREFILTER", None)
+            else:
+                os.environ["FJ_DIST_PREFILTER"] = saved
+        flag = engine.counts_tensor([1 if perr else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+        if int(flag.item()):
+            os.environ["FJ_DIST_PREFILTER"] = "0"
+            precheck = {"ok": False, "error": perr, "failed_ranks": int(flag.item()), "action": "FJ_DIST_PREFILTER=0 for the timed steps"}
+    return {"ok": nbad == 0, "error": err, "failed_ranks": nbad, "message_bytes": n * 8, "seconds": round(time.perf_counter() - t0, 3), "precheck": precheck}
 
 
 def _gather_rows(dist, group, engine, world, t, sizes: List[int], lo_frac=(0, 1), async_op=False):
@@ -980,36 +1057,48 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     if timings is not None:
         timings["strategy"] = "shuffle"
     if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
-        mode = _prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off"
+        standin = hasattr(engine, "dist_engine_ops")
+        mode = "off" if not hasattr(engine, "bloom_export") else _prefilter_mode(bloom) if standin else _chunk_prefilter_mode(bloom, world)
         nb_total, np_global = sum(sizes_b), sum(int(x[1]) for x in allsz)
         # the chunk form (the first radix pass of the global plan is the owner split) serves every counting shuffle whose
-        # global plan has two or more passes; the owner-scatter form below the small ones and the sender-side precheck
-        if (mode == "off" and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
+        # global plan has two or more passes, the sender-side precheck included (per-partition filters: fj_dist_join's
+        # prefilter_below); the owner-scatter form below serves the small ones (and a stand-in engine's precheck)
+        if ((mode == "off" or not standin) and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
                 and engine.shuffle_plan(nb_total, world) is not None):      # (ranks with few or no rows: the driver sends everything as one piece)
             # ONE driver for every transport: csrc/fj_dist.hip (fj_dist_join_count) - over RCCL under the nccl backend, over
             # callbacks into torch.distributed under gloo / a transport object, with a stand-in engine in the CPU tests.  A step
             # that fails on any rank fails on every rank (the driver agrees on it), so all of them fall back together to the
             # owner-scatter form, whose segments are sized from an owner histogram: the answer to heavily skewed keys (an owner
             # that receives far more than 1.5x its share overflows the chunk form's pools).
-            try:
-                return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport)
-            except RuntimeError as ex:
-                if os.environ.get("FJ_DIST_NO_FALLBACK"):
-                    raise
-                _abort_stream(engine)
-                if timings is not None:
-                    timings["chunk_form_error"] = str(ex)
+            below = {"off": 0.0, "on": 2.0}.get(mode)
+            if below is None:
+                below = _chunk_prefilter_break_even(world, nb_total, max(1, np_global // world))
+            for attempt in ((below, mode), (0.0, "off")) if below > 0 else ((0.0, mode),):     # (a failed step with the precheck is retried without it)
+                try:
+                    return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport, prefilter_below=attempt[0], prefilter_mode=attempt[1])
+                except RuntimeError as ex:
+                    if os.environ.get("FJ_DIST_NO_FALLBACK"):
+                        raise
+                    _abort_stream(engine)
+                    if timings is not None:
+                        timings["chunk_form_error"] = str(ex)
         if timings is not None:
             timings["shuffle_form"] = "owner-scatter"
+        if not standin and hasattr(engine, "bloom_export"):
+            mode = _prefilter_mode(bloom)               # (the owner-scatter form's own rule and break-even)
         return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings, prefilter=mode)
 
     # materialising joins: the chunk form too (the build rows travel with their values, the pairs stay with the owner: SURVEY 8(e)) -
-    # through the same driver; duplicate build keys, the sender-side precheck and small build sides take the owner-scatter form below
+    # through the same driver, sender-side precheck included; duplicate build keys and small build sides take the owner-scatter form below
     if (materialize and hasattr(engine, "emit_pairs") and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0"
-            and (_prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off") == "off"
             and engine.shuffle_plan(sum(sizes_b), world) is not None):
         try:
-            return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport, build_values=build_values, return_arrays=return_arrays)
+            mode = _chunk_prefilter_mode(bloom, world)
+            below = {"off": 0.0, "on": 2.0}.get(mode)
+            if below is None:
+                below = _chunk_prefilter_break_even(world, sum(sizes_b), max(1, sum(int(x[1]) for x in allsz) // world))
+            return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport, build_values=build_values, return_arrays=return_arrays,
+                                 prefilter_below=below, prefilter_mode=mode)
         except RuntimeError as ex:
             if os.environ.get("FJ_DIST_NO_FALLBACK"):
                 raise

@@ -198,6 +198,15 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
  *                                    over the piece (it unpacks the wire format in registers); asynchronous on `stream`, the
  *                                    piece stays allocated until the finish
  *   fj_stream_finish               - remaining passes, join, count.
+ * Sender-side precheck in this form (role of the reference's bloom directory, hash_join.cpp:60-74, :122, :183-189, moved in front
+ * of the exchange): an owner whose build side is complete writes one fj_shuffle_part_filter_bytes() (4 KiB) Bloom filter per FINAL
+ * partition it owns (fj_stream_export_part_filters: fj_shuffle_part_filter_range tells every rank where an owner's filters sit in
+ * the array of all partitions' filters - 1 byte per build key in all - which the caller assembles: an all-gather).  A sender then
+ * starts a probe piece with defer_plan = 1 - only the first pass is queued - and continues it with fj_shuffle_pack_filter once
+ * the filters have arrived: the piece's level-1 chunks are compacted in place to the keys some filter admits (the filters of one
+ * level-1 bucket are 2 MiB and stay in L2 while its chunks stream by), then counts / copy / exchange as before over fewer keys.
+ * fj_shuffle_pack_kept (after fj_shuffle_pack_counts) = the keys the piece kept.  fj_part_filter_sample tests every stride-th of n
+ * RAW probe keys (synchronous): the share that would travel.  No key of the build side is ever dropped.
  * Materialising joins (_hash_join_radix_materialize, hash_join.cpp:315-381, across GPUs): open with with_vals = 1 and append the
  * build side with its values (256 per chunk, as fj_shuffle_pack_finish wrote them; d_vals == NULL otherwise); fj_stream_finish
  * then returns the count and leaves the partitions resident, fj_emit_pairs writes this owner's (probe_key, build_value) pairs -
@@ -206,13 +215,20 @@ int fj_owner_scatter(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals
  */
 int fj_shuffle_plan(size_t nb_total, int nranks, int* fan_log0, int* npass);
 size_t fj_shuffle_chunk_bytes(size_t nb_total, int nranks);
-int fj_shuffle_pack_begin(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks, void* stream);
+int fj_shuffle_pack_begin(fj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, size_t n, size_t nb_total, int nranks, int defer_plan, void* stream);
 int fj_shuffle_pack_counts(fj_ctx* ctx, uint64_t* h_used);
 int fj_shuffle_pack_finish(fj_ctx* ctx, void* const* d_dst_chunks, uint64_t* const* d_dst_vals, uint32_t* const* d_dst_dir, void* stream);
 int fj_stream_open_shuffled(fj_ctx* ctx, size_t nb_total, int nranks, int rank, size_t nb_bound, int build_appends,
                             size_t np_bound, int probe_appends, int with_vals, void* stream);
 int fj_stream_append_build_chunks(fj_ctx* ctx, const void* d_chunks, const uint64_t* d_vals, uint32_t* d_dir, size_t nchunks, void* stream);
 int fj_stream_append_probe_chunks(fj_ctx* ctx, const void* d_chunks, uint32_t* d_dir, size_t nchunks, void* stream);
+size_t fj_shuffle_part_filter_bytes(void);
+int fj_shuffle_part_filter_range(size_t nb_total, int nranks, int rank, size_t* first_part, size_t* n_parts, size_t* total_parts);
+int fj_stream_export_part_filters(fj_ctx* ctx, void* d_out, void* stream);
+int fj_shuffle_pack_filter(fj_ctx* ctx, const void* d_part_filters, void* stream);
+uint64_t fj_shuffle_pack_kept(fj_ctx* ctx);
+int fj_part_filter_sample(fj_ctx* ctx, const uint64_t* d_raw_keys, size_t n, size_t stride, const void* d_part_filters, size_t nb_total, int nranks,
+                          void* stream, uint64_t* kept);
 
 /*
  * Sender-side bloom precheck of the owner shuffle (no reference counterpart).  fj_bloom_export: an owner partitions the
@@ -276,6 +292,10 @@ int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error
  *   fj_dist_join                - the same step, optionally materialising (materialize != 0: the build rows travel with their
  *                                 values, 16 bytes per build row on the wire): *out_local_count = pairs this rank owns; the
  *                                 caller then allocates them and calls fj_emit_pairs(ctx, ...) - before the next join on ctx.
+ *                                 prefilter_below: the sender-side precheck (above) runs when a sample of the probe rows says that
+ *                                 less than this share of them would travel - 0 = never (nothing is exported or sampled), >= 2 =
+ *                                 always (no sample); HIP engine only.  Costs one more kernel over a sender's probe rows and 1 byte
+ *                                 per build key to every rank, saves (1 - survivors) of the probe exchange and of the owner's work.
  */
 typedef struct fj_dist_comm fj_dist_comm;
 typedef struct fj_dist_timings {
@@ -285,6 +305,10 @@ typedef struct fj_dist_timings {
     uint64_t local_build_chunks, local_probe_chunks;   /* 256-key wire chunks this rank received (own share included) */
     uint64_t sent_chunks;                              /* ... and put on the links (own share excluded)            */
     int pieces, nranks, fan_log0, wire_chunk_bytes;    /* wire_chunk_bytes: 1792 (7 bytes per key) or 2048         */
+    int prefilter;                                     /* 1: the sender-side precheck ran                          */
+    double prefilter_sampled;                          /* share of the sampled probe rows that passed (-1: no sample) */
+    uint64_t probe_rows_kept;                          /* probe rows of this rank that went into wire chunks       */
+    uint64_t filter_bytes;                             /* bytes of partition filters this rank received            */
     fj_timings local;                                  /* device timings of this rank's local join (fj_stream_finish) */
 } fj_dist_timings;
 typedef struct fj_dist_transport {
@@ -323,7 +347,8 @@ int fj_dist_comm_size(const fj_dist_comm* comm);
 int fj_dist_join_count(fj_dist_comm* comm, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                        void* stream, uint64_t* out_global_count, fj_dist_timings* timings);
 int fj_dist_join(fj_dist_comm* comm, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, const uint64_t* d_probe_keys, size_t np,
-                 int pieces, int materialize, void* stream, uint64_t* out_global_count, uint64_t* out_local_count, fj_dist_timings* timings);
+                 int pieces, int materialize, double prefilter_below, void* stream, uint64_t* out_global_count, uint64_t* out_local_count,
+                 fj_dist_timings* timings);
 
 /*
  * Deterministic synthetic relations, generated in HBM:

@@ -361,3 +361,25 @@ def test_distributed_join_gloo(world, strategy, oracle):
         assert owned and npairs == local        # pairs stay sharded by owner
         total_pairs += npairs
     assert total_pairs == rows[0][1]
+
+
+def test_chunk_form_precheck_break_even_model(monkeypatch):
+    """distributed._chunk_prefilter_break_even: never on one rank or for joins too small for the filters' fixed cost; generous where
+    one or three links carry the shuffle; around one half at 8 GPUs with 45 GB/s links; zero again when the links outrun the
+    kernels.  _chunk_prefilter_mode: "auto" for every multi-rank join unless FJ_DIST_PREFILTER says otherwise."""
+    from flash_hash_join_amd import distributed as D
+    monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False); monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW", raising=False)
+    monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 45e9)
+    f = D._chunk_prefilter_break_even
+    assert f(1, 125_000_000, 1_250_000_000) == 0.0 and f(8, 8_000_000, 10_000_000) == 0.0 and f(4, 10**9, 0) == 0.0
+    assert 0.8 < f(2, 250_000_000, 1_250_000_000) < 0.95 and 0.75 < f(4, 500_000_000, 1_250_000_000) < 0.95
+    assert 0.45 < f(8, 10**9, 1_250_000_000) < 0.65
+    monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 200e9)
+    assert f(8, 10**9, 1_250_000_000) == 0.0
+    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.25")
+    assert f(1, 1, 1) == 0.25
+    assert D._chunk_prefilter_mode(False, 1) == "off" and D._chunk_prefilter_mode(True, 1) == "auto" and D._chunk_prefilter_mode(False, 8) == "auto"
+    monkeypatch.setenv("FJ_DIST_PREFILTER", "0")
+    assert D._chunk_prefilter_mode(True, 8) == "off"
+    monkeypatch.setenv("FJ_DIST_PREFILTER", "1")
+    assert D._chunk_prefilter_mode(False, 1) == "on"

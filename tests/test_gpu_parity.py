@@ -690,24 +690,33 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
             n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
             assert n == exp and k.numel() == exp
             assert bool(torch.all((v + 1) * M == k))
-        # sender-side bloom precheck of the probe exchange (fj_bloom_export -> all_gather -> fj_bloom_prefilter per owner)
+        # sender-side bloom precheck of the probe exchange: in chunk form (per-partition filters: fj_stream_export_part_filters ->
+        # all-gather -> fj_shuffle_pack_filter, inside the driver) and in the owner-scatter form (fj_bloom_export -> all_gather ->
+        # fj_bloom_prefilter per owner)
         monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle")
         lpk, lexp = datagen.probe_device(npk, nb, "cuda:0", seed=9, hit_bp=500)
-        for pre in ("1", "0"):
-            monkeypatch.setenv("FJ_DIST_PREFILTER", pre)
-            t = {}
-            n, sec = distributed_join(bk, bv, lpk, timings=t)
-            assert n == lexp and t["prefilter"] == (pre == "1")
-            assert t["probe_rows_sent"] == npk if pre == "0" else lexp <= t["probe_rows_sent"] < 0.07 * npk
-            tm = {}
-            n, sec, k, v = distributed_join(bk, bv, lpk, materialize=True, return_arrays=True, timings=tm)      # one-shot shuffle, same precheck
-            assert n == lexp and k.numel() == lexp and bool(torch.all((v + 1) * M == k))
-            assert tm["prefilter"] == (pre == "1") and tm["probe_rows_sent"] == t["probe_rows_sent"]
-        n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # FJ_DIST_PREFILTER=0 overrides the bloom argument
-        assert n == lexp and not t["prefilter"]
-        monkeypatch.delenv("FJ_DIST_PREFILTER")
-        n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # the *_bloom meaning of the multi-GPU join
-        assert n == lexp and t["prefilter"]
+        for chunk_form in ("1", "0"):
+            monkeypatch.setenv("FJ_DIST_CHUNK_SHUFFLE", chunk_form)
+            for pre in ("1", "0"):
+                monkeypatch.setenv("FJ_DIST_PREFILTER", pre)
+                t = {}
+                n, sec = distributed_join(bk, bv, lpk, timings=t)
+                assert n == lexp and t["prefilter"] == (pre == "1") and t["shuffle_form"].startswith("chunks" if chunk_form == "1" else "owner-scatter"), t
+                assert t["probe_rows_sent"] == npk if pre == "0" else lexp <= t["probe_rows_sent"] < 0.08 * npk
+                tm = {}
+                n, sec, k, v = distributed_join(bk, bv, lpk, materialize=True, return_arrays=True, timings=tm)      # materialising: the same precheck
+                assert n == lexp and k.numel() == lexp and bool(torch.all((v + 1) * M == k))
+                assert tm["prefilter"] == (pre == "1") and tm["probe_rows_sent"] == t["probe_rows_sent"]
+                assert tm["shuffle_form"].startswith("chunks" if chunk_form == "1" else "owner-scatter"), tm
+            n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # FJ_DIST_PREFILTER=0 overrides the bloom argument
+            assert n == lexp and not t["prefilter"]
+            monkeypatch.delenv("FJ_DIST_PREFILTER")
+            n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # the *_bloom meaning of the multi-GPU join: "auto"
+            assert n == lexp and t["prefilter_mode"] == "auto"
+            # (chunk form: a 20M-row probe side does not pay for the filters' fixed cost on one rank - nothing is exported or sampled;
+            #  the owner-scatter form's model has no fixed cost: it samples and filters)
+            assert t["prefilter"] == (chunk_form == "0"), t
+        monkeypatch.delenv("FJ_DIST_CHUNK_SHUFFLE")
         # a build side whose keys all land in ONE partition: the streamed (replicate) join re-partitions that partition alone
         # inside fj_stream_finish (round 3; rounds 1-2 fell back to one table in HBM)
         def hash_w1(kk):
@@ -1053,6 +1062,62 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
         n, sec = distributed_join(bk[: nb // 10], bv[: nb // 10], pk[: npk // 10], timings=t)
         assert t["shuffle_form"] == "chunks (fj_dist_join_count over RCCL)" and n == int(torch.isin(pk[: npk // 10], bk[: nb // 10]).sum())
         HipEngine.close_native_comms()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monkeypatch):
+    """fj_dist_join(prefilter_below): the owner exports one 4-KiB Bloom filter per final partition of the global plan
+    (fj_stream_export_part_filters), the sender compacts every probe piece's level-1 chunks in place to the keys some filter admits
+    (fj_shuffle_pack_filter) before they are rewritten for the wire.  Counts stay exact (no build key is ever dropped), the rows
+    that travel shrink to the hits plus 1-3 % of the misses; "auto" samples first (a strided 1M-row sample against the filters) and
+    decides against the model's break-even - zero on one rank, where no link is saved; materialising joins and the callback
+    transport take the same path."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import distributed_join
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        monkeypatch.setenv("FJ_FORCE_EXCHANGE", "1"); monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        for nb, npk in ((20_000_000, 200_000_000), (125_000_000, 1_250_000_000), (3_000_001, 10_000_003)):
+            bk, bv = datagen.build_device(nb, "cuda:0")
+            for hit_bp in (500, 5000):
+                pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=3, hit_bp=hit_bp)
+                monkeypatch.setenv("FJ_DIST_PREFILTER", "1")
+                for loop, native in (("0", "1"), ("1", "1"), ("0", "0")):
+                    if (loop, native) != ("0", "1") and npk > 200_000_000:
+                        continue
+                    monkeypatch.setenv("FJ_DIST_LOOPBACK", loop); monkeypatch.setenv("FJ_DIST_NATIVE", native)
+                    t = {}
+                    n, sec = distributed_join(bk, bv, pk, timings=t)
+                    assert n == exp and t["shuffle_form"].startswith("chunks") and t["prefilter"] is True and t["prefilter_mode"] == "on", t
+                    misses = npk - exp
+                    assert exp <= t["probe_rows_sent"] <= exp + 0.15 * misses + 4 * 65536, (t["probe_rows_sent"], exp, misses)
+                    assert t["local_probe_rows"] <= t["probe_rows_sent"] + 256 * 512 * 4, t
+                    print(f"precheck {nb}x{npk} at {hit_bp / 100:.0f} % hits: {t['probe_rows_sent'] / npk:.3f} of the probe rows travel ({(t['probe_rows_sent'] - exp) / max(1, misses):.3f} of the misses), step {sec * 1e3:.2f} ms")
+                monkeypatch.delenv("FJ_DIST_PREFILTER")
+                monkeypatch.setenv("FJ_DIST_LOOPBACK", "0"); monkeypatch.setenv("FJ_DIST_NATIVE", "1")
+                t = {}
+                n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t)              # "auto": on one rank the model always declines
+                assert n == exp and t["prefilter_mode"] == "auto" and t["prefilter_below"] == 0 and t["prefilter"] is False and t["prefilter_sampled_survivors"] is None, t
+                monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.3")                      # ... a threshold in its place: sample, then decide
+                n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t)
+                assert n == exp and abs(t["prefilter_sampled_survivors"] - (exp + 0.03 * (npk - exp)) / npk) < 0.03, t
+                assert t["prefilter"] == (t["prefilter_sampled_survivors"] < 0.3) == (hit_bp == 500), t
+                monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
+            if npk <= 200_000_000:
+                monkeypatch.setenv("FJ_DIST_PREFILTER", "1")
+                sub = pk[: min(npk, 50_000_000)]
+                t = {}
+                n, _, k, v = distributed_join(bk, bv, sub, materialize=True, return_arrays=True, timings=t)
+                M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
+                assert t["prefilter"] is True and n == k.numel() == int(torch.isin(sub, bk).sum()) and bool(torch.all((v + 1) * M == k)), t
+                monkeypatch.delenv("FJ_DIST_PREFILTER")
+            del bk, bv, pk
     finally:
         dist.destroy_process_group()
 

@@ -18,7 +18,7 @@ vp = ctypes.c_void_p
 for it in range(4):
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
-    lib.check(L.fj_shuffle_pack_begin(eng.ctx, pk.data_ptr(), None, n, nb_total, world, stream))
+    lib.check(L.fj_shuffle_pack_begin(eng.ctx, pk.data_ptr(), None, n, nb_total, world, 0, stream))
     used = (ctypes.c_uint64 * 64)()
     lib.check(L.fj_shuffle_pack_counts(eng.ctx, used))
     e1.record()

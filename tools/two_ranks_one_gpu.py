@@ -77,35 +77,45 @@ def worker(rank, world, port, q):
         e = torch.tensor([exp_local]); dist.all_reduce(e); exp = int(e.item())
         res = {}
         # the pre-flight check of a multi-rank job (distributed.self_check): passes, and reports a transport that moves wrong data
-        sk, sv = datagen.build_device(500_000, "cuda:0", first=rank * 500_000)
-        sp, se = datagen.probe_device(1_500_000, 500_000 * world, "cuda:0", seed=3, hit_bp=5000, first=rank * 1_500_000)
+        sk, sv = datagen.build_device(1_500_000, "cuda:0", first=rank * 1_500_000)      # (3M+ build rows in all: the chunk form applies)
+        sp, se = datagen.probe_device(1_500_000, 1_500_000 * world, "cuda:0", seed=3, hit_bp=5000, first=rank * 1_500_000)
         et = torch.tensor([se]); dist.all_reduce(et)
         chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim)
         assert chk["ok"] and chk["failed_ranks"] == 0, chk
+        assert chk["precheck"] and chk["precheck"]["ok"] and chk["precheck"]["ran"] and chk["precheck"]["form"].startswith("chunks"), chk   # the forced-precheck leg
         os.environ["FJ_SELFCHECK_CORRUPT"] = "1"
         chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim)
         del os.environ["FJ_SELFCHECK_CORRUPT"]
         assert not chk["ok"] and chk["failed_ranks"] == 1 and (rank != 0 or "elements received from rank" in chk["error"]), chk
-        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "scatter"), ("shuffle", "prefilter")):
+        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "scatter"), ("shuffle", "prefilter"), ("shuffle", "scatter-prefilter"), ("shuffle", "auto")):
             os.environ["FJ_DIST_STRATEGY"] = strategy; os.environ["FJ_REPLICATE_PIECES"] = pieces if pieces.isdigit() else "1"
-            os.environ["FJ_DIST_PREFILTER"] = "1" if pieces == "prefilter" else "0"
-            os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if pieces == "scatter" else "1"
+            os.environ["FJ_DIST_PREFILTER"] = "1" if "prefilter" in pieces else "auto" if pieces == "auto" else "0"
+            os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if "scatter" in pieces else "1"
+            chunk = "scatter" not in pieces
             t = {}
             n, sec = D.distributed_join(bk, bv, pk, timings=t, transport=shim)
             assert n == exp, (strategy, n, exp)
-            if pieces == "prefilter":                       # half the probe rows miss; the owners' filters stop nearly all of them
+            if "prefilter" in pieces:                       # half the probe rows miss; the owners' filters stop nearly all of them
                 assert t["prefilter"] and t["probe_rows_sent"] < 0.56 * (p1 - p0), t
+                if chunk:                                   # per-partition filters, all-gathered inside the driver (uneven ranges at 3 ranks)
+                    assert t["shuffle_form"].startswith("chunks") and t["filter_bytes_received"] > 0 and t["probe_rows_sent"] < 0.53 * (p1 - p0), t
+            if pieces == "auto":                            # every rank reaches the same verdict from the all-reduced sample
+                assert t["prefilter_mode"] == "auto" and t["shuffle_form"].startswith("chunks"), t
+                vs = [None] * world
+                dist.all_gather_object(vs, (t["prefilter"], t["prefilter_sampled_survivors"]))
+                assert len(set(vs)) == 1, vs
             tm = {}
             n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True, transport=shim, timings=tm)
             M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
             assert n2 == exp and bool(torch.all((v + 1) * M == k)), strategy
             if strategy == "shuffle":                        # materialising joins take the chunk form too (values travel with the build rows)
-                assert tm["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport" if pieces == "1" else "owner-scatter"), tm
+                assert tm["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport" if chunk else "owner-scatter"), tm
+                assert tm["prefilter"] == ("prefilter" in pieces) or pieces == "auto", tm
                 assert "chunk_form_error" not in tm, tm
             tot = torch.tensor([k.numel()]); dist.all_reduce(tot)
             assert int(tot.item()) == exp                   # the ranks' pair sets add up to the global result
             if strategy == "shuffle":
-                assert t["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport" if pieces == "1" else "owner-scatter"), t
+                assert t["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport" if chunk else "owner-scatter"), t
             res[strategy + pieces] = (t["strategy"], t["pieces"], t["local_build_rows"], t["local_probe_rows"])
         q.put((rank, exp, res))
     finally:
@@ -118,7 +128,18 @@ if __name__ == "__main__":
     ctx = mp.get_context("spawn"); q = ctx.Queue()
     ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps: p.start()
-    rows = [q.get(timeout=600) for _ in range(world)]
+    import queue as _queue
+    import time as _time
+    rows, t_end = [], _time.time() + 600
+    while len(rows) < world:                       # (a worker that died says so at once instead of after the queue's timeout)
+        try:
+            rows.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [p.exitcode for p in ps if p.exitcode not in (None, 0)]
+            if dead or _time.time() > t_end:
+                for p in ps:
+                    if p.is_alive(): p.terminate()
+                raise SystemExit(f"worker exit codes {[p.exitcode for p in ps]}" if dead else "timed out")
     for p in ps:
         p.join(timeout=60); assert p.exitcode == 0
     for r in sorted(rows): print(r)
