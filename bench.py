@@ -363,6 +363,7 @@ def main() -> None:
     kern = {}                       # single GPU: kernel name -> [(launch ms, algorithmic bytes)] over the timed steps
     dtimes = {"split_s": [], "exchange_s": [], "join_s": []}
     dlast = {}
+    dsampled = {}
 
     def record_kernels(lt) -> None:
         """Algorithmic HBM bytes of every timed kernel launch of one single-GPU join: a plain probe-side
@@ -393,6 +394,8 @@ def main() -> None:
         else:
             t = {}
             res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t, transport=transport)
+            if t.get("prefilter_sampled_survivors") is not None:       # (warm-up steps included: "auto" samples once per shape, then remembers)
+                dsampled.update(survivors=t["prefilter_sampled_survivors"], below=t.get("prefilter_below"))
             if record:
                 for k in dtimes:
                     dtimes[k].append(t.get(k, 0.0))
@@ -534,7 +537,9 @@ def main() -> None:
         phases.update({kk: round(mean(v) * 1e3, 3) for kk, v in (("split_ms", dtimes["split_s"]), ("exchange_ms", dtimes["exchange_s"]),
                                                                  ("local_join_ms", dtimes["join_s"]))})
         phases.update({"shuffle_prefilter": dlast.get("prefilter"), "shuffle_prefilter_mode": dlast.get("prefilter_mode"),
-                       "shuffle_prefilter_sampled_survivors": dlast.get("prefilter_sampled_survivors"),
+                       "shuffle_prefilter_decision": dlast.get("prefilter_decision"),
+                       "shuffle_prefilter_sampled_survivors": dsampled.get("survivors"), "shuffle_prefilter_break_even": dsampled.get("below"),
+                       "filter_bytes_received_rank0": dlast.get("filter_bytes_received"),
                        "probe_rows_sent_rank0": dlast.get("probe_rows_sent"), "shuffle_form": dlast.get("shuffle_form"),
                        # what rank 0 put on its links per step (chunks + directory words; its own share never travels) and per key sent
                        "wire_chunk_bytes": dlast.get("wire_chunk_bytes"), "wire_bytes_sent_rank0": dlast.get("wire_bytes_sent"),

@@ -195,58 +195,90 @@ __global__ __launch_bounds__(256) void fj_part_filter_export(FjChunkSet build, u
 }
 
 // sender: the chunks of a level-1 chunk set are compacted IN PLACE to the keys some filter admits, and a chunk's list entry gets its
-// new count.  A WAVE owns a chunk - four keys per lane, two 16-byte loads - and is on its own: four independent filter words in
-// flight per lane, survivor positions from ballots (their order inside the chunk is free), no LDS, no barrier; every key of the
-// chunk is in a register before the first survivor is written back.  A chunk without survivors keeps its first key (a key that
-// matches nothing is harmless on the wire; a list entry cannot say "empty").  Chunks are taken in list order = bucket after bucket
-// (see above).  part_shift: H >> part_shift = final partition.  The launch gives a wave ~9 chunks (strided: the resident waves stay
-// within a few buckets of each other): the kernel shares the CUs with the owner's partition passes on another stream, and a static
-// share per wave of a small grid waits for the slowest CU (16 workgroups per CU: 3.7 ms per 312M keys, ~9 chunks per wave: 2.3 ms).
-// Bound by the texture path: one divergent filter-word load per key (1.5 ms of the 2.3; tools/ubench_bloom_probe.hip: 205 G/s against
-// 1-2 MiB in L2), beside 0.6 ms of key streaming; the survivors' stores are free.  (First version: a workgroup per chunk, one key
-// per thread, two barriers per chunk: 3.9 ms.)
+// new count.  A WAVE owns a chunk - four keys per lane, two 16-byte loads - and is on its own while it works on it: four independent
+// filter words in flight per lane, survivor positions from ballots (their order inside the chunk is free), no LDS traffic; every key
+// of the chunk is in a register before the first survivor is written back.  A chunk without survivors keeps its first key (a key that
+// matches nothing is harmless on the wire; a list entry cannot say "empty").  part_shift: H >> part_shift = final partition.
+// Bound by the texture path: one divergent filter-word load per key (tools/ubench_bloom_probe.hip: ~205 G/s against 1-2 MiB in L2),
+// beside the key streaming; the survivors' stores are free - provided the filters in use stay in L2, which is what the order the
+// chunks are taken in is about (below).  (Rounds of this kernel per 312M keys at the 1-rank / 8-rank plan: a workgroup per chunk,
+// one key per thread, two barriers per chunk 3.9 ms / -; a wave per chunk, a static strided share per wave 2.3-3.7 / 4.7; XCD x
+// takes buckets x, x + 8, ... 1.7-2.0 / 4.4; chunks handed out in order 1.6 / 2.5.)
+template <u32 B>
 __global__ __launch_bounds__(256) void fj_part_filter_inplace(u64* keys, u32* list, const u32* __restrict__ boff, u32 nb,
-                                                              const u64* __restrict__ filters, u32 part_shift, unsigned long long* __restrict__ kept) {
-    const u32 lane = threadIdx.x & 63;
-    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), nw = gridDim.x * 4;
-    const u32 total = boff[nb];
-    if (w0 >= total) return;
+                                                              const u64* __restrict__ filters, u32 part_shift, unsigned long long* __restrict__ kept,
+                                                              u32* __restrict__ next_of_xcd) {
+    __shared__ u32 s_next;
+    const u32 lane = threadIdx.x & 63, wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD x (workgroup b runs on XCD b % 8: tools/ubench_xcc_map.hip) takes buckets x, x + 8, ... in order, and its workgroups take
+    // that list's chunks B at a time in the order they become free (one counter per XCD; an agent-scope atomic on a hot address
+    // takes ~100 ns: one per chunk made the kernel 15 ms): the chunks in flight on an XCD stay within one or two buckets, whose
+    // filters (2 MiB per bucket at 512 partitions) stay in that XCD's L2.  A static share per wave - strided over the whole list -
+    // had every wave in another bucket after each step: 4.4-4.7 ms per 312M keys at the 8-rank plan; batches of 16 from three
+    // workgroups per CU (at most 1536 chunks in flight per XCD, 2384 per bucket): 2.5 ms; 8 per CU and batches of 32: 3.6 ms.
+    const u32 xcd = blockIdx.x & 7u;
+    const u32 nbx = nb > xcd ? (nb - xcd + 7u) >> 3 : 0u;                        // <= 64 buckets per XCD (FJ_MAX_FAN_LOG = 9): one per lane
+    const u32 bstart = lane < nbx ? boff[xcd + 8u * lane] : 0u;
+    const u32 bcnt = lane < nbx ? boff[xcd + 8u * lane + 1u] - bstart : 0u;
+    u32 inc = bcnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
+    const u32 pre = inc - bcnt, total = __shfl(inc, 63, 64);                     // this XCD's chunks, in bucket order: ordinal o -> list index
+    u32* ctr = next_of_xcd + xcd;
+    auto locate = [&](u32 o) -> u32 {
+        const u32 j = (u32)__popcll(__ballot(lane < nbx && pre <= o)) - 1u;      // (o < total: the last bucket that starts at or before o holds it)
+        return (u32)__shfl((int)bstart, (int)j, 64) + (o - (u32)__shfl((int)pre, (int)j, 64));
+    };
     const u64 lt = (1ull << lane) - 1ull;
     unsigned long long mine = 0;
-    // software pipeline: the NEXT chunk's keys and the list entry after it are requested before this chunk's filter words are
-    // waited for (one memory latency per chunk instead of three; indices beyond the end are clamped - loaded, never used)
-    u32 e = list[w0];
-    const uint4* c4 = reinterpret_cast<const uint4*>(keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK);
-    uint4 a = c4[2 * lane], c = c4[2 * lane + 1];                                // keys 4 * lane .. 4 * lane + 3 (slack beyond the count: never counted)
-    u32 e1 = list[w0 + nw < total ? w0 + nw : total - 1];
-    for (u32 i = w0; i < total; i += nw) {
-        const uint4* n4 = reinterpret_cast<const uint4*>(keys + (u64)FJ_LIST_ID(e1) * FJ_CHUNK);
-        const uint4 an = n4[2 * lane], cn = n4[2 * lane + 1];
-        const u32 i2 = i + 2 * nw < total ? i + 2 * nw : total - 1;
-        const u32 e2 = list[i2];
-        const u32 cnt = FJ_LIST_CNT(e), id = FJ_LIST_ID(e);
-        const u64 h[4] = {(u64)a.y << 32 | a.x, (u64)a.w << 32 | a.z, (u64)c.y << 32 | c.x, (u64)c.w << 32 | c.z};
-        u64 word[4], m[4];
+    if (threadIdx.x == 0) s_next = atomicAdd(ctr, B);
+    __syncthreads();
+    u32 o0 = s_next;
+    while (o0 < total) {
+        __syncthreads();                                                         // (everyone has read s_next)
+        u32 nxt = 0;
+        if (threadIdx.x == 0) nxt = atomicAdd(ctr, B);                           // the next batch's ordinal is on its way while this one is worked on
+        // this wave's chunks of the batch: o0 + wave, + 4, ...; software pipeline: the NEXT chunk's keys are requested before this
+        // chunk's filter words are waited for (an ordinal beyond the end is clamped: loaded, never used)
+        const u32 oend = o0 + B < total ? o0 + B : total;
+        u32 o = o0 + wave;
+        if (o < oend) {
+            u32 li = locate(o);
+            u32 e = list[li];
+            const uint4* c4 = reinterpret_cast<const uint4*>(keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK);
+            uint4 a = c4[2 * lane], c = c4[2 * lane + 1];                        // keys 4 * lane .. 4 * lane + 3 (slack beyond the count: never counted)
+            for (; o < oend; o += 4) {
+                const u32 li1 = locate(o + 4 < oend ? o + 4 : o);
+                const u32 e1 = list[li1];
+                const uint4* n4 = reinterpret_cast<const uint4*>(keys + (u64)FJ_LIST_ID(e1) * FJ_CHUNK);
+                const uint4 an = n4[2 * lane], cn = n4[2 * lane + 1];
+                const u32 cnt = FJ_LIST_CNT(e), id = FJ_LIST_ID(e);
+                const u64 h[4] = {(u64)a.y << 32 | a.x, (u64)a.w << 32 | a.z, (u64)c.y << 32 | c.x, (u64)c.w << 32 | c.z};
+                u64 word[4], m[4];
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-            u32 b;
-            pf_bits(h[j], b, m[j]);
-            const u64 part = 4 * lane + j < cnt ? h[j] >> part_shift : 0ull;     // (slack lanes read partition 0's filter: unconditional loads)
-            const u64* fp = filters + part * (FJ_PFILT_BYTES / 8) + b;
-            word[j] = *fp;
-        }
-        u64* ck = keys + (u64)id * FJ_CHUNK;
-        u32 base = 0;
+                for (u32 j = 0; j < 4; ++j) {
+                    u32 b;
+                    pf_bits(h[j], b, m[j]);
+                    const u64 part = 4 * lane + j < cnt ? h[j] >> part_shift : 0ull;     // (slack lanes read partition 0's filter: unconditional loads)
+                    word[j] = filters[part * (FJ_PFILT_BYTES / 8) + b];
+                }
+                u64* ck = keys + (u64)id * FJ_CHUNK;
+                u32 base = 0;
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-            const bool pass = (word[j] & m[j]) == m[j] && 4 * lane + j < cnt;
-            const u64 bal = __ballot(pass);
-            if (pass) ck[base + (u32)__popcll(bal & lt)] = h[j];
-            base += (u32)__popcll(bal);
+                for (u32 j = 0; j < 4; ++j) {
+                    const bool pass = (word[j] & m[j]) == m[j] && 4 * lane + j < cnt;
+                    const u64 bal = __ballot(pass);
+                    if (pass) ck[base + (u32)__popcll(bal & lt)] = h[j];
+                    base += (u32)__popcll(bal);
+                }
+                if (lane == 0) list[li] = ((base ? base - 1u : 0u) << 24) | id;   // (no survivor: key 0 stays - its slot was not written)
+                mine += base;
+                e = e1; li = li1; a = an; c = cn;
+            }
         }
-        if (lane == 0) list[i] = ((base ? base - 1u : 0u) << 24) | id;            // (no survivor: key 0 stays - its slot was not written)
-        mine += base;
-        e = e1; e1 = e2; a = an; c = cn;
+        if (threadIdx.x == 0) s_next = nxt;
+        __syncthreads();
+        o0 = s_next;
     }
     if (lane == 0 && mine) atomicAdd(kept, mine);
 }
@@ -289,8 +321,9 @@ hipError_t fj_launch_part_filter_export(const FjChunkSet& build, u64* out, u32 g
     return hipGetLastError();
 }
 
-hipError_t fj_launch_part_filter_inplace(const FjChunkSet& cs, const u64* filters, u32 part_shift, unsigned long long* kept, u32 grid, hipStream_t s) {
-    hipLaunchKernelGGL(fj_part_filter_inplace, dim3(grid), dim3(256), 0, s, cs.keys, cs.list, cs.boff, cs.nb, filters, part_shift, kept);
+hipError_t fj_launch_part_filter_inplace(const FjChunkSet& cs, const u64* filters, u32 part_shift, unsigned long long* kept, u32* next_of_xcd, u32 grid, hipStream_t s) {
+    grid = (grid + 7u) & ~7u;                                  // (the same number of workgroups on every XCD)
+    hipLaunchKernelGGL(fj_part_filter_inplace<16>, dim3(grid), dim3(256), 0, s, cs.keys, cs.list, cs.boff, cs.nb, filters, part_shift, kept, next_of_xcd);
     return hipGetLastError();
 }
 

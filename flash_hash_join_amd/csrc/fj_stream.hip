@@ -309,12 +309,9 @@ namespace {
 int pack_plan_tail(fj_ctx* c, const u64* filters, hipStream_t s) {
     PackState& pk = c->pk;
     PassIter& it = pk.it;
-    HIPCHK(hipMemsetAsync(&c->d_sc->pack_kept, 0, sizeof(unsigned long long), s));
-    if (filters) {
-        const u64 chunks = it.n / FJ_CHUNK + pk.args.nb;                                   // (what the piece's first pass can have filled, roughly)
-        const u32 grid = (u32)std::min<u64>(65536, std::max<u64>(c->num_cus, chunks / 36));   // four waves per workgroup, ~9 chunks per wave
-        HIPCHK(fj_launch_part_filter_inplace(it.cs, filters, pk.part_shift, &c->d_sc->pack_kept, grid, s));
-    }
+    HIPCHK(hipMemsetAsync(&c->d_sc->pack_kept, 0, sizeof(unsigned long long) + 8 * sizeof(u32), s));     // (+ pack_xcd, right behind it)
+    if (filters)                                                                           // three workgroups per CU take batches of chunks as they become free
+        HIPCHK(fj_launch_part_filter_inplace(it.cs, filters, pk.part_shift, &c->d_sc->pack_kept, c->d_sc->pack_xcd, 3u * c->num_cus, s));
     HIPCHK(fj_launch_pack_plan(pk.args, s));
     HIPCHK(hipMemcpyAsync(c->pk_h, c->d_sc->pack_used, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->pk_h + 64, &c->d_sc->pack_err, sizeof(u32), hipMemcpyDeviceToHost, s));

@@ -182,10 +182,23 @@ class HipEngine:
     def shuffle_chunk_bytes(self, nb_total: int, world: int) -> int:
         return int(self.L.fj_shuffle_chunk_bytes(nb_total, world))
 
-    def shuffle_pack(self, keys, vals, nb_total: int, world: int):
+    def part_filter_range(self, nb_total: int, world: int, rank: int):
+        """(first, count, total, bytes_each): where rank's per-partition Bloom filters sit among all final partitions' filters."""
+        sz = ctypes.c_size_t
+        first, count, total = sz(0), sz(0), sz(0)
+        self._lib.check(self.L.fj_shuffle_part_filter_range(nb_total, world, rank, ctypes.byref(first), ctypes.byref(count), ctypes.byref(total)))
+        return int(first.value), int(count.value), int(total.value), int(self.L.fj_shuffle_part_filter_bytes())
+
+    def stream_export_part_filters(self, out):
+        """Filters of the final partitions this owner holds (build side complete), into the uint8 tensor `out`."""
+        self._lib.check(self.L.fj_stream_export_part_filters(self.ctx, out.data_ptr(), self.torch.cuda.current_stream(self.index).cuda_stream))
+
+    def shuffle_pack(self, keys, vals, nb_total: int, world: int, filters=None):
         """First pass of the global plan over local rows, rewritten for the wire (fj_shuffle_pack_begin / _counts / _finish).
         Returns (chunks, dir, used): per owner r a uint8 tensor of used[r] * shuffle_chunk_bytes() bytes (dense 256-key chunks
-        in the 7-byte wire format when the first pass has >= 256 buckets) and an int32 tensor of used[r] directory words."""
+        in the 7-byte wire format when the first pass has >= 256 buckets) and an int32 tensor of used[r] directory words.
+        filters: all partitions' Bloom filters (uint8 tensor) - the piece is prechecked against them (fj_shuffle_pack_filter);
+        self.last_pack_kept = the rows it kept."""
         t = self.torch
         keys = self._aligned(keys)
         stream = t.cuda.current_stream(self.index).cuda_stream
@@ -194,9 +207,13 @@ class HipEngine:
             raise RuntimeError(self._lib.last_error())
         if vals is not None:
             vals = self._aligned(vals)
-        self._lib.check(self.L.fj_shuffle_pack_begin(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, world, 0, stream))
+        self._lib.check(self.L.fj_shuffle_pack_begin(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, world,
+                                                     int(filters is not None), stream))
+        if filters is not None:
+            self._lib.check(self.L.fj_shuffle_pack_filter(self.ctx, filters.data_ptr(), stream))
         used = (ctypes.c_uint64 * 64)()
         self._lib.check(self.L.fj_shuffle_pack_counts(self.ctx, used))
+        self.last_pack_kept = int(self.L.fj_shuffle_pack_kept(self.ctx)) if filters is not None else keys.numel()
         used = [int(used[r]) for r in range(world)]
         chunks = [t.empty(max(16, u * cb), dtype=t.uint8, device=self.device) for u in used]
         dirs = [self.empty_i32(max(4, u)) for u in used]
@@ -380,10 +397,11 @@ def _prefilter_break_even(world: int) -> float:
 
 
 # the precheck in chunk form (fj_dist_join(prefilter_below), csrc/fj_pack.hip: fj_part_filter_inplace): what a config-5 shard costs
-# per local probe row on ONE MI355X through the driver (profiles/r04_prefilter_one_rank.txt: 15.5 ms without it; with it 17.1 ms at
-# 8 % survivors, 21.8 ms at 52 %), as  off = FIXED + REST,  on(f) = FIXED + FILTER + f x REST
+# per local probe row on ONE MI355X through the driver (profiles/r04_prefilter_one_rank.txt: 15.4-16.3 ms without it; with it the
+# same at 8 % survivors, +5.8 ms at 52 %), as  off = FIXED + REST,  on(f) = FIXED + FILTER + f x REST
 _CHUNK_FIXED_S_PER_ROW = 6.0e-12        # first pass of the global plan over the probe rows + the build side's and the host's share of the step
-_CHUNK_FILTER_S_PER_ROW = 6.9e-12       # the precheck: every row is tested (6.2 ps at 8 % survivors ... 7.5 ps at 52 %)
+_CHUNK_FILTER_S_PER_ROW = 8.1e-12       # the precheck at the 8-rank plan (512 partitions = 2 MiB of filters per first-pass bucket: 2.5 ms per
+                                        # 312M rows, profiles/r04_precheck_probe.txt; 4.9-6.6 ps at the 1-rank plan's 128 partitions per bucket)
 _CHUNK_REST_S_PER_ROW = 6.4e-12         # copy into the wire format + the owner's second pass, lists and join: scale with what survives
 _CHUNK_WIRE_BYTES_PER_ROW = 7.02
 
@@ -393,7 +411,7 @@ def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> flo
     probe row a step costs max(wire, kernels): wire = 7.02 B x f / (world x link rate) on each of the links that work in parallel,
     kernels as above; the filters cost 1 byte per build key to every rank (~nb_total / world bytes per link) and ~0.5 ms of
     latency before the first probe piece can be checked.  It never pays where the kernels bound the step (one rank; links faster
-    than ~12 ps per row); on wire-bound steps it does below ~55 % survivors at 8 GPUs and ~45 GB/s per link, below ~85 % at 2-4."""
+    than ~12 ps per row); on wire-bound steps it does below ~40 % survivors at 8 GPUs and ~45 GB/s per link, below ~85 % at 2-4."""
     env = os.environ.get("FJ_DIST_PREFILTER_BELOW")
     if env:
         return float(env)
@@ -412,6 +430,38 @@ def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> flo
         mid = 0.5 * (lo + hi)
         lo, hi = (mid, hi) if on(mid) < off else (lo, mid)
     return 0.9 * lo
+
+
+# "auto" remembers what the last join of the same shape sampled: exporting and all-gathering the filters only to decline again would
+# cost every step of a repeated join ~3 ms at 8 ranks (1 byte per build key to every rank).  (world, build rows, probe rows) ->
+# [calls, sampled survivor share]; every 32nd call samples afresh.  Collective calls keep the ranks' memos identical.
+_PRECHECK_MEMO: dict = {}
+_PRECHECK_RESAMPLE_EVERY = 32
+
+
+def _precheck_threshold(mode: str, world: int, nb_total: int, np_global: int):
+    """(prefilter_below for fj_dist_join, memo key or None, how it was decided)."""
+    if mode != "auto":
+        return {"off": 0.0, "on": 2.0}[mode], None, mode
+    below = _chunk_prefilter_break_even(world, nb_total, max(1, np_global // world))
+    key = (world, nb_total, np_global)
+    memo = _PRECHECK_MEMO.get(key)
+    if below <= 0.0:
+        return 0.0, None, "model: cannot pay"
+    if memo is not None and memo[0] % _PRECHECK_RESAMPLE_EVERY != 0:
+        return (2.0, key, "memo: runs") if memo[1] < below else (0.0, key, "memo: declined")
+    return below, key, "sampled"
+
+
+def _precheck_remember(key, timings: dict, decision: str) -> None:
+    timings["prefilter_decision"] = decision
+    if key is None:
+        return
+    memo = _PRECHECK_MEMO.get(key)
+    if decision == "sampled" and timings.get("prefilter_sampled_survivors") is not None:
+        _PRECHECK_MEMO[key] = [1, float(timings["prefilter_sampled_survivors"])]
+    elif memo is not None:
+        memo[0] += 1
 
 
 def _chunk_prefilter_mode(bloom: bool, world: int) -> str:
@@ -1070,12 +1120,13 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
             # that fails on any rank fails on every rank (the driver agrees on it), so all of them fall back together to the
             # owner-scatter form, whose segments are sized from an owner histogram: the answer to heavily skewed keys (an owner
             # that receives far more than 1.5x its share overflows the chunk form's pools).
-            below = {"off": 0.0, "on": 2.0}.get(mode)
-            if below is None:
-                below = _chunk_prefilter_break_even(world, nb_total, max(1, np_global // world))
+            below, memo_key, decision = _precheck_threshold(mode, world, nb_total, np_global)
             for attempt in ((below, mode), (0.0, "off")) if below > 0 else ((0.0, mode),):     # (a failed step with the precheck is retried without it)
                 try:
-                    return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport, prefilter_below=attempt[0], prefilter_mode=attempt[1])
+                    tt = timings if timings is not None else {}
+                    res = _driver_count(dist, group, engine, build_keys, probe_keys, pieces, tt, transport, prefilter_below=attempt[0], prefilter_mode=attempt[1])
+                    _precheck_remember(memo_key, tt, decision)
+                    return res
                 except RuntimeError as ex:
                     if os.environ.get("FJ_DIST_NO_FALLBACK"):
                         raise
@@ -1094,11 +1145,12 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
             and engine.shuffle_plan(sum(sizes_b), world) is not None):
         try:
             mode = _chunk_prefilter_mode(bloom, world)
-            below = {"off": 0.0, "on": 2.0}.get(mode)
-            if below is None:
-                below = _chunk_prefilter_break_even(world, sum(sizes_b), max(1, sum(int(x[1]) for x in allsz) // world))
-            return _driver_count(dist, group, engine, build_keys, probe_keys, pieces, timings, transport, build_values=build_values, return_arrays=return_arrays,
-                                 prefilter_below=below, prefilter_mode=mode)
+            below, memo_key, decision = _precheck_threshold(mode, world, sum(sizes_b), sum(int(x[1]) for x in allsz))
+            tt = timings if timings is not None else {}
+            res = _driver_count(dist, group, engine, build_keys, probe_keys, pieces, tt, transport, build_values=build_values, return_arrays=return_arrays,
+                                prefilter_below=below, prefilter_mode=mode)
+            _precheck_remember(memo_key, tt, decision)
+            return res
         except RuntimeError as ex:
             if os.environ.get("FJ_DIST_NO_FALLBACK"):
                 raise

@@ -373,7 +373,7 @@ def test_chunk_form_precheck_break_even_model(monkeypatch):
     f = D._chunk_prefilter_break_even
     assert f(1, 125_000_000, 1_250_000_000) == 0.0 and f(8, 8_000_000, 10_000_000) == 0.0 and f(4, 10**9, 0) == 0.0
     assert 0.8 < f(2, 250_000_000, 1_250_000_000) < 0.95 and 0.75 < f(4, 500_000_000, 1_250_000_000) < 0.95
-    assert 0.45 < f(8, 10**9, 1_250_000_000) < 0.65
+    assert 0.3 < f(8, 10**9, 1_250_000_000) < 0.5
     monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 200e9)
     assert f(8, 10**9, 1_250_000_000) == 0.0
     monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.25")

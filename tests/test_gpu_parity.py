@@ -1078,6 +1078,7 @@ def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monke
     import torch.distributed as dist
     from flash_hash_join_amd import datagen
     from flash_hash_join_amd.distributed import distributed_join
+    import flash_hash_join_amd.distributed as D
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -1105,9 +1106,15 @@ def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monke
                 n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t)              # "auto": on one rank the model always declines
                 assert n == exp and t["prefilter_mode"] == "auto" and t["prefilter_below"] == 0 and t["prefilter"] is False and t["prefilter_sampled_survivors"] is None, t
                 monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.3")                      # ... a threshold in its place: sample, then decide
+                D._PRECHECK_MEMO.clear()
                 n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t)
-                assert n == exp and abs(t["prefilter_sampled_survivors"] - (exp + 0.03 * (npk - exp)) / npk) < 0.03, t
+                assert n == exp and t["prefilter_decision"] == "sampled" and abs(t["prefilter_sampled_survivors"] - (exp + 0.03 * (npk - exp)) / npk) < 0.03, t
                 assert t["prefilter"] == (t["prefilter_sampled_survivors"] < 0.3) == (hit_bp == 500), t
+                t2 = {}
+                n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t2)             # the same shape again: the verdict is remembered,
+                assert n == exp and t2["prefilter"] == t["prefilter"] and t2["prefilter_sampled_survivors"] is None, t2      # nothing is sampled,
+                assert t2["prefilter_decision"] == ("memo: runs" if hit_bp == 500 else "memo: declined"), t2
+                assert t2["filter_bytes_received"] == 0 and (t2["prefilter"] or t2["prefilter_below"] == 0), t2              # and a declined precheck exports nothing
                 monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
             if npk <= 200_000_000:
                 monkeypatch.setenv("FJ_DIST_PREFILTER", "1")

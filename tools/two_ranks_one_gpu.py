@@ -92,6 +92,7 @@ def worker(rank, world, port, q):
             os.environ["FJ_DIST_PREFILTER"] = "1" if "prefilter" in pieces else "auto" if pieces == "auto" else "0"
             os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if "scatter" in pieces else "1"
             chunk = "scatter" not in pieces
+            D._PRECHECK_MEMO.clear()
             t = {}
             n, sec = D.distributed_join(bk, bv, pk, timings=t, transport=shim)
             assert n == exp, (strategy, n, exp)
