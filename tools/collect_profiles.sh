@@ -2,7 +2,7 @@
 # One GPU call that produces what is committed under profiles/ for a kernel version:  tools/collect_profiles.sh <tag>
 #   PMC passes (c3, c4, c3_mat, c2), rocprofv3 --kernel-trace --stats (c3, c4, c3_mat, c2 and the literal HBM-table forms),
 #   the default bench line, the other workloads' bench lines, the J1 harness log, traffic_latest.json, the one-rank multi-GPU step
-#   (tools/r4_dist_one_gpu.sh <tag>d) and tools/pack_probe.py.  Then: tools/publish_profiles.sh <tag>.
+#   (tools/r4_dist_one_gpu.sh <tag>d), tools/pack_probe.py, the precheck (tools/r4_prefilter_one_gpu.sh <tag>p, tools/precheck_probe.py).  Then: tools/publish_profiles.sh <tag>.
 TAG=${1:-r03}
 cd ${GRAFT_REPO_ROOT:-$PWD}
 O=gpurun_out/$TAG; mkdir -p $O
@@ -29,4 +29,8 @@ timeout 900 python tools/benchmark_j1.py --sizes 1e7,4e7 --cpu --duckdb > $O/j1_
 # the multi-GPU step of config 5 on one rank (C++ driver) and the sender side in isolation
 bash tools/r4_dist_one_gpu.sh ${TAG}d > $O/dist_one_gpu.txt 2>&1
 timeout 300 python tools/pack_probe.py > $O/pack_probe.txt 2>&1
+# the sender-side precheck in chunk form: one-rank steps off / on / auto, and the kernel at the 8-rank plan
+bash tools/r4_prefilter_one_gpu.sh ${TAG}p > $O/prefilter_one_rank.txt 2>&1
+tools/prof_py.sh ${TAG}_precheck_probe tools/precheck_probe.py > $O/precheck_probe_kernel_stats.txt 2>&1
+grep "the precheck:\|^filters of" gpurun_out/stats_${TAG}_precheck_probe.log > $O/precheck_probe.txt
 ls -la $O | head -50

@@ -1,5 +1,5 @@
 """Soak test of the multi-GPU driver on ONE rank (1-rank RCCL group): many consecutive steps alternating counting / materialising
-joins, the loop-back hook, the callback transport and an injected local failure; counts must stay exact and device memory must
+joins, the loop-back hook, the callback transport, an injected local failure, and the sender-side precheck off / on / auto; counts must stay exact and device memory must
 not creep.  usage: python tools/dist_soak.py [rounds=40]"""
 import os, socket, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,6 +24,8 @@ for r in range(rounds):
     os.environ["FJ_DIST_LOOPBACK"] = "1" if mode == 1 else "0"
     os.environ["FJ_DIST_NATIVE"] = "0" if mode == 2 else "1"
     os.environ.pop("FJ_DIST_INJECT_FAIL", None)
+    os.environ["FJ_DIST_PREFILTER"] = ("0", "1", "auto")[(r // 5) % 3]      # the sender-side precheck: off / forced / by a sample (threshold below)
+    os.environ["FJ_DIST_PREFILTER_BELOW"] = "0.7"
     if mode == 3:
         os.environ["FJ_DIST_INJECT_FAIL"] = "1"          # the chunk form fails (agreed), the step reruns in the owner-scatter form
     t = {}

@@ -20,5 +20,5 @@ FJ_DIST_PREFILTER=1 tools/prof_stats.sh ${TAG}_pf_c5_bloom --workload c5_bloom -
 cp $(find gpurun_out/stats_${TAG}_pf_c5_bloom -name "*kernel_stats.csv" | head -1) $O/pf_c5_bloom_kernel_stats.csv
 FJ_DIST_PREFILTER=1 tools/prof_stats.sh ${TAG}_pf_c5 --workload c5 --steps 5 --warmup 2 --no-host-entry > $O/pf_c5_kernel_stats.txt 2>&1
 cp $(find gpurun_out/stats_${TAG}_pf_c5 -name "*kernel_stats.csv" | head -1) $O/pf_c5_kernel_stats.csv
-grep -v "^[EW]2026" $O/pf_c5_bloom_kernel_stats.txt | cut -c1-200 | head -40
-grep -v "^[EW]2026" $O/pf_c5_kernel_stats.txt | cut -c1-200 | head -40
+grep -v "^[EW]2026" $O/pf_c5_bloom_kernel_stats.txt | cut -c1-200 | head -16
+grep -v "^[EW]2026" $O/pf_c5_kernel_stats.txt | cut -c1-200 | head -16
