@@ -244,6 +244,8 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         count = c->h_sc->total;
         t.path = 0; t.passes = 0; t.partitions = 1;
         t.total_ms = ev_ms(c, E_START, E_JOIN);
+        // a materialising shuffled join with an empty side has counted zero pairs: the fj_emit_pairs that follows finds that
+        if (st.shuffled && st.with_vals) { c->pend = Pending(); c->pend.valid = true; c->pend.count = 0; }
     }
     if (!t.fell_back) {
         t.build_phase_ms = ev_ms(c, E_SB0, E_SB1);              // the two sides may have run in either order

@@ -1152,6 +1152,11 @@ def test_driver_with_tiny_and_empty_probe_sides(fj, monkeypatch):
         n, _, k, v = distributed_join(bk, bv, pk[:7].clone(), materialize=True, return_arrays=True)
         M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
         assert n == int(torch.isin(pk[:7], bk).sum()) == k.numel() and bool(torch.all((v + 1) * M == k))
+        for pre in ("0", "1"):                               # an EMPTY probe side, materialising (found by tools/precheck_fuzz.py): zero pairs, not an error
+            monkeypatch.setenv("FJ_DIST_PREFILTER", pre)
+            t = {}
+            n, _, k, v = distributed_join(bk, bv, pk[:0], materialize=True, return_arrays=True, timings=t)
+            assert n == 0 and k.numel() == 0 and v.numel() == 0 and t["shuffle_form"].startswith("chunks"), t
     finally:
         dist.destroy_process_group()
 

@@ -42,6 +42,7 @@ for c in range(cases):
     os.environ["FJ_DIST_NATIVE"] = rng.choice(["1", "1", "0"])
     mat = rng.random() < 0.3 and exp < 60_000_000
     t = {}
+    print(f"case {c}: nb {nb} np {npk} hit_bp {hit_bp} pieces {os.environ['FJ_DIST_PIECES']} loop {os.environ['FJ_DIST_LOOPBACK']} native {os.environ['FJ_DIST_NATIVE']} mat {mat} exp {exp}", file=sys.stderr, flush=True)
     if mat:
         n, _, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True, timings=t)
         assert n == exp == k.numel() and bool(torch.all((v + 1) * M == k)) and (exp == 0 or (int(v.min()) >= first and int(v.max()) < first + nb)), (c, n, exp)
@@ -49,7 +50,8 @@ for c in range(cases):
     else:
         n, _ = distributed_join(bk, bv, pk, timings=t)
         assert n == exp, (c, nb, npk, hit_bp, n, exp, t)
-    assert t["shuffle_form"].startswith("chunks") and t["prefilter"] is True, t
+    one_shot = os.environ["FJ_DIST_PIECES"] == "1" and not mat           # (a counting join in one piece takes the owner-scatter form - with ITS precheck)
+    assert t["shuffle_form"].startswith("owner-scatter" if one_shot else "chunks") and t["prefilter"] is True, t
     assert exp == 0 or t["probe_rows_sent"] >= min(exp, 1), t
     kept_tot += t["probe_rows_sent"]; rows_tot += npk
     if c % 10 == 9:
