@@ -459,8 +459,7 @@ int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb
 int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                  int materialize, double prefilter_below, void* stream, uint64_t* out_global_count, uint64_t* out_local_count, fj_dist_timings* timings) {
     if (!dc) return derr("fj_dist_join_count: null communicator");
-    const bool want_pf = prefilter_below > 0;
-    if (want_pf && !dc->hip) return derr("fj_dist_join: the sender-side precheck needs the HIP engine");
+
     if (materialize && (!dc->hip || (nb && !d_build_vals) || ((uintptr_t)d_build_vals & 15))) return derr("fj_dist_join: a materialising join needs the HIP engine and 16-byte aligned build values");
     const bool mat = materialize != 0;
     if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: pieces must be 1..%d", MAX_PIECES);
@@ -477,10 +476,18 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     auto mark = [&](const char* what) { if (trace) marks.emplace_back(what, ms_since(t0)); };
 
     // relation sizes of every rank: one plan for everybody
-    std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 2));
-    { const unsigned long long v[2] = {nb, np}; if (net.all_gather(v, 2, m.data())) return 1; }
+    std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 3));
+    // (... and one precheck threshold: rank 0's - whether the filters are exchanged at all must not depend on the rank)
+    {
+        const double pb = prefilter_below > 0 ? std::min(prefilter_below, 4.0) : 0.0;
+        const unsigned long long v[3] = {nb, np, (unsigned long long)(pb * 1e9)};
+        if (net.all_gather(v, 3, m.data())) return 1;
+    }
     unsigned long long nb_total = 0, np_global = 0, np_min = ~0ull;
-    for (int r = 0; r < N; ++r) { nb_total += m[2 * r]; np_global += m[2 * r + 1]; np_min = std::min(np_min, m[2 * r + 1]); }
+    for (int r = 0; r < N; ++r) { nb_total += m[3 * r]; np_global += m[3 * r + 1]; np_min = std::min(np_min, m[3 * r + 1]); }
+    prefilter_below = (double)m[2] * 1e-9;
+    const bool want_pf = prefilter_below > 0;
+    if (want_pf && !dc->hip) return derr("fj_dist_join: the sender-side precheck needs the HIP engine");
     size_t CB = 0;
     if (eng.plan(nb_total, N, &CB)) return 1;                 // (same verdict on every rank: same arguments)
     if (np_min < 2ull * pieces) pieces = 1;

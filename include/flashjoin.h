@@ -294,7 +294,7 @@ int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error
  *                                 caller then allocates them and calls fj_emit_pairs(ctx, ...) - before the next join on ctx.
  *                                 prefilter_below: the sender-side precheck (above) runs when a sample of the probe rows says that
  *                                 less than this share of them would travel - 0 = never (nothing is exported or sampled), >= 2 =
- *                                 always (no sample); HIP engine only.  Costs one more kernel over a sender's probe rows and 1 byte
+ *                                 always (no sample); rank 0's value is used on every rank; HIP engine only.  Costs one more kernel over a sender's probe rows and 1 byte
  *                                 per build key to every rank, saves (1 - survivors) of the probe exchange and of the owner's work.
  */
 typedef struct fj_dist_comm fj_dist_comm;

@@ -383,3 +383,33 @@ def test_chunk_form_precheck_break_even_model(monkeypatch):
     assert D._chunk_prefilter_mode(True, 8) == "off"
     monkeypatch.setenv("FJ_DIST_PREFILTER", "1")
     assert D._chunk_prefilter_mode(False, 1) == "on"
+
+
+def test_precheck_verdict_is_remembered_per_join_shape(monkeypatch):
+    """distributed._precheck_threshold / _precheck_remember: "auto" samples once per (world, build rows, probe rows), then runs or
+    declines without exporting a filter, and samples afresh on every 32nd call; forced modes and joins the model rules out keep no memo."""
+    from flash_hash_join_amd import distributed as D
+    monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False)
+    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.4")
+    D._PRECHECK_MEMO.clear()
+    shape = (8, 10**9, 10**10)
+    assert D._precheck_threshold("on", *shape) == (2.0, None, "on") and D._precheck_threshold("off", *shape) == (0.0, None, "off")
+    below, key, how = D._precheck_threshold("auto", *shape)
+    assert (below, key, how) == (0.4, shape, "sampled")
+    t = {"prefilter_sampled_survivors": 0.55}
+    D._precheck_remember(key, t, how)
+    assert t["prefilter_decision"] == "sampled" and D._PRECHECK_MEMO[shape] == [1, 0.55]
+    for call in range(2, 33):                                    # calls 2..32: remembered - declined (0.55 >= 0.4), nothing sampled
+        below, key, how = D._precheck_threshold("auto", *shape)
+        assert (below, how) == (0.0, "memo: declined"), call
+        D._precheck_remember(key, {}, how)
+    below, key, how = D._precheck_threshold("auto", *shape)        # call 33: a fresh sample
+    assert (below, how) == (0.4, "sampled")
+    D._precheck_remember(key, {"prefilter_sampled_survivors": 0.1}, how)
+    assert D._precheck_threshold("auto", *shape)[::2] == (2.0, "memo: runs")      # few survivors now: runs, without sampling
+    assert D._precheck_threshold("auto", 8, 10**9, 5 * 10**9)[2] == "sampled"     # another shape: its own verdict
+    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0")
+    monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
+    monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 45e9)
+    assert D._precheck_threshold("auto", 1, 125_000_000, 1_250_000_000) == (0.0, None, "model: cannot pay")
+    D._PRECHECK_MEMO.clear()
