@@ -83,12 +83,17 @@ EngOpenFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint64, ctypes.c_int, c
 EngAppendFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, ctypes.c_uint64)
 EngFinishFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pu64)
 EngAbortFn = ctypes.CFUNCTYPE(None, _vp)
+EngFilterRangeFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _pu64, _pu64, _pu64, _pu64)
+EngExportFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp)
+EngPackFilterFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _pu64)
+EngSampleFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp, ctypes.c_uint64, ctypes.c_int, _pu64)
 
 
 class FjDistEngineOps(ctypes.Structure):
     _fields_ = [("user", _vp), ("chunk_bytes", ctypes.c_size_t), ("error", EngErrorFn), ("plan", EngPlanFn), ("alloc", EngAllocFn),
                 ("release", EngReleaseFn), ("pack_begin", EngPackBeginFn), ("pack_counts", EngPackCountsFn), ("pack_finish", EngPackFinishFn),
-                ("open", EngOpenFn), ("append", EngAppendFn), ("finish", EngFinishFn), ("abort", EngAbortFn)]
+                ("open", EngOpenFn), ("append", EngAppendFn), ("finish", EngFinishFn), ("abort", EngAbortFn),
+                ("filter_range", EngFilterRangeFn), ("export_filters", EngExportFn), ("pack_filter", EngPackFilterFn), ("sample", EngSampleFn)]
 
 
 def build_native(force: bool = False) -> str:

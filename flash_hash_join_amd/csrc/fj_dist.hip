@@ -120,7 +120,8 @@ struct Engine {
     // piece is prechecked against once `filters_ready` has happened (the first pass does not wait for it)
     virtual int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks, const void* filters, Token filters_ready) = 0;
     virtual unsigned long long pack_kept() { return 0; }                        // after pack_counts: rows the precheck kept
-    // sender-side precheck (HIP engine only): where rank r's partition filters sit; this owner's filters; a sample of raw rows
+    virtual bool has_precheck() const { return false; }
+    // sender-side precheck: where rank r's partition filters sit; this owner's filters; a sample of raw rows
     virtual int filter_range(size_t, int, int, size_t*, size_t*, size_t*, size_t*) { return derr("fj_dist: this engine has no sender-side precheck"); }
     virtual int export_filters(void*, Token*) { return derr("fj_dist: this engine has no sender-side precheck"); }
     virtual int sample(const void*, size_t, size_t, const void*, size_t, int, Token, unsigned long long*) { return derr("fj_dist: this engine has no sender-side precheck"); }
@@ -160,6 +161,7 @@ struct HipEngine : Engine {
         return fj_shuffle_pack_filter(ctx, filters, ps);
     }
     unsigned long long pack_kept() override { return fj_shuffle_pack_kept(ctx); }
+    bool has_precheck() const override { return true; }
     int filter_range(size_t nb_total, int nranks, int r, size_t* first, size_t* count, size_t* total, size_t* bytes_each) override {
         *bytes_each = fj_shuffle_part_filter_bytes();
         return fj_shuffle_part_filter_range(nb_total, nranks, r, first, count, total);
@@ -215,9 +217,29 @@ struct CallbackEngine : Engine {                             // a caller's stand
     int plan(size_t nb_total, int nranks, size_t* cb) override { if (o.plan(o.user, nb_total, nranks)) return fail("plan"); *cb = o.chunk_bytes; return 0; }
     void* alloc(size_t bytes) override { return o.alloc(o.user, bytes); }
     void release(void* p) override { if (p) o.release(o.user, p); }
+    uint64_t kept_ = 0;
+    bool has_precheck() const override { return o.filter_range && o.export_filters && o.pack_filter && o.sample; }
     int pack_begin(const void* rows, const void* vals, size_t n, size_t nb_total, int nranks, const void* filters, Token) override {
-        if (vals || filters) return derr("fj_dist: the stand-in engine carries no values and has no precheck");
-        return o.pack_begin(o.user, rows, n, nb_total, nranks) ? fail("pack_begin") : 0;
+        if (vals) return derr("fj_dist: the stand-in engine carries no values");
+        if (filters && !has_precheck()) return derr("fj_dist: this stand-in engine has no precheck");
+        if (o.pack_begin(o.user, rows, n, nb_total, nranks)) return fail("pack_begin");
+        kept_ = n;
+        return filters && o.pack_filter(o.user, filters, &kept_) ? fail("pack_filter") : 0;
+    }
+    unsigned long long pack_kept() override { return kept_; }
+    int filter_range(size_t nb_total, int nranks, int r, size_t* first, size_t* count, size_t* total, size_t* bytes_each) override {
+        if (!has_precheck()) return derr("fj_dist: this stand-in engine has no precheck");
+        uint64_t f = 0, c = 0, t = 0, b = 0;
+        if (o.filter_range(o.user, nb_total, nranks, r, &f, &c, &t, &b)) return fail("filter_range");
+        *first = f; *count = c; *total = t; *bytes_each = b;
+        return 0;
+    }
+    int export_filters(void* dst, Token* done) override { *done = nullptr; return o.export_filters(o.user, dst) ? fail("export_filters") : 0; }
+    int sample(const void* rows, size_t n, size_t stride, const void* filters, size_t nb_total, int nranks, Token, unsigned long long* kept) override {
+        uint64_t k = 0;
+        if (o.sample(o.user, rows, n, stride, filters, nb_total, nranks, &k)) return fail("sample");
+        *kept = k;
+        return 0;
     }
     int pack_counts(unsigned long long* used) override { return o.pack_counts(o.user, (uint64_t*)used) ? fail("pack_counts") : 0; }
     int pack_finish(void* const* dk, uint64_t* const*, uint32_t* const* dd, Token, Token* done) override { *done = nullptr; return o.pack_finish(o.user, dk, dd) ? fail("pack_finish") : 0; }
@@ -487,7 +509,7 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     for (int r = 0; r < N; ++r) { nb_total += m[3 * r]; np_global += m[3 * r + 1]; np_min = std::min(np_min, m[3 * r + 1]); }
     prefilter_below = (double)m[2] * 1e-9;
     const bool want_pf = prefilter_below > 0;
-    if (want_pf && !dc->hip) return derr("fj_dist_join: the sender-side precheck needs the HIP engine");
+    if (want_pf && !eng.has_precheck()) return derr("fj_dist_join: this engine has no sender-side precheck");
     size_t CB = 0;
     if (eng.plan(nb_total, N, &CB)) return 1;                 // (same verdict on every rank: same arguments)
     if (np_min < 2ull * pieces) pieces = 1;

@@ -759,9 +759,23 @@ def _engine_ops_struct(ops, keep: list):
         finish=_lib.EngFinishFn(guard(finish)),
         abort=_lib.EngAbortFn(guard(ops.abort, fail=None)),
     )
+    # the optional sender-side precheck of a stand-in (all four methods or none)
+    pre = [_lib.EngFilterRangeFn(), _lib.EngExportFn(), _lib.EngPackFilterFn(), _lib.EngSampleFn()]
+    if all(hasattr(ops, m) for m in ("filter_range", "export_filters", "pack_filter", "sample")):
+        def filter_range(nb_total, nranks, rank, first, count, total, each):
+            first[0], count[0], total[0], each[0] = (int(x) for x in ops.filter_range(nb_total, nranks, rank))
+
+        def pack_filter(filters, kept):
+            kept[0] = int(ops.pack_filter(filters))
+
+        def sample(rows, n, stride, filters, nb_total, nranks, kept):
+            kept[0] = int(ops.sample(rows, n, stride, filters, nb_total, nranks))
+        pre = [_lib.EngFilterRangeFn(guard(filter_range)), _lib.EngExportFn(guard(ops.export_filters)), _lib.EngPackFilterFn(guard(pack_filter)),
+               _lib.EngSampleFn(guard(sample))]
+    cbs["precheck"] = pre
     keep.append(cbs)
     return _lib.FjDistEngineOps(None, int(ops.chunk_bytes), cbs["error"], cbs["plan"], cbs["alloc"], cbs["release"], cbs["pack_begin"],
-                                cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"])
+                                cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"], *pre)
 
 
 def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport, build_values=None, return_arrays=False,
@@ -793,8 +807,8 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
         form = "chunks (fj_dist_join_count over a callback transport)"
     try:
         if standin:
-            rc = L.fj_dist_join_count(comm, build_keys.data_ptr(), build_keys.numel(), probe_keys.data_ptr(), probe_keys.numel(), pieces, None,
-                                      ctypes.byref(cnt), ctypes.byref(dt))
+            rc = L.fj_dist_join(comm, build_keys.data_ptr(), None, build_keys.numel(), probe_keys.data_ptr(), probe_keys.numel(), pieces, 0,
+                                float(prefilter_below), None, ctypes.byref(cnt), ctypes.byref(local), ctypes.byref(dt))
         else:
             tt = engine.torch
             bk, pk = engine._aligned(build_keys), engine._aligned(probe_keys)
@@ -820,7 +834,7 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
                        join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces), local_build_rows=int(dt.local_build_chunks) * 256,
                        local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=bool(dt.prefilter), prefilter_mode=prefilter_mode,
                        prefilter_sampled_survivors=(float(dt.prefilter_sampled) if dt.prefilter_sampled >= 0 else None), prefilter_below=float(prefilter_below),
-                       probe_rows_sent=int(dt.probe_rows_kept) if not standin else probe_keys.numel(), filter_bytes_received=int(dt.filter_bytes),
+                       probe_rows_sent=int(dt.probe_rows_kept) if (not standin or dt.prefilter) else probe_keys.numel(), filter_bytes_received=int(dt.filter_bytes),
                        rows_are_chunk_capacity=True,
                        wire_chunk_bytes=int(dt.wire_chunk_bytes), wire_bytes_sent=int(dt.sent_chunks) * (int(dt.wire_chunk_bytes) + 4))
     if pairs is not None:
@@ -1113,7 +1127,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
         # the chunk form (the first radix pass of the global plan is the owner split) serves every counting shuffle whose
         # global plan has two or more passes, the sender-side precheck included (per-partition filters: fj_dist_join's
         # prefilter_below); the owner-scatter form below serves the small ones (and a stand-in engine's precheck)
-        if ((mode == "off" or not standin) and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
+        if ((mode == "off" or not standin or getattr(engine, "chunk_precheck", False)) and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
                 and engine.shuffle_plan(nb_total, world) is not None):      # (ranks with few or no rows: the driver sends everything as one piece)
             # ONE driver for every transport: csrc/fj_dist.hip (fj_dist_join_count) - over RCCL under the nccl backend, over
             # callbacks into torch.distributed under gloo / a transport object, with a stand-in engine in the CPU tests.  A step

@@ -294,7 +294,8 @@ int fj_stream_abort(fj_ctx* ctx);             /* drop an open stream join (error
  *                                 caller then allocates them and calls fj_emit_pairs(ctx, ...) - before the next join on ctx.
  *                                 prefilter_below: the sender-side precheck (above) runs when a sample of the probe rows says that
  *                                 less than this share of them would travel - 0 = never (nothing is exported or sampled), >= 2 =
- *                                 always (no sample); rank 0's value is used on every rank; HIP engine only.  Costs one more kernel over a sender's probe rows and 1 byte
+ *                                 always (no sample); rank 0's value is used on every rank; the HIP engine, or a stand-in with the
+ *                                 optional precheck callbacks.  Costs one more kernel over a sender's probe rows and 1 byte
  *                                 per build key to every rank, saves (1 - survivors) of the probe exchange and of the owner's work.
  */
 typedef struct fj_dist_comm fj_dist_comm;
@@ -336,6 +337,13 @@ typedef struct fj_dist_engine_ops {   /* a stand-in for the rank's own work (the
     int (*append)(void* user, int side, const void* chunks, uint32_t* dir, uint64_t nchunks);
     int (*finish)(void* user, uint64_t* count);
     void (*abort)(void* user);
+    /* optional, all four or none (NULL: the stand-in has no sender-side precheck and fj_dist_join refuses prefilter_below > 0):
+     * what fj_shuffle_part_filter_range / fj_stream_export_part_filters / fj_shuffle_pack_filter (called right after pack_begin
+     * for a prechecked piece; *kept = rows it kept) / fj_part_filter_sample do */
+    int (*filter_range)(void* user, uint64_t nb_total, int nranks, int rank, uint64_t* first, uint64_t* count, uint64_t* total, uint64_t* bytes_each);
+    int (*export_filters)(void* user, void* dst);
+    int (*pack_filter)(void* user, const void* filters, uint64_t* kept);
+    int (*sample)(void* user, const void* rows, uint64_t n, uint64_t stride, const void* filters, uint64_t nb_total, int nranks, uint64_t* kept);
 } fj_dist_engine_ops;
 int fj_dist_unique_id(char* out128);
 fj_dist_comm* fj_dist_comm_create(fj_ctx* ctx, const char* unique_id128, int nranks, int rank);

@@ -84,6 +84,10 @@ class OracleEngine:
     def dist_engine_ops(self, world):
         return _StandInOps(self, world)
 
+    @property
+    def chunk_precheck(self):                    # the stand-in's sender-side precheck in chunk form (its optional engine callbacks): opt-in per test
+        return os.environ.get("FJ_TEST_CHUNK_PRECHECK") == "1"
+
     def shuffle_plan(self, nb_total, world):
         return 5 if nb_total >= 10000 and world <= 32 else None
 
@@ -215,6 +219,104 @@ class _StandInOps:
 
     def abort(self):
         self.chunks = None
+
+    # ---- the optional precheck callbacks: one 4096-byte bitmap per first-pass bucket ("partition" of this stand-in), bit = 15 bits of the mixed key ----
+    FB = 4096
+
+    @staticmethod
+    def _bit(k):
+        return ((_fmix64(k.copy()) >> np.uint64(20)) & np.uint64(32767)).astype(np.int64)
+
+    def _bucket(self, k):
+        return (_fmix64(k.copy()) >> np.uint64(64 - self.F0LOG)).astype(np.int64)
+
+    def filter_range(self, nb_total, nranks, rank):
+        mine = [bb for bb in range(32) if (bb * nranks) >> self.F0LOG == rank]
+        return (mine[0] if mine else 0), len(mine), 32, self.FB
+
+    def export_filters(self, dst):
+        if self.fail == "export":
+            raise RuntimeError("injected export failure")
+        assert self.left[0] == 0                                   # the build side is complete
+        out = self._view(dst, len(self.mine) * self.FB, np.uint8)
+        out[:] = 0
+        for c in self.chunks[0]:
+            k = c.view(np.uint64)
+            pos = (self._bucket(k) - self.mine[0]) * (self.FB * 8) + self._bit(k)
+            np.bitwise_or.at(out, pos >> 3, (1 << (pos & 7)).astype(np.uint8))
+
+    def _passes(self, k, filters):
+        f = self._view(filters, 32 * self.FB, np.uint8)
+        pos = self._bucket(k) * (self.FB * 8) + self._bit(k)
+        return (f[pos >> 3] >> (pos & 7).astype(np.uint8)) & 1 != 0
+
+    def pack_filter(self, filters):
+        kept, per = 0, [[] for _ in range(self.world)]
+        for o, chunks in enumerate(self.packed):
+            by_bucket = {}
+            for bb, rws in chunks:
+                by_bucket.setdefault(bb, []).append(rws)
+            for bb, parts in by_bucket.items():
+                rws = np.concatenate(parts)
+                rws = rws[self._passes(rws.view(np.uint64), filters)]
+                kept += rws.size
+                for i in range(0, rws.size, 200):
+                    per[o].append((bb, rws[i: i + 200]))
+        self.packed = per
+        return kept
+
+    def sample(self, rows, n, stride, filters, nb_total, nranks):
+        k = self._view(rows, n * stride, np.uint64)[::stride][:n]
+        return int(self._passes(k, filters).sum()) if n else 0
+
+
+def _worker_chunk_precheck(rank, world, port, nb, npk, q):
+    """The sender-side precheck of the chunk form through the C++ driver with the stand-in engine's optional callbacks: forced,
+    by a sample on both sides of the threshold (and remembered), and with one rank's filter export failing."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FJ_DIST_STRATEGY="shuffle", FJ_TEST_CHUNK_PRECHECK="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flash_hash_join_amd import datagen
+        import flash_hash_join_amd.distributed as D
+        b0, b1 = rank * nb // world, (rank + 1) * nb // world
+        p0, p1 = rank * npk // world, (rank + 1) * npk // world
+        bk, bv = datagen.build_numpy(b1 - b0, first=b0)
+        pk, exp_local = datagen.probe_numpy(p1 - p0, nb, seed=1, hit_bp=5000, first=p0)
+        tb, tv, tp = (torch.from_numpy(x.view(np.int64)) for x in (bk, bv, pk))
+        e = torch.tensor([exp_local]); dist.all_reduce(e); exp = int(e.item())
+        out = {}
+        for name, env in (("on", {"FJ_DIST_PREFILTER": "1"}), ("auto_runs", {"FJ_DIST_PREFILTER": "auto", "FJ_DIST_PREFILTER_BELOW": "0.9"}),
+                          ("auto_again", {"FJ_DIST_PREFILTER": "auto", "FJ_DIST_PREFILTER_BELOW": "0.9"}),
+                          ("auto_declines", {"FJ_DIST_PREFILTER": "auto", "FJ_DIST_PREFILTER_BELOW": "0.05"}),
+                          ("export_fails", {"FJ_DIST_PREFILTER": "1", "FJ_TEST_FAIL": f"export:{world - 1}"})):
+            for k in ("FJ_DIST_PREFILTER", "FJ_DIST_PREFILTER_BELOW", "FJ_TEST_FAIL"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            if name in ("auto_runs", "auto_declines"):
+                D._PRECHECK_MEMO.clear()
+            t = {}
+            cnt, _ = D.distributed_join(tb, tv, tp, engine=OracleEngine(), timings=t)
+            assert cnt == exp, (name, cnt, exp)
+            assert t["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport"), (name, t)
+            glob = torch.tensor([t["probe_rows_sent"]]); dist.all_reduce(glob)
+            if name in ("on", "auto_runs", "auto_again"):
+                assert t["prefilter"] is True and "chunk_form_error" not in t, (name, t)
+                assert exp <= int(glob.item()) < 0.56 * npk                # 50 % hits; a 32768-bit filter per bucket lets few misses pass
+                assert t["filter_bytes_received"] == (32 - len([bb for bb in range(32) if (bb * world) >> 5 == rank])) * 4096, t
+            if name == "auto_runs":
+                assert t["prefilter_decision"] == "sampled" and 0.45 < t["prefilter_sampled_survivors"] < 0.6, t
+            if name == "auto_again":
+                assert t["prefilter_decision"] == "memo: runs" and t["prefilter_sampled_survivors"] is None, t
+            if name == "auto_declines":
+                assert t["prefilter"] is False and t["prefilter_decision"] == "sampled" and int(glob.item()) == npk, t
+            if name == "export_fails":       # agreed on by every rank before any filter is exchanged; the step is retried without the precheck
+                assert t["prefilter"] is False and "partition filters could not be prepared on 1 rank" in t["chunk_form_error"], t
+                assert ("injected export failure" in t["chunk_form_error"]) == (rank == world - 1), t
+            out[name] = (t["prefilter"], int(glob.item()))
+        q.put((rank, exp, out))
+    finally:
+        dist.destroy_process_group()
 
 
 def _worker(rank, world, port, nb, npk, q, strategy):
@@ -361,6 +463,25 @@ def test_distributed_join_gloo(world, strategy, oracle):
         assert owned and npairs == local        # pairs stay sharded by owner
         total_pairs += npairs
     assert total_pairs == rows[0][1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_chunk_form_precheck_through_the_driver_gloo(world, oracle):
+    """fj_dist_join(prefilter_below) at world 2 and 3 without a GPU: the C++ driver runs the precheck's protocol - build side first,
+    the owners' filters exported and exchanged over the transport (uneven ranges at world 3), probe pieces compacted, the sample's
+    all-reduced verdict, an export failure agreed on by every rank - over the stand-in engine's optional callbacks."""
+    nb, npk = 20000, 90000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chunk_precheck, args=(r, world, port, nb, npk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rows = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({(exp, tuple(sorted(out.items()))) for _, exp, out in rows}) == 1        # every rank reports the same verdicts and totals
 
 
 def test_chunk_form_precheck_break_even_model(monkeypatch):
