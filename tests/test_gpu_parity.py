@@ -1023,6 +1023,63 @@ def test_config5_chunk_form_every_owner_at_full_size_on_one_gpu(fj):
     assert total == expected, (total, expected)
 
 
+def test_config5_chunk_form_with_the_precheck_every_owner_at_full_size_on_one_gpu(fj):
+    """The same full-size emulation (1B x 10B rows, the 8-rank plan: 9 + 9 bits, 262144 final partitions) with the sender-side
+    precheck of the chunk form: every owner appends the 8 build shares and exports its 32768 partitions' Bloom filters
+    (fj_stream_export_part_filters: 1 GiB in all, assembled as the driver's all-gather would), every sender compacts its probe
+    pieces against them before the copy into the wire format (fj_shuffle_pack_filter), every owner joins what is left.  The owners'
+    counts still add up to the closed-form count of the whole join - no build key's probe row is ever dropped - while ~48 % of the
+    probe rows never reach the wire (the hits + ~3 % of the misses travel)."""
+    import torch
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    world, nb_rank, np_rank = 8, 125_000_000, 1_250_000_000
+    nb_total = nb_rank * world
+    eng = HipEngine("cuda:0")
+    bshare = []
+    for r in range(world):
+        bk, _ = datagen.build_device(nb_rank, "cuda:0", first=r * nb_rank)
+        ch, dw, used = eng.shuffle_pack(bk, None, nb_total, world)
+        torch.cuda.synchronize()
+        bshare.append([(c.clone(), d.clone()) for c, d in zip(ch, dw)])
+        del bk, ch, dw
+    first, count, total_parts, fb = eng.part_filter_range(nb_total, world, 0)
+    assert (total_parts, fb) == (1 << 18, 4096) and count == total_parts // world
+    filters = torch.zeros(total_parts * fb, dtype=torch.uint8, device="cuda:0")
+    for o in range(world):                                          # the owners' filters, where the all-gather would put them
+        first, count, _, _ = eng.part_filter_range(nb_total, world, o)
+        eng.stream_open_shuffled(nb_total, world, o, sum(bshare[r][o][1].numel() for r in range(world)) * 256, world, 1 << 20, 1)
+        for r in range(world):
+            eng.stream_append_chunks(0, bshare[r][o][0].clone(), bshare[r][o][1].clone())     # (directory words are rewritten in place: the shares are needed again)
+        eng.stream_export_part_filters(filters[first * fb: (first + count) * fb])
+        torch.cuda.synchronize()
+        eng.L.fj_stream_abort(eng.ctx)
+    pshare, expected, kept, wire_bytes = [], 0, 0, 0
+    for r in range(world):
+        pk, e = datagen.probe_device(np_rank, nb_total, "cuda:0", seed=1, hit_bp=5000, first=r * np_rank)
+        expected += e
+        ch, dw, used = eng.shuffle_pack(pk, None, nb_total, world, filters=filters)
+        torch.cuda.synchronize()
+        kept += eng.last_pack_kept
+        assert e <= eng.last_pack_kept <= e + 0.04 * (np_rank - e)   # every hit + at most 4 % of the misses
+        pshare.append([(c.clone(), d.clone()) for c, d in zip(ch, dw)])
+        wire_bytes += sum(c.numel() + 4 * d.numel() for c, d in zip(ch, dw))
+        del pk, ch, dw
+        torch.cuda.empty_cache()
+    assert 0.50 < kept / (np_rank * world) < 0.53 and wire_bytes / (np_rank * world) < 0.53 * 7.03
+    total = 0
+    for o in range(world):
+        nbc = sum(bshare[r][o][1].numel() for r in range(world)); npc = sum(pshare[r][o][1].numel() for r in range(world))
+        eng.stream_open_shuffled(nb_total, world, o, nbc * 256, world, npc * 256, world)
+        for r in range(world):
+            eng.stream_append_chunks(0, bshare[r][o][0], bshare[r][o][1])
+        for r in range(world):
+            eng.stream_append_chunks(1, pshare[r][o][0], pshare[r][o][1])
+        total += eng.stream_finish()
+    assert total == expected, (total, expected)
+    print(f"precheck at the 8-rank plan, full size: {kept / (np_rank * world):.4f} of the probe rows travel, {wire_bytes / (np_rank * world):.3f} wire bytes per probe row")
+
+
 def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, monkeypatch):
     """fj_dist_join_count (csrc/fj_dist.hip) at the size the scaling run times it: one config-5 shard, 125M x 1.25B rows, on a
     1-rank RCCL communicator - plan for the shard, 8 + 7 bits, 7-byte wire chunks, four probe pieces on three streams - against
