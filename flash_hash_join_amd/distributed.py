@@ -408,21 +408,23 @@ _CHUNK_WIRE_BYTES_PER_ROW = 7.02
 
 def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> float:
     """Survivor fraction below which the precheck of the chunk form pays (FJ_DIST_PREFILTER_BELOW overrides the model).  Per local
-    probe row a step costs max(wire, kernels): wire = 7.02 B x f / (world x link rate) on each of the links that work in parallel,
-    kernels as above; the filters cost 1 byte per build key to every rank (~nb_total / world bytes per link) and ~0.5 ms of
-    latency before the first probe piece can be checked.  It never pays where the kernels bound the step (one rank; links faster
-    than ~12 ps per row); on wire-bound steps it does below ~40 % survivors at 8 GPUs and ~45 GB/s per link, below ~85 % at 2-4."""
+    probe row a step costs max(wire, kernels) - the model of tools/scale_model.py: wire = 7.02 B x (f x probe rows + build rows) /
+    (world x link rate) on each of the links that work in parallel, plus - with the precheck - the filters (1.07 bytes per build
+    key to every rank: ~nb_total / world bytes per link); kernels as above; ~0.5 ms of latency before the first probe piece can be
+    checked.  It never pays where the kernels bound the step (one rank; links faster than ~12 ps per row); on wire-bound steps it
+    does: below ~60 % survivors at 8 GPUs and 45 GB/s per link (~50 % at 55 GB/s), below ~85 % at 2-4 GPUs."""
     env = os.environ.get("FJ_DIST_PREFILTER_BELOW")
     if env:
         return float(env)
-    if np_local <= 0:
+    if np_local <= 0 or world <= 1:
         return 0.0
-    wire = _CHUNK_WIRE_BYTES_PER_ROW / (world * _LINK_BYTES_PER_S) if world > 1 else 0.0
-    head = ((nb_total / world / _LINK_BYTES_PER_S if world > 1 else 0.0) + 0.5e-3) / np_local
-    off = max(wire, _CHUNK_FIXED_S_PER_ROW + _CHUNK_REST_S_PER_ROW)
+    build_share = nb_total / world / np_local                                # build rows per probe row: they travel either way
+    per_row = _CHUNK_WIRE_BYTES_PER_ROW / (world * _LINK_BYTES_PER_S)        # one row's share of one link
+    filters = 1.07 * build_share / _LINK_BYTES_PER_S                         # the all-gathered filters, per probe row
+    off = max(per_row * (1.0 + build_share), _CHUNK_FIXED_S_PER_ROW + _CHUNK_REST_S_PER_ROW)
 
     def on(f):
-        return max(wire * f, _CHUNK_FIXED_S_PER_ROW + _CHUNK_FILTER_S_PER_ROW + f * _CHUNK_REST_S_PER_ROW) + head
+        return max(per_row * (f + build_share) + filters, _CHUNK_FIXED_S_PER_ROW + _CHUNK_FILTER_S_PER_ROW + f * _CHUNK_REST_S_PER_ROW) + 0.5e-3 / np_local
     if on(0.0) >= off:
         return 0.0
     lo, hi = 0.0, 1.0
