@@ -70,7 +70,7 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     u32 pack_alloc, pack_seg, pack_err, rx_alloc;   // chunk allocator / segment counter / error word of the packing pass; chunk count of a received piece
     unsigned long long pack_used[64];  // wire-format chunks per owner GPU (fj_pack_offsets)
     unsigned long long pack_kept;      // probe keys a piece kept after the sender-side precheck (fj_part_filter_inplace) / passing keys of a sample
-    u32 pack_xcd[8];                   // ... and its per-XCD work counters (directly behind pack_kept: one memset clears both)
+    u32 pack_xcd[8 * FJ_PF_COUNTERS];  // ... and its per-XCD work counters (directly behind pack_kept: one memset clears both)
 };
 
 enum Slot {

@@ -125,11 +125,12 @@ struct FjPackArgs {
 };
 hipError_t fj_launch_pack_plan(const FjPackArgs& a, hipStream_t s);       // fills fi, bkeys, obase, used
 // sender-side precheck in chunk form (csrc/fj_pack.hip): FJ_PFILT_BYTES of Bloom filter per final partition of the global plan
+#define FJ_PF_COUNTERS 4u              // work counters per XCD of fj_part_filter_inplace
 #ifndef FJ_PFILT_BYTES
 #define FJ_PFILT_BYTES 4096u
 #endif
 hipError_t fj_launch_part_filter_export(const FjChunkSet& build, u64* out, u32 grid, hipStream_t s);            // owner: [build.nb][FJ_PFILT_BYTES / 8]
-hipError_t fj_launch_part_filter_inplace(const FjChunkSet& cs, const u64* filters, u32 part_shift, unsigned long long* kept, u32* next_of_xcd /* [8], zeroed */, u32 grid, hipStream_t s);
+hipError_t fj_launch_part_filter_inplace(const FjChunkSet& cs, const u64* filters, u32 part_shift, unsigned long long* kept, u32* next_of_xcd /* [8 * FJ_PF_COUNTERS], zeroed */, u32 grid, hipStream_t s);
 hipError_t fj_launch_part_filter_sample(const u64* raw, u64 n, u64 stride, const u64* filters, u32 part_shift, unsigned long long* kept, hipStream_t s);
 hipError_t fj_launch_pack_squeeze(const FjPackArgs& a, u32 grid, hipStream_t s);
 

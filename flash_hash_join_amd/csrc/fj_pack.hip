@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void fj_part_filter_export(FjChunkSet build, u
 // beside the key streaming; the survivors' stores are free - provided the filters in use stay in L2, which is what the order the
 // chunks are taken in is about (below).  (Rounds of this kernel per 312M keys at the 1-rank / 8-rank plan: a workgroup per chunk,
 // one key per thread, two barriers per chunk 3.9 ms / -; a wave per chunk, a static strided share per wave 2.3-3.7 / 4.7; XCD x
-// takes buckets x, x + 8, ... 1.7-2.0 / 4.4; chunks handed out in order 1.6 / 2.5.)
+// takes buckets x, x + 8, ... 1.7-2.0 / 4.4; chunks handed out in order 1.5-2.1 / 2.3.)
 template <u32 B>
 __global__ __launch_bounds__(256) void fj_part_filter_inplace(u64* keys, u32* list, const u32* __restrict__ boff, u32 nb,
                                                               const u64* __restrict__ filters, u32 part_shift, unsigned long long* __restrict__ kept,
@@ -214,8 +214,10 @@ __global__ __launch_bounds__(256) void fj_part_filter_inplace(u64* keys, u32* li
     // that list's chunks B at a time in the order they become free (one counter per XCD; an agent-scope atomic on a hot address
     // takes ~100 ns: one per chunk made the kernel 15 ms): the chunks in flight on an XCD stay within one or two buckets, whose
     // filters (2 MiB per bucket at 512 partitions) stay in that XCD's L2.  A static share per wave - strided over the whole list -
-    // had every wave in another bucket after each step: 4.4-4.7 ms per 312M keys at the 8-rank plan; batches of 16 from three
-    // workgroups per CU (at most 1536 chunks in flight per XCD, 2384 per bucket): 2.5 ms; 8 per CU and batches of 32: 3.6 ms.
+    // had every wave in another bucket after each step: 4.4-4.7 ms per 312M keys at the 8-rank plan; 8 workgroups per CU taking
+    // batches of 32 from one counter per XCD 3.6 ms; 3 per CU and batches of 16 (at most 1536 chunks in flight per XCD, 2384 per
+    // bucket) 2.5 ms; 4 per CU and batches of 4 from four interleaved counters per XCD 2.3 ms (a plateau: 2.3-2.5 ms for 2-6
+    // workgroups per CU and batches of 4-16).
     const u32 xcd = blockIdx.x & 7u;
     const u32 nbx = nb > xcd ? (nb - xcd + 7u) >> 3 : 0u;                        // <= 64 buckets per XCD (FJ_MAX_FAN_LOG = 9): one per lane
     const u32 bstart = lane < nbx ? boff[xcd + 8u * lane] : 0u;
@@ -224,20 +226,24 @@ __global__ __launch_bounds__(256) void fj_part_filter_inplace(u64* keys, u32* li
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
     const u32 pre = inc - bcnt, total = __shfl(inc, 63, 64);                     // this XCD's chunks, in bucket order: ordinal o -> list index
-    u32* ctr = next_of_xcd + xcd;
+    // (K counters per XCD, a workgroup uses one of them: batch t of counter k covers ordinals (t * K + k) * B ..., so the counters
+    //  advance together and an agent-scope atomic on a hot address - ~100 ns - is paid once per K * B chunks of the XCD)
+    constexpr u32 K = FJ_PF_COUNTERS;
+    const u32 kk = (blockIdx.x >> 3) % K;
+    u32* ctr = next_of_xcd + xcd * K + kk;
     auto locate = [&](u32 o) -> u32 {
         const u32 j = (u32)__popcll(__ballot(lane < nbx && pre <= o)) - 1u;      // (o < total: the last bucket that starts at or before o holds it)
         return (u32)__shfl((int)bstart, (int)j, 64) + (o - (u32)__shfl((int)pre, (int)j, 64));
     };
     const u64 lt = (1ull << lane) - 1ull;
     unsigned long long mine = 0;
-    if (threadIdx.x == 0) s_next = atomicAdd(ctr, B);
+    if (threadIdx.x == 0) s_next = (atomicAdd(ctr, 1u) * K + kk) * B;
     __syncthreads();
     u32 o0 = s_next;
     while (o0 < total) {
         __syncthreads();                                                         // (everyone has read s_next)
         u32 nxt = 0;
-        if (threadIdx.x == 0) nxt = atomicAdd(ctr, B);                           // the next batch's ordinal is on its way while this one is worked on
+        if (threadIdx.x == 0) nxt = (atomicAdd(ctr, 1u) * K + kk) * B;           // the next batch's ordinal is on its way while this one is worked on
         // this wave's chunks of the batch: o0 + wave, + 4, ...; software pipeline: the NEXT chunk's keys are requested before this
         // chunk's filter words are waited for (an ordinal beyond the end is clamped: loaded, never used)
         const u32 oend = o0 + B < total ? o0 + B : total;
@@ -323,7 +329,7 @@ hipError_t fj_launch_part_filter_export(const FjChunkSet& build, u64* out, u32 g
 
 hipError_t fj_launch_part_filter_inplace(const FjChunkSet& cs, const u64* filters, u32 part_shift, unsigned long long* kept, u32* next_of_xcd, u32 grid, hipStream_t s) {
     grid = (grid + 7u) & ~7u;                                  // (the same number of workgroups on every XCD)
-    hipLaunchKernelGGL(fj_part_filter_inplace<16>, dim3(grid), dim3(256), 0, s, cs.keys, cs.list, cs.boff, cs.nb, filters, part_shift, kept, next_of_xcd);
+    hipLaunchKernelGGL(fj_part_filter_inplace<4>, dim3(grid), dim3(256), 0, s, cs.keys, cs.list, cs.boff, cs.nb, filters, part_shift, kept, next_of_xcd);
     return hipGetLastError();
 }
 

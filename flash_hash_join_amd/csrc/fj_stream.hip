@@ -311,9 +311,9 @@ namespace {
 int pack_plan_tail(fj_ctx* c, const u64* filters, hipStream_t s) {
     PackState& pk = c->pk;
     PassIter& it = pk.it;
-    HIPCHK(hipMemsetAsync(&c->d_sc->pack_kept, 0, sizeof(unsigned long long) + 8 * sizeof(u32), s));     // (+ pack_xcd, right behind it)
-    if (filters)                                                                           // three workgroups per CU take batches of chunks as they become free
-        HIPCHK(fj_launch_part_filter_inplace(it.cs, filters, pk.part_shift, &c->d_sc->pack_kept, c->d_sc->pack_xcd, 3u * c->num_cus, s));
+    HIPCHK(hipMemsetAsync(&c->d_sc->pack_kept, 0, sizeof(unsigned long long) + sizeof(c->d_sc->pack_xcd), s));     // (+ pack_xcd, right behind it)
+    if (filters)                                                                           // four workgroups per CU take batches of chunks as they become free
+        HIPCHK(fj_launch_part_filter_inplace(it.cs, filters, pk.part_shift, &c->d_sc->pack_kept, c->d_sc->pack_xcd, 4u * c->num_cus, s));
     HIPCHK(fj_launch_pack_plan(pk.args, s));
     HIPCHK(hipMemcpyAsync(c->pk_h, c->d_sc->pack_used, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(c->pk_h + 64, &c->d_sc->pack_err, sizeof(u32), hipMemcpyDeviceToHost, s));

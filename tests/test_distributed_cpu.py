@@ -486,7 +486,7 @@ def test_chunk_form_precheck_through_the_driver_gloo(world, oracle):
 
 def test_chunk_form_precheck_break_even_model(monkeypatch):
     """distributed._chunk_prefilter_break_even: never on one rank or for joins too small for the filters' fixed cost; generous where
-    one or three links carry the shuffle; at 8 GPUs ~0.75 with 45 GB/s links, ~0.43 with 55, next to nothing from 65; zero when the links outrun the
+    one or three links carry the shuffle; at 8 GPUs ~0.75 with 45 GB/s links, ~0.5 with 55, ~0.15 with 65; zero when the links outrun the
     kernels.  _chunk_prefilter_mode: "auto" for every multi-rank join unless FJ_DIST_PREFILTER says otherwise."""
     from flash_hash_join_amd import distributed as D
     monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False); monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW", raising=False)

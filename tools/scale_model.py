@@ -10,7 +10,7 @@ SINGLE_GPU_GPS = 117.9e9               # c3 on one GPU (profiles/r04_c3_bench.js
 WIRE_B_PER_KEY = 7.017                 # tools/pack_probe.py
 KERNELS_MS = 14.1                      # per rank and step without the precheck (profiles/r04_c5_one_rank_kernel_stats.csv)
 HEAD_TAIL_MS = 2.5                     # first pack before the wire starts + last piece's pass and the join after it ends
-FILTER_MS = 4 * 2.5                    # fj_part_filter_inplace at the 8-rank plan, four pieces (profiles/r04_precheck_probe_kernel_stats.txt)
+FILTER_MS = 4 * 2.3                    # fj_part_filter_inplace at the 8-rank plan, four pieces (profiles/r04_precheck_probe_kernel_stats.txt)
 REST_SCALING_MS = 10.3                 # copy into the wire format + owner's pass + probe side of the join: scale with what survives
 FALSE_POSITIVES = 0.031                # share of the misses that pass the filters
 FILTER_BYTES_PER_BUILD_KEY = 1.07
