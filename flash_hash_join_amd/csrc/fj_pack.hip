@@ -18,7 +18,7 @@
 namespace {
 
 constexpr u32 PK_NT = 256;             // threads of the scan and squeeze workgroups = keys per chunk
-constexpr u32 PK_CPW = 8;              // output chunks a squeeze workgroup handles per step (four per half workgroup: independent load chains in flight)
+constexpr u32 PK_CPW = 4;              // output chunks a squeeze workgroup handles per step (two per half workgroup: independent load chains in flight)
 
 // keys per first-pass bucket: one workgroup per bucket sums its chunk list's counts
 __global__ __launch_bounds__(PK_NT) void fj_pack_count(FjPackArgs a) {
@@ -94,6 +94,8 @@ __global__ __launch_bounds__(PK_NT) void fj_pack_scan(FjPackArgs a) {
 // wire format leave straight from registers - 8 bytes of low words and 4 bytes of 16-bit fields per lane, even lanes the four
 // bytes of their group: a wave's stores cover 512 / 256 / 128 contiguous bytes.  (Rounds of this kernel: LDS transpose + a
 // per-chunk binary search over the bucket offsets 3.0 TB/s; one key per lane 4.4 TB/s.)
+// The launch gives a workgroup one or two steps (512 workgroups per CU in the grid): with 16 per CU and a static share of ~40 steps
+// each the kernel waited for its slowest CUs - 1.05 ms per 312M keys instead of 0.84 ms = 5.6 TB/s, the pool's plain-copy rate.
 struct __attribute__((packed, aligned(8))) u64x2u { u64 x, y; };
 template <bool W7, bool VALS>
 __global__ __launch_bounds__(PK_NT) void fj_pack_squeeze(FjPackArgs a, const uint4* __restrict__ fi, const u32* __restrict__ fb, const u32* __restrict__ list,

@@ -413,7 +413,7 @@ int fj_shuffle_pack_finish(fj_ctx* c, void* const* d_dst_chunks, uint64_t* const
     }
     pk.begun = false;
     if (total == 0) return 0;
-    const u32 grid = (u32)std::min<u64>(16u * c->num_cus, (total + 7) / 8);       // 256-thread workgroups, eight chunks per step
+    const u32 grid = (u32)std::min<u64>(512u * c->num_cus, (total + 3) / 4);      // 256-thread workgroups, four chunks per step, one or two steps each
     HIPCHK(fj_launch_pack_squeeze(a, grid, (hipStream_t)stream));
     return 0;
 }

@@ -397,12 +397,12 @@ def _prefilter_break_even(world: int) -> float:
 
 
 # the precheck in chunk form (fj_dist_join(prefilter_below), csrc/fj_pack.hip: fj_part_filter_inplace): what a config-5 shard costs
-# per local probe row on ONE MI355X through the driver (profiles/r04_prefilter_one_rank.txt: 15.4-16.3 ms without it; with it the
+# per local probe row on ONE MI355X through the driver (profiles/r04_prefilter_one_rank.txt: 15.0-16.3 ms without it; with it the
 # same at 8 % survivors, +4.7-5.8 ms at 52 %), as  off = FIXED + REST,  on(f) = FIXED + FILTER + f x REST
 _CHUNK_FIXED_S_PER_ROW = 6.0e-12        # first pass of the global plan over the probe rows + the build side's and the host's share of the step
 _CHUNK_FILTER_S_PER_ROW = 7.4e-12       # the precheck at the 8-rank plan (512 partitions = 2 MiB of filters per first-pass bucket: 2.3 ms per
                                         # 312M rows, profiles/r04_precheck_probe.txt; 4.9-6.6 ps at the 1-rank plan's 128 partitions per bucket)
-_CHUNK_REST_S_PER_ROW = 6.4e-12         # copy into the wire format + the owner's second pass, lists and join: scale with what survives
+_CHUNK_REST_S_PER_ROW = 6.1e-12         # copy into the wire format + the owner's second pass, lists and join: scale with what survives
 _CHUNK_WIRE_BYTES_PER_ROW = 7.02
 
 
@@ -412,7 +412,7 @@ def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> flo
     (world x link rate) on each of the links that work in parallel, plus - with the precheck - the filters (1.07 bytes per build
     key to every rank: ~nb_total / world bytes per link); kernels as above; ~0.5 ms of latency before the first probe piece can be
     checked.  It never pays where the kernels bound the step (one rank; links faster than ~12 ps per row); on wire-bound steps it
-    does: below ~75 % survivors at 8 GPUs and 45 GB/s per link (~50 % at 55 GB/s, ~15 % at 65), below ~85 % at 2-4 GPUs."""
+    does: below ~75 % survivors at 8 GPUs and 45 GB/s per link (~55 % at 55 GB/s, ~15 % at 65), below ~85 % at 2-4 GPUs."""
     env = os.environ.get("FJ_DIST_PREFILTER_BELOW")
     if env:
         return float(env)

@@ -8,10 +8,10 @@ hits = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 ROWS_B, ROWS_P = 125e6, 1.25e9
 SINGLE_GPU_GPS = 117.9e9               # c3 on one GPU (profiles/r04_c3_bench.json: 8.48-8.8 ms)
 WIRE_B_PER_KEY = 7.017                 # tools/pack_probe.py
-KERNELS_MS = 14.1                      # per rank and step without the precheck (profiles/r04_c5_one_rank_kernel_stats.csv)
+KERNELS_MS = 13.4                      # per rank and step without the precheck (profiles/r04_c5_one_rank_kernel_stats.csv)
 HEAD_TAIL_MS = 2.5                     # first pack before the wire starts + last piece's pass and the join after it ends
 FILTER_MS = 4 * 2.3                    # fj_part_filter_inplace at the 8-rank plan, four pieces (profiles/r04_precheck_probe_kernel_stats.txt)
-REST_SCALING_MS = 10.3                 # copy into the wire format + owner's pass + probe side of the join: scale with what survives
+REST_SCALING_MS = 9.6                  # copy into the wire format + owner's pass + probe side of the join: scale with what survives
 FALSE_POSITIVES = 0.031                # share of the misses that pass the filters
 FILTER_BYTES_PER_BUILD_KEY = 1.07
 
