@@ -10,7 +10,10 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libflashjoin_hip.so")
+# FJ_LIB_VARIANT=<name>: load lib/ab/<name>.so instead (same-box A/B of two builds of the library, tools/r5_wide_ab.sh; the in-tree
+# library itself is never overwritten by a measurement script)
+LIB_PATH = (os.path.join(_PKG, "lib", "ab", os.environ["FJ_LIB_VARIANT"] + ".so") if os.environ.get("FJ_LIB_VARIANT")
+            else os.path.join(_PKG, "lib", "libflashjoin_hip.so"))
 CSRC = os.path.join(_PKG, "csrc")
 
 # every symbol include/flashjoin.h declares

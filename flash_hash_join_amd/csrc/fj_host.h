@@ -120,6 +120,7 @@ struct PassIter {
     int slot = 0, cs_base = 0;           // ping-pong workspace slot of the next output level / base index of cs's buffers
     // probe side of a join: the final level's consumer is the join kernel; its item table (tiles of the final probe chunk
     // lists) and per-item count array are produced by the final level's bookkeeping launches
+    u32 item_tc_max = 0;                 // > 0: the join's items hold at most this many probe chunks (32: the 16384-slot counting kernel will run, fj_join_wide.hip)
     bool want_items = false; u32 items_cap = 0; u32* part_count = nullptr; int part_count_slot = W_PART_COUNT;
     // bloom precheck (probe side): run the filter stage once `bloom_level` passes are complete, against bloom_build
     bool bloom_done = false; const FjChunkSet* bloom_build = nullptr;
@@ -201,7 +202,9 @@ namespace fjh {
 struct Options {
     size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; u32 plan_target_keys;
     int bloom_variant, bloom_auto, bloom_auto_max_hit_bp, mat_single_pass;
+    int join_wide;                     // counting joins on the 16384-slot table (fj_join_wide.hip): 0 never, 1 whenever eligible, 2 (default) when the average final partition holds > FJ_WIDE_MIN_KEYS build keys
     Options() {
+        join_wide = getenv("FJ_JOIN_WIDE") ? atoi(getenv("FJ_JOIN_WIDE")) : 2;
         mat_single_pass = getenv("FJ_MAT_SINGLE_PASS") ? atoi(getenv("FJ_MAT_SINGLE_PASS")) : 1;
         bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
         bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2300;     // measured break-even at c4 sizes: 24 % hits (profiles/r03_bloom_threshold.csv; round 2: 28 % - the plain plan gained more since)
@@ -232,6 +235,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s);
 int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_t n, hipStream_t s, int* ev_cursor);
 bool bloom_stage_follows(const PassIter& it, int level);
 void join_item_geometry(u64 nparts, size_t np, u64 chunk_bound, u32* tc, u64* max_items);
+bool wide_join_planned(bool materialize, size_t nb, size_t np, int bits);
 int level_finish(fj_ctx* c, PassIter& it, bool final_level, hipStream_t s);
 int pass_complete(fj_ctx* c, PassIter& it, hipStream_t s);
 int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s);

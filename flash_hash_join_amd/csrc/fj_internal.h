@@ -170,6 +170,7 @@ struct FjLdsJoinArgs {
     u32 want_dups;               // counting pass of a materialising join: report duplicate build keys (FJ_STAT_DUPS)
     u32 dedup;                   // materialising pass: build 'values' are row indices, the smallest wins, then orig_vals[idx]
     const u64* orig_vals;        // the caller's build_values (dedup only)
+    u32 avg_build_keys;          // build rows per final partition on average (host hint: selects the 16384-slot counting kernel, fj_join_wide.hip)
     unsigned long long* dbg;     // diagnostic: per-item phase stamps (s_memrealtime), nullptr in production
     u32 dbg_flags;               // diagnostic ablations: 1 = skip lookups, 2 = skip inserts, 4 = no output stores (results wrong on purpose); 8 = test hook: the cuckoo emit kernel sends every 7th item down its retry path (results exact)
 };
@@ -178,6 +179,20 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
                               u32 persistent_min_items = 8192);
 // the single-pass materialising join over chunk lists (a.out_cursor != nullptr; unique build keys: duplicates are reported, FJ_STAT_DUPS)
 hipError_t fj_launch_emit_single(const FjLdsJoinArgs& a, hipStream_t s, u32* next_item);
+// ---- counting join with a 16384-slot table, one 1024-thread workgroup per CU (csrc/fj_join_wide.hip) ----
+// for partitions whose build side is not thin against the probe side (> FJ_WIDE_MIN_KEYS build keys on average), and for the
+// multi-GPU build-broadcast form, whose build side arrives as dense per-partition runs from every rank (DENSE)
+#define FJ_WIDE_MAXSRC 16u
+#define FJ_WIDE_MIN_KEYS 3400u
+struct FjWideArgs {
+    const u32* toff; u32 part_lo, part_hi;       // toff != nullptr: only the items of partitions [part_lo, part_hi) (toff = first item of every partition)
+    // DENSE build side: source s keeps, at byte offsets into base, an offset table u32[nparts + 1] (keys before partition p), the keys'
+    // low words u32[n_s] and the low (32 - bits) bits of their high words as u16[n_s] (mid_bytes == 2) or u32[n_s]; partition p supplies the top `bits` bits
+    const unsigned char* base; u32 nsrc, bits, mid_bytes, pad;
+    u64 offs_off[FJ_WIDE_MAXSRC], lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC];
+};
+hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w, bool dense, u32 grid, hipStream_t s);
+
 // second chance for the items whose partition overflowed the cuckoo table (load > ~0.45): the tagged 2x4-slot table
 // with linear-probing overflow holds up to 8128 keys; only a partition beyond that raises FJ_ERR_LDS_FULL
 hipError_t fj_launch_lds_join_retry(const FjLdsJoinArgs& a, hipStream_t s);

@@ -1,0 +1,419 @@
+// fj_join_wide.hip -- counting join for partitions whose build side is NOT thin against the probe side (MI355X, gfx950).
+//
+// Same role as fj_count_join_persistent (fj_join.hip): insert_local + probe_vectorized of one radix partition
+// (hash_join.cpp:112-128, :153-182) inside _hash_join_radix_count (:498-534).  That kernel keeps an 8192-slot cuckoo table per
+// workgroup, two workgroups per CU, and its item is a chain of latency-bound steps: table reset -> claims (two dependent LDS
+// round trips per KEY) -> barrier -> eviction chains (at ~3800 keys, load 0.47, the longest is 24 dependent exchanges) ->
+// barrier -> probe.  With ~3000-3800 build keys against ~3800-4800 probe keys per partition the table build is what the item
+// costs (profiles/r04: 0.38 of the HBM peak).  Here ONE 1024-thread workgroup per CU owns a 16384-slot table (128 KiB of the
+// CU's 160 KiB) and the item is a software pipeline without a dependent chain in it:
+//   * open addressing WITHOUT evictions: a key lives at the first free slot of l1, l2, l3 (three hashed locations), l3+1, ... -
+//     slots are claimed with atomic ORs on a slot BITMAP, the table itself only sees plain stores and reads.  At load 0.23
+//     1.2 % of the keys go beyond l3.  A lookup reads its three locations unconditionally and walks on only where all three
+//     are taken by other keys;
+//   * because claims touch the bitmap only, the claims of item k+1 run WHILE item k is probed (two bitmaps, alternating): their
+//     LDS round trips hide under the probe's lookups; the slots a thread was assigned stay in its registers;
+//   * no table reset: after the probe every thread stores the empty marker over the slots it filled (no evictions: they are
+//     exactly the occupied ones), then the new keys go in with plain stores: two short throughput-bound phases;
+//   * every wave owns whole 256-key chunks (4 keys per lane and chunk, two 16-B loads), so no lane looks up padding;
+//   * nothing in the loop waits for a dependent global load: item descriptors are fetched by one thread five items ahead and
+//     parked in LDS, chunk-list entries three items ahead, build keys two, probe keys one (no scalar loads in the loop: they
+//     share the LDS wait counter);
+//   * DENSE: the build side is not a chunk set but the multi-GPU "build broadcast" wire format (fj_bcast.hip): per source rank
+//     one run of keys per final partition, stored as two planes (low word, remaining bits of the high word) behind an offset
+//     table; the partition id supplies the top bits.  Nothing is re-partitioned or copied on the receiving side.
+// Items are dealt round-robin (item = blockIdx.x + k * gridDim.x): all of a launch's workgroups are resident.
+// Items whose build side does not fit (a claim walks W_MAXWALK slots in vain) are marked FJ_ITEM_RETRY exactly as
+// fj_count_join_persistent does; the host's retry / re-partition ladder (radix_join_tail) is unchanged.
+#include "fj_internal.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int WNT = 1024;
+constexpr u32 WSLOG = 14, WS = 1u << WSLOG;
+constexpr u32 W_META_P = 32;              // probe-side list entries staged per item = the most an item of this kernel has
+constexpr u32 W_META_B = 32;              // build-side list entries staged per item / 2 words per source (DENSE)
+constexpr u32 W_STRIDE = W_META_P + W_META_B;
+constexpr u32 W_MAXWALK = 48;             // slots a claim walks beyond l3 before the table counts as full
+constexpr u32 W_WAVES = WNT / 64;
+constexpr u32 W_NOSLOT = 0xFFFFFFFFu;
+
+struct WHdr {
+    u32 cnt, pad0[3];
+    u32 has_empty[2], full[2];             // per bitmap parity: the item whose claims ran on it
+    u32 dring[8][8];                       // item descriptors: {probe list pos, probe chunks, partition, item id, b0, nbc, -, -}
+    u64 lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC], offs_off[FJ_WIDE_MAXSRC];
+};
+
+__device__ __forceinline__ u32 w_l1(u64 h) { return FJ_HW2(h) & (WS - 1); }
+__device__ __forceinline__ u32 w_l2(u64 h) { return (FJ_HW2(h) >> WSLOG) & (WS - 1); }
+__device__ __forceinline__ u32 w_l3(u64 h) { return ((FJ_HW2(h) >> 28) ^ (FJ_HW1(h) << 4) ^ (FJ_HW2(h) >> 7)) & (WS - 1); }
+
+template <bool DENSE>
+__global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWideArgs w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WHdr* hdr = reinterpret_cast<WHdr*>(smem);
+    u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(WHdr));
+    u32* bits0 = reinterpret_cast<u32*>(tkeys + WS);               // [2][WS / 32] slot bitmaps
+    u32* meta = bits0 + 2 * (WS / 32);                             // [4][W_STRIDE]: ring of staged list entries
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    u32 item_lo = 0, item_hi = *a.nitems_dev;
+    if (w.toff) { item_lo = w.toff[w.part_lo]; item_hi = w.toff[w.part_hi]; }
+    if (item_lo + blockIdx.x >= item_hi) return;
+    const u32 nmine = (item_hi - item_lo - blockIdx.x + gridDim.x - 1) / gridDim.x;     // items of this workgroup
+    auto id_of = [&](u32 q) { return item_lo + blockIdx.x + q * gridDim.x; };
+    auto ring = [&](u32 q, u32 f) -> u32 { return __builtin_amdgcn_readfirstlane(hdr->dring[q & 7][f]); };   // descriptor field, wave-uniform
+
+    // descriptor fetch, one thread: the item-table entry of item q (q >= nmine: a dead item: no chunks on either side)
+    auto fetch_items = [&](u32 q) -> uint4 { return q < nmine ? a.items[id_of(q)] : make_uint4(0, 0, 0, 0); };
+    auto store_items = [&](u32 q, uint4 it) {
+        u32* r = hdr->dring[q & 7];
+        r[0] = it.x; r[1] = q < nmine ? it.y : 0u; r[2] = it.z; r[3] = q < nmine ? id_of(q) : 0xFFFFFFFFu; r[4] = 0; r[5] = 0;
+        r[6] = it.w;                                               // (every loaded word is used: a half-dead load register gets reused and the reuse waits for ALL loads in flight)
+    };
+    auto fetch_boff = [&](u32 q) -> uint2 {                        // (chunk-list build side) needs store_items(q) to be visible
+        if (DENSE || q >= nmine) return make_uint2(0, 0);
+        const u32 part = hdr->dring[q & 7][2];
+        return make_uint2(a.build.boff[part], a.build.boff[part + 1]);
+    };
+    auto store_boff = [&](u32 q, uint2 b) { u32* r = hdr->dring[q & 7]; r[4] = b.x; r[5] = b.y - b.x; };
+
+    // list entries of item q -> registers (one global load per side and thread), later parked in a ring slot
+    auto request = [&](u32 q, u32 ns, u32 nbc, u32& mp, u32& mb) {
+        mp = 0; mb = 0;
+        const u32 np0 = ns < W_META_P ? ns : W_META_P;
+        if (tid < np0) mp = a.probe.list[ring(q, 0) + tid];
+        if (DENSE) {
+            if (q < nmine && tid < 2 * w.nsrc) mb = reinterpret_cast<const u32*>(w.base + hdr->offs_off[tid >> 1])[ring(q, 2) + (tid & 1u)];
+        } else {
+            const u32 nb0 = nbc < W_META_B ? nbc : W_META_B;
+            if (tid < nb0) mb = a.build.list[ring(q, 4) + tid];
+        }
+    };
+    auto park = [&](u32* slot, u32 mp, u32 mb) {
+        if (tid < W_META_P) slot[tid] = mp;
+        if (tid < (DENSE ? 2 * FJ_WIDE_MAXSRC : W_META_B)) slot[W_META_P + tid] = mb;
+    };
+    auto dense_total = [&](const u32* slot) -> u32 {               // build keys of the item whose entries sit in `slot`
+        u32 t = 0;
+        for (u32 s = 0; s < w.nsrc; ++s) t += slot[W_META_P + 2 * s + 1] - slot[W_META_P + 2 * s];
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+
+    // ---- build keys of one batch -> registers ---------------------------------------------------------------------------
+    // chunk lists: wave v takes chunks first + v and first + v + 16 of the `nstaged` staged entries (4 keys per lane each); DENSE:
+    // thread t takes keys first + t, first + t + 1024, ... of the sources' concatenated runs (`total` keys).  The loads are
+    // unconditional (validity is a mask; a chunk that does not exist is one 16-byte line for the whole wave).  am = the key
+    // slots that hold anything for this WAVE (uniform): everything downstream skips the others.
+    auto load_build = [&](const u32* slot, u32 part, u32 first, u32 nstaged, u32 total, u64 (&bk)[8], u32& bok, u32& am) {
+        const u32* bm = slot + W_META_P;
+        bok = 0; am = 0;
+        if (DENSE) {
+            u32 src[8], gi[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { src[j] = 0; gi[j] = 0; }
+            u32 cum = 0;
+            for (u32 s = 0; s < w.nsrc; ++s) {
+                const u32 b = bm[2 * s], n = bm[2 * s + 1] - b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const u32 i = first + (u32)j * WNT + tid;
+                    if (i >= cum && i - cum < n) { src[j] = s; gi[j] = b + (i - cum); bok |= 1u << j; }
+                }
+                cum += n;
+            }
+            const u32 top = w.bits ? part << (32u - w.bits) : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (first + (u32)j * WNT + (wave << 6) < total) am |= 1u << j;
+                const u32 lo = reinterpret_cast<const u32*>(w.base + hdr->lo_off[src[j]])[gi[j]];
+                u32 mid;
+                if (w.mid_bytes == 2) mid = reinterpret_cast<const u16*>(w.base + hdr->mid_off[src[j]])[gi[j]];
+                else mid = reinterpret_cast<const u32*>(w.base + hdr->mid_off[src[j]])[gi[j]];
+                bk[j] = ((u64)(top | mid) << 32) | lo;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32 c = first + wave + (u32)i * W_WAVES;
+                const bool have = c < nstaged;
+                const u32 e = nstaged ? bm[have ? c : nstaged - 1] : 0u, cnt = have ? FJ_LIST_CNT(e) : 0u;
+                const u64* ck = a.build.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + (have ? 2 * lane : 0u);
+                const u64x2 q0 = *reinterpret_cast<const u64x2*>(ck);
+                const u64x2 q1 = *reinterpret_cast<const u64x2*>(ck + (have ? 128 : 0));
+                bk[4 * i] = q0.x; bk[4 * i + 1] = q0.y; bk[4 * i + 2] = q1.x; bk[4 * i + 3] = q1.y;
+                bok |= ((2 * lane < cnt ? 1u : 0u) | (2 * lane + 1 < cnt ? 2u : 0u) | (128 + 2 * lane < cnt ? 4u : 0u) | (129 + 2 * lane < cnt ? 8u : 0u)) << (4 * i);
+                if (have) am |= (cnt > 128 ? 0xFu : 0x3u) << (4 * i);
+            }
+        }
+        am = __builtin_amdgcn_readfirstlane(am);
+    };
+
+    // ---- claims of a batch on bitmap `bits`: sl[j] = the slot key j will be stored in (W_NOSLOT: none) ------------------------
+    // per group of 4 key slots (a chunk of the wave / 4096 keys of the workgroup; groups without keys are skipped, wave-uniformly):
+    // stage A (l1 of every key: the thread's atomics in flight together), B (l2 of the losers), C (l3), then the rare linear walk
+    auto claim4 = [&](auto G, u32* bits, const u64 (&bk8)[8], u32 vm, u32 par, u32 (&sl8)[8]) {
+        constexpr int g4 = 4 * decltype(G)::value;
+        u32 o[4], sl[4]; u64 bk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bk[j] = bk8[g4 + j];
+        auto fin = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl8[g4 + j] = sl[j];
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sl[j] = W_NOSLOT; o[j] = 0; if (bk[j] == FJ_EMPTY_KEY) { if ((vm >> j) & 1u) hdr->has_empty[par] = 1; vm &= ~(1u << j); } }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 l = w_l1(bk[j]);
+            if ((vm >> j) & 1u) { sl[j] = l; o[j] = atomicOr(&bits[l >> 5], 1u << (l & 31)); }
+        }
+#pragma unroll
+        for (int which = 2; which <= 3; ++which) {
+            u32 need = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT && ((o[j] >> (sl[j] & 31)) & 1u)) need |= 1u << j;
+            if (__ballot(need != 0) == 0) { fin(); return; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = 0u;                                         // (settled keys read as "won")
+                if ((need >> j) & 1u) {
+                    const u32 l = which == 2 ? w_l2(bk[j]) : w_l3(bk[j]);
+                    sl[j] = l; o[j] = atomicOr(&bits[l >> 5], 1u << (l & 31));
+                }
+            }
+        }
+        u32 need = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT && ((o[j] >> (sl[j] & 31)) & 1u)) need |= 1u << j;
+        if (__ballot(need != 0) == 0) { fin(); return; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!((need >> j) & 1u)) continue;
+            u32 s = sl[j];
+            bool got = false;
+            for (u32 step = 0; step < W_MAXWALK && !got; ++step) {
+                s = (s + 1) & (WS - 1);
+                got = !((atomicOr(&bits[s >> 5], 1u << (s & 31)) >> (s & 31)) & 1u);
+            }
+            if (got) sl[j] = s; else { sl[j] = W_NOSLOT; hdr->full[par] = 1; }
+        }
+        fin();
+    };
+    auto claim = [&](u32* bits, const u64 (&bk)[8], u32 bok, u32 am, u32 par, u32 (&sl)[8]) {
+        if (am & 0xFu) claim4(std::integral_constant<int, 0>(), bits, bk, bok & 0xFu, par, sl); else { sl[0] = sl[1] = sl[2] = sl[3] = W_NOSLOT; }
+        if (am >> 4) claim4(std::integral_constant<int, 1>(), bits, bk, bok >> 4, par, sl); else { sl[4] = sl[5] = sl[6] = sl[7] = W_NOSLOT; }
+    };
+    auto store_keys = [&](const u64 (&bk)[8], const u32 (&sl)[8], u32 am) {
+        if (am & 0xFu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = bk[j];
+        }
+        if (am >> 4) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = bk[j];
+        }
+    };
+    auto clear_slots = [&](const u32 (&sl)[8], u32 am) {
+        if (am & 0xFu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = FJ_EMPTY_KEY;
+        }
+        if (am >> 4) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = FJ_EMPTY_KEY;
+        }
+    };
+    auto reset_table = [&]() {
+        const ulonglong2 e2 = make_ulonglong2(FJ_EMPTY_KEY, FJ_EMPTY_KEY);
+        for (u32 i = tid; i < WS / 2; i += WNT) reinterpret_cast<ulonglong2*>(tkeys)[i] = e2;
+    };
+
+    // ---- probe side: a wave's chunk -> 4 keys per lane ---------------------------------------------------------------------
+    // ---- probe side: a wave's chunk -> 4 keys per lane (whole chunks per wave: units of 64 keys - 8-byte loads, perfectly balanced
+    // waves - were 30 % slower, units of 128 keys 7 %: the address path charges per load instruction) --------------------------------
+    auto load_chunk = [&](const u32* pm, u32 c, u32 nb, u64 (&k)[4], u32& vm) {
+        const bool have = c < nb;
+        const u32 e = nb ? pm[have ? c : nb - 1] : 0u, cnt = have ? FJ_LIST_CNT(e) : 0u;
+        const u64* ck = a.probe.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + (have ? 2 * lane : 0u);
+        const u64x2 q0 = *reinterpret_cast<const u64x2*>(ck);
+        const u64x2 q1 = *reinterpret_cast<const u64x2*>(ck + (have ? 128 : 0));
+        k[0] = q0.x; k[1] = q0.y; k[2] = q1.x; k[3] = q1.y;
+        vm = (2 * lane < cnt ? 1u : 0u) | (2 * lane + 1 < cnt ? 2u : 0u) | (128 + 2 * lane < cnt ? 4u : 0u) | (129 + 2 * lane < cnt ? 8u : 0u);
+    };
+    auto probe2 = [&](u64 k0, u64 k1, u32 vm, u64 he) -> u32 {   // two keys per lane: six lookups in flight
+        const u64 k[2] = {k0, k1};
+        u64 c1[2], c2[2], c3[2];
+        u32 l3[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            l3[i] = w_l3(k[i]);
+            c1[i] = tkeys[w_l1(k[i])];
+            c2[i] = tkeys[w_l2(k[i])];
+            c3[i] = tkeys[l3[i]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u32 hits = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bool found = (c1[i] == k[i]) | (c2[i] == k[i]) | (c3[i] == k[i]);
+            // a key beyond l3 sits behind three occupied slots: walk on only where all three are taken by other keys
+            bool walk = !found && c1[i] != FJ_EMPTY_KEY && c2[i] != FJ_EMPTY_KEY && c3[i] != FJ_EMPTY_KEY && ((vm >> i) & 1u) && k[i] != FJ_EMPTY_KEY;
+            if (__ballot(walk)) {
+                u32 s = l3[i];
+                for (u32 step = 0; step < W_MAXWALK && __ballot(walk); ++step) {
+                    s = (s + 1) & (WS - 1);
+                    if (walk) { const u64 c = tkeys[s]; if (c == k[i]) { found = true; walk = false; } else if (c == FJ_EMPTY_KEY) walk = false; }
+                }
+            }
+            const u64 hit = __ballot(found);
+            const u64 ise = __ballot(k[i] == FJ_EMPTY_KEY);        // the empty marker is never stored in the table
+            const u64 ok = __ballot((vm >> i) & 1u);
+            hits += (u32)__popcll(ok & ((hit & ~ise) | (ise & he)));
+        }
+        return hits;
+    };
+    auto probe4 = [&](const u64 (&k)[4], u32 vm, u64 he) -> u32 { return probe2(k[0], k[1], vm, he) + probe2(k[2], k[3], vm >> 2, he); };
+
+    // a partition of more than 32 build chunks / 8192 build keys is not offered to the table at all: its items are marked for the
+    // host's retry ladder like any partition the table cannot hold (no rarely-taken loads inside the loop: they would make every
+    // wait on the loads in flight conservative)
+    auto is_big = [&](u32 nbc, u32 total) -> bool { return DENSE ? total > 8 * WNT : nbc > 2 * W_WAVES; };
+
+    // ---- prologue (synchronous): descriptors 0..4, entries of items 0..2, item 0 built, probe keys of item 0, build keys of item 1
+    if (DENSE && tid < w.nsrc) { hdr->lo_off[tid] = w.lo_off[tid]; hdr->mid_off[tid] = w.mid_off[tid]; hdr->offs_off[tid] = w.offs_off[tid]; }
+    if (tid < 5) store_items(tid, fetch_items(tid));
+    if (tid == 0) { hdr->cnt = 0; hdr->has_empty[0] = hdr->has_empty[1] = 0; hdr->full[0] = hdr->full[1] = 0; }
+    reset_table();
+    for (u32 i = tid; i < 2 * (WS / 32); i += WNT) bits0[i] = 0;
+    __syncthreads();
+    if (tid < 4) store_boff(tid, fetch_boff(tid));
+    __syncthreads();
+    // descriptor fields kept in scalar registers, rotated every iteration: probe chunks of items k .. k+2, build chunks of k+1, k+2
+    u32 ns0 = ring(0, 1), ns1 = ring(1, 1), ns2 = ring(2, 1), nbc1 = ring(1, 5), nbc2 = ring(2, 5), part2 = ring(2, 2);
+    u32* sl_k = meta, * sl_k1 = meta + W_STRIDE, * sl_k2 = meta + 2 * W_STRIDE, * sl_k3 = meta + 3 * W_STRIDE;
+    {
+        u32 mp, mb;
+        request(0, ns0, ring(0, 5), mp, mb); park(sl_k, mp, mb);
+        request(1, ns1, nbc1, mp, mb); park(sl_k1, mp, mb);
+        request(2, ns2, nbc2, mp, mb); park(sl_k2, mp, mb);
+    }
+    __syncthreads();
+    u64 bkA[8], bkB[8];
+    u32 bokA = 0, bokB = 0, amA = 0, amB = 0;
+    u32 slots[8], am_cur = 0;                                      // of the item in the table (this thread's keys)
+    {
+        const u32 nbc0 = ring(0, 5), tot0 = DENSE ? dense_total(sl_k) : 0u;
+        load_build(sl_k, ring(0, 2), 0, nbc0 < W_META_B ? nbc0 : W_META_B, tot0, bkA, bokA, amA);
+        claim(bits0, bkA, bokA, amA, 0, slots);
+        store_keys(bkA, slots, amA);
+        am_cur = amA;
+        if (is_big(nbc0, tot0)) hdr->full[0] = 1;
+    }
+    u64 ka[4], kb[4];
+    u32 va = 0, vb = 0;
+    {
+        const u32 nb = ns0 < W_META_P ? ns0 : W_META_P;
+        load_chunk(sl_k, wave, nb, ka, va);
+        load_chunk(sl_k, wave + W_WAVES, nb, kb, vb);
+    }
+    u32 tot1 = DENSE ? dense_total(sl_k1) : 0u;
+    load_build(sl_k1, ring(1, 2), 0, nbc1 < W_META_B ? nbc1 : W_META_B, tot1, bkA, bokA, amA);
+    __syncthreads();                                               // item 0's keys are in the table
+
+#ifdef FJ_LAB      // diagnostic build (make EXTRA=-DFJ_LAB): where thread 0's time goes, per pipeline stage (FJ_WIDE_STAMPS=1)
+    unsigned long long* tacc = reinterpret_cast<unsigned long long*>(meta + 4 * W_STRIDE);    // (the launch adds 72 bytes of LDS)
+    if (tid == 0) { for (int i = 0; i < 8; ++i) tacc[i] = 0; tacc[8] = __builtin_amdgcn_s_memrealtime(); }
+#define W_STAMP(i) do { if (a.dbg && tid == 0) { const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tacc[i] += tn_ - tacc[8]; tacc[8] = tn_; } } while (0)
+#else
+#define W_STAMP(i) do { } while (0)
+#endif
+    for (u32 k = 0; k < nmine; ++k) {
+        // at entry: the table holds item k (this thread's keys of it: slots[], am_cur), bitmap k&1 marks them; ka/kb = first probe
+        // chunks of item k; bkA = first build batch of item k+1 (tot1 keys if DENSE); ring slots sl_k, sl_k1, sl_k2 hold the entries of
+        // items k, k+1, k+2; descriptors complete up to k+3, the item-table part of k+4 is in the ring
+        const u32 par = k & 1u, parn = par ^ 1u;
+        u32* bitsn = bits0 + parn * (WS / 32);
+        // ---- 1. requests: descriptor parts (one thread), entries of k+3, build keys of k+2 ----
+        uint4 it5 = make_uint4(0, 0, 0, 0); uint2 bo4 = make_uint2(0, 0);
+        if (tid == 0) { bo4 = fetch_boff(k + 4); it5 = fetch_items(k + 5); }
+        const u32 ns3 = ring(k + 3, 1), nbc3 = ring(k + 3, 5);
+        u32 mp, mb;
+        request(k + 3, ns3, nbc3, mp, mb);
+        const u32 tot2 = DENSE ? dense_total(sl_k2) : 0u;
+        load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, bkB, bokB, amB);
+        W_STAMP(0);
+        // ---- 2a. probe item k; then its successor's first probe chunks are requested into the same registers ----
+        const bool full = hdr->full[par] != 0 || ns0 > 2 * W_WAVES;      // (an item longer than 32 probe chunks - a host-side bug - goes to the retry ladder)
+        const u64 he = hdr->has_empty[par] ? ~0ull : 0ull;
+        u32 wave_hits = 0;
+        const bool skip = full || ns0 == 0;
+        const u32 nb = ns0 < 2 * W_WAVES ? ns0 : 2 * W_WAVES;      // (items of this kernel have at most 32 probe chunks: the host cuts them so)
+        if (!skip && wave < nb) wave_hits += probe4(ka, va, he);
+        if (!skip && wave + W_WAVES < nb) wave_hits += probe4(kb, vb, he);
+        {
+            const u32 nbn = ns1 < W_META_P ? ns1 : W_META_P;
+            load_chunk(sl_k1, wave, nbn, ka, va);
+            load_chunk(sl_k1, wave + W_WAVES, nbn, kb, vb);
+        }
+        W_STAMP(1);
+        // ---- 2b. claims of item k+1 on the other bitmap (other waves are still probing: the round trips overlap their lookups) ----
+        u32 nslots[8];
+        claim(bitsn, bkA, bokA, amA, parn, nslots);
+        if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
+        W_STAMP(2);
+        // ---- 3. park what was requested ----
+        park(sl_k3, mp, mb);
+        if (tid == 0) { store_boff(k + 4, bo4); store_items(k + 5, it5); }
+        if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
+        W_STAMP(3);
+        __syncthreads();                                         // A: every wave is done with the table and with bitmap parn
+        W_STAMP(4);
+        // ---- 4. item k's result; the table is emptied by the owners of its keys; bitmap `par` is cleared for item k+2 ----
+        if (tid == 0) {
+            const u32 cnt = skip ? 0u : hdr->cnt;
+            hdr->cnt = 0; hdr->has_empty[par] = 0; hdr->full[par] = 0;
+            if (full) atomicOr(a.err, FJ_STAT_RETRY);            // the table could not hold the partition: redone with the tagged table
+            a.part_count[id_of(k)] = full ? FJ_ITEM_RETRY : cnt;
+            if (cnt) atomicAdd(a.total, (unsigned long long)cnt);
+        }
+        clear_slots(slots, am_cur);
+        if (tid < WS / 32) bits0[par * (WS / 32) + tid] = 0;
+        W_STAMP(5);
+        __syncthreads();                                         // B
+        // ---- 5. item k+1 goes in ----
+        store_keys(bkA, nslots, amA);
+        W_STAMP(6);
+        __syncthreads();                                         // C
+        W_STAMP(7);
+        // ---- 6. rotate ----
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { slots[j] = nslots[j]; bkA[j] = bkB[j]; }
+        bokA = bokB; am_cur = amA; amA = amB; tot1 = tot2;
+        ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part2 = DENSE ? ring(k + 3, 2) : 0u;
+        u32* t = sl_k; sl_k = sl_k1; sl_k1 = sl_k2; sl_k2 = sl_k3; sl_k3 = t;
+    }
+#ifdef FJ_LAB
+    if (a.dbg && tid == 0 && blockIdx.x < 4096) { for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 8 + i] = tacc[i]; }
+#endif
+}
+
+}  // namespace
+
+u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + 2 * (WS / 8) + 4 * W_STRIDE * 4 + 80); }
+
+// counting join over the final chunk sets with the 16384-slot table: a.items / a.nitems_dev / a.part_count / a.total / a.err as
+// for fj_launch_lds_join.  dense: the build side comes from w (build-broadcast wire format).
+hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w, bool dense, u32 grid, hipStream_t s) {
+    if (!a.probe.list || !a.items || (!dense && !a.build.list) || a.want_dups) return hipErrorInvalidValue;
+    if (dense && (w.nsrc == 0 || w.nsrc > FJ_WIDE_MAXSRC || !w.base || (w.mid_bytes != 2 && w.mid_bytes != 4) || w.bits > 32)) return hipErrorInvalidValue;
+    const u32 lds = fj_wide_lds_bytes();
+    auto kern = dense ? fj_count_join_wide<true> : fj_count_join_wide<false>;
+    hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WNT), lds, s, a, w);
+    return hipGetLastError();
+}

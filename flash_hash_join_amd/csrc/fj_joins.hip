@@ -270,6 +270,25 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
         HIPCHK(hipMemsetAsync(&c->d_sc->err, 0, sizeof(u32), s));
     }
     if (getenv("FJ_JOIN_STAMPS") && stamps_begin(&ja.dbg, s)) return 1;
+    // (wide_join_planned: the probe side's final bookkeeping cut the items for the 16384-slot kernel, fj_join_wide.hip)
+    const bool wide = pit.item_tc_max == 32 && !materialize && !ja.dbg && !ja.dbg_flags && ja.probe.list && ja.build.list && ja.items;
+    if (wide) {
+        FjWideArgs wa{};
+        FjLdsJoinArgs jw = ja;
+        if (getenv("FJ_WIDE_STAMPS") && stamps_begin(&jw.dbg, s)) return 1;      // (diagnostic: where a workgroup's time goes, per pipeline stage)
+        const u32 grid = std::min<u32>(nitems, c->num_cus);
+        HIPCHK(fj_launch_count_join_wide(jw, wa, false, grid, s));
+        if (jw.dbg) {
+            std::vector<unsigned long long> h(4096 * 8);
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(h.data(), jw.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (u32 g = 0; g < grid && g < 4096; ++g) for (int i = 0; i < 8; ++i) acc[i] += (double)h[g * 8 + i] * 0.01;
+            const double per = (double)std::min<u32>(grid, 4096) * ((double)nitems / grid);
+            fprintf(stderr, "[FJ_WIDE_STAMPS] us per item (thread 0): requests %.3f  probe %.3f  claims %.3f  park %.3f  barA %.3f  clear %.3f  barB+store %.3f  barC %.3f\n",
+                    acc[0] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per, acc[5] / per, acc[6] / per, acc[7] / per);
+        }
+    } else
     HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item, options().persistent_min_items));
     if (ja.dbg) { if (stamps_report("FJ_JOIN_STAMPS", ja.dbg, nitems, s)) return 1; ja.dbg = nullptr; }
     HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
@@ -358,10 +377,12 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     }
     pass_init(pit, 1, false, np, pplan, top_bits);
     pit.want_items = true;
+    if (plan.bloom_level == 0 && wide_join_planned(materialize != 0, nb, np, plan.bits)) pit.item_tc_max = 32;
     // bloom precheck: the probe side's level `bloom_level` is filtered against the build side's same level
     if (plan.bloom_level > 0) pit.bloom_build = &bit.saved;
     if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;
     HIPCHK(hipEventRecord(c->ev[E_PPART], s));
+    ja.avg_build_keys = (u32)std::min<u64>(0xFFFFFFFFu, (u64)nb >> plan.bits);
     if (radix_join_tail(c, materialize, ja, plan, np, pit, s, t, evc, out_count, lds_full, top_bits, so)) return 1;
     if (c->pend.valid) { c->pend.bk = bk; c->pend.bv = bv; c->pend.nb = nb; c->pend.top_bits = top_bits; }
     return 0;

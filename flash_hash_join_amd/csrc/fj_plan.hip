@@ -204,6 +204,15 @@ void join_item_geometry(u64 nparts, size_t np, u64 chunk_bound, u32* tc, u64* ma
     *max_items = bound / *tc + nparts + 1;
 }
 
+// Counting joins whose partitions are neither thin (load of the 8192-slot cuckoo table above ~0.4: long eviction chains) nor probe-
+// heavy (the kernel's items hold at most 32 probe chunks, each item builds the partition's table) run the 16384-slot kernel
+// (fj_join_wide.hip).  Decided before the probe side's passes: the final level's bookkeeping cuts the items to 32 chunks.
+bool wide_join_planned(bool materialize, size_t nb, size_t np, int bits) {
+    if (materialize || bits <= 0 || options().join_wide == 0) return false;
+    if (options().join_wide == 1) return true;
+    return (nb >> bits) > FJ_WIDE_MIN_KEYS && (np >> bits) <= 32u * FJ_CHUNK;
+}
+
 // Bookkeeping of the level in it.cs (buffers at it.cs_base), two launches: chunk-list offsets + lists, and the tile table
 // of whatever reads the level next - the bloom stage, the next pass, or (probe side, final level) the join's item table
 // together with its per-item count array.
@@ -212,7 +221,10 @@ int level_finish(fj_ctx* c, PassIter& it, bool final_level, hipStream_t s) {
     u32 tc = 0; u64 max_tiles = 0; u32* zero_tail = nullptr;
     if (bloom_stage_follows(it, it.i)) tc = fj_bloom_tile_chunks();
     else if (!final_level) tc = fj_partition_tile_chunks((u32)it.plan.fan_log[it.i], it.has_vals);
-    else if (it.want_items) join_item_geometry(cs.nb, it.n, it.lbound, &tc, &max_tiles);
+    else if (it.want_items) {
+        join_item_geometry(cs.nb, it.n, it.lbound, &tc, &max_tiles);
+        if (it.item_tc_max && tc > it.item_tc_max) { tc = it.item_tc_max; max_tiles = std::max<u64>(it.lbound, (it.n + FJ_CHUNK - 1) / FJ_CHUNK) / tc + cs.nb + 1; }
+    }
     if (tc && !max_tiles) max_tiles = it.lbound / tc + cs.nb + 1;
     if (max_tiles >= (1ull << 31)) return set_err("internal error: tile table too large");
     u32* toff = nullptr; uint4* tiles = nullptr;
@@ -368,6 +380,7 @@ int fj_set_option(const char* name, long long value) {
     if (!strcmp(name, "mat_single_pass")) { options().mat_single_pass = value != 0; return 0; }
     if (!strcmp(name, "bloom_auto_max_hit_bp")) { if (value < 0 || value > 10000) return set_err("fj_set_option: bloom_auto_max_hit_bp must be 0..10000"); options().bloom_auto_max_hit_bp = (int)value; return 0; }
     if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); options().bloom_variant = (int)value; return 0; }
+    if (!strcmp(name, "join_wide")) { if (value < 0 || value > 2) return set_err("fj_set_option: join_wide must be 0..2"); options().join_wide = (int)value; return 0; }
     if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
     return set_err("fj_set_option: unknown option '%s'", name);
 }
@@ -376,6 +389,7 @@ long long fj_get_option(const char* name) {
     if (name && !strcmp(name, "radix_threshold")) return (long long)options().radix_threshold;
     if (name && !strcmp(name, "scalar_hbm_table")) return options().scalar_hbm_table;
     if (name && !strcmp(name, "persistent_min_items")) return options().persistent_min_items;
+    if (name && !strcmp(name, "join_wide")) return options().join_wide;
     if (name && !strcmp(name, "plan_target_keys")) return options().plan_target_keys;
     if (name && !strcmp(name, "bloom_variant")) return options().bloom_variant;
     if (name && !strcmp(name, "bloom_auto")) return options().bloom_auto;

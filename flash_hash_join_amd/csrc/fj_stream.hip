@@ -208,6 +208,7 @@ int fj_stream_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* t
         HIPCHK(hipEventRecord(c->ev[E_PPART], s));
         bool lds_full = false;
         const int mat = st.shuffled && st.with_vals ? 1 : 0;     // counting pass of a materialising join: the pairs follow with fj_emit_pairs
+        st.ja.avg_build_keys = st.ja.build.list && st.ja.build.nb ? (u32)std::min<u64>(0xFFFFFFFFu, (u64)st.nb_seen / st.ja.build.nb) : 0u;
         if (radix_join_tail(c, mat, st.ja, st.plan, st.np_seen, st.pit, s, &t, st.evc, &count, &lds_full, st.top_bits)) return 1;
         if (mat && c->pend.valid && (c->pend.has_dups || c->pend.has_second)) {
             // first-occurrence semantics for duplicate build keys (and the re-partitioning of an oversized partition) need the

@@ -28,21 +28,24 @@ def fj():
     return flash_join
 
 
-@pytest.fixture(params=[0, 1, 2, 4], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "deep_plans"])
+@pytest.fixture(params=[0, 1, 2, 4, 5, 6], ids=["scalar=planned", "scalar=hbm_table", "persistent_join", "deep_plans", "wide_join", "wide_join_deep_plans"])
 def scalar_mode(request, fj):
     """Run a test under the dispatch variants of the native library: the hash_join* functions served by the partitioned
     plan (default) or by the literal one-table-in-HBM algorithm (linear probing, bloom word per group); every
     partitioned counting join through the persistent join kernel (by default only plans with >= 8192 items use it); and
     "deep_plans": 32 build keys per final partition instead of 4096, so that the small inputs of these tests run the two-
     and three-pass plans -- and, in the *_bloom functions, the bloom precheck between the probe side's passes -- that
-    production only takes for build sides above a million rows."""
-    fj.set_option("plan_target_keys", 32 if request.param == 4 else 4096)
+    production only takes for build sides above a million rows; "wide_join": every partitioned counting join on the 16384-slot
+    table kernel (fj_join_wide.hip; by default only plans whose partitions average > 3300 build keys), also under deep plans."""
+    fj.set_option("plan_target_keys", 32 if request.param in (4, 6) else 4096)
+    fj.set_option("join_wide", 1 if request.param in (5, 6) else 2)
     fj.set_option("scalar_hbm_table", int(request.param == 1))
     fj.set_option("persistent_min_items", 0 if request.param == 2 else 8192)
     yield request.param
     fj.set_option("scalar_hbm_table", 0)
     fj.set_option("persistent_min_items", 8192)
     fj.set_option("plan_target_keys", 4096)
+    fj.set_option("join_wide", 2)
 
 
 def _digest(oracle, k, v):
