@@ -29,6 +29,7 @@ SYMBOLS = [
     "fj_shuffle_plan", "fj_shuffle_chunk_bytes", "fj_shuffle_pack_begin", "fj_shuffle_pack_counts", "fj_shuffle_pack_finish", "fj_stream_open_shuffled",
     "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
     "fj_shuffle_part_filter_bytes", "fj_shuffle_part_filter_range", "fj_stream_export_part_filters", "fj_shuffle_pack_filter", "fj_shuffle_pack_kept", "fj_part_filter_sample",
+    "fj_bcast_plan", "fj_bcast_region_bytes", "fj_bcast_piece_span", "fj_bcast_pack", "fj_bcast_pack_bounds", "fj_bcast_probe", "fj_bcast_join", "fj_bcast_finish", "fj_bcast_abort",
     "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_from_transport", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
     "fj_dist_join_count", "fj_dist_join",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
@@ -188,6 +189,16 @@ def load() -> ctypes.CDLL:
     L.fj_dist_comm_destroy.restype = None; L.fj_dist_comm_destroy.argtypes = [vp]
     L.fj_dist_comm_rank.restype = i32; L.fj_dist_comm_rank.argtypes = [vp]
     L.fj_dist_comm_size.restype = i32; L.fj_dist_comm_size.argtypes = [vp]
+    psz, pi32, pu32 = ctypes.POINTER(sz), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_uint32)
+    L.fj_bcast_plan.restype = i32; L.fj_bcast_plan.argtypes = [sz, pi32, pu32, pi32]
+    L.fj_bcast_region_bytes.restype = sz; L.fj_bcast_region_bytes.argtypes = [sz, sz]
+    L.fj_bcast_piece_span.restype = i32; L.fj_bcast_piece_span.argtypes = [sz, sz, sz, sz, i32, psz, psz]
+    L.fj_bcast_pack.restype = i32; L.fj_bcast_pack.argtypes = [vp, vp, sz, sz, vp, i32, vp]
+    L.fj_bcast_pack_bounds.restype = i32; L.fj_bcast_pack_bounds.argtypes = [vp, pu64]
+    L.fj_bcast_probe.restype = i32; L.fj_bcast_probe.argtypes = [vp, vp, sz, sz, vp]
+    L.fj_bcast_join.restype = i32; L.fj_bcast_join.argtypes = [vp, vp, i32, pu64, pu64, ctypes.c_uint32, ctypes.c_uint32, vp]
+    L.fj_bcast_finish.restype = i32; L.fj_bcast_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
+    L.fj_bcast_abort.restype = None; L.fj_bcast_abort.argtypes = [vp]
     L.fj_dist_join_count.restype = i32; L.fj_dist_join_count.argtypes = [vp, vp, sz, vp, sz, i32, vp, pu64, ctypes.POINTER(FjDistTimings)]
     L.fj_dist_join.restype = i32; L.fj_dist_join.argtypes = [vp, vp, vp, sz, vp, sz, i32, i32, ctypes.c_double, vp, pu64, pu64, ctypes.POINTER(FjDistTimings)]
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]

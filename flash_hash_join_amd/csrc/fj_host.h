@@ -71,6 +71,7 @@ struct Scalars {                       // device scratch words, mirrored in pinn
     unsigned long long pack_used[64];  // wire-format chunks per owner GPU (fj_pack_offsets)
     unsigned long long pack_kept;      // probe keys a piece kept after the sender-side precheck (fj_part_filter_inplace) / passing keys of a sample
     u32 pack_xcd[8 * FJ_PF_COUNTERS];  // ... and its per-XCD work counters (directly behind pack_kept: one memset clears both)
+    u32 bc_bounds[20];                 // build broadcast (fj_bcast_pack): key index at which piece q of the rank's region starts
 };
 
 enum Slot {
@@ -162,6 +163,13 @@ struct StreamState {            // fj_stream_*: a counting join whose relations 
     bool with_vals = false;         // ... and the build side carries values: a materialising join (pairs stay with the owner: fj_emit_pairs after the finish)
 };
 
+struct BcastState {             // fj_bcast_*: one step of the multi-GPU build-broadcast join on this rank (csrc/fj_bcast.hip)
+    bool packed = false, probed = false;
+    size_t nb_total = 0, nb = 0, np = 0;
+    int pieces = 1, evc = 0;
+    fjh::Plan plan; fjh::PassIter pit; FjLdsJoinArgs ja{};
+};
+
 struct fj_ctx {
     int device = 0;
     fjh::Buf bufs[fjh::W_NSLOTS];
@@ -172,6 +180,7 @@ struct fj_ctx {
     fjh::Pending pend;
     StreamState st;
     PackState pk;
+    BcastState bc;
     hipEvent_t pk_ev = nullptr;        // the packing pass's counts have landed in pk_h
     unsigned long long* pk_h = nullptr;   // pinned: [64] chunks per owner, [64] = the pass's error word, [65] = keys kept by the precheck, [66] = sample result
     size_t ws_bytes = 0;

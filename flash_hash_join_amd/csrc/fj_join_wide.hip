@@ -34,7 +34,8 @@ constexpr int WNT = 1024;
 constexpr u32 WSLOG = 14, WS = 1u << WSLOG;
 constexpr u32 W_META_P = 32;              // probe-side list entries staged per item = the most an item of this kernel has
 constexpr u32 W_META_B = 32;              // build-side list entries staged per item / 2 words per source (DENSE)
-constexpr u32 W_STRIDE = W_META_P + W_META_B;
+constexpr u32 W_UNITS = 32;               // DENSE: 256-slot load units per item (uint4 each: source, first key slot, run begin, run end) + their count
+constexpr u32 W_STRIDE = W_META_P + 4 * W_UNITS + 4;
 constexpr u32 W_MAXWALK = 48;             // slots a claim walks beyond l3 before the table counts as full
 constexpr u32 W_WAVES = WNT / 64;
 constexpr u32 W_NOSLOT = 0xFFFFFFFFu;
@@ -92,47 +93,67 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             if (tid < nb0) mb = a.build.list[ring(q, 4) + tid];
         }
     };
+    // DENSE: the first wave turns the sources' (run begin, run end) pairs into the item's load units: the runs of the partition, one per
+    // source, cut into units of 256 key slots that start at a multiple of 4 keys; one 16-byte descriptor per unit, so that a wave
+    // fetching a unit reads ONE LDS word (every wave walking the sources' pairs cost 50 LDS instructions per wave and item: as much
+    // as the lookups)
     auto park = [&](u32* slot, u32 mp, u32 mb) {
         if (tid < W_META_P) slot[tid] = mp;
-        if (tid < (DENSE ? 2 * FJ_WIDE_MAXSRC : W_META_B)) slot[W_META_P + tid] = mb;
+        if (!DENSE) { if (tid < W_META_B) slot[W_META_P + tid] = mb; return; }
+        if (wave == 0) {
+            const u32 b = __shfl(mb, (2 * lane) & 63, 64), e = __shfl(mb, (2 * lane + 1) & 63, 64);     // lane s: source s
+            const bool act = lane < w.nsrc && e > b;
+            const u32 a0 = b & ~3u, nu = act ? (e - a0 + 255u) >> 8 : 0u;
+            u32 inc = nu;
+#pragma unroll
+            for (int d = 1; d < (int)FJ_WIDE_MAXSRC; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
+            const u32 excl = inc - nu, total = __shfl(inc, FJ_WIDE_MAXSRC - 1, 64);
+            uint4* ud = reinterpret_cast<uint4*>(slot + W_META_P);
+            for (u32 k = 0; k < nu; ++k) if (excl + k < W_UNITS) ud[excl + k] = make_uint4(lane, a0 + (k << 8), b, e);
+            if (lane == 0) slot[W_META_P + 4 * W_UNITS] = total;
+        }
     };
-    auto dense_total = [&](const u32* slot) -> u32 {               // build keys of the item whose entries sit in `slot`
-        u32 t = 0;
-        for (u32 s = 0; s < w.nsrc; ++s) t += slot[W_META_P + 2 * s + 1] - slot[W_META_P + 2 * s];
-        return __builtin_amdgcn_readfirstlane(t);
-    };
+    auto dense_total = [&](const u32* slot) -> u32 { return __builtin_amdgcn_readfirstlane(slot[W_META_P + 4 * W_UNITS]); };   // load units of the item parked in `slot`
 
     // ---- build keys of one batch -> registers ---------------------------------------------------------------------------
     // chunk lists: wave v takes chunks first + v and first + v + 16 of the `nstaged` staged entries (4 keys per lane each); DENSE:
-    // thread t takes keys first + t, first + t + 1024, ... of the sources' concatenated runs (`total` keys).  The loads are
+    // wave v takes the 256-slot units v and v + 16 of the sources' runs (see below).  The loads are
     // unconditional (validity is a mask; a chunk that does not exist is one 16-byte line for the whole wave).  am = the key
     // slots that hold anything for this WAVE (uniform): everything downstream skips the others.
     auto load_build = [&](const u32* slot, u32 part, u32 first, u32 nstaged, u32 total, u64 (&bk)[8], u32& bok, u32& am) {
         const u32* bm = slot + W_META_P;
         bok = 0; am = 0;
         if (DENSE) {
-            u32 src[8], gi[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { src[j] = 0; gi[j] = 0; }
-            u32 cum = 0;
-            for (u32 s = 0; s < w.nsrc; ++s) {
-                const u32 b = bm[2 * s], n = bm[2 * s + 1] - b;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const u32 i = first + (u32)j * WNT + tid;
-                    if (i >= cum && i - cum < n) { src[j] = s; gi[j] = b + (i - cum); bok |= 1u << j; }
-                }
-                cum += n;
-            }
+            // wave v takes load units v and v + 16 (park): per unit one 16-byte load (4 low words per lane) and one 8- or 16-byte load
+            // (their high-word bits).  (One 4-byte and one 2-byte load per KEY: the address path charges per load instruction.)
             const u32 top = w.bits ? part << (32u - w.bits) : 0u;
+            const uint4* units = reinterpret_cast<const uint4*>(bm);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (first + (u32)j * WNT + (wave << 6) < total) am |= 1u << j;
-                const u32 lo = reinterpret_cast<const u32*>(w.base + hdr->lo_off[src[j]])[gi[j]];
-                u32 mid;
-                if (w.mid_bytes == 2) mid = reinterpret_cast<const u16*>(w.base + hdr->mid_off[src[j]])[gi[j]];
-                else mid = reinterpret_cast<const u32*>(w.base + hdr->mid_off[src[j]])[gi[j]];
-                bk[j] = ((u64)(top | mid) << 32) | lo;
+            for (int i = 0; i < 2; ++i) {
+                const u32 u = first + wave + (u32)i * W_WAVES;
+                const bool have = u < total && u < W_UNITS;
+                const uint4 d4 = units[have ? u : 0u];
+                const u32 us = have ? __builtin_amdgcn_readfirstlane(d4.x) : 0u, ua0 = __builtin_amdgcn_readfirstlane(d4.y);
+                const u32 ub = __builtin_amdgcn_readfirstlane(d4.z), ue = __builtin_amdgcn_readfirstlane(d4.w);
+                const u32 k0 = ua0 + 4 * lane;
+                const bool in = have && k0 < ue;                           // (lanes past the run read its first word: nothing beyond the plane's 16 bytes of padding is touched)
+                const u32 kk = in ? k0 : (have ? ua0 : 0u);
+                const uint4 lo4 = *reinterpret_cast<const uint4*>(w.base + hdr->lo_off[us] + (u64)kk * 4);
+                u32 m[4];
+                if (w.mid_bytes == 2) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(w.base + hdr->mid_off[us] + (u64)kk * 2);
+                    m[0] = q.x & 0xFFFFu; m[1] = q.x >> 16; m[2] = q.y & 0xFFFFu; m[3] = q.y >> 16;
+                } else {
+                    const uint4 q = *reinterpret_cast<const uint4*>(w.base + hdr->mid_off[us] + (u64)kk * 4);
+                    m[0] = q.x; m[1] = q.y; m[2] = q.z; m[3] = q.w;
+                }
+                const u32 l[4] = {lo4.x, lo4.y, lo4.z, lo4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bk[4 * i + j] = ((u64)(top | m[j]) << 32) | l[j];
+                    if (in && k0 + j >= ub && k0 + j < ue) bok |= 1u << (4 * i + j);
+                }
+                if (have) am |= 0xFu << (4 * i);
             }
         } else {
 #pragma unroll
@@ -280,7 +301,8 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     // a partition of more than 32 build chunks / 8192 build keys is not offered to the table at all: its items are marked for the
     // host's retry ladder like any partition the table cannot hold (no rarely-taken loads inside the loop: they would make every
     // wait on the loads in flight conservative)
-    auto is_big = [&](u32 nbc, u32 total) -> bool { return DENSE ? total > 8 * WNT : nbc > 2 * W_WAVES; };
+    // (DENSE: `total` = the partition's 256-slot units over all sources, dense_total)
+    auto is_big = [&](u32 nbc, u32 total) -> bool { return DENSE ? total > 2 * W_WAVES : nbc > 2 * W_WAVES; };
 
     // ---- prologue (synchronous): descriptors 0..4, entries of items 0..2, item 0 built, probe keys of item 0, build keys of item 1
     if (DENSE && tid < w.nsrc) { hdr->lo_off[tid] = w.lo_off[tid]; hdr->mid_off[tid] = w.mid_off[tid]; hdr->offs_off[tid] = w.offs_off[tid]; }

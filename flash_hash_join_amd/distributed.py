@@ -244,6 +244,46 @@ class HipEngine:
             self._lib.check(self.L.fj_stream_append_build_chunks(self.ctx, chunks.data_ptr(), vals.data_ptr() if vals is not None else None, dirw.data_ptr(),
                                                                  dirw.numel(), stream))
 
+    # ---- build-broadcast form (csrc/fj_bcast.hip): probe rows never move, every rank's build rows travel as dense per-partition runs ----
+    def bcast_plan(self, nb_total: int):
+        """(radix bits, final partitions, bytes of the high-word plane per key) of the plan for a total build side, or None when
+        that plan has no pass (such joins take the owner-scatter form)."""
+        b, n, m = ctypes.c_int(0), ctypes.c_uint32(0), ctypes.c_int(0)
+        if self.L.fj_bcast_plan(nb_total, ctypes.byref(b), ctypes.byref(n), ctypes.byref(m)):
+            return None
+        return b.value, n.value, m.value
+
+    def bcast_region_bytes(self, nb_total: int, nkeys: int) -> int:
+        return int(self.L.fj_bcast_region_bytes(nb_total, nkeys))
+
+    def bcast_pack(self, keys, nb_total: int, region, pieces: int) -> None:
+        """Asynchronous: this rank's build keys -> `region` (a uint8 tensor view of bcast_region_bytes(nb_total, keys.numel()) bytes)."""
+        s = self.torch.cuda.current_stream(self.index).cuda_stream
+        self._lib.check(self.L.fj_bcast_pack(self.ctx, keys.data_ptr(), keys.numel(), nb_total, region.data_ptr(), pieces, s))
+
+    def bcast_pack_bounds(self, pieces: int) -> List[int]:
+        b = (ctypes.c_uint64 * (pieces + 1))()
+        self._lib.check(self.L.fj_bcast_pack_bounds(self.ctx, b))
+        return [int(x) for x in b]
+
+    def bcast_probe(self, probe_keys, nb_total: int) -> None:
+        s = self.torch.cuda.current_stream(self.index).cuda_stream
+        self._lib.check(self.L.fj_bcast_probe(self.ctx, probe_keys.data_ptr(), probe_keys.numel(), nb_total, s))
+
+    def bcast_join(self, base, region_off: List[int], nkeys: List[int], part_lo: int, part_hi: int) -> None:
+        n = len(region_off)
+        ro, nk = (ctypes.c_uint64 * n)(*region_off), (ctypes.c_uint64 * n)(*nkeys)
+        s = self.torch.cuda.current_stream(self.index).cuda_stream
+        self._lib.check(self.L.fj_bcast_join(self.ctx, base.data_ptr(), n, ro, nk, part_lo, part_hi, s))
+
+    def bcast_finish(self) -> int:
+        cnt = ctypes.c_uint64(0)
+        t = self._lib.FjTimings()
+        s = self.torch.cuda.current_stream(self.index).cuda_stream
+        self._lib.check(self.L.fj_bcast_finish(self.ctx, s, ctypes.byref(cnt), ctypes.byref(t)))
+        self.last_bcast_timings = t.as_dict()
+        return int(cnt.value)
+
     def emit_pairs(self, n: int):
         """The pairs of the materialising join that was just counted on this context (fj_emit_pairs): two int64 tensors of n rows."""
         ok, ov = self.empty(max(n, 2)), self.empty(max(n, 2))

@@ -231,6 +231,36 @@ int fj_part_filter_sample(fj_ctx* ctx, const uint64_t* d_raw_keys, size_t n, siz
                           void* stream, uint64_t* kept);
 
 /*
+ * Multi-GPU counting join, BUILD-BROADCAST form (csrc/fj_bcast.hip; no reference counterpart: the reference is one process,
+ * hash_join.cpp:318 - what is exploited is that radix partitions are independent join units, :340-356, :515-525): the probe
+ * rows never move.  Every rank plans for the TOTAL build side, runs both passes of that plan over its own build rows and packs
+ * them densely, final partition after final partition, without the bits a partition implies (6 bytes per key from 134M build rows
+ * in all): region = offset table u32[nparts + 1] | low words u32[n] | rest of the high words u16[n] or u32[n].  The regions are
+ * exchanged (fj_dist_join does that; any transport can: fj_bcast_piece_span says which bytes form a piece of consecutive
+ * partitions), and every rank joins its own probe rows, partitioned by the same plan, against the runs of all ranks where they lie.
+ *   fj_bcast_plan          - bits / final partitions / bytes per key of the high-word plane for a total build side (error: the
+ *                            plan has no pass - such joins take the owner-scatter form)
+ *   fj_bcast_region_bytes  - bytes of a rank's region holding nkeys keys (0: no such plan)
+ *   fj_bcast_pack          - asynchronous: local build rows -> d_region (16-byte aligned, fj_bcast_region_bytes(nb_total, nb) bytes);
+ *                            starts the step on this context
+ *   fj_bcast_pack_bounds   - blocks until the pack has run: h_bounds[q] = first key index of piece q, h_bounds[pieces] = nb
+ *   fj_bcast_probe         - asynchronous: local probe rows through the plan's passes
+ *   fj_bcast_join          - asynchronous: partitions [part_lo, part_hi) of the local probe rows against nsrc (<= 16) regions inside
+ *                            d_base (region i of nkeys[i] keys at byte region_off[i]); call once per landed piece
+ *   fj_bcast_finish        - blocks; the local match count.  A final partition beyond the LDS table (skewed build keys) is an error:
+ *                            the caller takes another form (fj_dist_join does).
+ */
+int fj_bcast_plan(size_t nb_total, int* bits, uint32_t* nparts, int* mid_bytes);
+size_t fj_bcast_region_bytes(size_t nb_total, size_t nkeys);
+int fj_bcast_piece_span(size_t nb_total, size_t nkeys, size_t k_lo, size_t k_hi, int part, size_t* offset, size_t* bytes);
+int fj_bcast_pack(fj_ctx* ctx, const uint64_t* d_build_keys, size_t nb, size_t nb_total, void* d_region, int pieces, void* stream);
+int fj_bcast_pack_bounds(fj_ctx* ctx, uint64_t* h_bounds);
+int fj_bcast_probe(fj_ctx* ctx, const uint64_t* d_probe_keys, size_t np, size_t nb_total, void* stream);
+int fj_bcast_join(fj_ctx* ctx, const void* d_base, int nsrc, const uint64_t* region_off, const uint64_t* nkeys, uint32_t part_lo, uint32_t part_hi, void* stream);
+int fj_bcast_finish(fj_ctx* ctx, void* stream, uint64_t* out_count, fj_timings* timings);
+void fj_bcast_abort(fj_ctx* ctx);
+
+/*
  * Sender-side bloom precheck of the owner shuffle (no reference counterpart).  fj_bloom_export: an owner partitions the
  * nb build keys it owns by 9 radix bits (at the hash_top_bits it will join with) and writes one Bloom filter per bucket,
  * fj_bloom_filter_words() 32-bit words each, 512 buckets, into d_filters (the caller all-gathers them).  fj_bloom_prefilter:

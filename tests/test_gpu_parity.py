@@ -1026,6 +1026,98 @@ def test_config5_chunk_form_every_owner_at_full_size_on_one_gpu(fj):
     assert total == expected, (total, expected)
 
 
+def _bcast_emulated(eng, world, bks, pks, nb_total, pieces):
+    """All ranks of a build-broadcast join on one GPU: every rank's build block packed into its region, then every rank's probe
+    block joined against all regions, range by range.  Returns the sum of the ranks' counts."""
+    import torch
+    sizes = [int(b.numel()) for b in bks]
+    rbs = [eng.bcast_region_bytes(nb_total, n) for n in sizes]
+    offs = [sum(rbs[:r]) for r in range(world)]
+    base = torch.empty(sum(rbs), dtype=torch.uint8, device="cuda:0")
+    bits, nparts, _ = eng.bcast_plan(nb_total)
+    empty = torch.empty(16, dtype=torch.int64, device="cuda:0")[:0]
+    for r in range(world):
+        eng.bcast_pack(bks[r], nb_total, base[offs[r]: offs[r] + rbs[r]], pieces)
+        b = eng.bcast_pack_bounds(pieces)
+        assert b[0] == 0 and b[-1] == sizes[r] and all(x <= y for x, y in zip(b, b[1:]))
+        eng.bcast_probe(empty, nb_total)
+        assert eng.bcast_finish() == 0
+    total = 0
+    for r in range(world):
+        eng.bcast_pack(bks[r], nb_total, base[offs[r]: offs[r] + rbs[r]], pieces)      # (a step starts with the rank's own pack)
+        eng.bcast_probe(pks[r], nb_total)
+        for q in range(pieces):
+            eng.bcast_join(base, offs, sizes, nparts * q // pieces, nparts * (q + 1) // pieces)
+        total += eng.bcast_finish()
+    return total
+
+
+@pytest.mark.parametrize("world,nb_total,np_total,target", [(2, 70_000, 300_001, 32), (3, 250_000, 1_000_000, 32), (8, 9_000_000, 12_000_000, 4096),
+                                                              (4, 40_000, 90_000, 256), (5, 3_000_000, 2_000_000, 32)])
+def test_build_broadcast_form_matches_the_oracle(fj, oracle, world, nb_total, np_total, target):
+    """The build-broadcast form of the multi-GPU join (csrc/fj_bcast.hip + fj_count_join_wide<DENSE>), all ranks played by this GPU,
+    against the NumPy oracle: ragged blocks (one rank holds no build rows, one no probe rows), repeated probe keys, both widths of the
+    high-word plane (bits < 16 / >= 16 under plan_target_keys), 1..5 pieces."""
+    import torch
+    from flash_hash_join_amd.distributed import HipEngine
+    fj.set_option("plan_target_keys", target)
+    try:
+        eng = HipEngine("cuda:0")
+        rng = np.random.default_rng(world * 1000 + nb_total % 97)
+        bk = np.unique(rng.integers(0, 2**64, size=nb_total, dtype=np.uint64))
+        pk = np.concatenate([rng.choice(bk, np_total // 2), rng.integers(0, 2**64, size=np_total - np_total // 2, dtype=np.uint64)])
+        rng.shuffle(pk)
+        exp = oracle.np_join(bk, bk, pk)
+        assert eng.bcast_plan(bk.size) is not None
+        cutb = sorted(rng.integers(0, bk.size, size=world - 1).tolist()); cutb[0] = 0            # rank 0: no build rows
+        cutp = sorted(rng.integers(0, pk.size, size=world - 1).tolist()); cutp[-1] = pk.size      # last rank: no probe rows
+        bks = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.split(bk, cutb)]
+        pks = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.split(pk, cutp)]
+        for pieces in (1, 1 + world % 5):
+            assert _bcast_emulated(eng, world, bks, pks, int(bk.size), pieces) == exp
+    finally:
+        fj.set_option("plan_target_keys", 4096)
+
+
+def test_config5_build_broadcast_every_rank_at_full_size_on_one_gpu(fj):
+    """BASELINE configs[4] (1B build x 10B probe rows over 8 GPUs) at FULL size in the build-broadcast form, all 8 ranks played by
+    this one GPU: every rank's 125M build rows are packed into its 0.75-GB region (18-bit plan: 262144 final partitions, 6 wire bytes
+    per key), then every rank joins its own 1.25B probe rows against the 8 regions in 4 ranges.  The ranks' counts add up to the
+    closed-form count of the whole join."""
+    import torch
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.distributed import HipEngine
+    world, nb_rank, np_rank, pieces = 8, 125_000_000, 1_250_000_000, 4
+    nb_total = nb_rank * world
+    eng = HipEngine("cuda:0")
+    assert eng.bcast_plan(nb_total) == (18, 262144, 2)
+    rb = eng.bcast_region_bytes(nb_total, nb_rank)
+    assert 6.0 < rb / nb_rank < 6.02
+    base = torch.empty(rb * world, dtype=torch.uint8, device="cuda:0")
+    offs = [r * rb for r in range(world)]
+    empty = torch.empty(16, dtype=torch.int64, device="cuda:0")[:0]
+    for r in range(world):
+        bk, _ = datagen.build_device(nb_rank, "cuda:0", first=r * nb_rank)
+        eng.bcast_pack(bk, nb_total, base[offs[r]: offs[r] + rb], pieces)
+        b = eng.bcast_pack_bounds(pieces)
+        assert b[-1] == nb_rank and all(abs(b[q] - nb_rank * q / pieces) < 6 * nb_rank ** 0.5 for q in range(pieces + 1))
+        eng.bcast_probe(empty, nb_total); eng.bcast_finish()
+        del bk
+    total = expected = 0
+    for r in range(world):
+        bk, _ = datagen.build_device(nb_rank, "cuda:0", first=r * nb_rank)
+        pk, e = datagen.probe_device(np_rank, nb_total, "cuda:0", seed=1, hit_bp=5000, first=r * np_rank)
+        expected += e
+        eng.bcast_pack(bk, nb_total, base[offs[r]: offs[r] + rb], pieces)
+        eng.bcast_probe(pk, nb_total)
+        for q in range(pieces):
+            eng.bcast_join(base, offs, [nb_rank] * world, 262144 * q // pieces, 262144 * (q + 1) // pieces)
+        total += eng.bcast_finish()
+        del bk, pk
+    assert abs(expected - 0.5 * np_rank * world) < 6 * (np_rank * world) ** 0.5
+    assert total == expected, (total, expected)
+
+
 def test_config5_chunk_form_with_the_precheck_every_owner_at_full_size_on_one_gpu(fj):
     """The same full-size emulation (1B x 10B rows, the 8-rank plan: 9 + 9 bits, 262144 final partitions) with the sender-side
     precheck of the chunk form: every owner appends the 8 build shares and exports its 32768 partitions' Bloom filters
