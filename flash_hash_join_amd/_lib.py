@@ -31,7 +31,7 @@ SYMBOLS = [
     "fj_shuffle_part_filter_bytes", "fj_shuffle_part_filter_range", "fj_stream_export_part_filters", "fj_shuffle_pack_filter", "fj_shuffle_pack_kept", "fj_part_filter_sample",
     "fj_bcast_plan", "fj_bcast_region_bytes", "fj_bcast_piece_span", "fj_bcast_pack", "fj_bcast_pack_bounds", "fj_bcast_probe", "fj_bcast_join", "fj_bcast_finish", "fj_bcast_abort",
     "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_from_transport", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
-    "fj_dist_join_count", "fj_dist_join",
+    "fj_dist_join_count", "fj_dist_join", "fj_dist_comm_set_form", "fj_dist_model",
     "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
     "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h", "fj_memcpy_d2d",
 ]
@@ -60,6 +60,7 @@ class FjDistTimings(ctypes.Structure):
         ("sent_chunks", ctypes.c_uint64),
         ("pieces", ctypes.c_int), ("nranks", ctypes.c_int), ("fan_log0", ctypes.c_int), ("wire_chunk_bytes", ctypes.c_int),
         ("prefilter", ctypes.c_int), ("prefilter_sampled", ctypes.c_double), ("probe_rows_kept", ctypes.c_uint64), ("filter_bytes", ctypes.c_uint64),
+        ("form", ctypes.c_int), ("form_reserved", ctypes.c_int), ("wire_bytes_sent", ctypes.c_uint64),
         ("local", FjTimings),
     ]
 
@@ -91,13 +92,23 @@ EngFilterRangeFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint64, ctypes.c
 EngExportFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp)
 EngPackFilterFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _pu64)
 EngSampleFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp, ctypes.c_uint64, ctypes.c_int, _pu64)
+_u64c, _pu32 = ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)
+EngBcRegionFn = ctypes.CFUNCTYPE(ctypes.c_uint64, _vp, _u64c, _u64c)
+EngBcSpanFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _u64c, _u64c, _u64c, _u64c, ctypes.c_int, _pu64, _pu64)
+EngBcNpartsFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _u64c, _pu32)
+EngBcPackFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _u64c, _u64c, _vp, ctypes.c_int, _pu64)
+EngBcProbeFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _u64c, _u64c)
+EngBcJoinFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_int, _pu64, _pu64, ctypes.c_uint32, ctypes.c_uint32)
+EngBcFinishFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pu64)
 
 
 class FjDistEngineOps(ctypes.Structure):
     _fields_ = [("user", _vp), ("chunk_bytes", ctypes.c_size_t), ("error", EngErrorFn), ("plan", EngPlanFn), ("alloc", EngAllocFn),
                 ("release", EngReleaseFn), ("pack_begin", EngPackBeginFn), ("pack_counts", EngPackCountsFn), ("pack_finish", EngPackFinishFn),
                 ("open", EngOpenFn), ("append", EngAppendFn), ("finish", EngFinishFn), ("abort", EngAbortFn),
-                ("filter_range", EngFilterRangeFn), ("export_filters", EngExportFn), ("pack_filter", EngPackFilterFn), ("sample", EngSampleFn)]
+                ("filter_range", EngFilterRangeFn), ("export_filters", EngExportFn), ("pack_filter", EngPackFilterFn), ("sample", EngSampleFn),
+                ("bc_region_bytes", EngBcRegionFn), ("bc_span", EngBcSpanFn), ("bc_nparts", EngBcNpartsFn), ("bc_pack", EngBcPackFn),
+                ("bc_probe", EngBcProbeFn), ("bc_join", EngBcJoinFn), ("bc_finish", EngBcFinishFn)]
 
 
 def build_native(force: bool = False) -> str:
@@ -199,6 +210,9 @@ def load() -> ctypes.CDLL:
     L.fj_bcast_join.restype = i32; L.fj_bcast_join.argtypes = [vp, vp, i32, pu64, pu64, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.fj_bcast_finish.restype = i32; L.fj_bcast_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
     L.fj_bcast_abort.restype = None; L.fj_bcast_abort.argtypes = [vp]
+    pdbl = ctypes.POINTER(ctypes.c_double)
+    L.fj_dist_model.restype = i32; L.fj_dist_model.argtypes = [i32, u64, u64, u64, u64, u64, ctypes.c_double, pdbl, pdbl]
+    L.fj_dist_comm_set_form.restype = i32; L.fj_dist_comm_set_form.argtypes = [vp, i32, ctypes.c_double]
     L.fj_dist_join_count.restype = i32; L.fj_dist_join_count.argtypes = [vp, vp, sz, vp, sz, i32, vp, pu64, ctypes.POINTER(FjDistTimings)]
     L.fj_dist_join.restype = i32; L.fj_dist_join.argtypes = [vp, vp, vp, sz, vp, sz, i32, i32, ctypes.c_double, vp, pu64, pu64, ctypes.POINTER(FjDistTimings)]
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]

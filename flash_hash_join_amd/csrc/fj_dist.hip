@@ -133,6 +133,17 @@ struct Engine {
     virtual void abort() = 0;
     virtual int drain() = 0;                                                    // everything this engine enqueued has finished
     virtual void reserve(bool) {}                                               // leave room for the transport's own kernels (HIP engine over RCCL)
+    // ---- build-broadcast form (csrc/fj_bcast.hip) ----
+    virtual bool has_bcast() const { return false; }
+    virtual size_t bc_region_bytes(size_t, size_t) { return 0; }               // 0: no such plan
+    virtual int bc_span(size_t, size_t, size_t, size_t, int, size_t*, size_t*) { return derr("fj_dist: this engine has no build-broadcast form"); }
+    virtual int bc_nparts(size_t, uint32_t*) { return derr("fj_dist: this engine has no build-broadcast form"); }
+    virtual int bc_pack(const void*, size_t, size_t, void*, int, Token*) { return derr("fj_dist: this engine has no build-broadcast form"); }   // asynchronous
+    virtual int bc_bounds(int, unsigned long long*) { return derr("fj_dist: this engine has no build-broadcast form"); }                      // blocks
+    virtual int bc_probe(const void*, size_t, size_t) { return derr("fj_dist: this engine has no build-broadcast form"); }
+    virtual int bc_join(const void*, int, const uint64_t*, const uint64_t*, uint32_t, uint32_t, Token) { return derr("fj_dist: this engine has no build-broadcast form"); }
+    virtual int bc_finish(uint64_t*, fj_timings*) { return derr("fj_dist: this engine has no build-broadcast form"); }
+    virtual void bc_abort() {}
 };
 
 struct HipEngine : Engine {
@@ -208,6 +219,24 @@ struct HipEngine : Engine {
         static const unsigned n = getenv("FJ_DIST_RESERVE_CUS") ? (unsigned)atoi(getenv("FJ_DIST_RESERVE_CUS")) : 32u;
         fj_ctx_reserve_cus(ctx, on ? n : 0u);
     }
+    bool has_bcast() const override { return true; }
+    size_t bc_region_bytes(size_t nb_total, size_t nkeys) override { return fj_bcast_region_bytes(nb_total, nkeys); }
+    int bc_span(size_t nb_total, size_t nkeys, size_t lo, size_t hi, int part, size_t* off, size_t* bytes) override { return fj_bcast_piece_span(nb_total, nkeys, lo, hi, part, off, bytes); }
+    int bc_nparts(size_t nb_total, uint32_t* n) override { return fj_bcast_plan(nb_total, nullptr, n, nullptr); }
+    int bc_pack(const void* rows, size_t n, size_t nb_total, void* region, int pieces, Token* packed) override {
+        if (fj_bcast_pack(ctx, (const uint64_t*)rows, n, nb_total, region, pieces, js)) return 1;
+        DHIP(hipEventRecord(ev_filt, js));
+        *packed = ev_filt;
+        return 0;
+    }
+    int bc_bounds(int pieces, unsigned long long* b) override { (void)pieces; return fj_bcast_pack_bounds(ctx, (uint64_t*)b); }
+    int bc_probe(const void* rows, size_t n, size_t nb_total) override { return fj_bcast_probe(ctx, (const uint64_t*)rows, n, nb_total, js); }
+    int bc_join(const void* base, int nsrc, const uint64_t* off, const uint64_t* nk, uint32_t lo, uint32_t hi, Token after) override {
+        if (after) DHIP(hipStreamWaitEvent(js, (hipEvent_t)after, 0));
+        return fj_bcast_join(ctx, base, nsrc, off, nk, lo, hi, js);
+    }
+    int bc_finish(uint64_t* count, fj_timings* lt) override { return fj_bcast_finish(ctx, js, count, lt); }
+    void bc_abort() override { fj_bcast_abort(ctx); }
 };
 
 struct CallbackEngine : Engine {                             // a caller's stand-in (tests): everything is synchronous, tokens are null
@@ -248,6 +277,27 @@ struct CallbackEngine : Engine {                             // a caller's stand
     int finish(uint64_t* count, fj_timings* lt) override { memset(lt, 0, sizeof *lt); return o.finish(o.user, count) ? fail("finish") : 0; }
     void abort() override { if (o.abort) o.abort(o.user); }
     int drain() override { return 0; }
+    bool has_bcast() const override { return o.bc_region_bytes && o.bc_span && o.bc_nparts && o.bc_pack && o.bc_probe && o.bc_join && o.bc_finish; }
+    size_t bc_region_bytes(size_t nb_total, size_t nkeys) override { return has_bcast() ? (size_t)o.bc_region_bytes(o.user, nb_total, nkeys) : 0; }
+    int bc_span(size_t nb_total, size_t nkeys, size_t lo, size_t hi, int part, size_t* off, size_t* bytes) override {
+        uint64_t a = 0, b = 0;
+        if (o.bc_span(o.user, nb_total, nkeys, lo, hi, part, &a, &b)) return fail("bc_span");
+        *off = a; *bytes = b;
+        return 0;
+    }
+    int bc_nparts(size_t nb_total, uint32_t* n) override { return o.bc_nparts(o.user, nb_total, n) ? fail("bc_nparts") : 0; }
+    std::vector<uint64_t> bounds_;
+    int bc_pack(const void* rows, size_t n, size_t nb_total, void* region, int pieces, Token* packed) override {
+        bounds_.assign((size_t)pieces + 1, 0);
+        *packed = nullptr;
+        return o.bc_pack(o.user, rows, n, nb_total, region, pieces, bounds_.data()) ? fail("bc_pack") : 0;
+    }
+    int bc_bounds(int pieces, unsigned long long* b) override { for (int q = 0; q <= pieces; ++q) b[q] = bounds_[q]; return 0; }
+    int bc_probe(const void* rows, size_t n, size_t nb_total) override { return o.bc_probe(o.user, rows, n, nb_total) ? fail("bc_probe") : 0; }
+    int bc_join(const void* base, int nsrc, const uint64_t* off, const uint64_t* nk, uint32_t lo, uint32_t hi, Token) override {
+        return o.bc_join(o.user, base, nsrc, off, nk, lo, hi) ? fail("bc_join") : 0;
+    }
+    int bc_finish(uint64_t* count, fj_timings* lt) override { memset(lt, 0, sizeof *lt); return o.bc_finish(o.user, count) ? fail("bc_finish") : 0; }
 };
 
 // ---- Net: what moves between ranks --------------------------------------------------------------------------------------
@@ -386,6 +436,8 @@ struct fj_dist_comm {
     DBuf pool_k[2], pool_d[2], pool_v;                      // send pools (alternating per piece; values: the build piece only)
     DBuf recv_k[MAX_PIECES + 1], recv_d[MAX_PIECES + 1], recv_v;   // what arrives: [0] build side, [1 + c] probe piece c
     DBuf filt;                                              // every final partition's Bloom filter (sender-side precheck)
+    DBuf bcast;                                             // build-broadcast form: the regions of all ranks, rank after rank
+    int form = FJ_DIST_FORM_AUTO; double link_rate = 0.0;   // fj_dist_comm_set_form
     int grow(DBuf& b, size_t bytes) {
         if (bytes == 0) bytes = 16;
         if (b.bytes >= bytes) return 0;
@@ -399,9 +451,117 @@ struct fj_dist_comm {
     void free_all() {
         for (auto* arr : {pool_k, pool_d}) for (int i = 0; i < 2; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
         for (auto* arr : {recv_k, recv_d}) for (int i = 0; i <= MAX_PIECES; ++i) if (arr[i].p) { eng->release(arr[i].p); arr[i] = DBuf(); }
-        for (DBuf* b : {&pool_v, &recv_v, &filt}) if (b->p) { eng->release(b->p); *b = DBuf(); }
+        for (DBuf* b : {&pool_v, &recv_v, &filt, &bcast}) if (b->p) { eng->release(b->p); *b = DBuf(); }
     }
 };
+
+// ---- the step in its BUILD-BROADCAST form ----------------------------------------------------------------------------------------
+// The probe rows never move.  Every rank packs its build rows into its region (fj_bcast_pack: both passes of the plan for the
+// TOTAL build side, then one run per final partition, 6 bytes per key), queues both passes over its own probe rows behind that,
+// and - while those run - learns where the pieces of its region (consecutive partitions) begin, tells the others, and sends every
+// piece to every peer (grouped send / recv: one link per peer on an xGMI mesh).  The join of partition range q against the runs of
+// ALL ranks is queued behind piece q's arrival.  One blocking point per step (the bounds), two small control collectives, one
+// agreement on the buffers; a rank-local failure is agreed on like in the shuffle form.
+static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
+                           const std::vector<uint64_t>& nb_of, unsigned long long nb_total, uint64_t* out_global_count, uint64_t* out_local_count,
+                           fj_dist_timings* timings) {
+    Net& net = *dc->net; Engine& eng = *dc->eng;
+    const int N = net.nranks, me = net.rank;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    uint32_t nparts = 0;
+    if (eng.bc_nparts(nb_total, &nparts)) return 1;
+    if ((uint32_t)pieces > nparts) pieces = (int)nparts;
+    std::vector<uint64_t> roff(N + 1, 0);
+    for (int r = 0; r < N; ++r) roff[r + 1] = roff[r] + ((eng.bc_region_bytes(nb_total, (size_t)nb_of[r]) + 255) & ~(size_t)255);
+    net.begin_step();
+    const bool reserve = net.shares_the_gpu() && (N > 1 || getenv("FJ_DIST_RESERVE_ALWAYS"));
+    struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(false); } } reserve_guard{eng, reserve};
+    if (reserve) eng.reserve(true);
+    bool begun = false;
+    auto bail = [&](const std::string& why) { (void)net.drain(); (void)eng.drain(); if (begun) eng.bc_abort(); return derr("%s", why.c_str()); };
+
+    // buffers, agreed on
+    unsigned long long bad = dc->grow(dc->bcast, (size_t)roff[N]) ? 1 : 0;
+    const std::string why0 = bad ? fj_last_error() : "";
+    const bool mine_bad = bad != 0;
+    if (net.all_reduce(&bad, 1)) return 1;
+    if (bad) { char b[1200]; snprintf(b, sizeof b, "fj_dist_join_count: the broadcast buffer could not be allocated on %llu rank(s)%s%s", bad, mine_bad ? "; this rank: " : "", why0.c_str()); return derr("%s", b); }
+    char* base = (char*)dc->bcast.p;
+
+    // pack + probe passes queued; the host then waits for the pack's bounds only
+    Token packed = nullptr;
+    bool ok = eng.bc_pack(d_build_keys, nb, nb_total, base + roff[me], pieces, &packed) == 0;
+    begun = ok;
+    std::string why = ok ? "" : fj_last_error();
+    if (ok && eng.bc_probe(d_probe_keys, np, nb_total)) { ok = false; why = fj_last_error(); }
+    const auto tb = std::chrono::steady_clock::now();
+    std::vector<unsigned long long> v((size_t)pieces + 2, 0), all((size_t)N * (pieces + 2));
+    if (ok && eng.bc_bounds(pieces, v.data())) { ok = false; why = fj_last_error(); }
+    const double split_ms = ms_since(tb);
+    v[pieces + 1] = ok ? 0 : FAIL;
+    if (net.all_gather(v.data(), pieces + 2, all.data())) return bail(fj_last_error());
+    int nfail = 0;
+    for (int r = 0; r < N; ++r) if (all[(size_t)r * (pieces + 2) + pieces + 1] >= FAIL) ++nfail;
+    if (nfail) { char b[1200]; snprintf(b, sizeof b, "fj_dist_join_count: packing the build side failed on %d rank(s)%s%s", nfail, ok ? "" : "; this rank: ", why.c_str()); return bail(b); }
+    auto bound = [&](int r, int q) { return (size_t)all[(size_t)r * (pieces + 2) + q]; };
+
+    // piece q of every region to every peer; the join of range q behind its arrival
+    std::string failed;
+    auto guarded = [&](int rc) { if (rc && failed.empty()) failed = fj_last_error(); return rc; };
+    size_t wire_sent = 0;
+    std::vector<const void*> sp(3 * N); std::vector<void*> rp(3 * N); std::vector<size_t> sb(3 * N), rb(3 * N);
+    for (int q = 0; q < pieces; ++q) {
+        std::fill(sp.begin(), sp.end(), nullptr); std::fill(rp.begin(), rp.end(), nullptr); std::fill(sb.begin(), sb.end(), 0); std::fill(rb.begin(), rb.end(), 0);
+        size_t largest = 0;
+        bool spans_ok = true;
+        for (int r = 0; r < N; ++r) {
+            if (r == me) continue;
+            for (int part = q == 0 ? 0 : 1; part < 3; ++part) {
+                size_t off = 0, bytes = 0;
+                spans_ok = spans_ok && eng.bc_span(nb_total, (size_t)nb_of[me], bound(me, q), bound(me, q + 1), part, &off, &bytes) == 0;     // what I send to r
+                sp[part * N + r] = base + roff[me] + off; sb[part * N + r] = bytes; wire_sent += bytes;
+                largest = std::max(largest, bytes);
+                spans_ok = spans_ok && eng.bc_span(nb_total, (size_t)nb_of[r], bound(r, q), bound(r, q + 1), part, &off, &bytes) == 0;       // what r sends to me
+                rp[part * N + r] = base + roff[r] + off; rb[part * N + r] = bytes;
+                largest = std::max(largest, bytes);
+            }
+        }
+        if (!spans_ok) return bail(fj_last_error());               // (same arguments on every rank: everybody bails)
+        // `largest` must be the same on both ends of every message: the largest piece of ANY region
+        for (int r = 0; r < N; ++r) for (int part = 0; part < 3; ++part) {
+            size_t off = 0, bytes = 0;
+            if (eng.bc_span(nb_total, (size_t)nb_of[r], bound(r, q), bound(r, q + 1), part, &off, &bytes) == 0) largest = std::max(largest, bytes);
+        }
+        Token done = nullptr;
+        if (net.exchange(3, sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, q)) return bail(fj_last_error());
+        if (failed.empty()) {
+            const uint32_t plo = (uint32_t)(((uint64_t)nparts * q) / pieces), phi = (uint32_t)(((uint64_t)nparts * (q + 1)) / pieces);
+            guarded(eng.bc_join(base, N, roff.data(), nb_of.data(), plo, phi, done ? done : packed));
+        }
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    uint64_t local = 0;
+    fj_timings lt; memset(&lt, 0, sizeof lt);
+    if (failed.empty()) { guarded(eng.bc_finish(&local, &lt)); if (failed.empty()) begun = false; }
+    if (!failed.empty()) { local = 0; if (begun) eng.bc_abort(); begun = false; }
+    unsigned long long res[2] = {local, failed.empty() ? 0ull : 1ull};
+    if (net.all_reduce(res, 2)) return bail(fj_last_error());
+    if (net.drain() || eng.drain()) return 1;
+    if (res[1]) return derr("fj_dist_join_count: the local join failed on %llu rank(s)%s%s", res[1], failed.empty() ? "" : "; this rank: ", failed.c_str());
+    if (out_global_count) *out_global_count = res[0];
+    if (out_local_count) *out_local_count = local;
+    if (timings) {
+        memset(timings, 0, sizeof *timings);
+        timings->total_ms = ms_since(t0); timings->split_ms = split_ms; timings->join_ms = ms_since(t2);
+        timings->exchange_ms = std::max(0.0, timings->total_ms - timings->join_ms - split_ms);
+        timings->local_count = local; timings->pieces = pieces; timings->nranks = N; timings->local = lt;
+        timings->form = FJ_DIST_FORM_BROADCAST; timings->wire_bytes_sent = wire_sent; timings->prefilter_sampled = -1.0;
+        timings->probe_rows_kept = np;
+        timings->local_build_chunks = nb_total; timings->local_probe_chunks = np;       // (this form: ROWS this rank joined - every rank's build rows, its own probe rows)
+    }
+    return 0;
+}
 
 extern "C" {
 
@@ -470,6 +630,34 @@ void fj_dist_comm_destroy(fj_dist_comm* dc) {
     delete dc;
 }
 
+// The cost model behind FJ_DIST_FORM_AUTO, as plain arithmetic (also what tools/scale_model.py prints): seconds of one counting step in
+// either form = max(bytes per link / link rate, kernel seconds per rank) + what cannot overlap.  Kernel seconds per row measured on
+// one MI355X at config 5's per-rank sizes (profiles/r05_bcast_one_rank.txt, r04_c5_one_rank_kernel_stats.csv): broadcast - pack 1.65 ms
+// per 125M build rows, two probe-side passes 8.7 ms per 1.25B rows, dense join 7.1 ms per 2.25B rows of both sides, all of it kernels
+// of this rank (the wire overlaps everything behind the pack); shuffle - 13.4 ms of kernels per 1.375B rows of both relations + ~2.5
+// ms of head and tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: nb_max * 6.01).
+int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
+                  double* t_shuffle, double* t_broadcast) {
+    const double rate = link_bytes_per_s > 0 ? link_bytes_per_s : 55e9, N = nranks < 1 ? 1 : nranks;
+    if (region_max == 0) region_max = (uint64_t)((double)nb_max * 6.01) + (1u << 20);
+    const double pack = (double)nb_max * 13.2e-12, passes = (double)np_max * 7.0e-12, join = ((double)nb_total + (double)np_max) * 3.2e-12;
+    const double wire_b = N > 1 ? (double)region_max / rate : 0.0;
+    const double t_b = std::max(wire_b + pack + join / 8.0, pack + passes + join);        // (the last of ~8 partition ranges is joined after the wire is done)
+    const double rows = (double)nb_max + (double)np_max;
+    const double wire_s = N > 1 ? 7.02 * ((double)np_global + (double)nb_total) / (N * N) / rate : 0.0;
+    const double t_s = std::max(wire_s, rows * 9.75e-12) + 2.5e-3 * rows / 1.375e9;
+    if (t_shuffle) *t_shuffle = t_s;
+    if (t_broadcast) *t_broadcast = t_b;
+    return t_b < t_s ? FJ_DIST_FORM_BROADCAST : FJ_DIST_FORM_SHUFFLE;
+}
+
+int fj_dist_comm_set_form(fj_dist_comm* dc, int form, double link_bytes_per_s) {
+    if (!dc) return derr("fj_dist_comm_set_form: null communicator");
+    if (form != FJ_DIST_FORM_AUTO && form != FJ_DIST_FORM_SHUFFLE && form != FJ_DIST_FORM_BROADCAST) return derr("fj_dist_comm_set_form: unknown form %d", form);
+    dc->form = form; dc->link_rate = link_bytes_per_s;
+    return 0;
+}
+
 int fj_dist_comm_rank(const fj_dist_comm* dc) { return dc ? dc->net->rank : -1; }
 int fj_dist_comm_size(const fj_dist_comm* dc) { return dc ? dc->net->nranks : 0; }
 
@@ -498,18 +686,40 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     auto mark = [&](const char* what) { if (trace) marks.emplace_back(what, ms_since(t0)); };
 
     // relation sizes of every rank: one plan for everybody
-    std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 3));
-    // (... and one precheck threshold: rank 0's - whether the filters are exchanged at all must not depend on the rank)
+    std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 20));
+    // (... and one precheck threshold, one form, one link rate, one piece count: rank 0's - what is exchanged, and in how many rounds,
+    //  must not depend on the rank)
     {
         const double pb = prefilter_below > 0 ? std::min(prefilter_below, 4.0) : 0.0;
-        const unsigned long long v[3] = {nb, np, (unsigned long long)(pb * 1e9)};
-        if (net.all_gather(v, 3, m.data())) return 1;
+        const unsigned long long v[5] = {nb, np, (unsigned long long)(pb * 1e9), (unsigned long long)dc->form | ((unsigned long long)pieces << 8),
+                                         (unsigned long long)(dc->link_rate > 0 ? dc->link_rate : 0.0)};
+        if (net.all_gather(v, 5, m.data())) return 1;
     }
-    unsigned long long nb_total = 0, np_global = 0, np_min = ~0ull;
-    for (int r = 0; r < N; ++r) { nb_total += m[3 * r]; np_global += m[3 * r + 1]; np_min = std::min(np_min, m[3 * r + 1]); }
+    unsigned long long nb_total = 0, np_global = 0, np_min = ~0ull, nb_max = 0, np_max = 0;
+    std::vector<uint64_t> nb_of(N);
+    for (int r = 0; r < N; ++r) {
+        nb_of[r] = m[5 * r]; nb_total += m[5 * r]; np_global += m[5 * r + 1]; np_min = std::min(np_min, m[5 * r + 1]);
+        nb_max = std::max(nb_max, m[5 * r]); np_max = std::max(np_max, m[5 * r + 1]);
+    }
     prefilter_below = (double)m[2] * 1e-9;
+    pieces = (int)(m[3] >> 8);
+    if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: rank 0 asks for %d pieces (1..%d)", pieces, MAX_PIECES);
+    const int form_req = (int)(m[3] & 0xFF);
+    const double link_rate = m[4] > 0 ? (double)m[4] : 55e9;
     const bool want_pf = prefilter_below > 0;
     if (want_pf && !eng.has_precheck()) return derr("fj_dist_join: this engine has no sender-side precheck");
+    // ---- which form (same inputs, hence the same verdict, on every rank) ----
+    if (!mat && !want_pf && form_req != FJ_DIST_FORM_SHUFFLE) {
+        bool can = eng.has_bcast() && N <= (int)FJ_WIDE_MAXSRC && nb_total > 0;
+        size_t region_max = 0;
+        for (int r = 0; can && r < N; ++r) { const size_t b = eng.bc_region_bytes(nb_total, (size_t)nb_of[r]); can = b != 0; region_max = std::max(region_max, b); }
+        bool bcast = can && form_req == FJ_DIST_FORM_BROADCAST;
+        if (can && form_req == FJ_DIST_FORM_AUTO && N > 1)
+            bcast = fj_dist_model(N, nb_max, np_max, nb_total, np_global, region_max, link_rate, nullptr, nullptr) == FJ_DIST_FORM_BROADCAST;
+        if (form_req == FJ_DIST_FORM_BROADCAST && !can)
+            return derr("fj_dist_join_count: the build-broadcast form needs an engine that has it, <= %u ranks and a total build side with a partitioned plan (%llu rows)", FJ_WIDE_MAXSRC, nb_total);
+        if (bcast) return dist_join_bcast(dc, d_build_keys, nb, d_probe_keys, np, pieces, nb_of, nb_total, out_global_count, out_local_count, timings);
+    }
     size_t CB = 0;
     if (eng.plan(nb_total, N, &CB)) return 1;                 // (same verdict on every rank: same arguments)
     if (np_min < 2ull * pieces) pieces = 1;
@@ -704,6 +914,7 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
         timings->local_count = local; timings->local_build_chunks = B.chunks; timings->local_probe_chunks = rows_recv_chunks;
         timings->pieces = pieces; timings->nranks = N; timings->fan_log0 = 0; timings->local = lt;
         timings->wire_chunk_bytes = (int)CB; timings->sent_chunks = sent_chunks;
+        timings->form = FJ_DIST_FORM_SHUFFLE; timings->wire_bytes_sent = (uint64_t)sent_chunks * (CB + 4);
         timings->prefilter = pf ? 1 : 0; timings->prefilter_sampled = sampled; timings->probe_rows_kept = kept_rows; timings->filter_bytes = filter_bytes;
     }
     return 0;

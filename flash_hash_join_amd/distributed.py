@@ -815,13 +815,38 @@ def _engine_ops_struct(ops, keep: list):
         pre = [_lib.EngFilterRangeFn(guard(filter_range)), _lib.EngExportFn(guard(ops.export_filters)), _lib.EngPackFilterFn(guard(pack_filter)),
                _lib.EngSampleFn(guard(sample))]
     cbs["precheck"] = pre
+    # the optional build-broadcast form of a stand-in (all seven methods or none)
+    bc = [_lib.EngBcRegionFn(), _lib.EngBcSpanFn(), _lib.EngBcNpartsFn(), _lib.EngBcPackFn(), _lib.EngBcProbeFn(), _lib.EngBcJoinFn(), _lib.EngBcFinishFn()]
+    if all(hasattr(ops, m) for m in ("bc_region_bytes", "bc_span", "bc_nparts", "bc_pack", "bc_probe", "bc_join", "bc_finish")):
+        def bc_span(nb_total, nkeys, k_lo, k_hi, part, off, nbytes):
+            off[0], nbytes[0] = (int(x) for x in ops.bc_span(nb_total, nkeys, k_lo, k_hi, part))
+
+        def bc_nparts(nb_total, out):
+            out[0] = int(ops.bc_nparts(nb_total))
+
+        def bc_pack(rows, n, nb_total, region, pieces, bounds):
+            for q, b in enumerate(ops.bc_pack(rows, n, nb_total, region, pieces)):
+                bounds[q] = int(b)
+
+        def bc_join(base, nsrc, off, nk, lo, hi):
+            return ops.bc_join(base, [int(off[i]) for i in range(nsrc)], [int(nk[i]) for i in range(nsrc)], lo, hi)
+
+        def bc_finish(out):
+            out[0] = int(ops.bc_finish())
+        bc = [_lib.EngBcRegionFn(guard(lambda nb_total, nkeys: int(ops.bc_region_bytes(nb_total, nkeys)), fail=0)), _lib.EngBcSpanFn(guard(bc_span)),
+              _lib.EngBcNpartsFn(guard(bc_nparts)), _lib.EngBcPackFn(guard(bc_pack)), _lib.EngBcProbeFn(guard(ops.bc_probe)), _lib.EngBcJoinFn(guard(bc_join)),
+              _lib.EngBcFinishFn(guard(bc_finish))]
+    cbs["bcast"] = bc
     keep.append(cbs)
     return _lib.FjDistEngineOps(None, int(ops.chunk_bytes), cbs["error"], cbs["plan"], cbs["alloc"], cbs["release"], cbs["pack_begin"],
-                                cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"], *pre)
+                                cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"], *pre, *bc)
+
+
+FORM_AUTO, FORM_SHUFFLE, FORM_BROADCAST = 0, 1, 2      # include/flashjoin.h: FJ_DIST_FORM_*
 
 
 def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport, build_values=None, return_arrays=False,
-                  prefilter_below: float = 0.0, prefilter_mode: str = "off"):
+                  prefilter_below: float = 0.0, prefilter_mode: str = "off", form: int = FORM_SHUFFLE):
     """The owner shuffle in chunk form through the ONE driver, csrc/fj_dist.hip (fj_dist_join): natively over RCCL under the nccl
     backend; over a callback transport (torch.distributed with host staging: gloo, a transport object) otherwise; with a stand-in
     engine's callbacks in the CPU test-suite.  build_values: a materialising join (the pairs stay with the owner; returned when
@@ -838,7 +863,7 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
     native = (not standin and transport is None and os.environ.get("FJ_DIST_NATIVE", "1") != "0" and dist.get_backend(group) == "nccl")
     if native:
         comm, own = engine.native_comm(dist, group), False
-        form = "chunks (fj_dist_join_count over RCCL)"
+        form_label = "chunks (fj_dist_join_count over RCCL)"
     else:
         tr = _CallbackTransport(dist, group, "host" if standin else "device", None if standin else engine.device)
         ops = _engine_ops_struct(engine.dist_engine_ops(tr.world), keep) if standin else None
@@ -846,8 +871,9 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
         if not comm:
             raise RuntimeError(_lib.last_error())
         own = True
-        form = "chunks (fj_dist_join_count over a callback transport)"
+        form_label = "chunks (fj_dist_join_count over a callback transport)"
     try:
+        _lib.check(L.fj_dist_comm_set_form(comm, int(form), float(_LINK_BYTES_PER_S)))
         if standin:
             rc = L.fj_dist_join(comm, build_keys.data_ptr(), None, build_keys.numel(), probe_keys.data_ptr(), probe_keys.numel(), pieces, 0,
                                 float(prefilter_below), None, ctypes.byref(cnt), ctypes.byref(local), ctypes.byref(dt))
@@ -871,8 +897,14 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
     sec = time.perf_counter() - t0
     if not standin:
         engine.api._last = dt.local
-    if timings is not None:
-        timings.update(strategy="shuffle", shuffle_form=form, split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
+    if timings is not None and int(dt.form) == FORM_BROADCAST:
+        timings.update(strategy="broadcast", shuffle_form="build broadcast (fj_dist_join_count: probe rows stay, dense 6-byte build runs to every peer)",
+                       split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3, join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces),
+                       local_build_rows=int(dt.local_build_chunks), local_probe_rows=probe_keys.numel(), local_count=int(dt.local_count), prefilter=False, prefilter_mode="off",
+                       prefilter_sampled_survivors=None, prefilter_below=0.0, probe_rows_sent=0, filter_bytes_received=0, wire_chunk_bytes=0,
+                       wire_bytes_sent=int(dt.wire_bytes_sent))
+    elif timings is not None:
+        timings.update(strategy="shuffle", shuffle_form=form_label, split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
                        join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces), local_build_rows=int(dt.local_build_chunks) * 256,
                        local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=bool(dt.prefilter), prefilter_mode=prefilter_mode,
                        prefilter_sampled_survivors=(float(dt.prefilter_sampled) if dt.prefilter_sampled >= 0 else None), prefilter_below=float(prefilter_below),
@@ -930,6 +962,15 @@ def strategy_costs(world: int, nb: int, np_: int, materialize: bool) -> dict:
     return {"shuffle": t_shuffle, "replicate": t_replicate}
 
 
+def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] = None) -> dict:
+    """The C++ driver's cost model for a counting step of `world` ranks holding nb x np_ rows each (fj_dist_model: what
+    FJ_DIST_FORM_AUTO decides with): modelled seconds in either form and the pick."""
+    from . import _lib
+    ts, tb = ctypes.c_double(0), ctypes.c_double(0)
+    f = _lib.load().fj_dist_model(world, nb, np_, nb * world, np_ * world, 0, float(link_bytes_per_s or _LINK_BYTES_PER_S), ctypes.byref(ts), ctypes.byref(tb))
+    return {"shuffle": ts.value, "broadcast": tb.value, "pick": "broadcast" if f == FORM_BROADCAST else "shuffle"}
+
+
 _LINK_MEASURED = False
 
 
@@ -943,17 +984,16 @@ def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
 
 
 def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
-    """'shuffle' (the owner exchange north_star names) or 'replicate', for per-rank relation sizes nb x np_ (the maxima
-    over the ranks).  FJ_DIST_STRATEGY=replicate|shuffle forces one, =auto lets the cost model decide (with the link rate
-    of set_link_rate when one was measured).  Unset: ALWAYS the shuffle - a measured link rate informs the model, it never
-    changes what an unconfigured job runs (round 2 switched silently; a scaling curve must measure what it says)."""
-    forced = os.environ.get("FJ_DIST_STRATEGY", "shuffle")
-    if forced in ("replicate", "shuffle"):
+    """What a multi-rank join runs as, for per-rank relation sizes nb x np_ (the maxima over the ranks):
+      'auto'      (unset FJ_DIST_STRATEGY) counting joins: the C++ driver's per-link / per-rank cost model picks the owner shuffle or the
+                  build broadcast for the step's sizes (csrc/fj_dist.hip: the same verdict on every rank); materialising joins shuffle;
+      'shuffle'   always the owner shuffle (north_star's all-to-all of radix partitions);
+      'broadcast' counting joins in the build-broadcast form (probe rows never move; csrc/fj_bcast.hip), materialising joins shuffle;
+      'replicate' the build KEYS all-gathered unpartitioned (rounds 1-4's alternative; kept for comparison)."""
+    forced = os.environ.get("FJ_DIST_STRATEGY", "auto")
+    if forced in ("replicate", "shuffle", "broadcast", "auto"):
         return forced
-    if world * nb >= (1 << 31):               # replicated build side must stay inside one GPU's chunk directory
-        return "shuffle"
-    c = strategy_costs(world, nb, np_, materialize)
-    return "replicate" if c["replicate"] <= c["shuffle"] else "shuffle"
+    raise ValueError(f"FJ_DIST_STRATEGY={forced!r}: shuffle | broadcast | replicate | auto")
 
 
 def self_check(dist, group, engine, small_inputs, expected_small: int, message_elems: int, transport=None) -> dict:
@@ -1162,6 +1202,26 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
                                 return_arrays, int(os.environ.get("FJ_REPLICATE_PIECES", "4")), timings)
     if timings is not None:
         timings["strategy"] = "shuffle"
+    form = {"auto": FORM_AUTO, "broadcast": FORM_BROADCAST}.get(strategy, FORM_SHUFFLE)
+    if not materialize and form != FORM_SHUFFLE:
+        # counting joins: the driver may take the build-broadcast form (a stand-in engine: when it has that form's callbacks)
+        can = (hasattr(engine, "bcast_plan") and engine.bcast_plan(sum(sizes_b)) is not None) if not hasattr(engine, "dist_engine_ops") else getattr(engine, "has_bcast", False)
+        if not can or world > 16:
+            if strategy == "broadcast" and os.environ.get("FJ_DIST_NO_FALLBACK"):
+                raise RuntimeError("FJ_DIST_STRATEGY=broadcast: this join cannot take the build-broadcast form (engine, > 16 ranks, or a total build side without a partitioned plan)")
+            form = FORM_SHUFFLE
+        elif form == FORM_BROADCAST or not hasattr(engine, "shuffle_plan") or engine.shuffle_plan(sum(sizes_b), world) is None or pieces <= 1:
+            # (forced, or the chunk form of the shuffle is not available for these sizes: nothing for the driver to choose between)
+            try:
+                tt = timings if timings is not None else {}
+                return _driver_count(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, form=FORM_BROADCAST)
+            except RuntimeError as ex:
+                if os.environ.get("FJ_DIST_NO_FALLBACK"):
+                    raise
+                _abort_stream(engine)
+                if timings is not None:
+                    timings["broadcast_form_error"] = str(ex)
+                form = FORM_SHUFFLE
     if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
         standin = hasattr(engine, "dist_engine_ops")
         mode = "off" if not hasattr(engine, "bloom_export") else _prefilter_mode(bloom) if standin else _chunk_prefilter_mode(bloom, world)
@@ -1180,7 +1240,9 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
             for attempt in ((below, mode), (0.0, "off")) if below > 0 else ((0.0, mode),):     # (a failed step with the precheck is retried without it)
                 try:
                     tt = timings if timings is not None else {}
-                    res = _driver_count(dist, group, engine, build_keys, probe_keys, pieces, tt, transport, prefilter_below=attempt[0], prefilter_mode=attempt[1])
+                    # (form AUTO: the driver weighs the build broadcast against the shuffle for these sizes; a precheck asks for the shuffle)
+                    res = _driver_count(dist, group, engine, build_keys, probe_keys, pieces, tt, transport, prefilter_below=attempt[0], prefilter_mode=attempt[1],
+                                        form=form if attempt[0] == 0.0 else FORM_SHUFFLE)
                     _precheck_remember(memo_key, tt, decision)
                     return res
                 except RuntimeError as ex:
@@ -1189,6 +1251,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
                     _abort_stream(engine)
                     if timings is not None:
                         timings["chunk_form_error"] = str(ex)
+                    form = FORM_SHUFFLE                      # (a broadcast step that failed - a skewed partition - is retried as the shuffle)
         if timings is not None:
             timings["shuffle_form"] = "owner-scatter"
         if not standin and hasattr(engine, "bloom_export"):

@@ -333,13 +333,16 @@ typedef struct fj_dist_timings {
     double total_ms, split_ms, exchange_ms, join_ms;   /* host wall clock of this rank: whole step; waiting for the packing passes'
                                                           counts; the rest up to the local join's finish; finish + all-reduce */
     uint64_t local_count;                              /* matches this rank found in what it owns                 */
-    uint64_t local_build_chunks, local_probe_chunks;   /* 256-key wire chunks this rank received (own share included) */
+    uint64_t local_build_chunks, local_probe_chunks;   /* 256-key wire chunks this rank received (own share included); broadcast form: ROWS it joined (all ranks' build rows, its own probe rows) */
     uint64_t sent_chunks;                              /* ... and put on the links (own share excluded)            */
     int pieces, nranks, fan_log0, wire_chunk_bytes;    /* wire_chunk_bytes: 1792 (7 bytes per key) or 2048         */
     int prefilter;                                     /* 1: the sender-side precheck ran                          */
     double prefilter_sampled;                          /* share of the sampled probe rows that passed (-1: no sample) */
     uint64_t probe_rows_kept;                          /* probe rows of this rank that went into wire chunks       */
     uint64_t filter_bytes;                             /* bytes of partition filters this rank received            */
+    int form;                                          /* FJ_DIST_FORM_SHUFFLE or FJ_DIST_FORM_BROADCAST: what the step ran as */
+    int form_reserved;
+    uint64_t wire_bytes_sent;                          /* bytes this rank put on the links (all peers)             */
     fj_timings local;                                  /* device timings of this rank's local join (fj_stream_finish) */
 } fj_dist_timings;
 typedef struct fj_dist_transport {
@@ -374,7 +377,33 @@ typedef struct fj_dist_engine_ops {   /* a stand-in for the rank's own work (the
     int (*export_filters)(void* user, void* dst);
     int (*pack_filter)(void* user, const void* filters, uint64_t* kept);
     int (*sample)(void* user, const void* rows, uint64_t n, uint64_t stride, const void* filters, uint64_t nb_total, int nranks, uint64_t* kept);
+    /* optional, all seven or none (NULL: the stand-in has no build-broadcast form): what fj_bcast_region_bytes / fj_bcast_piece_span /
+     * fj_bcast_plan (final partitions) / fj_bcast_pack + fj_bcast_pack_bounds (synchronous: bounds[pieces + 1]) / fj_bcast_probe /
+     * fj_bcast_join / fj_bcast_finish do */
+    uint64_t (*bc_region_bytes)(void* user, uint64_t nb_total, uint64_t nkeys);
+    int (*bc_span)(void* user, uint64_t nb_total, uint64_t nkeys, uint64_t k_lo, uint64_t k_hi, int part, uint64_t* offset, uint64_t* bytes);
+    int (*bc_nparts)(void* user, uint64_t nb_total, uint32_t* nparts);
+    int (*bc_pack)(void* user, const void* rows, uint64_t n, uint64_t nb_total, void* region, int pieces, uint64_t* bounds);
+    int (*bc_probe)(void* user, const void* rows, uint64_t n, uint64_t nb_total);
+    int (*bc_join)(void* user, const void* base, int nsrc, const uint64_t* region_off, const uint64_t* nkeys, uint32_t part_lo, uint32_t part_hi);
+    int (*bc_finish)(void* user, uint64_t* count);
 } fj_dist_engine_ops;
+/* The form a counting step takes (rank 0's setting is used on every rank):
+ *   FJ_DIST_FORM_SHUFFLE   - the owner shuffle in chunk form: every row of both relations travels to the owner of its first radix
+ *                            digit, 7 bytes per key;
+ *   FJ_DIST_FORM_BROADCAST - the build broadcast (fj_bcast_* above): the probe rows stay, every rank's build rows travel to every
+ *                            peer, 6 bytes per key; up to 16 ranks, counting joins;
+ *   FJ_DIST_FORM_AUTO      - (default) whichever a per-link / per-rank cost model puts ahead for the step's sizes: bytes per link
+ *                            over link_bytes_per_s (<= 0: 55e9) against the kernel time per rank measured on one MI355X
+ *                            (profiles/r05_scale_model.txt).  Probe-heavy joins (BASELINE configs[4]: 10 probe rows per build row)
+ *                            broadcast at every N <= 16; build-heavy ones shuffle. */
+#define FJ_DIST_FORM_AUTO 0
+#define FJ_DIST_FORM_SHUFFLE 1
+#define FJ_DIST_FORM_BROADCAST 2
+int fj_dist_comm_set_form(fj_dist_comm* comm, int form, double link_bytes_per_s);
+/* the model behind FJ_DIST_FORM_AUTO: modelled seconds of one counting step in either form (NULL: not wanted); returns the form it picks */
+int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
+                  double* t_shuffle, double* t_broadcast);
 int fj_dist_unique_id(char* out128);
 fj_dist_comm* fj_dist_comm_create(fj_ctx* ctx, const char* unique_id128, int nranks, int rank);
 fj_dist_comm* fj_dist_comm_from_nccl(fj_ctx* ctx, void* nccl_comm);

@@ -204,38 +204,31 @@ def test_dispatch_options_round_trip(lib):
 
 
 def test_multi_gpu_strategy_model():
-    """The exchange-strategy choice is pure host arithmetic: probe-heavy joins replicate the build side on small meshes,
-    balanced joins and large meshes shuffle; the environment override wins; the plan mirror matches the native planner's
+    """What a multi-rank join runs as is pure host arithmetic: the environment names a strategy, or (unset: "auto") the C++ driver's
+    cost model weighs the owner shuffle against the build broadcast for a counting step's sizes (fj_dist_model: the same verdict on
+    every rank) - probe-heavy joins broadcast the build side, balanced ones shuffle; the plan mirror matches the native planner's
     documented break points."""
     from flash_hash_join_amd import distributed as D
     os.environ.pop("FJ_DIST_STRATEGY", None)
-    for world in (2, 4, 8, 16):
-        assert D.choose_strategy(world, 100_000_000, 1_000_000_000, False) == "shuffle"      # the default is the owner shuffle
-    os.environ["FJ_DIST_STRATEGY"] = "auto"                                                  # the model decides
-    for world in (2, 4, 8):
-        assert D.choose_strategy(world, 100_000_000, 1_000_000_000, False) == "replicate"
-    assert D.choose_strategy(16, 100_000_000, 1_000_000_000, False) == "shuffle"
-    assert D.choose_strategy(8, 100_000_000, 100_000_000, False) == "shuffle"
-    assert D.choose_strategy(8, 400_000_000, 4_000_000_000, False) == "shuffle"        # 3.2e9 replicated rows: past one GPU's directory
-    c = D.strategy_costs(2, 100_000_000, 1_000_000_000, False)
-    assert c["shuffle"] > 3 * c["replicate"]                                           # one xGMI link between two GPUs
+    assert D.choose_strategy(8, 100_000_000, 1_000_000_000, False) == "auto"
+    for forced in ("shuffle", "broadcast", "replicate", "auto"):
+        os.environ["FJ_DIST_STRATEGY"] = forced
+        assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == forced
+    os.environ["FJ_DIST_STRATEGY"] = "bogus"
+    with pytest.raises(ValueError):
+        D.choose_strategy(2, 1, 1, False)
     os.environ.pop("FJ_DIST_STRATEGY")
-    old = D._LINK_BYTES_PER_S
-    D.set_link_rate(45e9)                                                                    # a MEASURED link rate informs the model ...
-    try:
-        assert D.choose_strategy(2, 125_000_000, 1_250_000_000, False) == "shuffle"          # ... but never changes what an unconfigured job runs
-        os.environ["FJ_DIST_STRATEGY"] = "auto"
-        assert D.choose_strategy(2, 125_000_000, 1_250_000_000, False) == "replicate"        # one link would carry half of everything
-        D.set_link_rate(400e9)
-        assert D.choose_strategy(8, 100_000_000, 1_000_000_000, False) == "shuffle"
-    finally:
-        os.environ.pop("FJ_DIST_STRATEGY", None)
-        D.set_link_rate(old, measured=False)
-    os.environ["FJ_DIST_STRATEGY"] = "replicate"
-    try:
-        assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == "replicate"
-    finally:
-        os.environ.pop("FJ_DIST_STRATEGY")
+    # BASELINE configs[4]'s per-rank sizes: every link carries 0.75 GB (broadcast) against 9.7 / 2.4 / 1.2 GB (shuffle at N = 2 / 4 / 8)
+    for world in (2, 4, 8):
+        for rate in (45e9, 55e9, 65e9):
+            m = D.form_model(world, 125_000_000, 1_250_000_000, rate)
+            assert m["pick"] == "broadcast" and m["broadcast"] < 0.02 and m["shuffle"] > 0.02, (world, rate, m)
+    m = D.form_model(8, 125_000_000, 1_250_000_000, 55e9)
+    assert 0.0165 < m["broadcast"] < 0.0185 and 0.023 < m["shuffle"] < 0.026, m           # kernel-bound at ~17.5 ms against a wire-bound ~24.4 ms
+    assert D.form_model(8, 500_000_000, 500_000_000, 55e9)["pick"] == "shuffle"          # as many build rows as probe rows: the regions outweigh the rows
+    assert D.form_model(8, 125_000_000, 1_250_000_000, 4000e9)["pick"] == "shuffle"      # links as fast as HBM: the form with fewer kernels
+    c = D.strategy_costs(2, 100_000_000, 1_000_000_000, False)
+    assert c["shuffle"] > 3 * c["replicate"]                                           # (rounds 1-4's model of the unpartitioned replicate)
     # passes: none up to 3950 rows (one cuckoo table), one up to 9 radix bits (512 buckets), two up to 18 bits,
     # then three; a build side just under 4096 * 2^k takes one more bit where that costs no extra pass
     assert [D._plan_passes(n) for n in (1, 3950, 3951, 4096, 4097, 1 << 20, (1 << 20) + 1, 2_000_000, 2_100_000, 100_000_000,

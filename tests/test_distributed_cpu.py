@@ -88,6 +88,8 @@ class OracleEngine:
     def chunk_precheck(self):                    # the stand-in's sender-side precheck in chunk form (its optional engine callbacks): opt-in per test
         return os.environ.get("FJ_TEST_CHUNK_PRECHECK") == "1"
 
+    has_bcast = True                             # the stand-in's engine callbacks include the build-broadcast form
+
     def shuffle_plan(self, nb_total, world):
         return 5 if nb_total >= 10000 and world <= 32 else None
 
@@ -220,6 +222,61 @@ class _StandInOps:
     def abort(self):
         self.chunks = None
 
+    # ---- the optional build-broadcast callbacks: 64 "final partitions" (6 bits of the mixed key); a region = offset table u32[65]
+    # (272 bytes with padding) + the rank's keys sorted by partition as whole 8-byte words; no third part ----
+    BC_PARTS, BC_HDR = 64, 272
+
+    def _bc_part(self, k):
+        return (_fmix64(k.copy()) >> np.uint64(58)).astype(np.int64)
+
+    def bc_region_bytes(self, nb_total, nkeys):
+        return self.BC_HDR + 8 * nkeys + 16 if nb_total >= 5000 else 0
+
+    def bc_span(self, nb_total, nkeys, k_lo, k_hi, part):
+        assert 0 <= k_lo <= k_hi <= nkeys
+        return {0: (0, 4 * (self.BC_PARTS + 1)), 1: (self.BC_HDR + 8 * k_lo, 8 * (k_hi - k_lo)), 2: (0, 0)}[part]
+
+    def bc_nparts(self, nb_total):
+        return self.BC_PARTS
+
+    def bc_pack(self, rows, n, nb_total, region, pieces):
+        if self.fail == "bcpack":
+            raise RuntimeError("injected packing failure")
+        k = self._view(rows, n, np.uint64).copy()
+        p = self._bc_part(k)
+        order = np.argsort(p, kind="stable")
+        offs = np.zeros(self.BC_PARTS + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum(np.bincount(p, minlength=self.BC_PARTS))
+        self._view(region, self.BC_PARTS + 1, np.uint32)[:] = offs
+        if n:
+            self._view(region + self.BC_HDR, n, np.uint64)[:] = k[order]
+        self.bc_probe_rows, self.bc_count = None, 0
+        return [int(offs[self.BC_PARTS * q // pieces]) for q in range(pieces + 1)]
+
+    def bc_probe(self, rows, n, nb_total):
+        k = self._view(rows, n, np.uint64).copy()
+        self.bc_probe_rows = (k, self._bc_part(k))
+
+    def bc_join(self, base, region_off, nkeys, part_lo, part_hi):
+        if self.fail == "bcjoin" and part_lo > 0:
+            raise RuntimeError("injected join failure")
+        assert len(region_off) == self.world and self.bc_probe_rows is not None
+        build = []
+        for off, n in zip(region_off, nkeys):
+            offs = self._view(base + off, self.BC_PARTS + 1, np.uint32)
+            assert int(offs[self.BC_PARTS]) == n
+            lo, hi = int(offs[part_lo]), int(offs[part_hi])
+            run = self._view(base + off + self.BC_HDR + 8 * lo, hi - lo, np.uint64)
+            assert np.all((self._bc_part(run) >= part_lo) & (self._bc_part(run) < part_hi))      # the piece has landed, and in the right place
+            build.append(run.copy())
+        k, p = self.bc_probe_rows
+        mine = k[(p >= part_lo) & (p < part_hi)]
+        self.bc_count += int(np.isin(mine, np.concatenate(build)).sum()) if mine.size else 0
+
+    def bc_finish(self):
+        self.bc_probe_rows = None
+        return self.bc_count
+
     # ---- the optional precheck callbacks: one 4096-byte bitmap per first-pass bucket ("partition" of this stand-in), bit = 15 bits of the mixed key ----
     FB = 4096
 
@@ -330,7 +387,7 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     os.environ["FJ_DIST_PREFILTER"] = {"prefilter": "1", "prefilterauto": "auto", "prefilterdeclined": "auto"}.get(variant, "0")
     os.environ["FJ_DIST_STRATEGY"] = strategy
     os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if variant == "scatter" else "1"
-    if variant in ("packfail", "appendfail"):    # one rank's packing pass / local join fails inside the C++ driver: EVERY rank sees the failure
+    if variant in ("packfail", "appendfail", "bcpackfail", "bcjoinfail"):    # one rank's packing pass / local join fails inside the C++ driver: EVERY rank sees the failure
         os.environ["FJ_TEST_FAIL"] = variant[:-4] + ":" + str(world - 1)
     if strategy == "replicate":
         os.environ["FJ_REPLICATE_PIECES"] = "3"
@@ -438,6 +495,59 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         dist.destroy_process_group()
 
 
+def _worker_broadcast(rank, world, port, nb, npk, q, variant):
+    """The build-broadcast form through the ONE C++ driver (csrc/fj_dist.hip: dist_join_bcast) over gloo, the rank's work done by the
+    stand-in engine's bc_* callbacks: forced (FJ_DIST_STRATEGY=broadcast), chosen by the driver's cost model (unset strategy, a
+    probe-heavy join), with empty blocks, and with one rank failing in the pack / in a range's join."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["FJ_DIST_PREFILTER"] = "0"
+    os.environ.pop("FJ_DIST_STRATEGY", None)
+    if variant != "auto":
+        os.environ["FJ_DIST_STRATEGY"] = "broadcast"
+    if variant in ("bcpackfail", "bcjoinfail"):
+        os.environ["FJ_TEST_FAIL"] = variant[:-4] + ":" + str(world - 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flash_hash_join_amd import datagen
+        from flash_hash_join_amd.distributed import distributed_join
+        b0, b1 = rank * nb // world, (rank + 1) * nb // world
+        p0, p1 = rank * npk // world, (rank + 1) * npk // world
+        if variant == "uneven":                 # every probe row on rank 0, every build row on the last rank: empty blocks elsewhere
+            b0, b1 = (0, nb) if rank == world - 1 else (0, 0)
+            p0, p1 = (0, npk) if rank == 0 else (0, 0)
+        bk, bv = datagen.build_numpy(b1 - b0, first=b0)
+        pk, exp_local = datagen.probe_numpy(p1 - p0, nb, seed=1, hit_bp=5000, first=p0)
+        tb, tv, tp = (torch.from_numpy(x.view(np.int64)) for x in (bk, bv, pk))
+        exp = torch.tensor([exp_local]); dist.all_reduce(exp)
+        if variant in ("bcpackfail", "bcjoinfail"):
+            os.environ["FJ_DIST_NO_FALLBACK"] = "1"
+            with pytest.raises(RuntimeError, match="packing the build side failed on 1 rank" if variant == "bcpackfail" else "the local join failed on 1 rank") as ei:
+                distributed_join(tb, tv, tp, engine=OracleEngine())
+            assert ("injected" in str(ei.value)) == (rank == world - 1)       # the failing rank says why, the others that somebody failed
+            del os.environ["FJ_DIST_NO_FALLBACK"]
+        tc = {}
+        cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)
+        assert cnt == int(exp.item()), (cnt, int(exp.item()))
+        if variant in ("bcpackfail", "bcjoinfail"):     # without FJ_DIST_NO_FALLBACK all ranks rerun together in another form
+            assert "failed on 1 rank" in tc["broadcast_form_error"] and tc["strategy"] == "shuffle", tc
+        else:
+            assert tc["strategy"] == "broadcast" and tc["shuffle_form"].startswith("build broadcast") and tc["probe_rows_sent"] == 0, tc
+            assert tc["pieces"] == 4 and tc["local_probe_rows"] == p1 - p0
+            # every rank's region (272 + 8 bytes per key, 260 bytes of offset table on the wire) went to every peer, nothing else did
+            assert tc["wire_bytes_sent"] == (world - 1) * (260 + 8 * (b1 - b0)), tc
+            glob = torch.tensor([tc["local_count"]]); dist.all_reduce(glob)
+            assert int(glob.item()) == int(exp.item())
+        # a materialising join under the same setting shuffles (the pairs stay with the owner of the key)
+        t = {}
+        res = distributed_join(tb, tv, tp, materialize=True, return_arrays=True, engine=OracleEngine(), timings=t)
+        assert res[0] == int(exp.item()) and t["strategy"] == "shuffle"
+        q.put((rank, int(cnt), int(exp.item())))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -463,6 +573,23 @@ def test_distributed_join_gloo(world, strategy, oracle):
         assert owned and npairs == local        # pairs stay sharded by owner
         total_pairs += npairs
     assert total_pairs == rows[0][1]
+
+
+@pytest.mark.parametrize("variant", ["", "auto", "uneven", "bcpackfail", "bcjoinfail"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_build_broadcast_form_through_the_driver_gloo(world, variant, oracle):
+    nb, npk = 20000, (400000 if variant == "auto" else 90000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_broadcast, args=(r, world, port, nb, npk, q, variant)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rows = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(cnt == exp for _, cnt, exp in rows) and len({exp for _, _, exp in rows}) == 1
 
 
 @pytest.mark.parametrize("world", [2, 3])

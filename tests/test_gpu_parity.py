@@ -671,14 +671,16 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
         bk, bv = datagen.build_device(nb, "cuda:0")
         pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=4, hit_bp=5000)
         M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
-        for strategy, rp in (("shuffle", "1"), ("shuffle", "python"), ("shuffle", "scatter"), ("replicate", "1"), ("replicate", "3")):
+        for strategy, rp in (("shuffle", "1"), ("shuffle", "python"), ("shuffle", "scatter"), ("replicate", "1"), ("replicate", "3"), ("broadcast", "1"), ("broadcast", "python")):
             monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
             monkeypatch.setenv("FJ_REPLICATE_PIECES", rp if rp.isdigit() else "1")
             monkeypatch.setenv("FJ_DIST_NATIVE", "0" if rp == "python" else "1")            # the same driver over callbacks into torch.distributed instead of RCCL directly
             monkeypatch.setenv("FJ_DIST_CHUNK_SHUFFLE", "0" if rp == "scatter" else "1")    # the owner-scatter form
             t = {}
             n, sec = distributed_join(bk, bv, pk, timings=t)
-            assert n == exp and t["strategy"] == strategy
+            assert n == exp and t["strategy"] == strategy, t
+            if strategy == "broadcast":                    # the build-broadcast form on a 1-rank communicator: pack -> (no peer) -> probe passes -> 4 range joins
+                assert t["shuffle_form"].startswith("build broadcast") and t["pieces"] == 4 and t["local_count"] == exp and t["wire_bytes_sent"] == 0, t
             if strategy == "shuffle":
                 form = {"1": "chunks (fj_dist_join_count over RCCL)", "python": "chunks (fj_dist_join_count over a callback transport)", "scatter": "owner-scatter"}[rp]
                 assert t["shuffle_form"] == form and t["pieces"] == 4 and t["local_count"] == exp and "chunk_form_error" not in t

@@ -87,7 +87,8 @@ def worker(rank, world, port, q):
         chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim)
         del os.environ["FJ_SELFCHECK_CORRUPT"]
         assert not chk["ok"] and chk["failed_ranks"] == 1 and (rank != 0 or "elements received from rank" in chk["error"]), chk
-        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "scatter"), ("shuffle", "prefilter"), ("shuffle", "scatter-prefilter"), ("shuffle", "auto")):
+        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "scatter"), ("shuffle", "prefilter"), ("shuffle", "scatter-prefilter"), ("shuffle", "auto"),
+                                 ("broadcast", "1"), ("auto", "1")):
             os.environ["FJ_DIST_STRATEGY"] = strategy; os.environ["FJ_REPLICATE_PIECES"] = pieces if pieces.isdigit() else "1"
             os.environ["FJ_DIST_PREFILTER"] = "1" if "prefilter" in pieces else "auto" if pieces == "auto" else "0"
             os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if "scatter" in pieces else "1"
@@ -96,6 +97,10 @@ def worker(rank, world, port, q):
             t = {}
             n, sec = D.distributed_join(bk, bv, pk, timings=t, transport=shim)
             assert n == exp, (strategy, n, exp)
+            if strategy in ("broadcast", "auto"):           # the build-broadcast form through the same driver (forced / picked by its model: 6.7 probe rows per build row)
+                assert t["strategy"] == "broadcast" and t["probe_rows_sent"] == 0 and t["local_build_rows"] == nb and t["local_probe_rows"] == p1 - p0, t
+                assert 0 < t["wire_bytes_sent"] <= (world - 1) * (8.1 * (b1 - b0) + 300_000), t        # (6M build rows in all: 11 bits, a 4-byte high-word plane)
+                assert "broadcast_form_error" not in t and "chunk_form_error" not in t, t
             if "prefilter" in pieces:                       # half the probe rows miss; the owners' filters stop nearly all of them
                 assert t["prefilter"] and t["probe_rows_sent"] < 0.56 * (p1 - p0), t
                 if chunk:                                   # per-partition filters, all-gathered inside the driver (uneven ranges at 3 ranks)
