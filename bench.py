@@ -258,11 +258,12 @@ def main() -> None:
         _flush_c_stdio()
         if force_dist:
             os.environ["FJ_FORCE_EXCHANGE"] = "1"
-        # `value` at N > 1 is always the strategy north_star names (the owner shuffle over an all-to-all); the cost model's
-        # alternative is measured beside it as `alt_strategy`, never instead of it
-        if os.environ.get("FJ_DIST_STRATEGY", "shuffle") != "shuffle":
-            print(f"bench.py: ignoring FJ_DIST_STRATEGY={os.environ['FJ_DIST_STRATEGY']} for the timed steps (value is the shuffle's)", file=sys.stderr)
-        os.environ["FJ_DIST_STRATEGY"] = "shuffle"
+        # `value` at N > 1: what an unconfigured job runs - the form the C++ driver's cost model picks for the step's sizes with the
+        # link rate measured below (fj_dist_model: build broadcast or owner shuffle); the other form is measured beside it as
+        # `alt_strategy`, never instead of it.  FJ_DIST_STRATEGY=shuffle|broadcast|replicate pins the timed form.
+        pinned_strategy = os.environ.get("FJ_DIST_STRATEGY")
+        if pinned_strategy in ("", "auto"):
+            pinned_strategy = None
 
     nb_gpu, np_gpu, hit_bp, fn_name = WORKLOADS[args.workload]
     nb_gpu, np_gpu = max(1, int(nb_gpu * args.scale)), max(1, int(np_gpu * args.scale))
@@ -301,6 +302,20 @@ def main() -> None:
         elif "error" not in link:
             link = {"error": "the link probe failed on another rank", **link}
 
+    form_pick = None
+    if world > 1 or force_dist:
+        from flash_hash_join_amd import distributed as _D
+        if pinned_strategy is None:
+            # the driver's model for THIS step's sizes and the measured link rate (every rank computes the same: the rate was agreed on above);
+            # pinned for the self-check and the timed steps so that what was checked is what is timed
+            form_pick = _D.form_model(world, nb_gpu, np_gpu)
+            if materialize or world == 1:
+                form_pick = dict(form_pick, pick="shuffle", note="one rank / materialising: the shuffle (FJ_BENCH_FORCE_FORM=broadcast times the other form on one rank)")
+            if os.environ.get("FJ_BENCH_FORCE_FORM"):
+                form_pick = dict(form_pick, pick=os.environ["FJ_BENCH_FORCE_FORM"])
+            os.environ["FJ_DIST_STRATEGY"] = form_pick["pick"]
+        timed_strategy = os.environ["FJ_DIST_STRATEGY"]
+
     # ---- self-check before anything is timed (N > 1): the exchange transport at the step's largest message size, and one
     #      small join against its closed-form count; a failure is ONE JSON line with `error` and a non-zero exit code ----------
     selfcheck = None
@@ -333,11 +348,18 @@ def main() -> None:
         threading.Thread(target=watchdog, daemon=True).start()
         # the default protocol first (chunk-form shuffle through the native entry); a form that fails its check - the ranks agree
         # on that - is replaced by the next simpler one, and the line says which one was timed
-        forms = [("chunks (fj_dist_join_count over RCCL)", {}), ("chunks (fj_dist_join_count over torch.distributed callbacks)", {"FJ_DIST_NATIVE": "0"}),
-                 ("owner-scatter", {"FJ_DIST_NATIVE": "0", "FJ_DIST_CHUNK_SHUFFLE": "0"})]
+        shuffle_forms = [("chunks (fj_dist_join_count over RCCL)", {"FJ_DIST_STRATEGY": "shuffle"}),
+                         ("chunks (fj_dist_join_count over torch.distributed callbacks)", {"FJ_DIST_STRATEGY": "shuffle", "FJ_DIST_NATIVE": "0"}),
+                         ("owner-scatter", {"FJ_DIST_STRATEGY": "shuffle", "FJ_DIST_NATIVE": "0", "FJ_DIST_CHUNK_SHUFFLE": "0"})]
+        forms = {"broadcast": [("build broadcast (fj_dist_join_count over RCCL)", {"FJ_DIST_STRATEGY": "broadcast"}),
+                               ("build broadcast (fj_dist_join_count over torch.distributed callbacks)", {"FJ_DIST_STRATEGY": "broadcast", "FJ_DIST_NATIVE": "0"})] + shuffle_forms,
+                 "replicate": [("replicate (all-gather of the build keys)", {"FJ_DIST_STRATEGY": "replicate"})] + shuffle_forms}.get(timed_strategy, shuffle_forms)
+        user_pins = {k: os.environ[k] for k in ("FJ_DIST_NATIVE", "FJ_DIST_CHUNK_SHUFFLE") if k in os.environ}
+        if pinned_strategy is not None:
+            user_pins["FJ_DIST_STRATEGY"] = pinned_strategy
         tried = []
         for name, env in forms:
-            if any(k in os.environ and os.environ[k] != v for k, v in env.items()):
+            if any(k in user_pins and user_pins[k] != v for k, v in env.items()):
                 continue                                     # the user pinned a form: honour it
             os.environ.update(env)
             selfcheck = self_check(dist, None, engine, (sbk, sbv, spk), int(e.item()), msg, transport=transport)
@@ -345,6 +367,7 @@ def main() -> None:
             tried.append({"form": name, "ok": selfcheck["ok"], "error": selfcheck["error"]})
             if selfcheck["ok"]:
                 break
+        timed_strategy = os.environ["FJ_DIST_STRATEGY"]
         selfcheck["forms_tried"] = tried
         done.set()
         del sbk, sbv, spk
@@ -409,6 +432,10 @@ def main() -> None:
                 npart = 1                                  # probe rows never move: one first-pass launch over all of them
                 units_per_launch[0] = t.get("local_probe_rows", np_gpu)
                 strategy_seen[0] = "replicate-build"
+            elif t.get("strategy") == "broadcast":
+                npart = min(4, int(lt["passes"]))          # probe rows never move: the plan's passes, each over all of this rank's probe rows
+                units_per_launch[0] = float(np_gpu)
+                strategy_seen[0] = "build-broadcast"
             else:
                 npart = min(4, int(t.get("pieces", 0)))    # pipelined exchange: first-pass launches, one per received piece
                 units_per_launch[0] = t.get("local_probe_rows", np_gpu) / max(1, int(t.get("pieces", 1)))
@@ -494,7 +521,8 @@ def main() -> None:
         bpu = 8.0 + (float(dlast["wire_chunk_bytes"]) / 256.0 if dlast.get("wire_chunk_bytes") else 8.0)
         alg_bytes = bpu * units_per_launch[0]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (the owner's radix pass over a received piece)",
+        roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys> (a probe-side radix pass over this rank's own probe rows)" if strategy_seen[0] == "build-broadcast" else
+                "fj_partition_kernel<keys-only> (the owner's radix pass over a received piece)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
                 "frac_of_this_pools_copy_rate": round(achieved / HBM_POOL_COPY_GBS, 4),
@@ -543,7 +571,8 @@ def main() -> None:
                        "probe_rows_sent_rank0": dlast.get("probe_rows_sent"), "shuffle_form": dlast.get("shuffle_form"),
                        # what rank 0 put on its links per step (chunks + directory words; its own share never travels) and per key sent
                        "wire_chunk_bytes": dlast.get("wire_chunk_bytes"), "wire_bytes_sent_rank0": dlast.get("wire_bytes_sent"),
-                       "chunk_form_error": dlast.get("chunk_form_error")})
+                       "chunk_form_error": dlast.get("chunk_form_error"), "broadcast_form_error": dlast.get("broadcast_form_error"),
+                       "strategy_timed": dlast.get("strategy"), "form_model": form_pick})
 
     out = {
         "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",
@@ -601,25 +630,30 @@ def main() -> None:
     if selfcheck is not None:
         out["self_check"] = selfcheck
     if world > 1 and not materialize:
-        # the cost model's alternative (build side replicated by all-gather, probe rows stay), a second, labelled measurement
-        os.environ["FJ_DIST_STRATEGY"] = "replicate"
+        # the form the model did NOT pick (or, for a pinned run, the broadcast / the shuffle), a second, labelled measurement
+        main = dlast.get("strategy", timed_strategy)
+        alt = "shuffle" if main == "broadcast" else "broadcast"
+        os.environ["FJ_DIST_STRATEGY"] = alt
         try:
             asteps = max(1, min(3, args.steps))
-            got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport)[0]      # untimed (workspace growth)
+            ta_ = {}
+            got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport, timings=ta_)[0]      # untimed (workspace growth)
             sync()
             ta = time.perf_counter()
             for _ in range(asteps):
-                got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport)[0]
+                got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport, timings=ta_)[0]
             sync()
             ea = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=device)
             dist.all_reduce(ea, op=dist.ReduceOp.MAX)
-            out["alt_strategy"] = {"strategy": "replicate-build", "steps": asteps, "ms_per_step": round(float(ea.item()) / asteps * 1e3, 3),
+            out["alt_strategy"] = {"strategy": {"shuffle": "owner-shuffle", "broadcast": "build-broadcast"}.get(ta_.get("strategy"), ta_.get("strategy")),
+                                   "form": ta_.get("shuffle_form"), "steps": asteps, "ms_per_step": round(float(ea.item()) / asteps * 1e3, 3),
                                    "value": round(np_total * asteps / float(ea.item()) / 1e9, 3), "unit": "Gprobes/s", "count_ok": int(got) == exp_total,
-                                   "note": "not `value`: the strategy north_star names is the owner shuffle"}
+                                   "wire_bytes_sent_rank0": ta_.get("wire_bytes_sent"),
+                                   "note": "not `value`: the other form of the multi-GPU step, measured beside the timed one"}
         except Exception as ex:
-            out["alt_strategy"] = {"strategy": "replicate-build", "error": repr(ex)}
+            out["alt_strategy"] = {"strategy": alt, "error": repr(ex)}
         finally:
-            os.environ["FJ_DIST_STRATEGY"] = "shuffle"
+            os.environ["FJ_DIST_STRATEGY"] = timed_strategy
     if priming:
         out["priming_steps"] = priming
     if share_gpu:

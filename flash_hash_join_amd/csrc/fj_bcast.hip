@@ -241,7 +241,7 @@ int fj_bcast_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* ti
     HIPCHK(hipEventRecord(c->ev[E_JOIN], s));
     if (read_scalars(c, s)) return 1;
     const u32 err = c->h_sc->err;
-    const int npass = bc.plan.npass;
+    const int npass = bc.plan.npass, bits = bc.plan.bits, evc = bc.evc;
     bc = BcastState();
     if (err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
     end_plan(c);
@@ -249,7 +249,8 @@ int fj_bcast_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* ti
     if (err & (FJ_STAT_RETRY | FJ_ERR_LDS_FULL)) return set_err("build broadcast: a final partition does not fit the LDS table (skewed build keys)");
     if (out_count) *out_count = c->h_sc->total;
     fj_timings t; memset(&t, 0, sizeof t);
-    t.path = 0; t.passes = npass; t.sampled_hit_bp = -1;
+    t.path = 0; t.passes = npass; t.radix_bits = bits; t.partitions = 1ull << bits; t.sampled_hit_bp = -1;
+    for (int i = 0; i < evc && i < 4; ++i) t.probe_part_kernel_ms[i] = ev_ms(c, E_PK0 + 2 * i, E_PK0 + 2 * i + 1);
     t.build_phase_ms = ev_ms(c, E_START, E_BUILD); t.join_ms = ev_ms(c, E_PPART, E_JOIN);
     t.probe_phase_ms = ev_ms(c, E_BUILD, E_JOIN); t.total_ms = ev_ms(c, E_START, E_JOIN);
     if (timings) *timings = t;

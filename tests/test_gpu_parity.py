@@ -793,10 +793,22 @@ def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
     assert d["config"]["bench_workload"] == "c5" and d["config"]["build_rows_total"] == 2 * 2_500_000
     assert d["config"]["parallelism"].endswith("x2") and "cpu_baseline" not in d and d["value"] > 0
     # the pre-flight self-check ran (under the host-staged transport only the torch.distributed forms apply) and is in the line;
-    # value is the shuffle's, the replicate strategy rides along as a labelled second measurement
+    # value is the form the driver's cost model picks for these sizes (10 probe rows per build row: the build broadcast), checked
+    # before it is timed; the other form rides along as a labelled second measurement
     assert d["self_check"]["ok"] and d["self_check"]["forms_tried"][-1]["ok"]
+    assert d["phases"]["form_model"]["pick"] == "broadcast" and d["phases"]["strategy_timed"] == "broadcast", d["phases"]
+    assert d["config"]["parallelism"].startswith("build-broadcast") and d["phases"]["shuffle_form"].startswith("build broadcast")
+    assert d["roofline"]["kernel"].startswith("fj_partition_kernel<keys> (a probe-side radix pass") and 0 < d["roofline"]["frac"] < 1
+    assert d["alt_strategy"]["strategy"] == "owner-shuffle" and d["alt_strategy"]["count_ok"] is True and d["alt_strategy"]["form"].startswith("chunks")
+    # ... and a pinned strategy is what gets timed
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=900, env=dict(env, FJ_DIST_STRATEGY="shuffle"), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["parallelism"].startswith("owner-shuffle") and d["phases"]["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport")
-    assert d["alt_strategy"]["strategy"] == "replicate-build" and d["alt_strategy"]["count_ok"] is True
+    assert d["alt_strategy"]["strategy"] == "build-broadcast" and d["alt_strategy"]["count_ok"] is True
     # a transport that moves wrong data (test hook): every shuffle form fails its check, ONE JSON line says so, exit code 3
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

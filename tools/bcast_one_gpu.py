@@ -2,16 +2,20 @@
 is packed into its region once (what the peers would have sent), then rank `rank`'s step is timed: pack of its own build rows ->
 both passes over its own probe rows -> the join of every partition range against all N regions.  No transport: what this measures
 is the kernel time per rank and step that tools/scale_model.py puts beside the wire time.
-usage: python tools/bcast_one_gpu.py [world=8] [nb_rank=125000000] [np_rank=1250000000] [pieces=4] [steps=5] [hit_bp=5000]"""
+usage: python tools/bcast_one_gpu.py [world=8] [nb_rank=125000000] [np_rank=1250000000] [pieces=4] [steps=5] [hit_bp=5000] [reserve_cus=0]
+(reserve_cus: CUs the passes and the join leave free, as they do while RCCL's kernels share the GPU at N > 1: csrc/fj_dist.hip reserves 32)"""
 import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flash_hash_join_amd import api, datagen
 from flash_hash_join_amd.distributed import HipEngine
 
 args = [int(x) for x in sys.argv[1:]]
-world, nb_rank, np_rank, pieces, steps, hit_bp = (args + [8, 125_000_000, 1_250_000_000, 4, 5, 5000][len(args):])[:6]
+world, nb_rank, np_rank, pieces, steps, hit_bp, reserve = (args + [8, 125_000_000, 1_250_000_000, 4, 5, 5000, 0][len(args):])[:7]
 rank = 0
 api.initialize(); eng = HipEngine("cuda:0")
+if reserve:
+    eng.L.fj_ctx_reserve_cus.argtypes = [__import__('ctypes').c_void_p, __import__('ctypes').c_uint]; eng.L.fj_ctx_reserve_cus.restype = None
+    eng.L.fj_ctx_reserve_cus(eng.ctx, reserve)
 nb_total = nb_rank * world
 bits, nparts, mid = eng.bcast_plan(nb_total)
 rb = eng.bcast_region_bytes(nb_total, nb_rank)
