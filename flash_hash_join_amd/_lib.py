@@ -19,7 +19,7 @@ CSRC = os.path.join(_PKG, "csrc")
 # every symbol include/flashjoin.h declares
 SYMBOLS = [
     "fj_initialize", "fj_last_error", "fj_device_count", "fj_version", "fj_key_mix64", "fj_key_unmix64",
-    "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes", "fj_ctx_trim", "fj_stream_abort",
+    "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_reserve_cus", "fj_ctx_workspace_bytes", "fj_ctx_trim", "fj_stream_abort",
     "fj_join_host", "fj_free_host", "fj_last_timings",
     "fj_join_device", "fj_emit_pairs", "fj_owner_split", "fj_owner_hist", "fj_owner_scatter",
     "fj_set_option", "fj_get_option",
@@ -150,6 +150,7 @@ def load() -> ctypes.CDLL:
     L.fj_key_unmix64.restype = u64; L.fj_key_unmix64.argtypes = [u64]
     L.fj_ctx_create.restype = vp; L.fj_ctx_create.argtypes = [i32]
     L.fj_ctx_destroy.restype = None; L.fj_ctx_destroy.argtypes = [vp]
+    L.fj_ctx_reserve_cus.restype = None; L.fj_ctx_reserve_cus.argtypes = [vp, ctypes.c_uint]
     L.fj_ctx_workspace_bytes.restype = sz; L.fj_ctx_workspace_bytes.argtypes = [vp]
     L.fj_ctx_trim.restype = i32; L.fj_ctx_trim.argtypes = [vp]
     L.fj_stream_abort.restype = i32; L.fj_stream_abort.argtypes = [vp]

@@ -25,8 +25,7 @@
 // time (dlopen of librccl.so.1 - in a PyTorch process that is the copy torch already loaded) through locally declared
 // prototypes: the library neither links against RCCL nor needs its headers.  RCCL moves wrong data when one point-to-point
 // message exceeds 4 GiB (tools/rccl_large_message_check.py): messages are cut into rounds of <= 1 GiB.
-#include "fj_internal.h"
-#include "../../include/flashjoin.h"
+#include "fj_host.h"
 
 #include <dlfcn.h>
 
@@ -203,7 +202,7 @@ struct HipEngine : Engine {
         return fj_stream_open_shuffled(ctx, nb_total, nranks, rank, nb_bound, 1, np_bound, pieces, with_vals ? 1 : 0, js);
     }
     int append(int side, const void* chunks, const uint64_t* vals, uint32_t* dir, size_t n, Token after) override {
-        if (side && getenv("FJ_DIST_INJECT_FAIL")) return derr("injected failure of a local append (test hook FJ_DIST_INJECT_FAIL)");
+        if (side && (fj_get_option("lab_hooks") & FJ_HOOK_INJECT_FAIL)) return derr("injected failure of a local append (test hook: lab_hooks & FJ_HOOK_INJECT_FAIL)");
         if (after) DHIP(hipStreamWaitEvent(js, (hipEvent_t)after, 0));
         return side ? fj_stream_append_probe_chunks(ctx, chunks, dir, n, js) : fj_stream_append_build_chunks(ctx, chunks, vals, dir, n, js);
     }
@@ -335,7 +334,8 @@ struct RcclNet : Net {
         // control collectives on a communicator of their own: on ONE communicator RCCL runs operations in the order they were
         // issued whatever their streams, and a count exchange must not wait for the previous piece's sends
         Rccl* R = rccl();
-        if (R->CommSplit && (nranks > 1 || getenv("FJ_DIST_SPLIT_ALWAYS")) && !getenv("FJ_DIST_ONE_COMM")) {      // (FJ_DIST_SPLIT_ALWAYS: test hook, a 1-rank communicator is split too)
+        const long long hooks = fj_get_option("lab_hooks");
+        if (R->CommSplit && (nranks > 1 || (hooks & FJ_HOOK_SPLIT_ALWAYS)) && !(hooks & FJ_HOOK_ONE_COMM)) {      // (FJ_HOOK_SPLIT_ALWAYS: test hook, a 1-rank communicator is split too)
             ncclComm_t c2 = nullptr;
             if (R->CommSplit(data, 0, rank, &c2, nullptr) == 0 && c2) { ctl = c2; own_ctl = true; }
         }
@@ -378,7 +378,7 @@ struct RcclNet : Net {
     }
     bool loopback() const override { return loop; }
     bool shares_the_gpu() const override { return true; }
-    void begin_step() override { const char* e = getenv("FJ_DIST_LOOPBACK"); loop = e && atoi(e) != 0; }      // test hook: a rank's own share travels through ncclSend / ncclRecv too
+    void begin_step() override { loop = (fj_get_option("lab_hooks") & FJ_HOOK_LOOPBACK) != 0; }      // test hook: a rank's own share travels through ncclSend / ncclRecv too
     bool is_peer(int r) const { return r != rank || loop; }
     int exchange(int nparts, const void* const* sp, const size_t* sb, void* const* rp, const size_t* rb, size_t largest, Token after, Token* done, int slot) override {
         Rccl* R = rccl();
@@ -475,7 +475,7 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
     std::vector<uint64_t> roff(N + 1, 0);
     for (int r = 0; r < N; ++r) roff[r + 1] = roff[r] + ((eng.bc_region_bytes(nb_total, (size_t)nb_of[r]) + 255) & ~(size_t)255);
     net.begin_step();
-    const bool reserve = net.shares_the_gpu() && (N > 1 || getenv("FJ_DIST_RESERVE_ALWAYS"));
+    const bool reserve = net.shares_the_gpu() && (N > 1 || (fj_get_option("lab_hooks") & FJ_HOOK_RESERVE_ALWAYS));
     struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(false); } } reserve_guard{eng, reserve};
     if (reserve) eng.reserve(true);
     bool begun = false;
@@ -725,7 +725,7 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     if (np_min < 2ull * pieces) pieces = 1;
     net.begin_step();
     const bool loop = net.loopback();
-    const bool reserve = net.shares_the_gpu() && (N > 1 || getenv("FJ_DIST_RESERVE_ALWAYS"));
+    const bool reserve = net.shares_the_gpu() && (N > 1 || (fj_get_option("lab_hooks") & FJ_HOOK_RESERVE_ALWAYS));
     struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(false); } } reserve_guard{eng, reserve};
     if (reserve) eng.reserve(true);
 

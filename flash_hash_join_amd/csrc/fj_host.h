@@ -160,6 +160,7 @@ struct StreamState {            // fj_stream_*: a counting join whose relations 
     // owner shuffle, receiver side (fj_stream_open_shuffled): the pieces are chunk pools that peers filled with the FIRST pass of
     // the global plan; this rank owns level-1 buckets [b_lo, b_lo + nbk) and runs the plan from its second pass on
     bool shuffled = false; u32 b_lo = 0, nbk = 0, nbk_pad = 0;
+    bool probe_prepared = true; u32 probe_appends = 0;      // shuffled: the probe side's pools are sized when its first piece is seen (an owner of hot probe keys receives far more than the mean)
     bool with_vals = false;         // ... and the build side carries values: a materialising join (pairs stay with the owner: fj_emit_pairs after the finish)
 };
 
@@ -208,27 +209,21 @@ namespace fjh {
 //                      otherwise run the partitioned plan.  One table for B rows means one cache-missing 64-B access
 //                      per probe in HBM -- more traffic than the 40 B per probe the two streaming passes + LDS join
 //                      move -- so on this machine "scalar" is the slower way to the same result at every size.
+// test / measurement hooks, one bit each in the option "lab_hooks" (fj_set_option; nothing reads the environment for them):
+#define FJ_HOOK_LOOPBACK 1        // multi-GPU driver: a rank's own share travels through ncclSend / ncclRecv too (the code path every peer's share takes at N > 1)
+#define FJ_HOOK_INJECT_FAIL 2     // multi-GPU driver: this rank's probe-side appends fail (agreed failures, reruns)
+#define FJ_HOOK_SPLIT_ALWAYS 4    // a 1-rank communicator gets its own control communicator too
+#define FJ_HOOK_ONE_COMM 8        // control collectives on the data communicator
+#define FJ_HOOK_RESERVE_ALWAYS 16 // the CU reserve of an N > 1 step on one rank too (measurement)
+#define FJ_HOOK_EMIT_TAGGED 32    // emitting pass on the tagged-table kernel (A/B)
+#define FJ_HOOK_EMIT_RETRY_7TH 64 // every 7th item of the cuckoo emit kernel takes its retry path (results exact)
 struct Options {
-    size_t radix_threshold; int scalar_hbm_table; u32 persistent_min_items; u32 plan_target_keys;
-    int bloom_variant, bloom_auto, bloom_auto_max_hit_bp, mat_single_pass;
-    int join_wide;                     // counting joins on the 16384-slot table (fj_join_wide.hip): 0 never, 1 whenever eligible, 2 (default) when the average final partition holds > FJ_WIDE_MIN_KEYS build keys
-    Options() {
-        join_wide = getenv("FJ_JOIN_WIDE") ? atoi(getenv("FJ_JOIN_WIDE")) : 2;
-        mat_single_pass = getenv("FJ_MAT_SINGLE_PASS") ? atoi(getenv("FJ_MAT_SINGLE_PASS")) : 1;
-        bloom_auto = getenv("FJ_BLOOM_AUTO") ? atoi(getenv("FJ_BLOOM_AUTO")) : 1;
-        bloom_auto_max_hit_bp = getenv("FJ_BLOOM_AUTO_MAX_HIT_BP") ? atoi(getenv("FJ_BLOOM_AUTO_MAX_HIT_BP")) : 2300;     // measured break-even at c4 sizes: 24 % hits (profiles/r03_bloom_threshold.csv; round 2: 28 % - the plain plan gained more since)
-        const char* bvr = getenv("FJ_BLOOM_VARIANT");
-        bloom_variant = bvr ? std::min(2, std::max(0, atoi(bvr))) : 0;
-        const char* pt = getenv("FJ_PLAN_TARGET_KEYS");
-        plan_target_keys = pt ? (u32)strtoul(pt, nullptr, 10) : FJ_PART_TARGET_KEYS;
-        if (plan_target_keys < 16 || plan_target_keys > FJ_PART_TARGET_KEYS) plan_target_keys = FJ_PART_TARGET_KEYS;
-        const char* th = getenv("FJ_RADIX_THRESHOLD");
-        radix_threshold = th ? (size_t)strtoull(th, nullptr, 10) : (size_t)0;
-        const char* sg = getenv("FJ_SCALAR_HBM_TABLE");
-        scalar_hbm_table = sg ? atoi(sg) : 0;
-        const char* pm = getenv("FJ_PERSISTENT_MIN_ITEMS");
-        persistent_min_items = pm ? (u32)strtoul(pm, nullptr, 10) : 8192u;
-    }
+    size_t radix_threshold = 0; int scalar_hbm_table = 0; u32 persistent_min_items = 8192; u32 plan_target_keys = FJ_PART_TARGET_KEYS;
+    int bloom_variant = 0, bloom_auto = 1, bloom_auto_max_hit_bp = 2300, mat_single_pass = 1;     // (2300: measured break-even at c4 sizes is 24 % hits, profiles/r03_bloom_threshold.csv)
+    int join_wide = 2;                 // counting joins on the 16384-slot table (fj_join_wide.hip): 0 never, 1 whenever eligible, 2 (default) when the average final partition holds > FJ_WIDE_MIN_KEYS build keys and <= 32 probe chunks
+    u32 lab_hooks = 0;                 // FJ_HOOK_* bits
+    u32 join_items_target = 2048;      // work items the join of a plan with few partitions is cut into (tuning knob)
+    Options();                         // initial values: FJ_OPTIONS="name=value,name=value" (the names of fj_set_option), the ONE environment variable behind all of them
 };
 Options& options();
 

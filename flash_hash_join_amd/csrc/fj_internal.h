@@ -138,7 +138,7 @@ hipError_t fj_launch_pack_squeeze(const FjPackArgs& a, u32 grid, hipStream_t s);
 // send / receive kernels hold some for the length of an exchange) starts when another one has finished, and the pass takes twice as
 // long.  While a multi-GPU step runs, the passes therefore launch num_cus - n workgroups (csrc/fj_dist.hip; internal, not part of the
 // public header).  n = 0 restores the full grid.
-extern "C" void fj_ctx_reserve_cus(struct fj_ctx* ctx, unsigned n);
+// (fj_ctx_reserve_cus: include/flashjoin.h)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
 hipError_t fj_set_max_lds_once(const void* fn, u32 bytes);

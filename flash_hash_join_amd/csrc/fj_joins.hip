@@ -35,8 +35,10 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
             HIPCHK(fj_launch_scan_u32_to_u64(pd.lds.part_count, (u64*)p, pd.nitems, s));
             pd.lds.out_off = (const u64*)p; pd.lds.out_keys = d_ok; pd.lds.out_vals = d_ov;
             pd.lds.dbg = nullptr;
+#ifdef FJ_LAB
             if (getenv("FJ_EMIT_STAMPS") && stamps_begin(&pd.lds.dbg, s)) return 1;
-            static const bool resident = !getenv("FJ_EMIT_PERSISTENT") || atoi(getenv("FJ_EMIT_PERSISTENT")) != 0;   // (A/B knob)
+#endif
+            const bool resident = !(options().lab_hooks & FJ_HOOK_EMIT_TAGGED);   // (A/B knob)
             if (resident) HIPCHK(hipMemsetAsync(&c->d_sc->next_emit_item, 0, sizeof(u32), s));
             HIPCHK(fj_launch_lds_join(pd.lds, true, s, resident ? &c->d_sc->next_emit_item : nullptr, 1u));
             if (pd.lds.dbg) { if (stamps_report("FJ_EMIT_STAMPS", pd.lds.dbg, pd.nitems, s)) return 1; pd.lds.dbg = nullptr; }
@@ -237,7 +239,10 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     ja.total = &c->d_sc->total; ja.err = &c->d_sc->err;
     ja.want_dups = materialize ? 1u : 0u; ja.dedup = 0; ja.orig_vals = nullptr; ja.retry_only = 0;
     ja.dbg = nullptr;
-    ja.dbg_flags = getenv("FJ_JOIN_ABLATE") ? (u32)atoi(getenv("FJ_JOIN_ABLATE")) : 0u;
+    ja.dbg_flags = (options().lab_hooks & FJ_HOOK_EMIT_RETRY_7TH) ? 8u : 0u;
+#ifdef FJ_LAB      // (make EXTRA=-DFJ_LAB: ablations - 1 skip lookups, 2 skip inserts, 4 no output stores: results wrong on purpose - and phase stamps)
+    if (getenv("FJ_JOIN_ABLATE")) ja.dbg_flags = (u32)atoi(getenv("FJ_JOIN_ABLATE"));
+#endif
     if (so && materialize && ja.probe.list && ja.build.list && ja.build.vals && ja.items && !ja.dbg_flags) {
         // Single-pass materialising join: every item is probed ONCE; a probe round reserves its pairs' range on a device cursor
         // (the plan's `total` word) and writes them - no counting pass, no scan, no second read of the probe side (c3 sizes:
@@ -269,13 +274,17 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
         HIPCHK(hipMemsetAsync(&c->d_sc->total, 0, sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(&c->d_sc->err, 0, sizeof(u32), s));
     }
+#ifdef FJ_LAB
     if (getenv("FJ_JOIN_STAMPS") && stamps_begin(&ja.dbg, s)) return 1;
+#endif
     // (wide_join_planned: the probe side's final bookkeeping cut the items for the 16384-slot kernel, fj_join_wide.hip)
     const bool wide = pit.item_tc_max == 32 && !materialize && !ja.dbg && !ja.dbg_flags && ja.probe.list && ja.build.list && ja.items;
     if (wide) {
         FjWideArgs wa{};
         FjLdsJoinArgs jw = ja;
+#ifdef FJ_LAB
         if (getenv("FJ_WIDE_STAMPS") && stamps_begin(&jw.dbg, s)) return 1;      // (diagnostic: where a workgroup's time goes, per pipeline stage)
+#endif
         const u32 grid = std::min<u32>(nitems, c->num_cus);
         HIPCHK(fj_launch_count_join_wide(jw, wa, false, grid, s));
         if (jw.dbg) {

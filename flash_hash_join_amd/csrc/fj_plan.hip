@@ -15,6 +15,22 @@ int set_err(const char* fmt, ...) {
 fj_timings& last_timings() { return g_last; }
 
 Options& options() { static Options o; return o; }
+static int set_option_value(Options& o, const char* name, long long value);
+Options::Options() {
+    const char* e = getenv("FJ_OPTIONS");
+    if (!e) return;
+    std::string str(e);
+    size_t pos = 0;
+    while (pos < str.size()) {
+        size_t end = str.find(',', pos);
+        if (end == std::string::npos) end = str.size();
+        const std::string item = str.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (eq != std::string::npos && set_option_value(*this, item.substr(0, eq).c_str(), strtoll(item.c_str() + eq + 1, nullptr, 10)))
+            fprintf(stderr, "flash_hash_join_amd: FJ_OPTIONS: ignoring '%s' (%s)\n", item.c_str(), fj_last_error());
+        pos = end + 1;
+    }
+}
 
 int get_buf(fj_ctx* c, int slot, size_t bytes, void** out) {
     Buf& b = c->bufs[slot];
@@ -198,7 +214,7 @@ void join_item_geometry(u64 nparts, size_t np, u64 chunk_bound, u32* tc, u64* ma
     const u64 bound = std::max<u64>(chunk_bound, pchunks);
     const u64 avg = std::max<u64>(1, bound / nparts);
     u64 want = 1;
-    static const u64 target_items = getenv("FJ_JOIN_ITEMS_TARGET") ? strtoull(getenv("FJ_JOIN_ITEMS_TARGET"), nullptr, 10) : 2048;   // (tuning knob)
+    const u64 target_items = options().join_items_target;
     if (nparts < target_items) want = std::min<u64>((target_items + nparts - 1) / nparts, std::max<u64>(1, (pchunks / nparts) / 32));
     *tc = (u32)(want > 1 ? std::max<u64>(8, (avg * 9 / 8 + want - 1) / want) : std::max<u64>(512, 4 * avg));
     *max_items = bound / *tc + nparts + 1;
@@ -361,6 +377,21 @@ int stamps_report(const char* label, const unsigned long long* dbg, u32 nitems, 
     return 0;
 }
 
+static int set_option_value(Options& o, const char* name, long long value) {
+    if (!strcmp(name, "radix_threshold")) { if (value < 0) return set_err("fj_set_option: radix_threshold must be >= 0"); o.radix_threshold = (size_t)value; return 0; }
+    if (!strcmp(name, "scalar_hbm_table")) { o.scalar_hbm_table = value != 0; return 0; }
+    if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); o.plan_target_keys = (u32)value; return 0; }
+    if (!strcmp(name, "bloom_auto")) { o.bloom_auto = value != 0; return 0; }
+    if (!strcmp(name, "mat_single_pass")) { o.mat_single_pass = value != 0; return 0; }
+    if (!strcmp(name, "bloom_auto_max_hit_bp")) { if (value < 0 || value > 10000) return set_err("fj_set_option: bloom_auto_max_hit_bp must be 0..10000"); o.bloom_auto_max_hit_bp = (int)value; return 0; }
+    if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); o.bloom_variant = (int)value; return 0; }
+    if (!strcmp(name, "join_wide")) { if (value < 0 || value > 2) return set_err("fj_set_option: join_wide must be 0..2"); o.join_wide = (int)value; return 0; }
+    if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); o.persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
+    if (!strcmp(name, "lab_hooks")) { if (value < 0 || value > 0xFFFF) return set_err("fj_set_option: lab_hooks is a mask of FJ_HOOK_* bits"); o.lab_hooks = (u32)value; return 0; }
+    if (!strcmp(name, "join_items_target")) { if (value < 1 || value > (1 << 20)) return set_err("fj_set_option: join_items_target must be 1..1048576"); o.join_items_target = (u32)value; return 0; }
+    return set_err("fj_set_option: unknown option '%s'", name);
+}
+
 }  // namespace fjh
 using namespace fjh;
 
@@ -373,28 +404,22 @@ const char* fj_version(void) { return "flash_hash_join_amd 0.2 (gfx950)"; }
 
 int fj_set_option(const char* name, long long value) {
     if (!name) return set_err("fj_set_option: null name");
-    if (!strcmp(name, "radix_threshold")) { if (value < 0) return set_err("fj_set_option: radix_threshold must be >= 0"); options().radix_threshold = (size_t)value; return 0; }
-    if (!strcmp(name, "scalar_hbm_table")) { options().scalar_hbm_table = value != 0; return 0; }
-    if (!strcmp(name, "plan_target_keys")) { if (value < 16 || value > (long long)FJ_PART_TARGET_KEYS) return set_err("fj_set_option: plan_target_keys must be 16..%u", FJ_PART_TARGET_KEYS); options().plan_target_keys = (u32)value; return 0; }
-    if (!strcmp(name, "bloom_auto")) { options().bloom_auto = value != 0; return 0; }
-    if (!strcmp(name, "mat_single_pass")) { options().mat_single_pass = value != 0; return 0; }
-    if (!strcmp(name, "bloom_auto_max_hit_bp")) { if (value < 0 || value > 10000) return set_err("fj_set_option: bloom_auto_max_hit_bp must be 0..10000"); options().bloom_auto_max_hit_bp = (int)value; return 0; }
-    if (!strcmp(name, "bloom_variant")) { if (value < 0 || value > 2) return set_err("fj_set_option: bloom_variant must be 0..2"); options().bloom_variant = (int)value; return 0; }
-    if (!strcmp(name, "join_wide")) { if (value < 0 || value > 2) return set_err("fj_set_option: join_wide must be 0..2"); options().join_wide = (int)value; return 0; }
-    if (!strcmp(name, "persistent_min_items")) { if (value < 0) return set_err("fj_set_option: persistent_min_items must be >= 0"); options().persistent_min_items = (u32)std::min<long long>(value, 0xFFFFFFFFll); return 0; }
-    return set_err("fj_set_option: unknown option '%s'", name);
+    return fjh::set_option_value(options(), name, value);
 }
 
 long long fj_get_option(const char* name) {
-    if (name && !strcmp(name, "radix_threshold")) return (long long)options().radix_threshold;
-    if (name && !strcmp(name, "scalar_hbm_table")) return options().scalar_hbm_table;
-    if (name && !strcmp(name, "persistent_min_items")) return options().persistent_min_items;
-    if (name && !strcmp(name, "join_wide")) return options().join_wide;
-    if (name && !strcmp(name, "plan_target_keys")) return options().plan_target_keys;
-    if (name && !strcmp(name, "bloom_variant")) return options().bloom_variant;
-    if (name && !strcmp(name, "bloom_auto")) return options().bloom_auto;
-    if (name && !strcmp(name, "mat_single_pass")) return options().mat_single_pass;
-    if (name && !strcmp(name, "bloom_auto_max_hit_bp")) return options().bloom_auto_max_hit_bp;
+    const Options& o = options();
+    if (name && !strcmp(name, "radix_threshold")) return (long long)o.radix_threshold;
+    if (name && !strcmp(name, "scalar_hbm_table")) return o.scalar_hbm_table;
+    if (name && !strcmp(name, "persistent_min_items")) return o.persistent_min_items;
+    if (name && !strcmp(name, "join_wide")) return o.join_wide;
+    if (name && !strcmp(name, "plan_target_keys")) return o.plan_target_keys;
+    if (name && !strcmp(name, "bloom_variant")) return o.bloom_variant;
+    if (name && !strcmp(name, "bloom_auto")) return o.bloom_auto;
+    if (name && !strcmp(name, "mat_single_pass")) return o.mat_single_pass;
+    if (name && !strcmp(name, "bloom_auto_max_hit_bp")) return o.bloom_auto_max_hit_bp;
+    if (name && !strcmp(name, "lab_hooks")) return o.lab_hooks;
+    if (name && !strcmp(name, "join_items_target")) return o.join_items_target;
     set_err("fj_get_option: unknown option '%s'", name ? name : "(null)");
     return -1;
 }

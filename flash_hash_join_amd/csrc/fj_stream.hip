@@ -419,6 +419,23 @@ int fj_shuffle_pack_finish(fj_ctx* c, void* const* d_dst_chunks, uint64_t* const
     return 0;
 }
 
+}  // extern "C"
+namespace {
+// one side of a shuffled stream join: the plan from its second pass on, over pieces that arrive as chunk lists (pass 1 ran at the senders)
+int shuffled_side_init(fj_ctx* c, StreamState& st, int side, size_t n, u32 appends, hipStream_t s) {
+    PassIter& it = side ? st.pit : st.bit;
+    const Plan& plan = st.plan;
+    const u32 F0 = 1u << plan.fan_log[0];
+    pass_init(it, side, side == 0 && st.with_vals, std::max<size_t>(n, 1), plan, 64);
+    it.i = 1; it.used = 64 - plan.fan_log[0]; it.parents = st.nbk_pad; it.slot = 1;
+    it.lbound = it.n / FJ_CHUNK + 1 + (u64)appends * ((u64)64 * F0 + 64);               // one partial chunk per (sender, bucket, piece)
+    it.in_pk7 = wire7(plan); it.in_b0 = st.b_lo; it.in_top_shift = (u32)std::max(0, plan.fan_log[0] - 8);
+    if (side) it.want_items = true;
+    return pass_prepare(c, it, appends, s);
+}
+}  // namespace
+extern "C" {
+
 int fj_stream_open_shuffled(fj_ctx* c, size_t nb_total, int nranks, int rank, size_t nb_bound, int build_appends, size_t np_bound, int probe_appends,
                             int with_vals, void* stream) {
     if (!c) return set_err("fj_stream_open_shuffled: null context");
@@ -441,16 +458,10 @@ int fj_stream_open_shuffled(fj_ctx* c, size_t nb_total, int nranks, int rank, si
     begin_plan(c);
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     if (clear_plan_scalars(c, s)) return 1;
-    auto init = [&](PassIter& it, int side, size_t n, u32 appends) -> int {
-        pass_init(it, side, side == 0 && with_vals, std::max<size_t>(n, 1), plan, 64);
-        it.i = 1; it.used = 64 - plan.fan_log[0]; it.parents = st.nbk_pad; it.slot = 1;     // pass 1 of the plan ran at the senders
-        it.lbound = it.n / FJ_CHUNK + 1 + (u64)appends * ((u64)64 * F0 + 64);               // one partial chunk per (sender, bucket, piece)
-        it.in_pk7 = wire7(plan); it.in_b0 = st.b_lo; it.in_top_shift = (u32)std::max(0, plan.fan_log[0] - 8);
-        return pass_prepare(c, it, appends, s);
-    };
-    if (init(st.bit, 0, nb_bound, (u32)build_appends)) return 1;
-    if (init(st.pit, 1, np_bound, (u32)probe_appends)) return 1;
-    st.pit.want_items = true;
+    if (shuffled_side_init(c, st, 0, nb_bound, (u32)build_appends, s)) return 1;
+    // the probe side's pools are sized when its first piece arrives (fj_stream_append_probe_chunks): from the bound given here, or -
+    // for an owner of hot probe keys, whose share is far above the mean the bound was derived from - from 1.25x the first piece's rate
+    st.probe_prepared = false; st.probe_appends = (u32)probe_appends;
     st.active = true;
     return 0;
 }
@@ -523,6 +534,12 @@ int fj_stream_append_probe_chunks(fj_ctx* c, const void* d_chunks, uint32_t* d_d
     FJ_ENTER(c);
     --st.p_appends_left;
     if (nchunks == 0) return 0;
+    if (!st.probe_prepared) {
+        const size_t seen = (size_t)(1.25 * (double)nchunks * FJ_CHUNK * (st.p_appends_left + 1)) + ((size_t)1 << 20);
+        st.np_bound = std::max(st.np_bound, seen);
+        if (shuffled_side_init(c, st, 1, st.np_bound, st.probe_appends, (hipStream_t)stream)) return 1;
+        st.probe_prepared = true;
+    }
     st.np_seen += nchunks * FJ_CHUNK;
     return stream_append_chunks(c, 1, d_chunks, nullptr, d_dir, nchunks, (hipStream_t)stream);
 }

@@ -1252,6 +1252,11 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
                     if timings is not None:
                         timings["chunk_form_error"] = str(ex)
                     form = FORM_SHUFFLE                      # (a broadcast step that failed - a skewed partition - is retried as the shuffle)
+                    if attempt[0] > 0 and memo_key is not None:
+                        # a step that failed WITH the precheck (an owner of hot probe keys overflows pools sized from the mean before any
+                        # probe piece is seen) must not be attempted again on every later step of the same shape: remembered as declined,
+                        # re-examined with the next resample like any other verdict (all ranks fail together: the memos stay identical)
+                        _PRECHECK_MEMO[memo_key] = [1, 2.0]
         if timings is not None:
             timings["shuffle_form"] = "owner-scatter"
         if not standin and hasattr(engine, "bloom_export"):

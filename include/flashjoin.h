@@ -23,6 +23,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)       /* the library is built with -fvisibility=hidden: these entry points are all it exports */
+#endif
 
 /* algo: which of the reference's drivers the call stands for */
 #define FJ_ALGO_ADAPTIVE 0 /* adaptive_hash_join_{count,materialize}   hash_join.cpp:576-594 */
@@ -401,6 +404,11 @@ typedef struct fj_dist_engine_ops {   /* a stand-in for the rank's own work (the
 #define FJ_DIST_FORM_SHUFFLE 1
 #define FJ_DIST_FORM_BROADCAST 2
 int fj_dist_comm_set_form(fj_dist_comm* comm, int form, double link_bytes_per_s);
+/* While another library's kernels are resident on this GPU for the length of a step (RCCL's send / receive kernels during an exchange), the
+ * partition passes and the wide join - one workgroup per CU, each wanting a whole CU - launch num_cus - n workgroups.  fj_dist_join does this
+ * itself over RCCL (n = 32, FJ_DIST_RESERVE_CUS); a host that drives fj_bcast_* / fj_shuffle_* over its own GPU-side transport calls it.  n = 0
+ * restores the full grid. */
+void fj_ctx_reserve_cus(fj_ctx* ctx, unsigned n);
 /* the model behind FJ_DIST_FORM_AUTO: modelled seconds of one counting step in either form (NULL: not wanted); returns the form it picks */
 int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
                   double* t_shuffle, double* t_broadcast);
@@ -443,6 +451,9 @@ int fj_memcpy_h2d(void* d, const void* h, size_t bytes);
 int fj_memcpy_d2h(void* h, const void* d, size_t bytes);
 int fj_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

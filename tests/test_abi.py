@@ -34,6 +34,11 @@ def test_library_exports_every_declared_symbol(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     for name in declared:
         assert re.search(rf"\bT {name}\b", out), f"{name} is not an exported text symbol"
+    # ... and library -> header: the C ABI is ALL the library exports (built with -fvisibility=hidden; what remains beside it are
+    # the toolchain's own symbols: the HIP fat-binary handles and C++ runtime weak symbols)
+    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    extra = [e for e in exported if e not in declared]
+    assert extra == [], f"exported but not declared in include/flashjoin.h: {extra}"
 
 
 def test_key_mixer_is_a_bijection_and_matches_its_numpy_restatement(lib):

@@ -637,6 +637,51 @@ def test_chunk_form_precheck_break_even_model(monkeypatch):
     assert D._chunk_prefilter_mode(False, 1) == "on"
 
 
+def test_a_failed_precheck_attempt_is_remembered_as_declined(monkeypatch):
+    """a chunk-form step that fails WITH the sender-side precheck (an owner of hot probe keys overflows pools sized from
+    the mean) reran without it on EVERY later step of the same shape, roughly doubling the step.  The failed attempt is now memoised
+    as "declined" (survivor share 2.0: above any break-even) until the next resample."""
+    from flash_hash_join_amd import distributed as D
+    monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 10e9)
+    D._PRECHECK_MEMO.clear()
+    calls = []
+
+    def fake_driver(dist, group, engine, bk, pk, pieces, tt, transport, prefilter_below=0.0, prefilter_mode="off", form=0, **kw):
+        calls.append(prefilter_below)
+        if prefilter_below > 0:
+            raise RuntimeError("fj_dist_join_count: the local join failed on 1 rank(s)")
+        tt.update(strategy="shuffle", prefilter=False, prefilter_sampled_survivors=None)
+        return 7, 0.0
+
+    monkeypatch.setattr(D, "_driver_count", fake_driver)
+
+    class Eng:
+        def counts_tensor(self, c): return torch.tensor(c, dtype=torch.int64)
+        def stream_begin(self): pass
+        def bloom_export(self): pass
+        def shuffle_plan(self, nb_total, world): return 9
+        def stream_abort(self): pass
+        has_bcast = False
+        def dist_engine_ops(self, world): return None
+        chunk_precheck = True
+
+    class FakeDist:
+        def is_initialized(self): return True
+        def get_world_size(self, group=None): return 8
+        def all_gather_into_tensor(self, out, t, group=None): out.copy_(t.repeat(8))
+
+    monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_PREFILTER", "auto"); monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.6")
+    bk = torch.arange(125_000, dtype=torch.int64); pk = torch.arange(1_250_000, dtype=torch.int64)
+    below = D._precheck_threshold("auto", 8, 8 * 125_000, 8 * 1_250_000)[0]
+    assert below == 0.6                                    # a threshold in the model's place: sample, then decide
+    for _ in range(3):
+        t = {}
+        assert D.distributed_join(bk, bk, pk, engine=Eng(), transport=FakeDist(), timings=t)[0] == 7
+    # first step: the attempt with the precheck fails, the rerun without it succeeds; later steps go straight to the form that works
+    assert calls == [below, 0.0, 0.0, 0.0], calls
+    D._PRECHECK_MEMO.clear()
+
+
 def test_precheck_verdict_is_remembered_per_join_shape(monkeypatch):
     """distributed._precheck_threshold / _precheck_remember: "auto" samples once per (world, build rows, probe rows), then runs or
     declines without exporting a filter, and samples afresh on every 32nd call; forced modes and joins the model rules out keep no memo."""

@@ -210,17 +210,17 @@ def test_partition_over_the_cuckoo_limit_is_redone_on_the_tagged_table(fj, oracl
     # The emitting pass of a unique-key build runs on the cuckoo table too (fj_emit_join_persistent); a table that
     # overflows there marks its item and the host redoes the marked items on the tagged table.  (A partition the COUNTING
     # pass already had to retry reports "duplicates possible" and takes the tagged kernel anyway, so the path is driven by
-    # the kernel's test hook: FJ_JOIN_ABLATE=8 sends every 7th item through it.)
+    # the kernel's test hook: lab_hooks & 64 (FJ_HOOK_EMIT_RETRY_7TH) sends every 7th item through it.)
     ubk = np.concatenate([one[:3000], rest])
     ubv = np.arange(ubk.size, dtype=np.uint64) * np.uint64(3) + np.uint64(1)
     upk = np.concatenate([ubk, ubk[::2], cand[:50000]])
     exp, ek, ev = oracle.np_join(ubk, ubv, upk, return_arrays=True)
-    os.environ["FJ_JOIN_ABLATE"] = "8"
+    fj.set_option("lab_hooks", 64)
     try:
         n, _, k, v = fj.hash_join_radix(ubk, ubv, upk, return_arrays=True)
         t = fj.last_timings()
     finally:
-        os.environ.pop("FJ_JOIN_ABLATE")
+        fj.set_option("lab_hooks", 0)
     assert n == exp and t["fell_back"] == 0 and t["lds_retries"] == 1, t      # the emitting pass's retry launch
     a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -1208,7 +1208,7 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
         bk, bv = datagen.build_device(nb, "cuda:0")
         pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=1, hit_bp=5000)
         for loop, native in (("0", "1"), ("1", "1"), ("0", "0")):
-            monkeypatch.setenv("FJ_DIST_LOOPBACK", loop); monkeypatch.setenv("FJ_DIST_NATIVE", native)
+            fj.set_option("lab_hooks", int(loop)); monkeypatch.setenv("FJ_DIST_NATIVE", native)      # (lab_hooks & 1 = FJ_HOOK_LOOPBACK)
             t = {}
             n, sec = distributed_join(bk, bv, pk, timings=t)
             assert n == exp and t["local_count"] == exp and t["pieces"] == 4 and t["wire_chunk_bytes"] == 1792, t
@@ -1223,12 +1223,13 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
         # only splits under this test hook): a fresh communicator, the same step, the same count
         from flash_hash_join_amd.distributed import HipEngine
         HipEngine.close_native_comms()
-        monkeypatch.setenv("FJ_DIST_SPLIT_ALWAYS", "1"); monkeypatch.setenv("FJ_DIST_LOOPBACK", "1"); monkeypatch.setenv("FJ_DIST_NATIVE", "1")
+        fj.set_option("lab_hooks", 4 | 1); monkeypatch.setenv("FJ_DIST_NATIVE", "1")                 # FJ_HOOK_SPLIT_ALWAYS | FJ_HOOK_LOOPBACK
         t = {}
         n, sec = distributed_join(bk[: nb // 10], bv[: nb // 10], pk[: npk // 10], timings=t)
         assert t["shuffle_form"] == "chunks (fj_dist_join_count over RCCL)" and n == int(torch.isin(pk[: npk // 10], bk[: nb // 10]).sum())
         HipEngine.close_native_comms()
     finally:
+        fj.set_option("lab_hooks", 0)
         dist.destroy_process_group()
 
 
@@ -1258,7 +1259,7 @@ def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monke
                 for loop, native in (("0", "1"), ("1", "1"), ("0", "0")):
                     if (loop, native) != ("0", "1") and npk > 200_000_000:
                         continue
-                    monkeypatch.setenv("FJ_DIST_LOOPBACK", loop); monkeypatch.setenv("FJ_DIST_NATIVE", native)
+                    fj.set_option("lab_hooks", int(loop)); monkeypatch.setenv("FJ_DIST_NATIVE", native)
                     t = {}
                     n, sec = distributed_join(bk, bv, pk, timings=t)
                     assert n == exp and t["shuffle_form"].startswith("chunks") and t["prefilter"] is True and t["prefilter_mode"] == "on", t
@@ -1267,7 +1268,7 @@ def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monke
                     assert t["local_probe_rows"] <= t["probe_rows_sent"] + 256 * 512 * 4, t
                     print(f"precheck {nb}x{npk} at {hit_bp / 100:.0f} % hits: {t['probe_rows_sent'] / npk:.3f} of the probe rows travel ({(t['probe_rows_sent'] - exp) / max(1, misses):.3f} of the misses), step {sec * 1e3:.2f} ms")
                 monkeypatch.delenv("FJ_DIST_PREFILTER")
-                monkeypatch.setenv("FJ_DIST_LOOPBACK", "0"); monkeypatch.setenv("FJ_DIST_NATIVE", "1")
+                fj.set_option("lab_hooks", 0); monkeypatch.setenv("FJ_DIST_NATIVE", "1")
                 t = {}
                 n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t)              # "auto": on one rank the model always declines
                 assert n == exp and t["prefilter_mode"] == "auto" and t["prefilter_below"] == 0 and t["prefilter"] is False and t["prefilter_sampled_survivors"] is None, t
@@ -1767,18 +1768,19 @@ def test_stream_join_rejects_misuse(fj):
             assert distributed_join(big_bk, big_bv, big_pk)[0] == big_exp               # the context is free again
         # ... and so does the C++ driver of the chunk form (csrc/fj_dist.hip): a local append that fails (test hook) is agreed on in the
         # final all-reduce, the stream join is dropped, every rank raises; without FJ_DIST_NO_FALLBACK the ranks rerun in the owner-scatter form
-        os.environ["FJ_DIST_STRATEGY"] = "shuffle"; os.environ["FJ_DIST_INJECT_FAIL"] = "1"; os.environ["FJ_DIST_NO_FALLBACK"] = "1"
+        os.environ["FJ_DIST_STRATEGY"] = "shuffle"; fj.set_option("lab_hooks", 2); os.environ["FJ_DIST_NO_FALLBACK"] = "1"      # FJ_HOOK_INJECT_FAIL
         with pytest.raises(RuntimeError, match="the local join failed on 1 rank.*injected failure of a local append"):
             distributed_join(big_bk, big_bv, big_pk)
         os.environ.pop("FJ_DIST_NO_FALLBACK")
         t = {}
         assert distributed_join(big_bk, big_bv, big_pk, timings=t)[0] == big_exp and t["shuffle_form"] == "owner-scatter" and "injected" in t["chunk_form_error"]
-        os.environ.pop("FJ_DIST_INJECT_FAIL")
+        fj.set_option("lab_hooks", 0)
         t = {}
         assert distributed_join(big_bk, big_bv, big_pk, timings=t)[0] == big_exp and t["shuffle_form"].startswith("chunks") and "chunk_form_error" not in t
     finally:
-        for k_ in ("FJ_FORCE_EXCHANGE", "FJ_DIST_STRATEGY", "FJ_DIST_NATIVE", "FJ_DIST_CHUNK_SHUFFLE", "FJ_DIST_INJECT_FAIL", "FJ_DIST_NO_FALLBACK"):
+        for k_ in ("FJ_FORCE_EXCHANGE", "FJ_DIST_STRATEGY", "FJ_DIST_NATIVE", "FJ_DIST_CHUNK_SHUFFLE", "FJ_DIST_NO_FALLBACK"):
             os.environ.pop(k_, None)
+        fj.set_option("lab_hooks", 0)
         dist.destroy_process_group()
 
 

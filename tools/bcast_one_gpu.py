@@ -14,7 +14,6 @@ world, nb_rank, np_rank, pieces, steps, hit_bp, reserve = (args + [8, 125_000_00
 rank = 0
 api.initialize(); eng = HipEngine("cuda:0")
 if reserve:
-    eng.L.fj_ctx_reserve_cus.argtypes = [__import__('ctypes').c_void_p, __import__('ctypes').c_uint]; eng.L.fj_ctx_reserve_cus.restype = None
     eng.L.fj_ctx_reserve_cus(eng.ctx, reserve)
 nb_total = nb_rank * world
 bits, nparts, mid = eng.bcast_plan(nb_total)

@@ -23,7 +23,7 @@ timeout 900 python bench.py 2>&1 | tail -1 > $O/c3_bench.json
 for w in c2 c2_hbm_table c4 c4_scalar_bloom c4_adaptive c4_hbm_table_bloom c3_adaptive c3_mat small rep8 c5; do
   timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 >> $O/other_workloads.jsonl
 done
-FJ_MAT_SINGLE_PASS=0 timeout 300 python bench.py --workload c3_mat --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c3_mat_two_pass_bench.json
+FJ_OPTIONS=mat_single_pass=0 timeout 300 python bench.py --workload c3_mat --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c3_mat_two_pass_bench.json
 timeout 600 python tools/skew_build_partition_probe.py 4 > $O/skew_build_partition_probe.txt 2>&1
 timeout 900 python tools/benchmark_j1.py --sizes 1e7,4e7 --cpu --duckdb > $O/j1_shaped_benchmark.log 2>&1
 # the multi-GPU step of config 5 on one rank (C++ driver) and the sender side in isolation

@@ -5,7 +5,7 @@ import os, socket, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
-from flash_hash_join_amd import datagen
+from flash_hash_join_amd import api, datagen
 from flash_hash_join_amd.distributed import distributed_join
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -21,13 +21,13 @@ free0 = None
 t0 = time.time()
 for r in range(rounds):
     mode = r % 5
-    os.environ["FJ_DIST_LOOPBACK"] = "1" if mode == 1 else "0"
+    hooks = 1 if mode == 1 else 0           # lab_hooks: FJ_HOOK_LOOPBACK
     os.environ["FJ_DIST_NATIVE"] = "0" if mode == 2 else "1"
-    os.environ.pop("FJ_DIST_INJECT_FAIL", None)
+    api.set_option("lab_hooks", hooks)
     os.environ["FJ_DIST_PREFILTER"] = ("0", "1", "auto")[(r // 5) % 3]      # the sender-side precheck: off / forced / by a sample (threshold below)
     os.environ["FJ_DIST_PREFILTER_BELOW"] = "0.7"
     if mode == 3:
-        os.environ["FJ_DIST_INJECT_FAIL"] = "1"          # the chunk form fails (agreed), the step reruns in the owner-scatter form
+        api.set_option("lab_hooks", hooks | 2)              # the chunk form fails (agreed), the step reruns in the owner-scatter form
     t = {}
     if mode == 4:
         n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True, timings=t)

@@ -6,7 +6,7 @@ import os, random, socket, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
-from flash_hash_join_amd import datagen
+from flash_hash_join_amd import api, datagen
 from flash_hash_join_amd.distributed import distributed_join
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -38,7 +38,7 @@ for c in range(cases):
     pk = pk.contiguous()
     exp = int(torch.isin(pk, bk).sum()) if npk else 0
     os.environ["FJ_DIST_PIECES"] = str(rng.choice([1, 2, 4, 7]))
-    os.environ["FJ_DIST_LOOPBACK"] = rng.choice(["0", "1"])
+    os.environ["FJ_DIST_LOOPBACK"] = rng.choice(["0", "1"]); api.set_option("lab_hooks", int(os.environ["FJ_DIST_LOOPBACK"]))      # (lab_hooks & 1: the loop-back hook; the variable is only this script's label)
     os.environ["FJ_DIST_NATIVE"] = rng.choice(["1", "1", "0"])
     mat = rng.random() < 0.3 and exp < 60_000_000
     t = {}

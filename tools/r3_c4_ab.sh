@@ -6,7 +6,7 @@ B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry"
 : > $O/c4_ab.jsonl
 for v in ${VARIANTS:-2 0 1}; do
   echo "variant=$v" >> $O/c4_ab.jsonl
-  FJ_BLOOM_VARIANT=$v timeout 300 $B --workload c4 2>&1 | tail -1 >> $O/c4_ab.jsonl
+  FJ_OPTIONS=bloom_variant=$v timeout 300 $B --workload c4 2>&1 | tail -1 >> $O/c4_ab.jsonl
 done
 timeout 300 $B --workload c4_adaptive 2>&1 | tail -1 > $O/c4_adaptive.json
 timeout 300 $B --workload c3 2>&1 | tail -1 > $O/c3.json

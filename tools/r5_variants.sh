@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-$PWD}" || exit 1
 mkdir -p gpurun_out
 for wl in ${WLS:-c5_rep8 rep8}; do
   for r in 1 2; do for v in $VARS; do
-    FJ_LIB_VARIANT=$v FJ_JOIN_WIDE=${WIDE:-1} python bench.py --workload $wl --steps ${ST:-10} --warmup 2 --no-cpu-baseline --no-host-entry 2>/tmp/err.txt | tail -1 > /tmp/b.json
+    FJ_LIB_VARIANT=$v FJ_OPTIONS=join_wide=${WIDE:-1} python bench.py --workload $wl --steps ${ST:-10} --warmup 2 --no-cpu-baseline --no-host-entry 2>/tmp/err.txt | tail -1 > /tmp/b.json
     python - <<PY
 import json
 try:

@@ -1,11 +1,11 @@
 #!/bin/bash
-# same-box A/B of the counting join kernels: FJ_JOIN_WIDE=0 (8192-slot cuckoo, two workgroups per CU) / 1 (16384-slot kernel
+# same-box A/B of the counting join kernels: FJ_OPTIONS=join_wide=0 (8192-slot cuckoo, two workgroups per CU) / 1 (16384-slot kernel
 # wherever eligible) / 2 (auto) over several workloads.  usage (on the GPU box): [WLS="rep8 c5_rep8"] [MODES="0 2"] bash tools/r5_wide_ab.sh
 cd "${GRAFT_REPO_ROOT:-$PWD}" || exit 1
 mkdir -p gpurun_out
 for wl in ${WLS:-rep8 c5_rep8 c2 c4 c3}; do
   for r in 1 2; do for m in ${MODES:-0 1}; do
-    FJ_JOIN_WIDE=$m python bench.py --workload $wl --steps ${ST:-10} --warmup 2 --no-cpu-baseline --no-host-entry 2>/tmp/err.txt | tail -1 > /tmp/b.json
+    FJ_OPTIONS=join_wide=$m python bench.py --workload $wl --steps ${ST:-10} --warmup 2 --no-cpu-baseline --no-host-entry 2>/tmp/err.txt | tail -1 > /tmp/b.json
     python - <<PY
 import json
 try:
