@@ -99,6 +99,7 @@ struct Pending {
     u64 count = 0;
     // oversized partitions that skew_join re-partitioned: their sub-partitions are a second item set, emitted behind the first
     bool has_second = false; FjLdsJoinArgs lds2{}; u32 nitems2 = 0; u64 count_main = 0; std::vector<u32> flagged;
+    bool dups_main = false; std::vector<u32> sk_parts; int sk_bits = 0, sk_plan_bits = 0, sk_npass = 0;     // ... which partitions, by how many more bits (the first-occurrence emit path repeats it with row indices)
     // duplicate build keys seen by the counting pass: the emitting pass must pick the FIRST occurrence's value
     bool has_dups = false;
     const u64* bk = nullptr; const u64* bv = nullptr; size_t nb = 0; int top_bits = 64;

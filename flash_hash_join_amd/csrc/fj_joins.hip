@@ -5,6 +5,9 @@
 
 namespace fjh {
 
+static int skew_side(fj_ctx* c, PassIter& it, int side, bool vals, const FjChunkSet& in, const std::vector<u32>& off, u64 chunks, int S, int bits_left,
+                     int slot, int tiles_slot, u32* d_nt, hipStream_t s);
+
 int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_timings* t) {
     Pending& pd = c->pend;
     if (!pd.valid) return set_err("fj_emit_pairs: no counted materialising join is pending on this context");
@@ -28,6 +31,21 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
                 if (run_passes(c, bit, pd.bk, rowidx, s, &pd.lds.build, nullptr)) return 1;
                 end_plan(c);                  // (a pool error of these passes surfaces through the emit kernel's missing rows: same sizes as the counted join)
                 pd.lds.dedup = 1; pd.lds.orig_vals = pd.bv;
+                if (pd.has_second) {
+                    // ... and the oversized partitions once more from THAT level: their sub-partitions' build rows carry row indices too
+                    const u32 m = (u32)pd.sk_parts.size();
+                    std::vector<u32> bo(2 * m);
+                    for (u32 j = 0; j < m; ++j) HIPCHK(hipMemcpyAsync(&bo[2 * j], pd.lds.build.boff + pd.sk_parts[j], 8, hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    u64 bchunks = 0;
+                    for (u32 j = 0; j < m; ++j) bchunks += bo[2 * j + 1] - bo[2 * j];
+                    if (get_buf(c, W_SK_NT, 16, &p)) return 1;
+                    PassIter bit2;
+                    begin_plan(c);
+                    if (skew_side(c, bit2, 0, true, pd.lds.build, bo, bchunks, pd.sk_bits, pd.top_bits - pd.sk_plan_bits, pd.sk_npass, W_SK_TILES_B, (u32*)p, s)) return 1;
+                    end_plan(c);
+                    pd.lds2.build = bit2.prev;
+                }
             }
             if (pd.has_second)                  // the items of re-partitioned partitions emit nothing themselves: their sub-partitions do, below
                 for (u32 idx : pd.flagged) HIPCHK(hipMemsetAsync(&pd.lds.part_count[idx], 0, 4, s));
@@ -46,7 +64,7 @@ int emit_pending(fj_ctx* c, u64* d_ok, u64* d_ov, size_t cap, hipStream_t s, fj_
                 if (get_buf(c, W_OUT_OFF2, ((size_t)pd.nitems2 + 1) * 8, &p)) return 1;
                 HIPCHK(fj_launch_scan_u32_to_u64(pd.lds2.part_count, (u64*)p, pd.nitems2, s));
                 pd.lds2.out_off = (const u64*)p; pd.lds2.out_keys = d_ok + pd.count_main; pd.lds2.out_vals = d_ov + pd.count_main;
-                pd.lds2.dedup = 0; pd.lds2.orig_vals = nullptr; pd.lds2.dbg = nullptr;
+                pd.lds2.dedup = pd.has_dups ? 1u : 0u; pd.lds2.orig_vals = pd.has_dups ? pd.bv : nullptr; pd.lds2.dbg = nullptr;
                 HIPCHK(fj_launch_lds_emit_retry(pd.lds2, s, false));  // (the tagged emit kernel over every item of the set: a few hundred items)
             }
         } else if (pd.path == 2) {           // many-to-many: count per item -> scan -> emit
@@ -122,6 +140,35 @@ int join_global(fj_ctx* c, int bloom, int materialize, const u64* bk, const u64*
     return 0;
 }
 
+// one side of the per-partition skew recovery: the chunk lists of partitions `parts` of `in` (their list ranges in off[2j], off[2j+1]) go
+// through one more pass of S radix bits (the pass kernel reads any tile table); vals: the side's payload travels along (values, or -
+// first-occurrence emit of duplicate build keys - row indices).  The sub-partitions land in the ping-pong half `slot` does not hold.
+static int skew_side(fj_ctx* c, PassIter& it, int side, bool vals, const FjChunkSet& in, const std::vector<u32>& off, u64 chunks, int S, int bits_left,
+                     int slot, int tiles_slot, u32* d_nt, hipStream_t s) {
+    const u32 m = (u32)(off.size() / 2);
+    Plan p2; p2.bits = S; p2.npass = 1; p2.fan_log[0] = S;
+    const u32 tc = fj_partition_tile_chunks((u32)S, vals);
+    std::vector<uint4> tiles;
+    for (u32 j = 0; j < m; ++j)
+        for (u32 pos = off[2 * j]; pos < off[2 * j + 1]; pos += tc) tiles.push_back(make_uint4(pos, std::min(tc, off[2 * j + 1] - pos), j, 0));
+    const u32 nt = (u32)tiles.size();
+    void* p;
+    if (get_buf(c, tiles_slot, std::max<size_t>(1, tiles.size()) * sizeof(uint4), &p)) return 1;
+    if (nt) HIPCHK(hipMemcpyAsync(p, tiles.data(), tiles.size() * sizeof(uint4), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_nt, &nt, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                                         // (`tiles` and `nt` live on this stack frame)
+    pass_init(it, side, vals, std::max<u64>(1, chunks * FJ_CHUNK), p2, bits_left);
+    it.parents = m; it.lbound = chunks;
+    it.slot = slot;                                          // the ping-pong half that does NOT hold the final level
+    it.have_prev = true; it.prev = in; it.tiles = (const uint4*)p; it.ntiles = d_nt;
+    if (side) { it.want_items = true; it.part_count_slot = W_PART_COUNT2; }
+    // the main plan is done with its first pass's allocator and segment counter: they serve this pass
+    HIPCHK(hipMemsetAsync(&c->d_sc->alloc[side * 4], 0, 4, s));
+    HIPCHK(hipMemsetAsync(&c->d_sc->seg_counter[side * 4], 0, 4, s));
+    if (pass_prepare(c, it, 1, s) || pass_launch(c, it, nullptr, nullptr, 0, s, nullptr) || pass_complete(c, it, s)) return 1;
+    return 0;
+}
+
 // Build-side skew, recovered per partition (the reference maps partitions to threads statically and has no answer to skew,
 // hash_join.cpp:507-510; rounds 1-2 re-ran the WHOLE join on one table in HBM, a 4.5x cliff at config-3 sizes for one bad
 // partition).  The tagged kernel marked the items whose partition holds more distinct build keys than an LDS table takes
@@ -158,30 +205,6 @@ int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits
     if (((bmax * FJ_CHUNK) >> S) > 6000 || top_bits - plan.bits - S < 32) return 0;
     if (S < 5) S = std::min(5, top_bits - plan.bits - 32);                       // (a pass with a tiny fan-out serialises on its bucket threads)
     if (S < 1) return 0;
-    Plan p2; p2.bits = S; p2.npass = 1; p2.fan_log[0] = S;
-    auto run_side = [&](PassIter& it, int side, const FjChunkSet& in, const std::vector<u32>& off, u64 chunks, int tiles_slot, u32* d_nt) -> int {
-        const bool vals = materialize && side == 0;               // a materialising join's build rows travel with their values
-        const u32 tc = fj_partition_tile_chunks((u32)S, vals);
-        std::vector<uint4> tiles;
-        for (u32 j = 0; j < m; ++j)
-            for (u32 pos = off[2 * j]; pos < off[2 * j + 1]; pos += tc) tiles.push_back(make_uint4(pos, std::min(tc, off[2 * j + 1] - pos), j, 0));
-        const u32 nt = (u32)tiles.size();
-        void* p;
-        if (get_buf(c, tiles_slot, std::max<size_t>(1, tiles.size()) * sizeof(uint4), &p)) return 1;
-        if (nt) HIPCHK(hipMemcpyAsync(p, tiles.data(), tiles.size() * sizeof(uint4), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(d_nt, &nt, 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));                                         // (`tiles` and `nt` live on this stack frame)
-        pass_init(it, side, vals, std::max<u64>(1, chunks * FJ_CHUNK), p2, top_bits - plan.bits);
-        it.parents = m; it.lbound = chunks;
-        it.slot = side ? probe_slot : plan.npass;            // the ping-pong half that does NOT hold the final level (a bloom stage took a slot of its own on the probe side)
-        it.have_prev = true; it.prev = in; it.tiles = (const uint4*)p; it.ntiles = d_nt;
-        if (side) { it.want_items = true; it.part_count_slot = W_PART_COUNT2; }
-        // the main plan is done with its first pass's allocator and segment counter: they serve this pass
-        HIPCHK(hipMemsetAsync(&c->d_sc->alloc[side * 4], 0, 4, s));
-        HIPCHK(hipMemsetAsync(&c->d_sc->seg_counter[side * 4], 0, 4, s));
-        if (pass_prepare(c, it, 1, s) || pass_launch(c, it, nullptr, nullptr, 0, s, nullptr) || pass_complete(c, it, s)) return 1;
-        return 0;
-    };
     void* p;
     if (get_buf(c, W_SK_NT, 16, &p)) return 1;
     u32* d_nt = (u32*)p;
@@ -189,8 +212,8 @@ int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits
     const u64 count_main = c->h_sc->total;                                       // what every other partition found
     const bool had_dups = (c->h_sc->err & FJ_STAT_DUPS) != 0;
     HIPCHK(hipMemsetAsync(&c->d_sc->err, 0, 4, s));                              // the main join's status bits have been acted on
-    if (run_side(bit2, 0, ja.build, bo, bchunks, W_SK_TILES_B, d_nt)) return 1;
-    if (run_side(pit2, 1, ja.probe, po, pchunks, W_SK_TILES_P, d_nt + 1)) return 1;
+    if (skew_side(c, bit2, 0, materialize != 0, ja.build, bo, bchunks, S, top_bits - plan.bits, plan.npass, W_SK_TILES_B, d_nt, s)) return 1;
+    if (skew_side(c, pit2, 1, false, ja.probe, po, pchunks, S, top_bits - plan.bits, probe_slot, W_SK_TILES_P, d_nt + 1, s)) return 1;
     FjLdsJoinArgs j2 = ja;
     j2.build = bit2.prev; j2.probe = pit2.prev; j2.nparts = j2.probe.nb; j2.nsplit = 1;
     j2.items = pit2.tiles; j2.nitems_dev = pit2.ntiles; j2.items_cap = pit2.items_cap; j2.part_count = pit2.part_count;
@@ -204,9 +227,11 @@ int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits
     if (c->h_sc->err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted while re-partitioning a skewed partition");
     if (c->h_sc->err & FJ_ERR_LDS_FULL) return 0;                                // sub-partitions still too large (keys colliding in all of hash word 1)
     if (materialize) {
-        // duplicate build keys need the first-occurrence emit path, which re-partitions the whole build side: not combined with this one
-        if (had_dups || (c->h_sc->err & FJ_STAT_DUPS)) return 0;
+        // (duplicate build keys: the first-occurrence emit path re-partitions the whole build side with row indices, and then these
+        //  partitions again - emit_pending; what it needs to do that is kept here)
         pend->has_second = true; pend->lds2 = j2; pend->nitems2 = pit2.items_cap; pend->count_main = count_main; pend->flagged = flagged;
+        pend->sk_parts = parts; pend->sk_bits = S; pend->sk_plan_bits = plan.bits; pend->sk_npass = plan.npass;
+        pend->dups_main = had_dups;                          // (the main join's verdict: its status word was cleared above)
     }
     *ok = true; *nparts_redone = m;
     return 0;
@@ -215,7 +240,7 @@ int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits
 // launch the per-partition join over the final chunk sets, read back count + error word, fill the timings
 int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& plan, size_t np, const PassIter& pit, hipStream_t s,
                     fj_timings* t, int evc, u64* out_count, bool* lds_full, int top_bits, SingleOut* so) {
-    c->pend.has_second = false;
+    c->pend.has_second = false; c->pend.dups_main = false;
     ja.nparts = ja.probe.list ? ja.probe.nb : 1u << plan.bits;      // (an owner of a shuffled join holds a slice of the plan's partitions)
     const u64 pchunks = (np + FJ_CHUNK - 1) / FJ_CHUNK;
     void* p;
@@ -340,7 +365,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     c->pend.valid = false;
     if (materialize) {
         c->pend.valid = true; c->pend.path = 0; c->pend.lds = ja; c->pend.nitems = nitems; c->pend.count = *out_count;
-        c->pend.has_dups = (c->h_sc->err & FJ_STAT_DUPS) != 0;
+        c->pend.has_dups = (c->h_sc->err & FJ_STAT_DUPS) != 0 || c->pend.dups_main;
     }
     return 0;
 }

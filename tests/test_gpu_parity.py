@@ -149,15 +149,24 @@ def test_lds_overflow_falls_back_to_global_table(fj, oracle):
     assert np.array_equal(np.sort(k), np.sort(pk[np.isin(pk, bk)]))
     lt = fj.last_timings()
     assert lt["fell_back"] == 0 and lt["lds_retries"] == 2, lt      # ... and so do materialising joins (a second item set behind the first)
-    # duplicate build keys + an oversized partition: the first-occurrence emit path re-partitions the whole build side, so this
-    # combination still takes the one-table fallback - exact counts and keys; a duplicated key gets the value of SOME occurrence
-    # there (the reference's scalar path is racy in the same way)
+    # duplicate build keys + an oversized partition: the first-occurrence emit path re-partitions the whole build side with row
+    # indices and then the oversized partition again from that level - no fallback, and every duplicated key gets the value of its
+    # FIRST occurrence, as the reference's radix path does (stable partition + key-only dedup, hash_join.cpp:125, :226-234)
     bk2, bv2 = np.concatenate([bk, bk[:100]]), np.concatenate([bv, bv[:100] + np.uint64(5)])
     n, _, k, v = fj.hash_join_radix(bk2, bv2, pk, return_arrays=True)
-    assert n == exp and fj.last_timings()["fell_back"] == 1
+    lt = fj.last_timings()
+    assert n == exp and lt["fell_back"] == 0, lt
     assert np.array_equal(np.sort(k), np.sort(pk[np.isin(pk, bk)]))
+    assert np.all(v - k == 1)
+    # ... also when the later occurrence comes FIRST in the other order (the smallest row index wins, whatever the value)
+    bk3, bv3 = np.concatenate([bk[:100], bk]), np.concatenate([bv[:100] + np.uint64(5), bv])
+    n, _, k, v = fj.hash_join_radix(bk3, bv3, pk, return_arrays=True)
+    assert n == exp and fj.last_timings()["fell_back"] == 0
     d = v - k
-    assert np.all((d == 1) | ((d == 6) & np.isin(k, bk[:100])))
+    assert np.all(np.where(np.isin(k, bk[:100]), d == 6, d == 1))
+    ek, ev = oracle.c_join(bk3, bv3, pk, algo="radix", materialize=True, return_arrays=True)[2:]
+    a, b = oracle.canon_pairs(k, v), oracle.canon_pairs(ek, ev)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 @pytest.mark.parametrize("nb", [3_800, 4_096, 1 << 20, 1 << 27])
