@@ -20,7 +20,7 @@ python tools/trace_timeline.py gpurun_out/stats_${TAG}_c3_mat > $O/c3_mat_timeli
 python tools/traffic_json.py $O/c3_pmc_summary.txt $O/traffic_latest.json > /dev/null 2>&1
 timeout 900 python bench.py 2>&1 | tail -1 > $O/c3_bench.json
 : > $O/other_workloads.jsonl
-for w in c2 c2_hbm_table c4 c4_scalar_bloom c4_adaptive c4_hbm_table_bloom c3_adaptive c3_mat small rep8 c5; do
+for w in c2 c2_hbm_table c4 c4_scalar_bloom c4_adaptive c4_hbm_table_bloom c3_adaptive c3_mat small rep8 c5_rep8 c5; do
   timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 >> $O/other_workloads.jsonl
 done
 FJ_OPTIONS=mat_single_pass=0 timeout 300 python bench.py --workload c3_mat --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c3_mat_two_pass_bench.json
@@ -33,4 +33,14 @@ timeout 300 python tools/pack_probe.py > $O/pack_probe.txt 2>&1
 bash tools/r4_prefilter_one_gpu.sh ${TAG}p > $O/prefilter_one_rank.txt 2>&1
 tools/prof_py.sh ${TAG}_precheck_probe tools/precheck_probe.py > $O/precheck_probe_kernel_stats.txt 2>&1
 grep "the precheck:\|^filters of" gpurun_out/stats_${TAG}_precheck_probe.log > $O/precheck_probe.txt
-ls -la $O | head -50
+# round 5: the build-broadcast form as one rank of 8 sees it (8-rank plan: 262144 partitions; all peers' regions resident), with and without
+# the CU reserve of an N > 1 step; its kernel statistics; the step through the driver on one rank; the 16384-slot join kernel's counters;
+# the model table
+( python tools/bcast_one_gpu.py 8 125000000 1250000000 4 5 5000 0 | tail -7; echo "-- with the 32-CU reserve of an N > 1 step over RCCL:"; python tools/bcast_one_gpu.py 8 125000000 1250000000 4 5 5000 32 | tail -5 ) > $O/bcast_one_rank.txt 2>&1
+tools/prof_py.sh ${TAG}_bcast tools/bcast_one_gpu.py 8 125000000 1250000000 4 5 > $O/bcast_one_rank_kernel_stats.txt 2>&1
+cp $(find gpurun_out/stats_${TAG}_bcast -name "*kernel_stats.csv" | head -1) $O/bcast_one_rank_kernel_stats.csv
+FJ_BENCH_FORCE_DIST=1 FJ_BENCH_FORCE_FORM=broadcast timeout 600 python bench.py --workload c5 --steps 5 --warmup 2 --no-host-entry --no-cpu-baseline 2>&1 | tail -1 > $O/c5_one_rank_broadcast_bench.json
+FJ_OPTIONS=join_wide=1 ./tools/pmc.sh $O/pmc_wide --workload c5_rep8 --no-host-entry > $O/c5_rep8_wide_pmc_summary.txt 2>&1
+FJ_OPTIONS=join_wide=0 timeout 300 python bench.py --workload c5_rep8 --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c5_rep8_narrow_table_bench.json
+python tools/scale_model.py > $O/scale_model.txt 2>&1
+ls -la $O | head -60
