@@ -2,9 +2,13 @@
 // communicator (BASELINE configs[4]: 1B x 10B rows over 8 MI355X), ONE driver for every transport.
 //
 // No reference counterpart: the reference is one process (hash_join.cpp:318).  What is exploited is that radix partitions
-// are independent join units (hash_join.cpp:340-356, :515-525): the first radix pass of the plan for the TOTAL build side is
-// the owner split, the exchange is an all-to-all of dense wire-format chunks (7 bytes per key, fj_pack.hip),
-// and every owner runs the rest of the plan on what it received.
+// are independent join units (hash_join.cpp:340-356, :515-525).  Two forms of the step, one driver (fj_dist_comm_set_form; by
+// default a cost model over the all-gathered sizes picks, fj_dist_model):
+//   OWNER SHUFFLE - the first radix pass of the plan for the TOTAL build side is the owner split, the exchange is an
+//     all-to-all of dense wire-format chunks (7 bytes per key, fj_pack.hip), every owner runs the rest of the plan on what it
+//     received (the protocol sketched below);
+//   BUILD BROADCAST - the probe rows stay where they are; every rank's build rows, partitioned by the whole plan and packed to 6 bytes
+//     per key, go to every peer, and every rank joins its own probe partitions against all of them (dist_join_bcast, fj_bcast.hip).
 //
 //   sizes all-gathered -> plan -> build side as one piece -> probe side in `pieces` pieces; per piece:
 //     pack_begin (first pass, pack stream)  ->  counts to the host, all-gathered (control channel)  ->  buffers, agreed on  ->
@@ -21,7 +25,10 @@
 //   Engine - the HIP engine (fj_shuffle_pack_* / fj_stream_*_chunks of include/flashjoin.h), or a caller's stand-in
 //            (fj_dist_engine_ops: the CPU test-suite drives this file over gloo without a GPU).
 // A failure of one rank's packing or allocation is agreed on before anybody posts an exchange; a failure of its local join
-// never takes it out of step (the rank keeps taking part, the ranks agree in the final all-reduce).  RCCL is bound at run
+// never takes it out of step (the rank keeps taking part, the ranks agree in the final all-reduce).  NOT covered: a rank-local
+// failure BEHIND the agreement points of a piece - the copy into the wire format cannot be launched, ncclSend returns an error -
+// makes that rank return while its peers have posted the matching receives: they wait in the transport, and the job has to be torn
+// down from outside (RCCL's own behaviour for a rank that dies mid-collective; a watchdog around the step is the host's business).  RCCL is bound at run
 // time (dlopen of librccl.so.1 - in a PyTorch process that is the copy torch already loaded) through locally declared
 // prototypes: the library neither links against RCCL nor needs its headers.  RCCL moves wrong data when one point-to-point
 // message exceeds 4 GiB (tools/rccl_large_message_check.py): messages are cut into rounds of <= 1 GiB.
@@ -642,7 +649,7 @@ int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_tota
     if (region_max == 0) region_max = (uint64_t)((double)nb_max * 6.01) + (1u << 20);
     const double pack = (double)nb_max * 13.2e-12, passes = (double)np_max * 7.0e-12, join = ((double)nb_total + (double)np_max) * 3.2e-12;
     const double wire_b = N > 1 ? (double)region_max / rate : 0.0;
-    const double t_b = std::max(wire_b + pack + join / 8.0, pack + passes + join);        // (the last of ~8 partition ranges is joined after the wire is done)
+    const double t_b = std::max(wire_b + pack + join / 4.0, pack + passes + join);        // (the last of 4 partition ranges is joined after the wire is done)
     const double rows = (double)nb_max + (double)np_max;
     const double wire_s = N > 1 ? 7.02 * ((double)np_global + (double)nb_total) / (N * N) / rate : 0.0;
     const double t_s = std::max(wire_s, rows * 9.75e-12) + 2.5e-3 * rows / 1.375e9;

@@ -109,7 +109,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             for (int d = 1; d < (int)FJ_WIDE_MAXSRC; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
             const u32 excl = inc - nu, total = __shfl(inc, FJ_WIDE_MAXSRC - 1, 64);
             uint4* ud = reinterpret_cast<uint4*>(slot + W_META_P);
-            for (u32 k = 0; k < nu; ++k) if (excl + k < W_UNITS) ud[excl + k] = make_uint4(lane, a0 + (k << 8), b, e);
+            // {low-word plane / 16, high-word plane / 16 (byte offsets into base), first valid key slot (the unit starts at that & ~3), run end}
+            const u32 lo16 = act ? (u32)(hdr->lo_off[lane] >> 4) : 0u, mid16 = act ? (u32)(hdr->mid_off[lane] >> 4) : 0u;
+            for (u32 k = 0; k < nu; ++k) if (excl + k < W_UNITS) ud[excl + k] = make_uint4(lo16, mid16, k ? a0 + (k << 8) : b, e);
             if (lane == 0) slot[W_META_P + 4 * W_UNITS] = total;
         }
     };
@@ -133,18 +135,18 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
                 const u32 u = first + wave + (u32)i * W_WAVES;
                 const bool have = u < total && u < W_UNITS;
                 const uint4 d4 = units[have ? u : 0u];
-                const u32 us = have ? __builtin_amdgcn_readfirstlane(d4.x) : 0u, ua0 = __builtin_amdgcn_readfirstlane(d4.y);
-                const u32 ub = __builtin_amdgcn_readfirstlane(d4.z), ue = __builtin_amdgcn_readfirstlane(d4.w);
+                const u32 ulo = have ? __builtin_amdgcn_readfirstlane(d4.x) : (u32)(hdr->lo_off[0] >> 4), umid = have ? __builtin_amdgcn_readfirstlane(d4.y) : (u32)(hdr->mid_off[0] >> 4);
+                const u32 ub = __builtin_amdgcn_readfirstlane(d4.z), ue = __builtin_amdgcn_readfirstlane(d4.w), ua0 = ub & ~3u;
                 const u32 k0 = ua0 + 4 * lane;
                 const bool in = have && k0 < ue;                           // (lanes past the run read its first word: nothing beyond the plane's 16 bytes of padding is touched)
                 const u32 kk = in ? k0 : (have ? ua0 : 0u);
-                const uint4 lo4 = *reinterpret_cast<const uint4*>(w.base + hdr->lo_off[us] + (u64)kk * 4);
+                const uint4 lo4 = *reinterpret_cast<const uint4*>(w.base + ((u64)ulo << 4) + (u64)kk * 4);
                 u32 m[4];
                 if (w.mid_bytes == 2) {
-                    const uint2 q = *reinterpret_cast<const uint2*>(w.base + hdr->mid_off[us] + (u64)kk * 2);
+                    const uint2 q = *reinterpret_cast<const uint2*>(w.base + ((u64)umid << 4) + (u64)kk * 2);
                     m[0] = q.x & 0xFFFFu; m[1] = q.x >> 16; m[2] = q.y & 0xFFFFu; m[3] = q.y >> 16;
                 } else {
-                    const uint4 q = *reinterpret_cast<const uint4*>(w.base + hdr->mid_off[us] + (u64)kk * 4);
+                    const uint4 q = *reinterpret_cast<const uint4*>(w.base + ((u64)umid << 4) + (u64)kk * 4);
                     m[0] = q.x; m[1] = q.y; m[2] = q.z; m[3] = q.w;
                 }
                 const u32 l[4] = {lo4.x, lo4.y, lo4.z, lo4.w};

@@ -227,7 +227,7 @@ def test_multi_gpu_strategy_model():
     for world in (2, 4, 8):
         for rate in (45e9, 55e9, 65e9):
             m = D.form_model(world, 125_000_000, 1_250_000_000, rate)
-            assert m["pick"] == "broadcast" and m["broadcast"] < 0.02 and m["shuffle"] > 0.02, (world, rate, m)
+            assert m["pick"] == "broadcast" and m["broadcast"] < 0.021 and m["shuffle"] > 0.021, (world, rate, m)
     m = D.form_model(8, 125_000_000, 1_250_000_000, 55e9)
     assert 0.0165 < m["broadcast"] < 0.0185 and 0.023 < m["shuffle"] < 0.026, m           # kernel-bound at ~17.5 ms against a wire-bound ~24.4 ms
     assert D.form_model(8, 500_000_000, 500_000_000, 55e9)["pick"] == "shuffle"          # as many build rows as probe rows: the regions outweigh the rows
