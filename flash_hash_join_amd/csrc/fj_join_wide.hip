@@ -49,7 +49,8 @@ struct WHdr {
 
 __device__ __forceinline__ u32 w_l1(u64 h) { return FJ_HW2(h) & (WS - 1); }
 __device__ __forceinline__ u32 w_l2(u64 h) { return (FJ_HW2(h) >> WSLOG) & (WS - 1); }
-__device__ __forceinline__ u32 w_l3(u64 h) { return ((FJ_HW2(h) >> 28) ^ (FJ_HW1(h) << 4) ^ (FJ_HW2(h) >> 7)) & (WS - 1); }
+// (third location: the high word's low bits - radix digits come from its TOP - folded with 14 other bits of the low word: three instructions)
+__device__ __forceinline__ u32 w_l3(u64 h) { return (FJ_HW1(h) ^ (FJ_HW2(h) >> 18) ^ (FJ_HW2(h) >> 5)) & (WS - 1); }
 
 template <bool DENSE>
 __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWideArgs w) {
@@ -179,6 +180,53 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     // stage A (l1 of every key: the thread's atomics in flight together), B (l2 of the losers), C (l3), then the rare linear walk
     auto claim4 = [&](auto G, u32* bits, const u64 (&bk8)[8], u32 vm, u32 par, u32 (&sl8)[8]) {
         constexpr int g4 = 4 * decltype(G)::value;
+        u32 sl[4]; u64 bk[4];
+        u32 lost = 0;                                              // per-lane bit j: key j still has no slot
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bk[j] = bk8[g4 + j]; sl[j] = W_NOSLOT; if (bk[j] == FJ_EMPTY_KEY) { if ((vm >> j) & 1u) hdr->has_empty[par] = 1; vm &= ~(1u << j); } }
+        auto fin = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl8[g4 + j] = ((lost >> j) & 1u) ? W_NOSLOT : sl[j];
+        };
+        // a stage: every key that still needs a slot tries location loc(key): all of the thread's atomics in flight, then the answers
+        auto stage = [&](u32 need, int which) {
+            u32 o[4], bit[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = 0; bit[j] = 0;
+                if ((need >> j) & 1u) {
+                    const u32 l = which == 1 ? w_l1(bk[j]) : which == 2 ? w_l2(bk[j]) : w_l3(bk[j]);
+                    sl[j] = l; bit[j] = 1u << (l & 31);
+                    o[j] = atomicOr(&bits[l >> 5], bit[j]);
+                }
+            }
+            u32 l2 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (o[j] & bit[j]) l2 |= 1u << j;
+            return l2;
+        };
+        lost = stage(vm & 0xFu, 1);
+        if (__ballot(lost != 0)) lost = stage(lost, 2);
+        if (__ballot(lost != 0)) lost = stage(lost, 3);
+        if (__ballot(lost != 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((lost >> j) & 1u)) continue;
+                u32 s = sl[j];
+                bool got = false;
+                for (u32 step = 0; step < W_MAXWALK && !got; ++step) {
+                    s = (s + 1) & (WS - 1);
+                    got = !((atomicOr(&bits[s >> 5], 1u << (s & 31)) >> (s & 31)) & 1u);
+                }
+                if (got) { sl[j] = s; lost &= ~(1u << j); } else hdr->full[par] = 1;
+            }
+        }
+        fin();
+    };
+    // (the DENSE instantiation keeps the earlier formulation of the same stages: it compiles to 7.2 ms where this one gives 7.8 - and
+    //  the other way round from chunk lists: 5.76 against 5.89 ms; same-box A/Bs, profiles/r05_join_kernel_ab.txt)
+    auto claim4_dense = [&](auto G, u32* bits, const u64 (&bk8)[8], u32 vm, u32 par, u32 (&sl8)[8]) {
+        constexpr int g4 = 4 * decltype(G)::value;
         u32 o[4], sl[4]; u64 bk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bk[j] = bk8[g4 + j];
@@ -226,8 +274,10 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         fin();
     };
     auto claim = [&](u32* bits, const u64 (&bk)[8], u32 bok, u32 am, u32 par, u32 (&sl)[8]) {
-        if (am & 0xFu) claim4(std::integral_constant<int, 0>(), bits, bk, bok & 0xFu, par, sl); else { sl[0] = sl[1] = sl[2] = sl[3] = W_NOSLOT; }
-        if (am >> 4) claim4(std::integral_constant<int, 1>(), bits, bk, bok >> 4, par, sl); else { sl[4] = sl[5] = sl[6] = sl[7] = W_NOSLOT; }
+        if (am & 0xFu) { if constexpr (DENSE) claim4_dense(std::integral_constant<int, 0>(), bits, bk, bok & 0xFu, par, sl); else claim4(std::integral_constant<int, 0>(), bits, bk, bok & 0xFu, par, sl); }
+        else { sl[0] = sl[1] = sl[2] = sl[3] = W_NOSLOT; }
+        if (am >> 4) { if constexpr (DENSE) claim4_dense(std::integral_constant<int, 1>(), bits, bk, bok >> 4, par, sl); else claim4(std::integral_constant<int, 1>(), bits, bk, bok >> 4, par, sl); }
+        else { sl[4] = sl[5] = sl[6] = sl[7] = W_NOSLOT; }
     };
     auto store_keys = [&](const u64 (&bk)[8], const u32 (&sl)[8], u32 am) {
         if (am & 0xFu) {
