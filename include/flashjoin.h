@@ -73,30 +73,38 @@ const char* fj_last_error(void);
 int fj_device_count(void);
 const char* fj_version(void);
 
-/* Process-wide dispatch options (no reference counterpart; the reference hard-codes 1'000'000 at hash_join.cpp:576):
+/* Process-wide dispatch options (no reference counterpart; the reference hard-codes 1'000'000 at hash_join.cpp:576).  Initial values:
+ * the ONE environment variable FJ_OPTIONS="name=value,name=value" (read once):
  *   "radix_threshold"  - adaptive_* joins use the non-partitioned HBM table below this many build rows (default 0:
- *                        the partitioned driver wins at every size on MI355X; env FJ_RADIX_THRESHOLD);
+ *                        the partitioned driver wins at every size on MI355X);
  *   "scalar_hbm_table" - (the HBM-table path is NOT a fast path: probe 0.05-0.07 of the HBM peak, build by global CAS 20 ms per
  *                        100M rows, profiles/README.md; it exists as the literal form of the reference's scalar algorithm
  *                        and as the fallback for a partition of more than 8128 distinct keys)
  *                        1: the "scalar" functions (FJ_ALGO_SCALAR: hash_join*, hash_join.cpp:383-496, :536-567) keep
  *                        ONE table for the whole build side in HBM, as the reference does in DRAM; 0 (default): they
  *                        run the same partitioned plan as the radix functions (identical results, 2-4x faster here)
- *                        and the HBM table is only the overflow fallback (env FJ_SCALAR_HBM_TABLE).
+ *                        and the HBM table is only the overflow fallback.
  *   "persistent_min_items" - counting joins whose plan has at least this many (partition, probe slice) work items use
- *                        the persistent join kernel (default 8192; env FJ_PERSISTENT_MIN_ITEMS; a tuning/testing knob).
+ *                        the persistent join kernel (default 8192; a tuning/testing knob).
  *   "bloom_auto"       - 1 (default): the adaptive_* functions decide on the bloom precheck of the partitioned plan from a
  *                        sample of the probe side (4096 rows looked up in the partitioned build side): on when at most
  *                        "bloom_auto_max_hit_bp" (default 2300 = 23 %; measured break-even 24 %) of them hit; 0: adaptive_*_bloom filter, adaptive_* do
- *                        not, as named (env FJ_BLOOM_AUTO, FJ_BLOOM_AUTO_MAX_HIT_BP).  The explicit hash_join*_bloom
+ *                        not, as named.  The explicit hash_join*_bloom
  *                        functions always run the precheck when the plan has two or more passes; hash_join* never do.
- *   "bloom_variant"    - hash / bit layout of the filter, 0..2 (csrc/fj_bloom_dev.h; default 2; env FJ_BLOOM_VARIANT).  Must be
+ *   "bloom_variant"    - hash / bit layout of the filter, 0..2 (csrc/fj_bloom_dev.h; default 2).  Must be
  *                        the same on every rank of a multi-GPU job (fj_bloom_prefilter checks it against the exporter's).
  *   "mat_single_pass"  - 1 (default): a materialising join whose output buffers hold >= np pairs runs single-pass (above);
- *                        0: always count, scan, emit (env FJ_MAT_SINGLE_PASS).
+ *                        0: always count, scan, emit.
  *   "plan_target_keys" - average build keys per final partition the plan aims for (default and maximum 4096 = half an LDS
- *                        table; env FJ_PLAN_TARGET_KEYS).  A testing knob: small values make small inputs take the deep
+ *                        table).  A testing knob: small values make small inputs take the deep
  *                        (two- and three-pass, bloom-filtered) plans that production only uses for >1M-row build sides.
+ *   "join_wide"        - counting joins on the 16384-slot LDS table kernel (csrc/fj_join_wide.hip): 0 never, 1 whenever eligible,
+ *                        2 (default) when the average final partition holds > 3400 build keys and <= 32 probe chunks.
+ *   "join_items_target" - work items the join of a plan with few partitions is cut into (default 2048; a tuning knob).
+ *   "lab_hooks"        - test / measurement hooks, one bit each (csrc/fj_host.h FJ_HOOK_*; default 0): 1 a rank's own share of a
+ *                        multi-GPU exchange travels through ncclSend / ncclRecv too, 2 injected failure of a local append, 4 split a
+ *                        1-rank communicator, 8 one communicator, 16 the CU reserve on one rank too, 32 emitting pass on the tagged
+ *                        kernel, 64 every 7th emit item takes its retry path.
  * fj_get_option returns -1 for an unknown name. */
 int fj_set_option(const char* name, long long value);
 long long fj_get_option(const char* name);
