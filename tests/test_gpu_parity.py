@@ -704,6 +704,17 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
             n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
             assert n == exp and k.numel() == exp
             assert bool(torch.all((v + 1) * M == k))
+        # a build side with one key repeated 20000 times: its final partition does not fit the broadcast form's LDS table (that form has
+        # no per-partition recovery) - the step fails on every rank alike and is rerun as the shuffle, whose skew ladder takes it
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "broadcast"); monkeypatch.setenv("FJ_DIST_NATIVE", "1"); monkeypatch.setenv("FJ_DIST_CHUNK_SHUFFLE", "1")
+        hot = bk[12345:12346].repeat(20000)
+        sbk2, sbv2 = torch.cat([bk, hot]), torch.cat([bv, bv[12345:12346].repeat(20000)])
+        t = {}
+        n, sec = distributed_join(sbk2, sbv2, pk, timings=t)
+        assert n == exp and t["strategy"] == "shuffle" and "does not fit the LDS table" in t["broadcast_form_error"], t
+        t = {}
+        n, sec = distributed_join(bk, bv, pk, timings=t)                                 # ... and the next plain join broadcasts again
+        assert n == exp and t["strategy"] == "broadcast" and "broadcast_form_error" not in t, t
         # sender-side bloom precheck of the probe exchange: in chunk form (per-partition filters: fj_stream_export_part_filters ->
         # all-gather -> fj_shuffle_pack_filter, inside the driver) and in the owner-scatter form (fj_bloom_export -> all_gather ->
         # fj_bloom_prefilter per owner)
