@@ -543,6 +543,8 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
         Token done = nullptr;
         if (net.exchange(3, sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, q)) return bail(fj_last_error());
         if (failed.empty()) {
+            // (the last range's join starts when the last piece has landed: the transport's kernels are gone from this GPU by then)
+            if (reserve && q + 1 == pieces) eng.reserve(false);
             const uint32_t plo = (uint32_t)(((uint64_t)nparts * q) / pieces), phi = (uint32_t)(((uint64_t)nparts * (q + 1)) / pieces);
             guarded(eng.bc_join(base, N, roff.data(), nb_of.data(), plo, phi, done ? done : packed));
         }
