@@ -83,36 +83,44 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     auto store_boff = [&](u32 q, uint2 b) { u32* r = hdr->dring[q & 7]; r[4] = b.x; r[5] = b.y - b.x; };
 
     // list entries of item q -> registers (one global load per side and thread), later parked in a ring slot
-    auto request = [&](u32 q, u32 ns, u32 nbc, u32& mp, u32& mb) {
-        mp = 0; mb = 0;
+    // (DENSE: the LAST wave - it holds the fewest probe chunks of an item - looks after the build side's entries: lane s of it keeps
+    //  source s's plane offsets in registers and loads that source's (run begin, run end) for the item: mb, mb2)
+    const bool bwave = DENSE && wave == W_WAVES - 1;
+    u32 my_lo16 = 0, my_mid16 = 0; const u32* my_offs = nullptr;
+    auto dense_lane_setup = [&]() {                                // after hdr->*_off are visible
+        if (bwave && lane < w.nsrc) { my_lo16 = (u32)(hdr->lo_off[lane] >> 4); my_mid16 = (u32)(hdr->mid_off[lane] >> 4); my_offs = reinterpret_cast<const u32*>(w.base + hdr->offs_off[lane]); }
+    };
+    auto request = [&](u32 q, u32 ns, u32 nbc, u32& mp, u32& mb, u32& mb2) {
+        mp = 0; mb = 0; mb2 = 0;
         const u32 np0 = ns < W_META_P ? ns : W_META_P;
         if (tid < np0) mp = a.probe.list[ring(q, 0) + tid];
         if (DENSE) {
-            if (q < nmine && tid < 2 * w.nsrc) mb = reinterpret_cast<const u32*>(w.base + hdr->offs_off[tid >> 1])[ring(q, 2) + (tid & 1u)];
+            if (bwave && q < nmine && lane < w.nsrc) { const u32 part = ring(q, 2); mb = my_offs[part]; mb2 = my_offs[part + 1]; }
         } else {
             const u32 nb0 = nbc < W_META_B ? nbc : W_META_B;
             if (tid < nb0) mb = a.build.list[ring(q, 4) + tid];
         }
     };
-    // DENSE: the first wave turns the sources' (run begin, run end) pairs into the item's load units: the runs of the partition, one per
+    // DENSE: that wave turns the sources' (run begin, run end) pairs into the item's load units: the runs of the partition, one per
     // source, cut into units of 256 key slots that start at a multiple of 4 keys; one 16-byte descriptor per unit, so that a wave
     // fetching a unit reads ONE LDS word (every wave walking the sources' pairs cost 50 LDS instructions per wave and item: as much
-    // as the lookups)
-    auto park = [&](u32* slot, u32 mp, u32 mb) {
+    // as the lookups).  No LDS round trip in here (the prefix over the sources runs on lane reads): it sits in front of a barrier.
+    auto park = [&](u32* slot, u32 mp, u32 mb, u32 mb2) {
         if (tid < W_META_P) slot[tid] = mp;
         if (!DENSE) { if (tid < W_META_B) slot[W_META_P + tid] = mb; return; }
-        if (wave == 0) {
-            const u32 b = __shfl(mb, (2 * lane) & 63, 64), e = __shfl(mb, (2 * lane + 1) & 63, 64);     // lane s: source s
+        if (bwave) {
+            const u32 b = mb, e = mb2;                             // lane s: source s
             const bool act = lane < w.nsrc && e > b;
             const u32 a0 = b & ~3u, nu = act ? (e - a0 + 255u) >> 8 : 0u;
-            u32 inc = nu;
-#pragma unroll
-            for (int d = 1; d < (int)FJ_WIDE_MAXSRC; d <<= 1) { const u32 y = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += y; }
-            const u32 excl = inc - nu, total = __shfl(inc, FJ_WIDE_MAXSRC - 1, 64);
+            u32 excl = 0, total = 0;
+            for (u32 s = 0; s < w.nsrc; ++s) {
+                const u32 n_s = (u32)__builtin_amdgcn_readlane((int)nu, (int)s);
+                if (lane > s) excl += n_s;
+                total += n_s;
+            }
             uint4* ud = reinterpret_cast<uint4*>(slot + W_META_P);
             // {low-word plane / 16, high-word plane / 16 (byte offsets into base), first valid key slot (the unit starts at that & ~3), run end}
-            const u32 lo16 = act ? (u32)(hdr->lo_off[lane] >> 4) : 0u, mid16 = act ? (u32)(hdr->mid_off[lane] >> 4) : 0u;
-            for (u32 k = 0; k < nu; ++k) if (excl + k < W_UNITS) ud[excl + k] = make_uint4(lo16, mid16, k ? a0 + (k << 8) : b, e);
+            for (u32 k = 0; k < nu; ++k) if (excl + k < W_UNITS) ud[excl + k] = make_uint4(my_lo16, my_mid16, k ? a0 + (k << 8) : b, e);
             if (lane == 0) slot[W_META_P + 4 * W_UNITS] = total;
         }
     };
@@ -370,9 +378,11 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     u32* sl_k = meta, * sl_k1 = meta + W_STRIDE, * sl_k2 = meta + 2 * W_STRIDE, * sl_k3 = meta + 3 * W_STRIDE;
     {
         u32 mp, mb;
-        request(0, ns0, ring(0, 5), mp, mb); park(sl_k, mp, mb);
-        request(1, ns1, nbc1, mp, mb); park(sl_k1, mp, mb);
-        request(2, ns2, nbc2, mp, mb); park(sl_k2, mp, mb);
+        u32 mb2;
+        dense_lane_setup();
+        request(0, ns0, ring(0, 5), mp, mb, mb2); park(sl_k, mp, mb, mb2);
+        request(1, ns1, nbc1, mp, mb, mb2); park(sl_k1, mp, mb, mb2);
+        request(2, ns2, nbc2, mp, mb, mb2); park(sl_k2, mp, mb, mb2);
     }
     __syncthreads();
     u64 bkA[8], bkB[8];
@@ -415,7 +425,8 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         if (tid == 0) { bo4 = fetch_boff(k + 4); it5 = fetch_items(k + 5); }
         const u32 ns3 = ring(k + 3, 1), nbc3 = ring(k + 3, 5);
         u32 mp, mb;
-        request(k + 3, ns3, nbc3, mp, mb);
+        u32 mb2;
+        request(k + 3, ns3, nbc3, mp, mb, mb2);
         const u32 tot2 = DENSE ? dense_total(sl_k2) : 0u;
         load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, bkB, bokB, amB);
         W_STAMP(0);
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
         W_STAMP(2);
         // ---- 3. park what was requested ----
-        park(sl_k3, mp, mb);
+        park(sl_k3, mp, mb, mb2);
         if (tid == 0) { store_boff(k + 4, bo4); store_items(k + 5, it5); }
         if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
         W_STAMP(3);
