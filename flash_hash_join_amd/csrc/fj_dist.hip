@@ -24,11 +24,12 @@
 //            a test harness: fj_dist_transport);
 //   Engine - the HIP engine (fj_shuffle_pack_* / fj_stream_*_chunks of include/flashjoin.h), or a caller's stand-in
 //            (fj_dist_engine_ops: the CPU test-suite drives this file over gloo without a GPU).
-// A failure of one rank's packing or allocation is agreed on before anybody posts an exchange; a failure of its local join
-// never takes it out of step (the rank keeps taking part, the ranks agree in the final all-reduce).  NOT covered: a rank-local
-// failure BEHIND the agreement points of a piece - the copy into the wire format cannot be launched, ncclSend returns an error -
-// makes that rank return while its peers have posted the matching receives: they wait in the transport, and the job has to be torn
-// down from outside (RCCL's own behaviour for a rank that dies mid-collective; a watchdog around the step is the host's business).  RCCL is bound at run
+// A failure of one rank's packing or allocation is agreed on before anybody posts an exchange; a failure of its local join - or
+// of the copy into the wire format, behind a piece's agreement points: the shares then travel marked unusable - never takes it
+// out of step (the rank keeps taking part, the ranks agree in the final all-reduce).  NOT covered: a failure of the transport
+// itself behind the agreement points - ncclSend returns an error - makes that rank return while its peers have posted the
+// matching receives: they wait in the transport, and the job has to be torn down from outside (RCCL's own behaviour for a rank
+// that dies mid-collective; a watchdog around the step is the host's business).  RCCL is bound at run
 // time (dlopen of librccl.so.1 - in a PyTorch process that is the copy torch already loaded) through locally declared
 // prototypes: the library neither links against RCCL nor needs its headers.  RCCL moves wrong data when one point-to-point
 // message exceeds 4 GiB (tools/rccl_large_message_check.py): messages are cut into rounds of <= 1 GiB.
@@ -133,6 +134,8 @@ struct Engine {
     virtual int sample(const void*, size_t, size_t, const void*, size_t, int, Token, unsigned long long*) { return derr("fj_dist: this engine has no sender-side precheck"); }
     virtual int pack_counts(unsigned long long* used) = 0;                      // blocks until the counts are known
     virtual int pack_finish(void* const* dst_chunks, uint64_t* const* dst_vals, uint32_t* const* dst_dir, Token after, Token* done) = 0;
+    // pack_finish failed: the directory words of every share of the piece say "no chunk" (where the engine can write them: device memory of ours)
+    virtual void mark_unusable(uint32_t* const*, const unsigned long long*, int) {}
     virtual int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces, bool with_vals) = 0;
     virtual int append(int side, const void* chunks, const uint64_t* vals, uint32_t* dir, size_t nchunks, Token after) = 0;
     virtual int finish(uint64_t* count, fj_timings* lt) = 0;
@@ -204,6 +207,10 @@ struct HipEngine : Engine {
         DHIP(hipEventRecord(e, ps));
         *done = e;
         return 0;
+    }
+    void mark_unusable(uint32_t* const* dd, const unsigned long long* used, int n) override {
+        for (int d = 0; d < n; ++d) if (used[d] && dd[d]) (void)hipMemsetAsync(dd[d], 0xFF, (size_t)used[d] * 4, ps);      // FJ_DIR_INVALID
+        (void)hipStreamSynchronize(ps);
     }
     int open(size_t nb_total, int nranks, int rank, size_t nb_bound, size_t np_bound, int pieces, bool with_vals) override {
         return fj_stream_open_shuffled(ctx, nb_total, nranks, rank, nb_bound, 1, np_bound, pieces, with_vals ? 1 : 0, js);
@@ -806,7 +813,14 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
         }
         if (vals) largest = largest / CB * (FJ_CHUNK * 8);     // (the value part of a message is its largest: 2048 bytes per chunk)
         Token packed = nullptr, done = nullptr;
-        if (eng.pack_finish(dk.data(), vals ? dv.data() : nullptr, dd.data(), pool_free[pslot], &packed)) return bail(fj_last_error());
+        if (eng.pack_finish(dk.data(), vals ? dv.data() : nullptr, dd.data(), pool_free[pslot], &packed)) {
+            // behind the agreement points: the peers post this piece's receives whatever happens here.  The rank stays in step - its
+            // shares travel with directory words that say "no chunk", its later engine calls are skipped - and the failure is agreed
+            // on in the final all-reduce like any failure of a local join
+            guarded(1);
+            eng.mark_unusable(dd.data(), used.data(), N);
+            packed = nullptr;
+        }
         mark(" copy enqueued");
         if (net.exchange(nparts, sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, rslot)) return bail(fj_last_error());
         mark(" exchange enqueued");

@@ -628,6 +628,55 @@ __global__ __launch_bounds__(1024) void fj_level_scan(u32* __restrict__ bchunks,
     if (tid == 0) { boff[n] = (u32)carry; if (tc) toff[n] = (u32)(carry >> 32); }
 }
 
+// The same scan for a level of many buckets (8192 .. 2^19: second passes of plans of 14+ bits), one 1024-thread workgroup per
+// 4096 counts instead of one workgroup for all of them (262144 buckets = 16 sweeps on one CU took 120 us; two of them per
+// 18-bit join).  No workgroup waits for another: each first sums the counts in front of its own piece - the array is at most
+// 2 MiB and sits in L2 - then scans its piece.  Nobody may clear a count that a later workgroup still reads, so the counts are
+// cleared by the launch that follows (fj_level_lists, `clr`).
+__global__ __launch_bounds__(1024) void fj_level_scan_wide(const u32* __restrict__ bchunks, u32* __restrict__ boff, u32 n, u32 tc,
+                                                           u32* __restrict__ toff) {
+    __shared__ u64 wtot[2][16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+    const float rtc = tc ? 1.0f / (float)tc : 0.f;
+    auto tiles_of = [&](u32 c) -> u32 {
+        if (!tc) return 0u;
+        u32 q = (u32)((float)c * rtc);
+        while (q * tc < c) ++q;
+        while (q && (q - 1) * tc >= c) --q;
+        return q;
+    };
+    auto packed = [&](const uint4& x) -> u64 {
+        return ((u64)x.x + x.y + x.z + x.w) | ((u64)(tiles_of(x.x) + tiles_of(x.y) + tiles_of(x.z) + tiles_of(x.w)) << 32);
+    };
+    const u32 e0 = g * 4096u + 4u * tid;
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (e0 < n) x = *reinterpret_cast<const uint4*>(bchunks + e0);
+    u64 pre = 0;
+#pragma unroll 4
+    for (u32 j = 0; j < g; ++j) pre += packed(*reinterpret_cast<const uint4*>(bchunks + 4u * (j * 1024u + tid)));
+    const u64 own = packed(x);
+    u64 inc = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 y = __shfl_up(inc, d, 64), z = __shfl_up(pre, d, 64);
+        if ((int)lane >= d) { inc += y; pre += z; }
+    }
+    if (lane == 63) { wtot[0][wave] = inc; wtot[1][wave] = pre; }
+    __syncthreads();
+    u64 run = inc - own;
+    for (u32 w = 0; w < 16; ++w) { run += wtot[1][w]; if (w < wave) run += wtot[0][w]; }
+    if (e0 < n) {
+        uint4 ob, ot;
+        ob.x = (u32)run; ot.x = (u32)(run >> 32); run += (u64)x.x | ((u64)tiles_of(x.x) << 32);
+        ob.y = (u32)run; ot.y = (u32)(run >> 32); run += (u64)x.y | ((u64)tiles_of(x.y) << 32);
+        ob.z = (u32)run; ot.z = (u32)(run >> 32); run += (u64)x.z | ((u64)tiles_of(x.z) << 32);
+        ob.w = (u32)run; ot.w = (u32)(run >> 32); run += (u64)x.w | ((u64)tiles_of(x.w) << 32);
+        *reinterpret_cast<uint4*>(boff + e0) = ob;
+        if (tc) *reinterpret_cast<uint4*>(toff + e0) = ot;
+        if (e0 + 4u == n) { boff[n] = (u32)run; if (tc) toff[n] = (u32)(run >> 32); }       // (n % 4 == 0)
+    }
+}
+
 // tile t -> (first list index, chunks, bucket)
 // BALANCE (the join's items): a bucket's k tiles share its chunks evenly, ceil(chunks / k) each, instead of k-1 full tiles and
 // a short one - items of one size keep the workgroup slots level (k <= tc keeps every tile non-empty).
@@ -660,13 +709,14 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
                                u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
                                u32 max_segs, u32* __restrict__ list,
                                u32 nb, u32 tc, const u32* __restrict__ toff, uint4* __restrict__ tiles, u32 max_tiles,
-                               u32* __restrict__ zero_tail) {
+                               u32* __restrict__ zero_tail, u32* __restrict__ clr) {
     // a chain of dependent loads per chunk (dir/rel -> boff/seg_off -> store): four chains per thread and step are kept in
     // flight (the kernel is latency-bound: ~4M chunks at c3), and the grid fills the chip's thread slots.
     // RL > 0: the ids came in aligned runs of 2^RL per (segment, bucket), used in order with consecutive ranks - one chain
     // places a whole run (a 16-B directory load, one rel word, one pair of gathers, neighbouring list entries).
     u32 n = *nalloc; if (n > cap) n = cap;
     const u32 stride = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (clr) for (u32 i = gtid; i < nb / 4u; i += stride) reinterpret_cast<uint4*>(clr)[i] = make_uint4(0, 0, 0, 0);    // the bucket counts fj_level_scan_wide read (nb % 4 == 0)
     if (tc) {
         u32 total = toff[nb];
         if (total > max_tiles) total = max_tiles;
@@ -968,7 +1018,10 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
 // (no atomics) + the consumer's tile table.  tc == 0: no consumer tile table.
 hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s) {
     if (cs.nb & 3u) return hipErrorInvalidValue;           // fj_level_scan works in 16-B pieces
-    hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
+    // many buckets: one workgroup per 4096 counts, and the chunk-list launch clears the counts (fj_level_scan_wide)
+    const bool wide = cs.nb >= 8192u && cs.nb <= (1u << 19) && !(cs.run_log == 0 && cs.nb <= 512);
+    if (wide) hipLaunchKernelGGL(fj_level_scan_wide, dim3((cs.nb + 4095u) / 4096u), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
+    else hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
     static_assert(FJ_RUN_LOG == 1 || FJ_RUN_LOG == 2, "fj_level_lists reads a run's directory words with one 8-B or 16-B load");
     if (cs.run_log != 0 && cs.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
     if (cs.run_log == 0 && cs.nb <= 512 && cs.cap >= 4096) {       // few buckets, single ids: bin the list entries by bucket before storing them
@@ -979,7 +1032,7 @@ hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles
     }
     auto kern = cs.run_log ? fj_level_lists<FJ_RUN_LOG> : fj_level_lists<0>;
     hipLaunchKernelGGL(kern, dim3(2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
-                       cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
+                       cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail, wide ? cs.bchunks : (u32*)nullptr);
     return hipGetLastError();
 }
 

@@ -446,7 +446,7 @@ _CHUNK_REST_S_PER_ROW = 6.1e-12         # copy into the wire format + the owner'
 _CHUNK_WIRE_BYTES_PER_ROW = 7.02
 
 
-def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> float:
+def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int, link_bytes_per_s: Optional[float] = None) -> float:
     """Survivor fraction below which the precheck of the chunk form pays (FJ_DIST_PREFILTER_BELOW overrides the model).  Per local
     probe row a step costs max(wire, kernels) - the model of tools/scale_model.py: wire = 7.02 B x (f x probe rows + build rows) /
     (world x link rate) on each of the links that work in parallel, plus - with the precheck - the filters (1.07 bytes per build
@@ -458,9 +458,10 @@ def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> flo
         return float(env)
     if np_local <= 0 or world <= 1:
         return 0.0
+    link = float(link_bytes_per_s or _LINK_BYTES_PER_S)                      # (a multi-rank caller passes rank 0's: one verdict everywhere)
     build_share = nb_total / world / np_local                                # build rows per probe row: they travel either way
-    per_row = _CHUNK_WIRE_BYTES_PER_ROW / (world * _LINK_BYTES_PER_S)        # one row's share of one link
-    filters = 1.07 * build_share / _LINK_BYTES_PER_S                         # the all-gathered filters, per probe row
+    per_row = _CHUNK_WIRE_BYTES_PER_ROW / (world * link)                     # one row's share of one link
+    filters = 1.07 * build_share / link                                      # the all-gathered filters, per probe row
     off = max(per_row * (1.0 + build_share), _CHUNK_FIXED_S_PER_ROW + _CHUNK_REST_S_PER_ROW)
 
     def on(f):
@@ -475,18 +476,21 @@ def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int) -> flo
 
 
 # "auto" remembers what the last join of the same shape sampled: exporting and all-gathering the filters only to decline again would
-# cost every step of a repeated join ~3 ms at 8 ranks (1 byte per build key to every rank).  (world, build rows, probe rows) ->
-# [calls, sampled survivor share]; every 32nd call samples afresh.  Collective calls keep the ranks' memos identical.
+# cost every step of a repeated join ~3 ms at 8 ranks (1 byte per build key to every rank).  (world, build rows, probe rows, join_id)
+# -> [calls, sampled survivor share]; every 32nd call samples afresh.  Collective calls keep the ranks' memos identical: the
+# threshold is computed from rank 0's link rate (it travels with the relation sizes), never from a per-rank value.  join_id: what
+# the caller names the join (distributed_join(join_id=...)) - two joins of one shape but different hit rates (another probe column)
+# must not inherit each other's verdict; unnamed joins of one shape share one entry.
 _PRECHECK_MEMO: dict = {}
 _PRECHECK_RESAMPLE_EVERY = 32
 
 
-def _precheck_threshold(mode: str, world: int, nb_total: int, np_global: int):
+def _precheck_threshold(mode: str, world: int, nb_total: int, np_global: int, link_bytes_per_s: Optional[float] = None, join_id=None):
     """(prefilter_below for fj_dist_join, memo key or None, how it was decided)."""
     if mode != "auto":
         return {"off": 0.0, "on": 2.0}[mode], None, mode
-    below = _chunk_prefilter_break_even(world, nb_total, max(1, np_global // world))
-    key = (world, nb_total, np_global)
+    below = _chunk_prefilter_break_even(world, nb_total, max(1, np_global // world), link_bytes_per_s)
+    key = (world, nb_total, np_global, join_id)
     memo = _PRECHECK_MEMO.get(key)
     if below <= 0.0:
         return 0.0, None, "model: cannot pay"
@@ -1164,7 +1168,7 @@ def _replicated_join(dist, group, engine, world, build_keys, build_values, probe
 
 
 def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool = False, bloom: bool = False,
-                     group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None, transport=None):
+                     group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None, transport=None, join_id=None):
     """Join relations whose rows are block-distributed over the ranks of `group`.
 
     Every rank passes its LOCAL rows (int64 tensors on its GPU) and gets back
@@ -1172,6 +1176,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     rank owns.  `seconds` is this rank's wall time for the whole step (split + exchange + join).
     `transport`: an object with torch.distributed's collective functions (default: torch.distributed itself) - the
     self-tests that run several ranks on one GPU pass one that stages device tensors through the host for gloo.
+    `join_id` (hashable, the same on every rank): names a repeated join for the sender-side precheck's memory of what it sampled.
     """
     import torch.distributed as _td
     dist = transport if transport is not None else _td
@@ -1191,10 +1196,13 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
 
     pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
     # relation sizes of every rank: one tiny all-gather decides the strategy identically everywhere
-    mine = engine.counts_tensor([build_keys.numel(), probe_keys.numel()])
-    allsz = engine.counts_tensor([0] * (2 * world))
+    # (third word: this rank's per-link rate in kB/s - every rank models with rank 0's, so that hosts that called set_link_rate with
+    #  per-rank measurements still take the same decisions and the same fallback paths)
+    mine = engine.counts_tensor([build_keys.numel(), probe_keys.numel(), int(_LINK_BYTES_PER_S / 1e3)])
+    allsz = engine.counts_tensor([0] * (3 * world))
     dist.all_gather_into_tensor(allsz, mine, group=group)
-    allsz = allsz.reshape(world, 2).tolist()
+    allsz = allsz.reshape(world, 3).tolist()
+    link0 = float(allsz[0][2]) * 1e3
     sizes_b = [int(x[0]) for x in allsz]
     strategy = choose_strategy(world, max(sizes_b), max(int(x[1]) for x in allsz), materialize)
     if strategy == "replicate":
@@ -1236,7 +1244,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
             # that fails on any rank fails on every rank (the driver agrees on it), so all of them fall back together to the
             # owner-scatter form, whose segments are sized from an owner histogram: the answer to heavily skewed keys (an owner
             # that receives far more than 1.5x its share overflows the chunk form's pools).
-            below, memo_key, decision = _precheck_threshold(mode, world, nb_total, np_global)
+            below, memo_key, decision = _precheck_threshold(mode, world, nb_total, np_global, link0, join_id)
             for attempt in ((below, mode), (0.0, "off")) if below > 0 else ((0.0, mode),):     # (a failed step with the precheck is retried without it)
                 try:
                     tt = timings if timings is not None else {}
@@ -1269,7 +1277,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
             and engine.shuffle_plan(sum(sizes_b), world) is not None):
         try:
             mode = _chunk_prefilter_mode(bloom, world)
-            below, memo_key, decision = _precheck_threshold(mode, world, sum(sizes_b), sum(int(x[1]) for x in allsz))
+            below, memo_key, decision = _precheck_threshold(mode, world, sum(sizes_b), sum(int(x[1]) for x in allsz), link0, join_id)
             tt = timings if timings is not None else {}
             res = _driver_count(dist, group, engine, build_keys, probe_keys, pieces, tt, transport, build_values=build_values, return_arrays=return_arrays,
                                 prefilter_below=below, prefilter_mode=mode)

@@ -144,7 +144,8 @@ class _StandInOps:
         self.bufs = {}
         self.packed = None
         self.npacks = 0
-        # test hook FJ_TEST_FAIL = "pack:<rank>" / "append:<rank>": that rank's third packing pass / second probe append fails
+        # test hook FJ_TEST_FAIL = "pack:<rank>" / "copy:<rank>" / "append:<rank>": that rank's third packing pass / the copy into the
+        # wire format behind it / its second probe append fails
         what, _, who = os.environ.get("FJ_TEST_FAIL", ":").partition(":")
         self.fail = what if who != "" and int(who) == dist.get_rank() else ""
 
@@ -183,6 +184,9 @@ class _StandInOps:
         return [len(x) for x in self.packed]
 
     def pack_finish(self, dst_chunks, dst_dir):
+        if self.fail == "copy" and self.npacks == 3:      # behind the piece's agreement points: the peers are already posting its receives
+            self.packed = None                            # (the engine can start the next piece's pass: the failure is then agreed on in the final all-reduce)
+            raise RuntimeError("injected copy failure")
         for o, chunks in enumerate(self.packed):
             if not chunks:
                 continue
@@ -387,7 +391,7 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     os.environ["FJ_DIST_PREFILTER"] = {"prefilter": "1", "prefilterauto": "auto", "prefilterdeclined": "auto"}.get(variant, "0")
     os.environ["FJ_DIST_STRATEGY"] = strategy
     os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if variant == "scatter" else "1"
-    if variant in ("packfail", "appendfail", "bcpackfail", "bcjoinfail"):    # one rank's packing pass / local join fails inside the C++ driver: EVERY rank sees the failure
+    if variant in ("packfail", "copyfail", "appendfail", "bcpackfail", "bcjoinfail"):    # one rank's packing pass / local join fails inside the C++ driver: EVERY rank sees the failure
         os.environ["FJ_TEST_FAIL"] = variant[:-4] + ":" + str(world - 1)
     if strategy == "replicate":
         os.environ["FJ_REPLICATE_PIECES"] = "3"
@@ -437,16 +441,22 @@ def _worker(rank, world, port, nb, npk, q, strategy):
         res = distributed_join(tb, tv, tp, materialize=True, return_arrays=True, engine=OracleEngine(), timings=t)
         exp = torch.tensor([exp_local]); dist.all_reduce(exp)
         tc = {}
-        if variant in ("packfail", "appendfail"):
+        if variant in ("packfail", "copyfail", "appendfail"):
             os.environ["FJ_DIST_NO_FALLBACK"] = "1"
-            with pytest.raises(RuntimeError, match="packing a piece failed on 1 rank" if variant == "packfail" else "the local join failed on 1 rank") as ei:
+            # ("copyfail": the failing rank stays in step - nobody waits for an exchange it never posted - up to the final all-reduce,
+            #  where what it sent instead of the piece may have failed its receivers' joins too: "on N rank(s)")
+            with pytest.raises(RuntimeError, match={"packfail": "packing a piece failed on 1 rank", "copyfail": "the local join failed on [1-3] rank",
+                                                    "appendfail": "the local join failed on 1 rank"}[variant]) as ei:
                 distributed_join(tb, tv, tp, engine=OracleEngine())
-            assert ("injected" in str(ei.value)) == (rank == world - 1)       # the failing rank says why, the others that somebody failed
+            if variant == "copyfail":
+                assert rank != world - 1 or "injected copy failure" in str(ei.value)
+            else:
+                assert ("injected" in str(ei.value)) == (rank == world - 1)       # the failing rank says why, the others that somebody failed
             del os.environ["FJ_DIST_NO_FALLBACK"]
         cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)        # counting: pipelined exchange
         assert cnt == int(exp.item()) and tc["strategy"] == t["strategy"] == strategy
-        if variant in ("packfail", "appendfail"):    # ... and without FJ_DIST_NO_FALLBACK all ranks rerun in the owner-scatter form together
-            assert "failed on 1 rank" in tc["chunk_form_error"] and tc["shuffle_form"] == "owner-scatter"
+        if variant in ("packfail", "copyfail", "appendfail"):    # ... and without FJ_DIST_NO_FALLBACK all ranks rerun in the owner-scatter form together
+            assert "failed on " in tc["chunk_form_error"] and tc["shuffle_form"] == "owner-scatter"
         if variant in ("skew", "uneven"):
             assert tc["shuffle_form"].startswith("chunks") and "chunk_form_error" not in tc, tc
         if variant == "uneven":
@@ -552,7 +562,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_appendfail", "shuffle_skew", "shuffle_lateskew", "shuffle_uneven", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
+@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_copyfail", "shuffle_appendfail", "shuffle_skew", "shuffle_lateskew", "shuffle_uneven", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
                                       "replicate_small_messages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):
@@ -692,10 +702,10 @@ def test_precheck_verdict_is_remembered_per_join_shape(monkeypatch):
     shape = (8, 10**9, 10**10)
     assert D._precheck_threshold("on", *shape) == (2.0, None, "on") and D._precheck_threshold("off", *shape) == (0.0, None, "off")
     below, key, how = D._precheck_threshold("auto", *shape)
-    assert (below, key, how) == (0.4, shape, "sampled")
+    assert (below, key, how) == (0.4, shape + (None,), "sampled")
     t = {"prefilter_sampled_survivors": 0.55}
     D._precheck_remember(key, t, how)
-    assert t["prefilter_decision"] == "sampled" and D._PRECHECK_MEMO[shape] == [1, 0.55]
+    assert t["prefilter_decision"] == "sampled" and D._PRECHECK_MEMO[shape + (None,)] == [1, 0.55]
     for call in range(2, 33):                                    # calls 2..32: remembered - declined (0.55 >= 0.4), nothing sampled
         below, key, how = D._precheck_threshold("auto", *shape)
         assert (below, how) == (0.0, "memo: declined"), call
@@ -705,6 +715,13 @@ def test_precheck_verdict_is_remembered_per_join_shape(monkeypatch):
     D._precheck_remember(key, {"prefilter_sampled_survivors": 0.1}, how)
     assert D._precheck_threshold("auto", *shape)[::2] == (2.0, "memo: runs")      # few survivors now: runs, without sampling
     assert D._precheck_threshold("auto", 8, 10**9, 5 * 10**9)[2] == "sampled"     # another shape: its own verdict
+    assert D._precheck_threshold("auto", *shape, None, "orders x lineitem")[2] == "sampled"   # the same shape under a name: its own verdict too
+    # the threshold is a function of the link rate it is GIVEN (distributed_join passes rank 0's), not of this process's setting
+    monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
+    slow, fast = D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000, 45e9), D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000, 65e9)
+    monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 65e9)
+    assert slow > fast and D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000, 45e9) == slow and D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000) == fast
+    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.4")
     monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0")
     monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
     monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 45e9)

@@ -913,6 +913,30 @@ def test_full_size_closed_form_counts(fj, nb, npk, hit_bp, fn, hbm):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("nb,bits", [(100_000, 13), (6_000_000, 19), (12_000_000, 20)])
+def test_level_bookkeeping_at_the_bucket_counts_where_its_scan_changes_form(fj, nb, bits):
+    """After a pass the per-bucket chunk counts become chunk-list offsets: one workgroup up to 4096 buckets, one workgroup per 4096
+    buckets from 8192 to 2^19 (fj_level_scan_wide, the counts then cleared by the chunk-list launch), one workgroup again beyond.
+    16 build keys per final partition put small relations on 2^13, 2^19 and 2^20 final buckets; every join runs twice (the counts
+    must be zero again for the second) and the match count is the generator's closed form."""
+    import torch
+    from flash_hash_join_amd import datagen
+    fj.set_option("plan_target_keys", 16)
+    try:
+        dbk, dbv = datagen.build_device(nb, "cuda:0")
+        dpk, exp = datagen.probe_device(3 * nb + 17, nb, "cuda:0", seed=bits, hit_bp=4000)
+        for _ in range(2):
+            n, _sec = fj.hash_join_count_radix(dbk, dbv, dpk)
+            assert n == exp
+            assert fj.last_timings()["radix_bits"] == bits
+        n, _sec, k, v = fj.hash_join_radix(dbk, dbv, dpk, return_arrays=True)
+        assert n == exp and k.numel() == exp and v.numel() == exp
+    finally:
+        fj.set_option("plan_target_keys", 4096)
+    del dbk, dbv, dpk
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("hit_bp", [0, 500, 5000, 10000])
 @pytest.mark.parametrize("nb,npk", [(5_000_000, 40_000_000), (30_000_000, 60_000_000)])
 def test_bloom_precheck_prunes_misses_and_keeps_every_hit(fj, nb, npk, hit_bp):

@@ -1,10 +1,9 @@
 # usage (on the GPU box): VARS="old new" [WL=c3] bash tools/prof_variants.sh -- mean kernel durations of a bench run per library
 # variant in flash_hash_join_amd/lib/ab/<name>.so (rocprofv3 kernel trace, same box, one after the other, twice)
-cd $GRAFT_REPO_ROOT
-cp flash_hash_join_amd/lib/libflashjoin_hip.so /tmp/cur.so
+# (the variant is chosen with FJ_LIB_VARIANT, flash_hash_join_amd/_lib.py: the in-tree library is never overwritten)
+cd "${GRAFT_REPO_ROOT:-$PWD}" || exit 1
 for rep in 1 2; do for v in $VARS; do
-  cp flash_hash_join_amd/lib/ab/$v.so flash_hash_join_amd/lib/libflashjoin_hip.so
-  bash tools/prof_stats.sh pv_${v}_$rep --workload ${WL:-c3} --steps 12 --warmup 2 > /dev/null 2>&1
+  FJ_LIB_VARIANT=$v bash tools/prof_stats.sh pv_${v}_$rep --workload ${WL:-c3} --steps 12 --warmup 2 > /dev/null 2>&1
   python3 - $v gpurun_out/stats_pv_${v}_$rep <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
@@ -20,5 +19,4 @@ for (n, g), v in acc.items():
     if sum(v) / len(v) > 15: print("  %-60s grid %-8s n=%-4d mean %9.1f us" % (n, g, len(v), sum(v) / len(v)))
 PY
 done; done
-cp /tmp/cur.so flash_hash_join_amd/lib/libflashjoin_hip.so
 rm -rf gpurun_out/stats_pv_*

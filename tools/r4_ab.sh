@@ -1,12 +1,11 @@
 #!/bin/bash
 # same-box A/B of two library builds (flash_hash_join_amd/lib/ab/{old,new}.so) over several workloads: WLS="c3 c4 c2 c3_mat"
-cd $GRAFT_REPO_ROOT
+# (the build under test is chosen with FJ_LIB_VARIANT - flash_hash_join_amd/_lib.py - the in-tree library is never touched)
+cd "${GRAFT_REPO_ROOT:-$PWD}" || exit 1
 mkdir -p gpurun_out
-cp flash_hash_join_amd/lib/libflashjoin_hip.so /tmp/cur.so
 for wl in ${WLS:-c3 c4 c2 c3_mat}; do
   for r in 1 2; do for v in old new; do
-    cp flash_hash_join_amd/lib/ab/$v.so flash_hash_join_amd/lib/libflashjoin_hip.so
-    python bench.py --workload $wl --steps ${ST:-10} --warmup 2 --no-cpu-baseline --no-host-entry 2>/tmp/err.txt | tail -1 > /tmp/b.json
+    FJ_LIB_VARIANT=$v python bench.py --workload $wl --steps ${ST:-10} --warmup 2 --no-cpu-baseline --no-host-entry 2>/tmp/err.txt | tail -1 > /tmp/b.json
     python - <<PY
 import json
 try:
@@ -17,4 +16,3 @@ except Exception as ex:
 PY
   done; done
 done 2>&1 | tee gpurun_out/r4_ab_${TAG:-x}.txt
-cp /tmp/cur.so flash_hash_join_amd/lib/libflashjoin_hip.so
