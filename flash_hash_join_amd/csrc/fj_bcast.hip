@@ -272,6 +272,9 @@ int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* regio
     FjWideArgs w{};
     w.toff = bc.pit.toff; w.part_lo = part_lo; w.part_hi = part_hi;
     w.base = (const unsigned char*)d_base; w.nsrc = (u32)nsrc; w.bits = L0.bits; w.mid_bytes = L0.mid_bytes;
+    // few ranks = few, fat partitions: > ~28 probe chunks each means two or three items per partition (items hold <= 32 probe chunks),
+    // dealt in runs of 8 so that a partition's items find their table built (2 and 4 ranks of config 5: 3 and 2 items per partition)
+    w.group_log = bc.np / L0.nparts > 7000 ? 3u : 0u;
     for (int i = 0; i < nsrc; ++i) {
         Layout L;
         if (layout_of(bc.nb_total, (size_t)nkeys[i], &L)) return 1;

@@ -188,7 +188,8 @@ struct FjWideArgs {
     const u32* toff; u32 part_lo, part_hi;       // toff != nullptr: only the items of partitions [part_lo, part_hi) (toff = first item of every partition)
     // DENSE build side: source s keeps, at byte offsets into base, an offset table u32[nparts + 1] (keys before partition p), the keys'
     // low words u32[n_s] and the low (32 - bits) bits of their high words as u16[n_s] (mid_bytes == 2) or u32[n_s]; partition p supplies the top `bits` bits
-    const unsigned char* base; u32 nsrc, bits, mid_bytes, pad;
+    const unsigned char* base; u32 nsrc, bits, mid_bytes;
+    u32 group_log;                               // items are dealt to the workgroups in runs of 2^group_log consecutive ones (0: one by one); > 0 where partitions are cut into several items: a run's items of one partition share one table build
     u64 offs_off[FJ_WIDE_MAXSRC], lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC];
 };
 hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w, bool dense, u32 grid, hipStream_t s);

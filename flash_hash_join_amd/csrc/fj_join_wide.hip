@@ -22,7 +22,10 @@
 //   * DENSE: the build side is not a chunk set but the multi-GPU "build broadcast" wire format (fj_bcast.hip): per source rank
 //     one run of keys per final partition, stored as two planes (low word, remaining bits of the high word) behind an offset
 //     table; the partition id supplies the top bits.  Nothing is re-partitioned or copied on the receiving side.
-// Items are dealt round-robin (item = blockIdx.x + k * gridDim.x): all of a launch's workgroups are resident.
+// Items are dealt round-robin (item = blockIdx.x + k * gridDim.x): all of a launch's workgroups are resident.  When the probe side
+// of a partition is cut into several items (FjWideArgs::group_log > 0: the host sees > ~28 probe chunks per partition - the
+// broadcast form at 2 and 4 ranks) the deal is in runs of 2^group_log consecutive items instead, and an item whose predecessor in
+// the workgroup belongs to the same partition finds its table built: no claims, no clearing, no stores, no build-side loads.
 // Items whose build side does not fit (a claim walks W_MAXWALK slots in vain) are marked FJ_ITEM_RETRY exactly as
 // fj_count_join_persistent does; the host's retry / re-partition ladder (radix_join_tail) is unchanged.
 #include "fj_internal.h"
@@ -52,7 +55,7 @@ __device__ __forceinline__ u32 w_l2(u64 h) { return (FJ_HW2(h) >> WSLOG) & (WS -
 // (third location: the high word's low bits - radix digits come from its TOP - folded with 14 other bits of the low word: three instructions)
 __device__ __forceinline__ u32 w_l3(u64 h) { return (FJ_HW1(h) ^ (FJ_HW2(h) >> 18) ^ (FJ_HW2(h) >> 5)) & (WS - 1); }
 
-template <bool DENSE>
+template <bool DENSE, bool GROUPED>
 __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWideArgs w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WHdr* hdr = reinterpret_cast<WHdr*>(smem);
@@ -63,9 +66,15 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
 
     u32 item_lo = 0, item_hi = *a.nitems_dev;
     if (w.toff) { item_lo = w.toff[w.part_lo]; item_hi = w.toff[w.part_hi]; }
-    if (item_lo + blockIdx.x >= item_hi) return;
-    const u32 nmine = (item_hi - item_lo - blockIdx.x + gridDim.x - 1) / gridDim.x;     // items of this workgroup
-    auto id_of = [&](u32 q) { return item_lo + blockIdx.x + q * gridDim.x; };
+    // runs of G = 2^group_log consecutive items per workgroup and round (G = 1: plain round-robin)
+    // (GROUPED is a compile-time switch: the plain deal's code must not carry the other's registers - it cost the 8-rank join 7 %)
+    const u32 glog = GROUPED ? w.group_log : 0u, G = 1u << glog, per_round = gridDim.x << glog;
+    constexpr bool grouped = GROUPED;
+    if (item_hi <= item_lo) return;
+    const u32 nrounds = (item_hi - item_lo) / per_round, rem = (item_hi - item_lo) - nrounds * per_round;
+    const u32 nmine = (nrounds << glog) + (rem > (blockIdx.x << glog) ? (rem - (blockIdx.x << glog) < G ? rem - (blockIdx.x << glog) : G) : 0u);     // items of this workgroup
+    if (nmine == 0) return;
+    auto id_of = [&](u32 q) { return item_lo + (q >> glog) * per_round + (blockIdx.x << glog) + (q & (G - 1u)); };
     auto ring = [&](u32 q, u32 f) -> u32 { return __builtin_amdgcn_readfirstlane(hdr->dring[q & 7][f]); };   // descriptor field, wave-uniform
 
     // descriptor fetch, one thread: the item-table entry of item q (q >= nmine: a dead item: no chunks on either side)
@@ -375,6 +384,10 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     __syncthreads();
     // descriptor fields kept in scalar registers, rotated every iteration: probe chunks of items k .. k+2, build chunks of k+1, k+2
     u32 ns0 = ring(0, 1), ns1 = ring(1, 1), ns2 = ring(2, 1), nbc1 = ring(1, 5), nbc2 = ring(2, 5), part2 = ring(2, 2);
+    // grouped deals: partition ids of items k+1 (part1) and k+2 (part2) ride along; sameA / sameB: the item whose build keys
+    // bkA / bkB would hold finds its partition's table in place (its predecessor built it)
+    u32 part1 = grouped ? ring(1, 2) : 0u;
+    bool sameA = grouped && 1 < nmine && part1 == ring(0, 2), sameB = false;
     u32* sl_k = meta, * sl_k1 = meta + W_STRIDE, * sl_k2 = meta + 2 * W_STRIDE, * sl_k3 = meta + 3 * W_STRIDE;
     {
         u32 mp, mb;
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         load_chunk(sl_k, wave + W_WAVES, nb, kb, vb);
     }
     u32 tot1 = DENSE ? dense_total(sl_k1) : 0u;
-    load_build(sl_k1, ring(1, 2), 0, nbc1 < W_META_B ? nbc1 : W_META_B, tot1, bkA, bokA, amA);
+    if (!sameA) load_build(sl_k1, ring(1, 2), 0, nbc1 < W_META_B ? nbc1 : W_META_B, tot1, bkA, bokA, amA);
     __syncthreads();                                               // item 0's keys are in the table
 
 #ifdef FJ_LAB      // diagnostic build (make EXTRA=-DFJ_LAB): where thread 0's time goes, per pipeline stage (FJ_WIDE_STAMPS=1)
@@ -428,7 +441,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         u32 mb2;
         request(k + 3, ns3, nbc3, mp, mb, mb2);
         const u32 tot2 = DENSE ? dense_total(sl_k2) : 0u;
-        load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, bkB, bokB, amB);
+        sameB = grouped && k + 2 < nmine && part2 == part1;
+        if (!sameB) load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, bkB, bokB, amB);
+        else { bokB = 0; amB = 0; }
         W_STAMP(0);
         // ---- 2a. probe item k; then its successor's first probe chunks are requested into the same registers ----
         const bool full = hdr->full[par] != 0 || ns0 > 2 * W_WAVES;      // (an item longer than 32 probe chunks - a host-side bug - goes to the retry ladder)
@@ -446,8 +461,10 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         W_STAMP(1);
         // ---- 2b. claims of item k+1 on the other bitmap (other waves are still probing: the round trips overlap their lookups) ----
         u32 nslots[8];
-        claim(bitsn, bkA, bokA, amA, parn, nslots);
-        if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
+        if (!sameA) {
+            claim(bitsn, bkA, bokA, amA, parn, nslots);
+            if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
+        }
         W_STAMP(2);
         // ---- 3. park what was requested ----
         park(sl_k3, mp, mb, mb2);
@@ -459,25 +476,31 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         // ---- 4. item k's result; the table is emptied by the owners of its keys; bitmap `par` is cleared for item k+2 ----
         if (tid == 0) {
             const u32 cnt = skip ? 0u : hdr->cnt;
+            if (sameA) { hdr->has_empty[parn] = hdr->has_empty[par]; hdr->full[parn] = hdr->full[par]; }      // the table stays: so do its flags
             hdr->cnt = 0; hdr->has_empty[par] = 0; hdr->full[par] = 0;
             if (full) atomicOr(a.err, FJ_STAT_RETRY);            // the table could not hold the partition: redone with the tagged table
             a.part_count[id_of(k)] = full ? FJ_ITEM_RETRY : cnt;
             if (cnt) atomicAdd(a.total, (unsigned long long)cnt);
         }
-        clear_slots(slots, am_cur);
+        if (!sameA) clear_slots(slots, am_cur);
         if (tid < WS / 32) bits0[par * (WS / 32) + tid] = 0;
         W_STAMP(5);
         __syncthreads();                                         // B
         // ---- 5. item k+1 goes in ----
-        store_keys(bkA, nslots, amA);
+        if (!sameA) store_keys(bkA, nslots, amA);
         W_STAMP(6);
         __syncthreads();                                         // C
         W_STAMP(7);
         // ---- 6. rotate ----
+        if (!sameA) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { slots[j] = nslots[j]; bkA[j] = bkB[j]; }
-        bokA = bokB; am_cur = amA; amA = amB; tot1 = tot2;
-        ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part2 = DENSE ? ring(k + 3, 2) : 0u;
+            for (int j = 0; j < 8; ++j) slots[j] = nslots[j];
+            am_cur = amA;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bkA[j] = bkB[j];
+        bokA = bokB; amA = amB; tot1 = tot2; sameA = sameB;
+        ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part1 = part2; part2 = (DENSE || grouped) ? ring(k + 3, 2) : 0u;
         u32* t = sl_k; sl_k = sl_k1; sl_k1 = sl_k2; sl_k2 = sl_k3; sl_k3 = t;
     }
 #ifdef FJ_LAB
@@ -494,8 +517,10 @@ u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + 2 * (WS / 8) + 4 
 hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w, bool dense, u32 grid, hipStream_t s) {
     if (!a.probe.list || !a.items || (!dense && !a.build.list) || a.want_dups) return hipErrorInvalidValue;
     if (dense && (w.nsrc == 0 || w.nsrc > FJ_WIDE_MAXSRC || !w.base || (w.mid_bytes != 2 && w.mid_bytes != 4) || w.bits > 32)) return hipErrorInvalidValue;
+    if (w.group_log > 6) return hipErrorInvalidValue;
     const u32 lds = fj_wide_lds_bytes();
-    auto kern = dense ? fj_count_join_wide<true> : fj_count_join_wide<false>;
+    if (w.group_log && !dense) return hipErrorInvalidValue;        // (chunk-list build sides come with <= 32 probe chunks per partition: fj_plan.hip wide_join_planned)
+    auto kern = dense ? (w.group_log ? fj_count_join_wide<true, true> : fj_count_join_wide<true, false>) : fj_count_join_wide<false, false>;
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     if (grid == 0) grid = 1;

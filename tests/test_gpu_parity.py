@@ -1111,11 +1111,13 @@ def _bcast_emulated(eng, world, bks, pks, nb_total, pieces):
 
 
 @pytest.mark.parametrize("world,nb_total,np_total,target", [(2, 70_000, 300_001, 32), (3, 250_000, 1_000_000, 32), (8, 9_000_000, 12_000_000, 4096),
-                                                              (4, 40_000, 90_000, 256), (5, 3_000_000, 2_000_000, 32)])
+                                                              (4, 40_000, 90_000, 256), (5, 3_000_000, 2_000_000, 32),
+                                                              (2, 20_000, 9_000_000, 4096), (3, 400_000, 9_000_001, 4096), (4, 2_000_000, 30_000_000, 4096)])
 def test_build_broadcast_form_matches_the_oracle(fj, oracle, world, nb_total, np_total, target):
     """The build-broadcast form of the multi-GPU join (csrc/fj_bcast.hip + fj_count_join_wide<DENSE>), all ranks played by this GPU,
     against the NumPy oracle: ragged blocks (one rank holds no build rows, one no probe rows), repeated probe keys, both widths of the
-    high-word plane (bits < 16 / >= 16 under plan_target_keys), 1..5 pieces."""
+    high-word plane (bits < 16 / >= 16 under plan_target_keys), 1..5 pieces.  The last three: few, fat partitions whose probe side is
+    cut into 18 / 3 / 2 items each - dealt to the workgroups in runs, a partition's table built once per run (FjWideArgs::group_log)."""
     import torch
     from flash_hash_join_amd.distributed import HipEngine
     fj.set_option("plan_target_keys", target)

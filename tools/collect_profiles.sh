@@ -43,4 +43,6 @@ FJ_BENCH_FORCE_DIST=1 FJ_BENCH_FORCE_FORM=broadcast timeout 600 python bench.py 
 FJ_OPTIONS=join_wide=1 ./tools/pmc.sh $O/pmc_wide --workload c5_rep8 --no-host-entry > $O/c5_rep8_wide_pmc_summary.txt 2>&1
 FJ_OPTIONS=join_wide=0 timeout 300 python bench.py --workload c5_rep8 --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c5_rep8_narrow_table_bench.json
 python tools/scale_model.py > $O/scale_model.txt 2>&1
+# ... and as one rank of 2 and of 4 (16- and 17-bit plans: three and two items per partition, dealt in runs)
+( for w in 2 4; do python tools/bcast_one_gpu.py $w 125000000 1250000000 4 5 5000 0 2>&1 | grep "^world\|^step"; done ) > $O/bcast_one_rank_of_2_and_4.txt 2>&1
 ls -la $O | head -60
