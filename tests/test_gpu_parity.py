@@ -1139,6 +1139,38 @@ def test_build_broadcast_form_matches_the_oracle(fj, oracle, world, nb_total, np
         fj.set_option("plan_target_keys", 4096)
 
 
+@pytest.mark.parametrize("np_rank", [200_000, 4_000_000])
+def test_build_broadcast_refuses_a_partition_that_cannot_fit_the_table(fj, np_rank):
+    """One final partition of the global plan holds 20000 distinct build keys (built by inverting the key mixer: their mixed keys share
+    the partition's top bits) - more than the 16384-slot table takes.  The step must fail loudly (the dispatcher then reruns the join as
+    the owner shuffle), under the plain deal of items and - 4M probe rows per rank: 18 items per partition - under the deal in runs,
+    where the items of the oversized partition inherit its verdict from the one that tried to build it."""
+    import torch
+    from flash_hash_join_amd import _lib
+    from flash_hash_join_amd.distributed import HipEngine
+    L = _lib.load()
+    eng = HipEngine("cuda:0")
+    world, nb_total = 2, 400_000
+    bits, nparts, _ = eng.bcast_plan(nb_total)
+    assert 5 <= bits <= 8
+    rng = np.random.default_rng(99)
+    hot = np.unique(rng.integers(0, 2**(64 - bits), size=20_500, dtype=np.uint64))[:20_000] | (np.uint64(3) << np.uint64(64 - bits))   # mixed keys of partition 3
+    hot = np.array([L.fj_key_unmix64(int(x)) for x in hot], dtype=np.uint64)
+    rest = rng.integers(0, 2**64, size=nb_total - hot.size, dtype=np.uint64)
+    bk = np.unique(np.concatenate([hot, rest]))
+    rng.shuffle(bk)
+    pk = np.concatenate([rng.choice(bk, np_rank), rng.integers(0, 2**64, size=np_rank, dtype=np.uint64)])
+    bks = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.array_split(bk, world)]
+    pks = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.array_split(pk, world)]
+    with pytest.raises(RuntimeError, match="does not fit the LDS table"):
+        _bcast_emulated(eng, world, bks, pks, int(bk.size), 2)
+    # the context is usable afterwards: the same relations without the hot keys join exactly
+    bk2 = np.setdiff1d(bk, hot)
+    bks2 = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.array_split(bk2, world)]
+    exp = int(np.isin(pk, bk2).sum())
+    assert _bcast_emulated(eng, world, bks2, pks, int(bk2.size), 2) == exp
+
+
 def test_config5_build_broadcast_every_rank_at_full_size_on_one_gpu(fj):
     """BASELINE configs[4] (1B build x 10B probe rows over 8 GPUs) at FULL size in the build-broadcast form, all 8 ranks played by
     this one GPU: every rank's 125M build rows are packed into its 0.75-GB region (18-bit plan: 262144 final partitions, 6 wire bytes
