@@ -1,6 +1,6 @@
 """Timeline of the LAST join in a rocprofv3 kernel trace: python tools/trace_timeline.py <dir with *_kernel_trace.csv> [n_kernels]"""
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+import csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)      # (the newest, where several runs left traces)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # a join starts with the memset of its plan's scalars: the last fill that directly follows a copyBuffer (the read-back that
 # ended the previous join; a materialising join reads back more than once, its later stages do not start with a fill)
