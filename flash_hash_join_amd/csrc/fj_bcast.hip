@@ -16,6 +16,7 @@
 // receiving side) a rank puts 6 * nb_local bytes on every link however many probe rows there are: at BASELINE configs[4]
 // (125M x 1.25B rows per GPU, 8 GPUs) 0.75 GB per link instead of 1.2 GB, and no kernel beyond the plain join's but the pack.
 #include "fj_host.h"
+#include <type_traits>
 using namespace fjh;
 
 namespace {
@@ -107,24 +108,78 @@ __global__ __launch_bounds__(1024) void fj_dense_scan_wide(const u32* __restrict
     if (e0 + 4u == nparts) { offs[nparts] = run + own; bounds[pieces] = run + own; }
 }
 
-// one wave per final partition: its chunks' keys -> the two planes at the partition's offset
+// one wave per final partition: its chunks' keys -> the two planes at the partition's offset.  The keys are staged in a per-wave
+// LDS tile whose index mirrors the alignment of the output (tile_base is a multiple of 8 keys) and leave as whole 16-byte words
+// wherever a word belongs to this partition alone; the partition's first and last few keys - words shared with the neighbouring
+// partitions, other waves' business - go out one by one.  (One 4-byte and one 2-byte store per KEY made this copy 0.41 ms per 125M
+// keys: the memory pipeline charges per store instruction.)  LDS operations of one wave execute in order: no barrier.
+constexpr u32 DC_T = 512;                      // keys per tile (a multiple of 8)
 template <int MIDB>
 __global__ __launch_bounds__(DP_NT) void fj_dense_copy(const u64* __restrict__ keys, const u32* __restrict__ boff, const u32* __restrict__ list,
                                                       u32 nparts, const u32* __restrict__ offs, u32 midmask, u32* __restrict__ lo, void* __restrict__ mid) {
-    const u32 p = blockIdx.x * (DP_NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    typedef typename std::conditional<MIDB == 2, u16, u32>::type mid_t;
+    __shared__ __attribute__((aligned(16))) u32 s_lo[DP_NT / 64][DC_T];
+    __shared__ __attribute__((aligned(16))) mid_t s_mid[DP_NT / 64][DC_T];
+    const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 p = blockIdx.x * (DP_NT / 64) + wv;
     if (p >= nparts) return;
-    u32 o = offs[p];
+    u32* tl = s_lo[wv]; mid_t* tm = s_mid[wv];
+    mid_t* gm = reinterpret_cast<mid_t*>(mid);
+    const u32 o = offs[p], n = offs[p + 1] - o, end = o + n;
+    if (n == 0) return;
+    constexpr u32 MG = 16 / sizeof(mid_t);                           // high-word elements per 16-byte word
+    // the tile [tile_base, tile_base + DC_T) of the output leaves the LDS stage: whole words inside [o, end), single elements at its edges
+    auto flush = [&](u32 tile_base) {
+        const u32 vlo = o > tile_base ? o : tile_base, vhi = end < tile_base + DC_T ? end : tile_base + DC_T;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (u32 g = (vlo - tile_base) / 4 + lane; g * 4 < vhi - tile_base; g += 64) {
+            const u32 g0 = tile_base + 4 * g;
+            const uint4 q = *reinterpret_cast<const uint4*>(tl + 4 * g);
+            if (g0 >= vlo && g0 + 4 <= vhi) *reinterpret_cast<uint4*>(lo + g0) = q;
+            else {
+                const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (u32 e = 0; e < 4; ++e) if (g0 + e >= vlo && g0 + e < vhi) lo[g0 + e] = w[e];
+            }
+        }
+        for (u32 g = (vlo - tile_base) / MG + lane; g * MG < vhi - tile_base; g += 64) {
+            const u32 g0 = tile_base + MG * g;
+            const uint4 q = *reinterpret_cast<const uint4*>(tm + MG * g);
+            if (g0 >= vlo && g0 + MG <= vhi) *reinterpret_cast<uint4*>(gm + g0) = q;
+            else {
+#pragma unroll
+                for (u32 e = 0; e < MG; ++e) if (g0 + e >= vlo && g0 + e < vhi) gm[g0 + e] = tm[MG * g + e];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    };
+    u32 tile_base = o & ~7u, pos = o;                                // pos: output index of the next chunk's first key
     for (u32 i = boff[p]; i < boff[p + 1]; ++i) {
         const u32 e = list[i], cnt = FJ_LIST_CNT(e);
         const u64* ck = keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK;
-        for (u32 j = lane; j < cnt; j += 64) {
-            const u64 h = ck[j];
-            lo[o + j] = FJ_HW2(h);
-            if (MIDB == 2) reinterpret_cast<u16*>(mid)[o + j] = (u16)(FJ_HW1(h) & midmask);
-            else reinterpret_cast<u32*>(mid)[o + j] = FJ_HW1(h) & midmask;
+        u64x2 q[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                                // (only the lines that hold keys: the chunks of a final partition are ~2/3 full)
+            q[t].x = 0; q[t].y = 0;
+            if (2 * lane + 128 * t < cnt) q[t] = *reinterpret_cast<const u64x2*>(ck + 2 * lane + 128 * t);     // (chunks are allocated whole: the pair is readable)
         }
-        o += cnt;
+        const u64 h[4] = {q[0].x, q[0].y, q[1].x, q[1].y};
+        auto stage = [&]() {                                         // this chunk's keys that fall into the current tile
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u32 k = 2 * lane + 128 * (t >> 1) + (t & 1), at = pos + k - tile_base;      // (pos + k < tile_base wraps to a huge index)
+                if (k < cnt && at < DC_T) { tl[at] = FJ_HW2(h[t]); tm[at] = (mid_t)(FJ_HW1(h[t]) & midmask); }
+            }
+        };
+        stage();
+        if (pos + cnt >= tile_base + DC_T) {                         // the tile is full (cnt <= 256 < DC_T: at most once per chunk)
+            flush(tile_base);
+            tile_base += DC_T;
+            stage();
+        }
+        pos += cnt;
     }
+    if (pos > tile_base) flush(tile_base);
 }
 
 struct Layout { u32 bits, nparts, mid_bytes; size_t lo_off, mid_off, bytes; };
