@@ -55,8 +55,11 @@ __device__ __forceinline__ u32 w_l2(u64 h) { return (FJ_HW2(h) >> WSLOG) & (WS -
 // (third location: the high word's low bits - radix digits come from its TOP - folded with 14 other bits of the low word: three instructions)
 __device__ __forceinline__ u32 w_l3(u64 h) { return (FJ_HW1(h) ^ (FJ_HW2(h) >> 18) ^ (FJ_HW2(h) >> 5)) & (WS - 1); }
 
-template <bool DENSE, bool GROUPED>
+// MIDB: 0 = chunk-list build side; 2 / 4 = DENSE, the width of the high-word plane's elements (compile-time: the raw planes of a
+// batch wait in registers, and one set of registers must do)
+template <int MIDB, bool GROUPED>
 __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWideArgs w) {
+    constexpr bool DENSE = MIDB != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WHdr* hdr = reinterpret_cast<WHdr*>(smem);
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(WHdr));
@@ -99,15 +102,16 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     auto dense_lane_setup = [&]() {                                // after hdr->*_off are visible
         if (bwave && lane < w.nsrc) { my_lo16 = (u32)(hdr->lo_off[lane] >> 4); my_mid16 = (u32)(hdr->mid_off[lane] >> 4); my_offs = reinterpret_cast<const u32*>(w.base + hdr->offs_off[lane]); }
     };
-    auto request = [&](u32 q, u32 ns, u32 nbc, u32& mp, u32& mb, u32& mb2) {
+    // (ppos, part, b0: item q's descriptor fields 0, 2, 4 - the caller has them in scalar registers)
+    auto request = [&](u32 q, u32 ns, u32 nbc, u32 ppos, u32 part, u32 b0, u32& mp, u32& mb, u32& mb2) {
         mp = 0; mb = 0; mb2 = 0;
         const u32 np0 = ns < W_META_P ? ns : W_META_P;
-        if (tid < np0) mp = a.probe.list[ring(q, 0) + tid];
+        if (tid < np0) mp = a.probe.list[ppos + tid];
         if (DENSE) {
-            if (bwave && q < nmine && lane < w.nsrc) { const u32 part = ring(q, 2); mb = my_offs[part]; mb2 = my_offs[part + 1]; }
+            if (bwave && q < nmine && lane < w.nsrc) { mb = my_offs[part]; mb2 = my_offs[part + 1]; }
         } else {
             const u32 nb0 = nbc < W_META_B ? nbc : W_META_B;
-            if (tid < nb0) mb = a.build.list[ring(q, 4) + tid];
+            if (tid < nb0) mb = a.build.list[b0 + tid];
         }
     };
     // DENSE: that wave turns the sources' (run begin, run end) pairs into the item's load units: the runs of the partition, one per
@@ -140,39 +144,47 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     // wave v takes the 256-slot units v and v + 16 of the sources' runs (see below).  The loads are
     // unconditional (validity is a mask; a chunk that does not exist is one 16-byte line for the whole wave).  am = the key
     // slots that hold anything for this WAVE (uniform): everything downstream skips the others.
-    auto load_build = [&](const u32* slot, u32 part, u32 first, u32 nstaged, u32 total, u64 (&bk)[8], u32& bok, u32& am) {
+    // DENSE: what a batch's loads return stays RAW (low words; high-word bits) until the batch moves up at the end of the iteration:
+    // putting the keys together right behind the loads made every iteration wait for them on the spot (~1.4 us of HBM latency
+    // per item: the whole difference to the chunk-list form, whose keys need no assembling)
+    typedef typename std::conditional<MIDB == 2, uint2, uint4>::type midv_t;
+    struct RawBuild { uint4 lo[2]; midv_t mid[2]; };
+    auto assemble = [&](const RawBuild& r, u32 top, u64 (&bk)[8]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32 l[4] = {r.lo[i].x, r.lo[i].y, r.lo[i].z, r.lo[i].w};
+            u32 m[4];
+            if constexpr (MIDB == 2) { m[0] = r.mid[i].x & 0xFFFFu; m[1] = r.mid[i].x >> 16; m[2] = r.mid[i].y & 0xFFFFu; m[3] = r.mid[i].y >> 16; }
+            else if constexpr (MIDB == 4) { m[0] = r.mid[i].x; m[1] = r.mid[i].y; m[2] = r.mid[i].z; m[3] = r.mid[i].w; }
+            else { m[0] = m[1] = m[2] = m[3] = 0; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bk[4 * i + j] = ((u64)(top | m[j]) << 32) | l[j];
+        }
+    };
+    auto top_of = [&](u32 part) -> u32 { return w.bits ? part << (32u - w.bits) : 0u; };
+    const u32 lo0_16 = DENSE ? (u32)(w.lo_off[0] >> 4) : 0u, mid0_16 = DENSE ? (u32)(w.mid_off[0] >> 4) : 0u;      // (any readable plane: what a wave without a unit loads)
+    auto unit_desc = [&](const u32* slot, int i) -> uint4 { return reinterpret_cast<const uint4*>(slot + W_META_P)[wave + (u32)i * W_WAVES]; };     // DENSE: the wave's i-th load unit of the item parked in `slot` (garbage beyond the item's units)
+    auto load_build = [&](const u32* slot, u32 part, u32 first, u32 nstaged, u32 total, const uint4 (&ud)[2], u64 (&bk)[8], RawBuild& raw, u32& bok, u32& am) {
         const u32* bm = slot + W_META_P;
         bok = 0; am = 0;
         if (DENSE) {
             // wave v takes load units v and v + 16 (park): per unit one 16-byte load (4 low words per lane) and one 8- or 16-byte load
             // (their high-word bits).  (One 4-byte and one 2-byte load per KEY: the address path charges per load instruction.)
-            const u32 top = w.bits ? part << (32u - w.bits) : 0u;
-            const uint4* units = reinterpret_cast<const uint4*>(bm);
+            (void)part; (void)bm;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const u32 u = first + wave + (u32)i * W_WAVES;
                 const bool have = u < total && u < W_UNITS;
-                const uint4 d4 = units[have ? u : 0u];
-                const u32 ulo = have ? __builtin_amdgcn_readfirstlane(d4.x) : (u32)(hdr->lo_off[0] >> 4), umid = have ? __builtin_amdgcn_readfirstlane(d4.y) : (u32)(hdr->mid_off[0] >> 4);
+                const uint4 d4 = ud[i];
+                const u32 ulo = have ? __builtin_amdgcn_readfirstlane(d4.x) : lo0_16, umid = have ? __builtin_amdgcn_readfirstlane(d4.y) : mid0_16;
                 const u32 ub = __builtin_amdgcn_readfirstlane(d4.z), ue = __builtin_amdgcn_readfirstlane(d4.w), ua0 = ub & ~3u;
                 const u32 k0 = ua0 + 4 * lane;
                 const bool in = have && k0 < ue;                           // (lanes past the run read its first word: nothing beyond the plane's 16 bytes of padding is touched)
                 const u32 kk = in ? k0 : (have ? ua0 : 0u);
-                const uint4 lo4 = *reinterpret_cast<const uint4*>(w.base + ((u64)ulo << 4) + (u64)kk * 4);
-                u32 m[4];
-                if (w.mid_bytes == 2) {
-                    const uint2 q = *reinterpret_cast<const uint2*>(w.base + ((u64)umid << 4) + (u64)kk * 2);
-                    m[0] = q.x & 0xFFFFu; m[1] = q.x >> 16; m[2] = q.y & 0xFFFFu; m[3] = q.y >> 16;
-                } else {
-                    const uint4 q = *reinterpret_cast<const uint4*>(w.base + ((u64)umid << 4) + (u64)kk * 4);
-                    m[0] = q.x; m[1] = q.y; m[2] = q.z; m[3] = q.w;
-                }
-                const u32 l[4] = {lo4.x, lo4.y, lo4.z, lo4.w};
+                raw.lo[i] = *reinterpret_cast<const uint4*>(w.base + ((u64)ulo << 4) + (u64)kk * 4);
+                if constexpr (DENSE) raw.mid[i] = *reinterpret_cast<const midv_t*>(w.base + ((u64)umid << 4) + (u64)kk * (u64)MIDB);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bk[4 * i + j] = ((u64)(top | m[j]) << 32) | l[j];
-                    if (in && k0 + j >= ub && k0 + j < ue) bok |= 1u << (4 * i + j);
-                }
+                for (int j = 0; j < 4; ++j) if (in && k0 + j >= ub && k0 + j < ue) bok |= 1u << (4 * i + j);
                 if (have) am |= 0xFu << (4 * i);
             }
         } else {
@@ -393,17 +405,21 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         u32 mp, mb;
         u32 mb2;
         dense_lane_setup();
-        request(0, ns0, ring(0, 5), mp, mb, mb2); park(sl_k, mp, mb, mb2);
-        request(1, ns1, nbc1, mp, mb, mb2); park(sl_k1, mp, mb, mb2);
-        request(2, ns2, nbc2, mp, mb, mb2); park(sl_k2, mp, mb, mb2);
+        request(0, ns0, ring(0, 5), ring(0, 0), ring(0, 2), ring(0, 4), mp, mb, mb2); park(sl_k, mp, mb, mb2);
+        request(1, ns1, nbc1, ring(1, 0), ring(1, 2), ring(1, 4), mp, mb, mb2); park(sl_k1, mp, mb, mb2);
+        request(2, ns2, nbc2, ring(2, 0), ring(2, 2), ring(2, 4), mp, mb, mb2); park(sl_k2, mp, mb, mb2);
     }
     __syncthreads();
     u64 bkA[8], bkB[8];
+    RawBuild rawB;                                                 // DENSE: the planes of the batch bkB stands for
+    u32 topB = 0;
     u32 bokA = 0, bokB = 0, amA = 0, amB = 0;
     u32 slots[8], am_cur = 0;                                      // of the item in the table (this thread's keys)
     {
         const u32 nbc0 = ring(0, 5), tot0 = DENSE ? dense_total(sl_k) : 0u;
-        load_build(sl_k, ring(0, 2), 0, nbc0 < W_META_B ? nbc0 : W_META_B, tot0, bkA, bokA, amA);
+        const uint4 ud[2] = {unit_desc(sl_k, 0), unit_desc(sl_k, 1)};
+        load_build(sl_k, ring(0, 2), 0, nbc0 < W_META_B ? nbc0 : W_META_B, tot0, ud, bkA, rawB, bokA, amA);
+        if constexpr (DENSE) assemble(rawB, top_of(ring(0, 2)), bkA);
         claim(bits0, bkA, bokA, amA, 0, slots);
         store_keys(bkA, slots, amA);
         am_cur = amA;
@@ -417,7 +433,11 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         load_chunk(sl_k, wave + W_WAVES, nb, kb, vb);
     }
     u32 tot1 = DENSE ? dense_total(sl_k1) : 0u;
-    if (!sameA) load_build(sl_k1, ring(1, 2), 0, nbc1 < W_META_B ? nbc1 : W_META_B, tot1, bkA, bokA, amA);
+    if (!sameA) {
+        const uint4 ud[2] = {unit_desc(sl_k1, 0), unit_desc(sl_k1, 1)};
+        load_build(sl_k1, ring(1, 2), 0, nbc1 < W_META_B ? nbc1 : W_META_B, tot1, ud, bkA, rawB, bokA, amA);
+        if constexpr (DENSE) assemble(rawB, top_of(ring(1, 2)), bkA);
+    }
     __syncthreads();                                               // item 0's keys are in the table
 
 #ifdef FJ_LAB      // diagnostic build (make EXTRA=-DFJ_LAB): where thread 0's time goes, per pipeline stage (FJ_WIDE_STAMPS=1)
@@ -436,18 +456,28 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         // ---- 1. requests: descriptor parts (one thread), entries of k+3, build keys of k+2 ----
         uint4 it5 = make_uint4(0, 0, 0, 0); uint2 bo4 = make_uint2(0, 0);
         if (tid == 0) { bo4 = fetch_boff(k + 4); it5 = fetch_items(k + 5); }
-        const u32 ns3 = ring(k + 3, 1), nbc3 = ring(k + 3, 5);
+        // everything the first phases read from LDS in ONE batch - descriptor of item k+3, the flags of the table in place, (DENSE) the
+        // unit count and this wave's two unit descriptors of item k+2 - then the values move to scalar registers: each of these
+        // used to be a round trip of its own (read, wait, readfirstlane), six in a row at the top of every iteration
+        const u32* rq3 = hdr->dring[(k + 3) & 7];
+        const uint4 rq_a = *reinterpret_cast<const uint4*>(rq3);          // {probe list pos, probe chunks, partition, item id}
+        const uint2 rq_b = *reinterpret_cast<const uint2*>(rq3 + 4);      // {first build-list entry, build chunks}
+        const uint4 flg = *reinterpret_cast<const uint4*>(hdr->has_empty);     // has_empty[2], full[2]
+        const u32 tot2w = DENSE ? sl_k2[W_META_P + 4 * W_UNITS] : 0u;
+        uint4 ud2[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (DENSE) { ud2[0] = unit_desc(sl_k2, 0); ud2[1] = unit_desc(sl_k2, 1); }
+        const u32 ns3 = __builtin_amdgcn_readfirstlane(rq_a.y), nbc3 = __builtin_amdgcn_readfirstlane(rq_b.y), part3 = __builtin_amdgcn_readfirstlane(rq_a.z);
         u32 mp, mb;
         u32 mb2;
-        request(k + 3, ns3, nbc3, mp, mb, mb2);
-        const u32 tot2 = DENSE ? dense_total(sl_k2) : 0u;
+        request(k + 3, ns3, nbc3, __builtin_amdgcn_readfirstlane(rq_a.x), part3, __builtin_amdgcn_readfirstlane(rq_b.x), mp, mb, mb2);
+        const u32 tot2 = DENSE ? __builtin_amdgcn_readfirstlane(tot2w) : 0u;
         sameB = grouped && k + 2 < nmine && part2 == part1;
-        if (!sameB) load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, bkB, bokB, amB);
+        if (!sameB) { load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, ud2, bkB, rawB, bokB, amB); topB = DENSE ? top_of(part2) : 0u; }
         else { bokB = 0; amB = 0; }
         W_STAMP(0);
         // ---- 2a. probe item k; then its successor's first probe chunks are requested into the same registers ----
-        const bool full = hdr->full[par] != 0 || ns0 > 2 * W_WAVES;      // (an item longer than 32 probe chunks - a host-side bug - goes to the retry ladder)
-        const u64 he = hdr->has_empty[par] ? ~0ull : 0ull;
+        const bool full = __builtin_amdgcn_readfirstlane(par ? flg.w : flg.z) != 0 || ns0 > 2 * W_WAVES;      // (an item longer than 32 probe chunks - a host-side bug - goes to the retry ladder)
+        const u64 he = __builtin_amdgcn_readfirstlane(par ? flg.y : flg.x) ? ~0ull : 0ull;
         u32 wave_hits = 0;
         const bool skip = full || ns0 == 0;
         const u32 nb = ns0 < 2 * W_WAVES ? ns0 : 2 * W_WAVES;      // (items of this kernel have at most 32 probe chunks: the host cuts them so)
@@ -497,10 +527,13 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             for (int j = 0; j < 8; ++j) slots[j] = nslots[j];
             am_cur = amA;
         }
+        if constexpr (DENSE) assemble(rawB, topB, bkA);          // (the loads were issued at the top of the iteration: they are in)
+        else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bkA[j] = bkB[j];
+            for (int j = 0; j < 8; ++j) bkA[j] = bkB[j];
+        }
         bokA = bokB; amA = amB; tot1 = tot2; sameA = sameB;
-        ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part1 = part2; part2 = (DENSE || grouped) ? ring(k + 3, 2) : 0u;
+        ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part1 = part2; part2 = (DENSE || grouped) ? part3 : 0u;
         u32* t = sl_k; sl_k = sl_k1; sl_k1 = sl_k2; sl_k2 = sl_k3; sl_k3 = t;
     }
 #ifdef FJ_LAB
@@ -520,7 +553,9 @@ hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w
     if (w.group_log > 6) return hipErrorInvalidValue;
     const u32 lds = fj_wide_lds_bytes();
     if (w.group_log && !dense) return hipErrorInvalidValue;        // (chunk-list build sides come with <= 32 probe chunks per partition: fj_plan.hip wide_join_planned)
-    auto kern = dense ? (w.group_log ? fj_count_join_wide<true, true> : fj_count_join_wide<true, false>) : fj_count_join_wide<false, false>;
+    auto kern = !dense ? fj_count_join_wide<0, false>
+              : w.mid_bytes == 2 ? (w.group_log ? fj_count_join_wide<2, true> : fj_count_join_wide<2, false>)
+                                 : (w.group_log ? fj_count_join_wide<4, true> : fj_count_join_wide<4, false>);
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     if (grid == 0) grid = 1;
