@@ -650,7 +650,7 @@ void fj_dist_comm_destroy(fj_dist_comm* dc) {
 // either form = max(bytes per link / link rate, kernel seconds per rank) + what cannot overlap.  Kernel seconds per row measured on
 // one MI355X at config 5's per-rank sizes (profiles/r05_bcast_one_rank.txt, r04_c5_one_rank_kernel_stats.csv): broadcast - pack 1.45 ms
 // per 125M build rows; two probe-side passes 7.95 / 8.35 / 8.6 ms per 1.25B rows under the 16- / 17- / 18-bit plans of 2 / 4 / 8 ranks; dense
-// join 4.0 ps per build key of ALL ranks + 2.55 ps per local probe key (4.15 / 5.4 / 7.1 ms at 2 / 4 / 8 ranks), all of it kernels
+// join 3.2 ps per build key of ALL ranks + 2.45 ps per local probe key (3.85 / 4.8 / 6.25 ms at 2 / 4 / 8 ranks), all of it kernels
 // of this rank (the wire overlaps everything behind the pack); shuffle - 13.4 ms of kernels per 1.375B rows of both relations + ~2.5
 // ms of head and tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: nb_max * 6.01).
 int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
@@ -659,7 +659,7 @@ int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_tota
     if (region_max == 0) region_max = (uint64_t)((double)nb_max * 6.01) + (1u << 20);
     const int bits = fjh::make_plan((size_t)nb_total, 64).bits;
     const double pack = (double)nb_max * 11.6e-12, passes = (double)np_max * (6.36e-12 + 0.27e-12 * (bits > 16 ? std::min(bits, 18) - 16 : 0)),
-                 join = (double)nb_total * 4.0e-12 + (double)np_max * 2.55e-12;
+                 join = (double)nb_total * 3.2e-12 + (double)np_max * 2.45e-12;
     const double wire_b = N > 1 ? (double)region_max / rate : 0.0;
     const double t_b = std::max(wire_b + pack + join / 4.0, pack + passes + join);        // (the last of 4 partition ranges is joined after the wire is done)
     const double rows = (double)nb_max + (double)np_max;
