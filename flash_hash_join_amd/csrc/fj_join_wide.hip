@@ -87,11 +87,11 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         r[0] = it.x; r[1] = q < nmine ? it.y : 0u; r[2] = it.z; r[3] = q < nmine ? id_of(q) : 0xFFFFFFFFu; r[4] = 0; r[5] = 0;
         r[6] = it.w;                                               // (every loaded word is used: a half-dead load register gets reused and the reuse waits for ALL loads in flight)
     };
-    auto fetch_boff = [&](u32 q) -> uint2 {                        // (chunk-list build side) needs store_items(q) to be visible
+    auto fetch_boff_of = [&](u32 q, u32 part) -> uint2 {           // (chunk-list build side) part: descriptor field 2 of item q
         if (DENSE || q >= nmine) return make_uint2(0, 0);
-        const u32 part = hdr->dring[q & 7][2];
         return make_uint2(a.build.boff[part], a.build.boff[part + 1]);
     };
+    auto fetch_boff = [&](u32 q) -> uint2 { return fetch_boff_of(q, DENSE ? 0u : hdr->dring[q & 7][2]); };      // needs store_items(q) to be visible
     auto store_boff = [&](u32 q, uint2 b) { u32* r = hdr->dring[q & 7]; r[4] = b.x; r[5] = b.y - b.x; };
 
     // list entries of item q -> registers (one global load per side and thread), later parked in a ring slot
@@ -188,11 +188,15 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
                 if (have) am |= 0xFu << (4 * i);
             }
         } else {
+            // (both list entries are read before either is used: one LDS round trip, not two)
+            u32 e2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { const u32 c = first + wave + (u32)i * W_WAVES; e2[i] = bm[c < nstaged ? c : (nstaged ? nstaged - 1 : 0u)]; }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const u32 c = first + wave + (u32)i * W_WAVES;
                 const bool have = c < nstaged;
-                const u32 e = nstaged ? bm[have ? c : nstaged - 1] : 0u, cnt = have ? FJ_LIST_CNT(e) : 0u;
+                const u32 e = nstaged ? e2[i] : 0u, cnt = have ? FJ_LIST_CNT(e) : 0u;
                 const u64* ck = a.build.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + (have ? 2 * lane : 0u);
                 const u64x2 q0 = *reinterpret_cast<const u64x2*>(ck);
                 const u64x2 q1 = *reinterpret_cast<const u64x2*>(ck + (have ? 128 : 0));
@@ -336,14 +340,21 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     // ---- probe side: a wave's chunk -> 4 keys per lane ---------------------------------------------------------------------
     // ---- probe side: a wave's chunk -> 4 keys per lane (whole chunks per wave: units of 64 keys - 8-byte loads, perfectly balanced
     // waves - were 30 % slower, units of 128 keys 7 %: the address path charges per load instruction) --------------------------------
-    auto load_chunk = [&](const u32* pm, u32 c, u32 nb, u64 (&k)[4], u32& vm) {
-        const bool have = c < nb;
-        const u32 e = nb ? pm[have ? c : nb - 1] : 0u, cnt = have ? FJ_LIST_CNT(e) : 0u;
-        const u64* ck = a.probe.keys + (u64)FJ_LIST_ID(e) * FJ_CHUNK + (have ? 2 * lane : 0u);
-        const u64x2 q0 = *reinterpret_cast<const u64x2*>(ck);
-        const u64x2 q1 = *reinterpret_cast<const u64x2*>(ck + (have ? 128 : 0));
-        k[0] = q0.x; k[1] = q0.y; k[2] = q1.x; k[3] = q1.y;
-        vm = (2 * lane < cnt ? 1u : 0u) | (2 * lane + 1 < cnt ? 2u : 0u) | (128 + 2 * lane < cnt ? 4u : 0u) | (129 + 2 * lane < cnt ? 8u : 0u);
+    // a wave's two chunks of an item (c and c + W_WAVES): both list entries in one LDS round trip, then the four loads
+    auto load_chunks2 = [&](const u32* pm, u32 nb, u64 (&k0)[4], u32& vm0, u64 (&k1)[4], u32& vm1) {
+        const u32 last = nb ? nb - 1 : 0u;
+        const u32 c0 = wave, c1 = wave + W_WAVES;
+        const u32 ea = pm[c0 < nb ? c0 : last], eb = pm[c1 < nb ? c1 : last];
+        auto one = [&](u32 e, bool have, u64 (&k)[4], u32& vm) {
+            const u32 cnt = have ? FJ_LIST_CNT(e) : 0u;
+            const u64* ck = a.probe.keys + (u64)(nb ? FJ_LIST_ID(e) : 0u) * FJ_CHUNK + (have ? 2 * lane : 0u);
+            const u64x2 q0 = *reinterpret_cast<const u64x2*>(ck);
+            const u64x2 q1 = *reinterpret_cast<const u64x2*>(ck + (have ? 128 : 0));
+            k[0] = q0.x; k[1] = q0.y; k[2] = q1.x; k[3] = q1.y;
+            vm = (2 * lane < cnt ? 1u : 0u) | (2 * lane + 1 < cnt ? 2u : 0u) | (128 + 2 * lane < cnt ? 4u : 0u) | (129 + 2 * lane < cnt ? 8u : 0u);
+        };
+        one(ea, c0 < nb, k0, vm0);
+        one(eb, c1 < nb, k1, vm1);
     };
     auto probe2 = [&](u64 k0, u64 k1, u32 vm, u64 he) -> u32 {   // two keys per lane: six lookups in flight
         const u64 k[2] = {k0, k1};
@@ -429,8 +440,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     u32 va = 0, vb = 0;
     {
         const u32 nb = ns0 < W_META_P ? ns0 : W_META_P;
-        load_chunk(sl_k, wave, nb, ka, va);
-        load_chunk(sl_k, wave + W_WAVES, nb, kb, vb);
+        load_chunks2(sl_k, nb, ka, va, kb, vb);
     }
     u32 tot1 = DENSE ? dense_total(sl_k1) : 0u;
     if (!sameA) {
@@ -455,7 +465,6 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         u32* bitsn = bits0 + parn * (WS / 32);
         // ---- 1. requests: descriptor parts (one thread), entries of k+3, build keys of k+2 ----
         uint4 it5 = make_uint4(0, 0, 0, 0); uint2 bo4 = make_uint2(0, 0);
-        if (tid == 0) { bo4 = fetch_boff(k + 4); it5 = fetch_items(k + 5); }
         // everything the first phases read from LDS in ONE batch - descriptor of item k+3, the flags of the table in place, (DENSE) the
         // unit count and this wave's two unit descriptors of item k+2 - then the values move to scalar registers: each of these
         // used to be a round trip of its own (read, wait, readfirstlane), six in a row at the top of every iteration
@@ -463,9 +472,11 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         const uint4 rq_a = *reinterpret_cast<const uint4*>(rq3);          // {probe list pos, probe chunks, partition, item id}
         const uint2 rq_b = *reinterpret_cast<const uint2*>(rq3 + 4);      // {first build-list entry, build chunks}
         const uint4 flg = *reinterpret_cast<const uint4*>(hdr->has_empty);     // has_empty[2], full[2]
+        const u32 part4w = DENSE ? 0u : hdr->dring[(k + 4) & 7][2];      // (thread 0's build-list offsets of item k+4 hang on it)
         const u32 tot2w = DENSE ? sl_k2[W_META_P + 4 * W_UNITS] : 0u;
         uint4 ud2[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         if (DENSE) { ud2[0] = unit_desc(sl_k2, 0); ud2[1] = unit_desc(sl_k2, 1); }
+        if (tid == 0) { bo4 = fetch_boff_of(k + 4, part4w); it5 = fetch_items(k + 5); }
         const u32 ns3 = __builtin_amdgcn_readfirstlane(rq_a.y), nbc3 = __builtin_amdgcn_readfirstlane(rq_b.y), part3 = __builtin_amdgcn_readfirstlane(rq_a.z);
         u32 mp, mb;
         u32 mb2;
@@ -485,8 +496,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         if (!skip && wave + W_WAVES < nb) wave_hits += probe4(kb, vb, he);
         {
             const u32 nbn = ns1 < W_META_P ? ns1 : W_META_P;
-            load_chunk(sl_k1, wave, nbn, ka, va);
-            load_chunk(sl_k1, wave + W_WAVES, nbn, kb, vb);
+            load_chunks2(sl_k1, nbn, ka, va, kb, vb);
         }
         W_STAMP(1);
         // ---- 2b. claims of item k+1 on the other bitmap (other waves are still probing: the round trips overlap their lookups) ----
