@@ -326,7 +326,7 @@ int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* regio
     FJ_ENTER(c);
     FjWideArgs w{};
     w.toff = bc.pit.toff; w.part_lo = part_lo; w.part_hi = part_hi;
-    w.base = (const unsigned char*)d_base; w.nsrc = (u32)nsrc; w.bits = L0.bits; w.mid_bytes = L0.mid_bytes;
+    w.base = (const unsigned char*)d_base; w.nsrc = (u32)nsrc; w.bits = L0.bits; w.mid_bytes = L0.mid_bytes; w.pmask = fj_wide_pmask((int)L0.bits, 64);
     // few ranks = few, fat partitions: > ~28 probe chunks each means two or three items per partition (items hold <= 32 probe chunks),
     // dealt in runs of 8 so that a partition's items find their table built (2 and 4 ranks of config 5: 3 and 2 items per partition)
     w.group_log = bc.np / L0.nparts > 7000 ? 3u : 0u;

@@ -190,9 +190,13 @@ struct FjWideArgs {
     // low words u32[n_s] and the low (32 - bits) bits of their high words as u16[n_s] (mid_bytes == 2) or u32[n_s]; partition p supplies the top `bits` bits
     const unsigned char* base; u32 nsrc, bits, mid_bytes;
     u32 group_log;                               // items are dealt to the workgroups in runs of 2^group_log consecutive ones (0: one by one); > 0 where partitions are cut into several items: a run's items of one partition share one table build
+    u32 pmask;                                   // the bits of a mixed key's HIGH word that name its final partition (all radix digits come from hash word 1): what tells a
+                                                 // table entry of the partition in place from one that an earlier partition left behind (fj_wide_pmask)
     u64 offs_off[FJ_WIDE_MAXSRC], lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC];
 };
 hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w, bool dense, u32 grid, hipStream_t s);
+// FjWideArgs::pmask of a plan of `bits` radix bits taken from bit `top_bits` of the mixed key downwards (top_bits = 64 or 48)
+static inline u32 fj_wide_pmask(int bits, int top_bits) { return bits <= 0 ? 0u : (bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u) << (top_bits - 32 - bits)); }
 
 // second chance for the items whose partition overflowed the cuckoo table (load > ~0.45): the tagged 2x4-slot table
 // with linear-probing overflow holds up to 8128 keys; only a partition beyond that raises FJ_ERR_LDS_FULL

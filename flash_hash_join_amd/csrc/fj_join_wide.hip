@@ -1,20 +1,26 @@
 // fj_join_wide.hip -- counting join for partitions whose build side is NOT thin against the probe side (MI355X, gfx950).
 //
 // Same role as fj_count_join_persistent (fj_join.hip): insert_local + probe_vectorized of one radix partition
-// (hash_join.cpp:112-128, :153-182) inside _hash_join_radix_count (:498-534).  That kernel keeps an 8192-slot cuckoo table per
-// workgroup, two workgroups per CU, and its item is a chain of latency-bound steps: table reset -> claims (two dependent LDS
-// round trips per KEY) -> barrier -> eviction chains (at ~3800 keys, load 0.47, the longest is 24 dependent exchanges) ->
-// barrier -> probe.  With ~3000-3800 build keys against ~3800-4800 probe keys per partition the table build is what the item
-// costs (profiles/r04: 0.38 of the HBM peak).  Here ONE 1024-thread workgroup per CU owns a 16384-slot table (128 KiB of the
-// CU's 160 KiB) and the item is a software pipeline without a dependent chain in it:
-//   * open addressing WITHOUT evictions: a key lives at the first free slot of l1, l2, l3 (three hashed locations), l3+1, ... -
-//     slots are claimed with atomic ORs on a slot BITMAP, the table itself only sees plain stores and reads.  At load 0.23
-//     1.2 % of the keys go beyond l3.  A lookup reads its three locations unconditionally and walks on only where all three
-//     are taken by other keys;
-//   * because claims touch the bitmap only, the claims of item k+1 run WHILE item k is probed (two bitmaps, alternating): their
-//     LDS round trips hide under the probe's lookups; the slots a thread was assigned stay in its registers;
-//   * no table reset: after the probe every thread stores the empty marker over the slots it filled (no evictions: they are
-//     exactly the occupied ones), then the new keys go in with plain stores: two short throughput-bound phases;
+// (hash_join.cpp:112-128, :153-182) inside _hash_join_radix_count (:498-534).  ONE 1024-thread workgroup per CU owns a 16384-slot
+// table of bare 64-bit keys (128 KiB of the CU's 160 KiB).  Round 5's table (three hashed locations + a walk, slots claimed on a
+// bitmap in three stages, owners clearing their slots, plain stores: three barriers and ~36 vector instructions per build key)
+// is replaced by a BUCKETED table that needs neither claims nor clearing:
+//   * the table is NBK = 16384 / BS buckets of BS consecutive slots (BS = 4: 32 bytes); a key's home bucket is the low bits of
+//     its hash word 2.  INSERT = one returning LDS atomic add on the bucket's fill count + one plain store at that position; a
+//     key that finds its bucket full (0.35 % of them at load 0.23) tries the next bucket, and so on: linear probing over buckets;
+//   * LOOKUP = the home bucket read whole (BS / 2 ds_read_b128, the order of the pieces rotated by a hash bit so that the lanes
+//     of a wave spread over all LDS banks), BS 64-bit compares, and on to the next bucket only where this one is FULL;
+//   * NOTHING IS EVER CLEARED.  Chunk pools hold the mixed key H, whose top radix bits ARE the partition: an entry that an
+//     earlier partition left behind can never equal a probe key of the partition in place, so stale entries are harmless and
+//     the table needs no reset and no empty marker - only the fill counts (NBK words) are zeroed, during the previous item's
+//     probe phase.  "This bucket is full" is read off the entry in its last slot: it belongs to the partition in place (same
+//     partition bits as the probe key, FjWideArgs::pmask) exactly if the bucket's BS-th key went in (a stale same-partition
+//     entry - the same partition rebuilt by this workgroup - can only make a lookup walk one bucket further than it had to);
+//     the table starts out filled with FJ_EMPTY_KEY, which reads as a key of the LAST partition: before that partition goes
+//     in, the table is filled once more with a key no probe key of it can equal;
+//   * an item is two phases and two barriers: P (probe item k; zero the fill counts; requests and prefetches as before) | barrier
+//     | I (insert item k+1: its keys have been in registers for an iteration) | barrier.  Round 5 overlapped its claims with the
+//     probe and then paid a clear phase, a store phase and three barriers;
 //   * every wave owns whole 256-key chunks (4 keys per lane and chunk, two 16-B loads), so no lane looks up padding;
 //   * nothing in the loop waits for a dependent global load: item descriptors are fetched by one thread five items ahead and
 //     parked in LDS, chunk-list entries three items ahead, build keys two, probe keys one (no scalar loads in the loop: they
@@ -23,11 +29,11 @@
 //     one run of keys per final partition, stored as two planes (low word, remaining bits of the high word) behind an offset
 //     table; the partition id supplies the top bits.  Nothing is re-partitioned or copied on the receiving side.
 // Items are dealt round-robin (item = blockIdx.x + k * gridDim.x): all of a launch's workgroups are resident.  When the probe side
-// of a partition is cut into several items (FjWideArgs::group_log > 0: the host sees > ~28 probe chunks per partition - the
-// broadcast form at 2 and 4 ranks) the deal is in runs of 2^group_log consecutive items instead, and an item whose predecessor in
-// the workgroup belongs to the same partition finds its table built: no claims, no clearing, no stores, no build-side loads.
-// Items whose build side does not fit (a claim walks W_MAXWALK slots in vain) are marked FJ_ITEM_RETRY exactly as
-// fj_count_join_persistent does; the host's retry / re-partition ladder (radix_join_tail) is unchanged.
+// of a partition is cut into several items (FjWideArgs::group_log > 0) the deal is in runs of 2^group_log consecutive items
+// instead, and an item whose predecessor in the workgroup belongs to the same partition finds its table built: no inserts, no
+// build-side loads.  Duplicate build keys simply occupy several slots (a lookup stops at the first match).  Items whose build
+// side does not fit (more than 8192 key slots, or a chain of more than W_MAXWALK full buckets: thousands of copies of one key)
+// are marked FJ_ITEM_RETRY exactly as fj_count_join_persistent does; the host's retry / re-partition ladder is unchanged.
 #include "fj_internal.h"
 #include <type_traits>
 
@@ -35,25 +41,28 @@ namespace {
 
 constexpr int WNT = 1024;
 constexpr u32 WSLOG = 14, WS = 1u << WSLOG;
+#ifndef FJ_WIDE_BS
+#define FJ_WIDE_BS 4
+#endif
+constexpr u32 BS = FJ_WIDE_BS;            // slots per bucket (4 or 8)
+constexpr u32 BSLOG = BS == 4 ? 2 : 3, NBKLOG = WSLOG - BSLOG, NBK = 1u << NBKLOG, NPC = BS / 2;     // buckets; 16-byte pieces per bucket
+static_assert(BS == 4 || BS == 8, "bucket size");
 constexpr u32 W_META_P = 32;              // probe-side list entries staged per item = the most an item of this kernel has
 constexpr u32 W_META_B = 32;              // build-side list entries staged per item / 2 words per source (DENSE)
 constexpr u32 W_UNITS = 32;               // DENSE: 256-slot load units per item (uint4 each: source, first key slot, run begin, run end) + their count
 constexpr u32 W_STRIDE = W_META_P + 4 * W_UNITS + 4;
-constexpr u32 W_MAXWALK = 48;             // slots a claim walks beyond l3 before the table counts as full
+constexpr u32 W_MAXWALK = 64;             // full buckets a key walks past before the table counts as full (insert) / the lookup gives up
 constexpr u32 W_WAVES = WNT / 64;
-constexpr u32 W_NOSLOT = 0xFFFFFFFFu;
+// what the table is filled with before the LAST partition goes in: a key of the first partition (high word 0), so no probe key of
+// the last partition - whose partition bits are all ones - can equal it
+constexpr u64 W_POISON2 = 0x00000000FFFFFFFFull;
 
 struct WHdr {
     u32 cnt, pad0[3];
-    u32 has_empty[2], full[2];             // per bitmap parity: the item whose claims ran on it
+    u32 has_empty[2], full[2];             // per parity of the item whose keys are / go in the table
     u32 dring[8][8];                       // item descriptors: {probe list pos, probe chunks, partition, item id, b0, nbc, -, -}
     u64 lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC], offs_off[FJ_WIDE_MAXSRC];
 };
-
-__device__ __forceinline__ u32 w_l1(u64 h) { return FJ_HW2(h) & (WS - 1); }
-__device__ __forceinline__ u32 w_l2(u64 h) { return (FJ_HW2(h) >> WSLOG) & (WS - 1); }
-// (third location: the high word's low bits - radix digits come from its TOP - folded with 14 other bits of the low word: three instructions)
-__device__ __forceinline__ u32 w_l3(u64 h) { return (FJ_HW1(h) ^ (FJ_HW2(h) >> 18) ^ (FJ_HW2(h) >> 5)) & (WS - 1); }
 
 // MIDB: 0 = chunk-list build side; 2 / 4 = DENSE, the width of the high-word plane's elements (compile-time: the raw planes of a
 // batch wait in registers, and one set of registers must do)
@@ -63,14 +72,15 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WHdr* hdr = reinterpret_cast<WHdr*>(smem);
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(WHdr));
-    u32* bits0 = reinterpret_cast<u32*>(tkeys + WS);               // [2][WS / 32] slot bitmaps
-    u32* meta = bits0 + 2 * (WS / 32);                             // [4][W_STRIDE]: ring of staged list entries
+    u32* fill = reinterpret_cast<u32*>(tkeys + WS);                // [NBK] keys that asked for a slot of the bucket
+    u32* meta = fill + NBK;                                        // [4][W_STRIDE]: ring of staged list entries
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 pmask = w.pmask;
 
     u32 item_lo = 0, item_hi = *a.nitems_dev;
     if (w.toff) { item_lo = w.toff[w.part_lo]; item_hi = w.toff[w.part_hi]; }
     // runs of G = 2^group_log consecutive items per workgroup and round (G = 1: plain round-robin)
-    // (GROUPED is a compile-time switch: the plain deal's code must not carry the other's registers - it cost the 8-rank join 7 %)
+    // (GROUPED is a compile-time switch: the plain deal's code must not carry the other's registers)
     const u32 glog = GROUPED ? w.group_log : 0u, G = 1u << glog, per_round = gridDim.x << glog;
     constexpr bool grouped = GROUPED;
     if (item_hi <= item_lo) return;
@@ -208,136 +218,60 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         am = __builtin_amdgcn_readfirstlane(am);
     };
 
-    // ---- claims of a batch on bitmap `bits`: sl[j] = the slot key j will be stored in (W_NOSLOT: none) ------------------------
-    // per group of 4 key slots (a chunk of the wave / 4096 keys of the workgroup; groups without keys are skipped, wave-uniformly):
-    // stage A (l1 of every key: the thread's atomics in flight together), B (l2 of the losers), C (l3), then the rare linear walk
-    auto claim4 = [&](auto G, u32* bits, const u64 (&bk8)[8], u32 vm, u32 par, u32 (&sl8)[8]) {
-        constexpr int g4 = 4 * decltype(G)::value;
-        u32 sl[4]; u64 bk[4];
-        u32 lost = 0;                                              // per-lane bit j: key j still has no slot
+    // ---- insert a batch: one returning atomic add per key on its home bucket's fill count, one store; the few keys whose bucket
+    // was full walk on, all of a thread's stragglers together (one more round trip per step whatever the wave holds) --------------
+    auto insert = [&](const u64 (&bk)[8], u32 bok, u32 am, u32 par) {
+        u32 bkt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, old[8] = {BS, BS, BS, BS, BS, BS, BS, BS};
+        u32 vm = bok;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { bk[j] = bk8[g4 + j]; sl[j] = W_NOSLOT; if (bk[j] == FJ_EMPTY_KEY) { if ((vm >> j) & 1u) hdr->has_empty[par] = 1; vm &= ~(1u << j); } }
-        auto fin = [&]() {
+        for (int g = 0; g < 2; ++g) {
+            if (!((am >> (4 * g)) & 0xFu)) { vm &= ~(0xFu << (4 * g)); continue; }       // (wave-uniform)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sl8[g4 + j] = ((lost >> j) & 1u) ? W_NOSLOT : sl[j];
-        };
-        // a stage: every key that still needs a slot tries location loc(key): all of the thread's atomics in flight, then the answers
-        auto stage = [&](u32 need, int which) {
-            u32 o[4], bit[4];
+            for (int j = 4 * g; j < 4 * g + 4; ++j) {
+                if (bk[j] == FJ_EMPTY_KEY) { if ((vm >> j) & 1u) hdr->has_empty[par] = 1; vm &= ~(1u << j); }    // never stored: a flag stands for it
+                bkt[j] = FJ_HW2(bk[j]) & (NBK - 1u);
+                old[j] = BS;
+                if ((vm >> j) & 1u) old[j] = atomicAdd(&fill[bkt[j]], 1u);
+            }
+        }
+        u32 pend = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = 0; bit[j] = 0;
-                if ((need >> j) & 1u) {
-                    const u32 l = which == 1 ? w_l1(bk[j]) : which == 2 ? w_l2(bk[j]) : w_l3(bk[j]);
-                    sl[j] = l; bit[j] = 1u << (l & 31);
-                    o[j] = atomicOr(&bits[l >> 5], bit[j]);
+        for (int g = 0; g < 2; ++g) {
+            if (!((am >> (4 * g)) & 0xFu)) continue;
+#pragma unroll
+            for (int j = 4 * g; j < 4 * g + 4; ++j) {
+                if (!((vm >> j) & 1u)) continue;
+                if (old[j] < BS) tkeys[(bkt[j] << BSLOG) + old[j]] = bk[j];
+                else pend |= 1u << j;
+            }
+        }
+        if (__ballot(pend != 0)) {
+            u32 step = 0;
+            do {
+                ++step;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    old[j] = BS;
+                    if ((pend >> j) & 1u) { bkt[j] = (bkt[j] + 1u) & (NBK - 1u); old[j] = atomicAdd(&fill[bkt[j]], 1u); }
                 }
-            }
-            u32 l2 = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (o[j] & bit[j]) l2 |= 1u << j;
-            return l2;
-        };
-        lost = stage(vm & 0xFu, 1);
-        if (__ballot(lost != 0)) lost = stage(lost, 2);
-        if (__ballot(lost != 0)) lost = stage(lost, 3);
-        if (__ballot(lost != 0)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (!((lost >> j) & 1u)) continue;
-                u32 s = sl[j];
-                bool got = false;
-                for (u32 step = 0; step < W_MAXWALK && !got; ++step) {
-                    s = (s + 1) & (WS - 1);
-                    got = !((atomicOr(&bits[s >> 5], 1u << (s & 31)) >> (s & 31)) & 1u);
-                }
-                if (got) { sl[j] = s; lost &= ~(1u << j); } else hdr->full[par] = 1;
-            }
-        }
-        fin();
-    };
-    // (the DENSE instantiation keeps the earlier formulation of the same stages: it compiles to 7.2 ms where this one gives 7.8 - and
-    //  the other way round from chunk lists: 5.76 against 5.89 ms; same-box A/Bs, profiles/r05_join_kernel_ab.txt)
-    auto claim4_dense = [&](auto G, u32* bits, const u64 (&bk8)[8], u32 vm, u32 par, u32 (&sl8)[8]) {
-        constexpr int g4 = 4 * decltype(G)::value;
-        u32 o[4], sl[4]; u64 bk[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bk[j] = bk8[g4 + j];
-        auto fin = [&]() {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sl8[g4 + j] = sl[j];
-        };
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sl[j] = W_NOSLOT; o[j] = 0; if (bk[j] == FJ_EMPTY_KEY) { if ((vm >> j) & 1u) hdr->has_empty[par] = 1; vm &= ~(1u << j); } }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32 l = w_l1(bk[j]);
-            if ((vm >> j) & 1u) { sl[j] = l; o[j] = atomicOr(&bits[l >> 5], 1u << (l & 31)); }
-        }
-#pragma unroll
-        for (int which = 2; which <= 3; ++which) {
-            u32 need = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT && ((o[j] >> (sl[j] & 31)) & 1u)) need |= 1u << j;
-            if (__ballot(need != 0) == 0) { fin(); return; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = 0u;                                         // (settled keys read as "won")
-                if ((need >> j) & 1u) {
-                    const u32 l = which == 2 ? w_l2(bk[j]) : w_l3(bk[j]);
-                    sl[j] = l; o[j] = atomicOr(&bits[l >> 5], 1u << (l & 31));
-                }
-            }
-        }
-        u32 need = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT && ((o[j] >> (sl[j] & 31)) & 1u)) need |= 1u << j;
-        if (__ballot(need != 0) == 0) { fin(); return; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!((need >> j) & 1u)) continue;
-            u32 s = sl[j];
-            bool got = false;
-            for (u32 step = 0; step < W_MAXWALK && !got; ++step) {
-                s = (s + 1) & (WS - 1);
-                got = !((atomicOr(&bits[s >> 5], 1u << (s & 31)) >> (s & 31)) & 1u);
-            }
-            if (got) sl[j] = s; else { sl[j] = W_NOSLOT; hdr->full[par] = 1; }
-        }
-        fin();
-    };
-    auto claim = [&](u32* bits, const u64 (&bk)[8], u32 bok, u32 am, u32 par, u32 (&sl)[8]) {
-        if (am & 0xFu) { if constexpr (DENSE) claim4_dense(std::integral_constant<int, 0>(), bits, bk, bok & 0xFu, par, sl); else claim4(std::integral_constant<int, 0>(), bits, bk, bok & 0xFu, par, sl); }
-        else { sl[0] = sl[1] = sl[2] = sl[3] = W_NOSLOT; }
-        if (am >> 4) { if constexpr (DENSE) claim4_dense(std::integral_constant<int, 1>(), bits, bk, bok >> 4, par, sl); else claim4(std::integral_constant<int, 1>(), bits, bk, bok >> 4, par, sl); }
-        else { sl[4] = sl[5] = sl[6] = sl[7] = W_NOSLOT; }
-    };
-    auto store_keys = [&](const u64 (&bk)[8], const u32 (&sl)[8], u32 am) {
-        if (am & 0xFu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = bk[j];
-        }
-        if (am >> 4) {
-#pragma unroll
-            for (int j = 4; j < 8; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = bk[j];
+                for (int j = 0; j < 8; ++j)
+                    if (((pend >> j) & 1u) && old[j] < BS) { tkeys[(bkt[j] << BSLOG) + old[j]] = bk[j]; pend &= ~(1u << j); }
+            } while (__ballot(pend != 0) && step < W_MAXWALK);
+            if (pend) hdr->full[par] = 1;
         }
     };
-    auto clear_slots = [&](const u32 (&sl)[8], u32 am) {
-        if (am & 0xFu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = FJ_EMPTY_KEY;
-        }
-        if (am >> 4) {
-#pragma unroll
-            for (int j = 4; j < 8; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = FJ_EMPTY_KEY;
-        }
-    };
-    auto reset_table = [&]() {
-        const ulonglong2 e2 = make_ulonglong2(FJ_EMPTY_KEY, FJ_EMPTY_KEY);
+    auto fill_table = [&](u64 v) {
+        const ulonglong2 e2 = make_ulonglong2(v, v);
         for (u32 i = tid; i < WS / 2; i += WNT) reinterpret_cast<ulonglong2*>(tkeys)[i] = e2;
     };
+    auto zero_fill_counts = [&]() {
+        for (u32 i = tid; i < NBK / 4; i += WNT) reinterpret_cast<uint4*>(fill)[i] = make_uint4(0, 0, 0, 0);
+    };
+    // the partition whose keys' partition bits are all ones - the last one - must not find FJ_EMPTY_KEY (what the table starts out
+    // with: all ones) in a bucket's last slot: every untouched bucket would read as full.  Uniform over the workgroup; rare.
+    auto is_last_part = [&](u32 part) -> bool { return part + 1u == a.nparts; };
 
-    // ---- probe side: a wave's chunk -> 4 keys per lane ---------------------------------------------------------------------
     // ---- probe side: a wave's chunk -> 4 keys per lane (whole chunks per wave: units of 64 keys - 8-byte loads, perfectly balanced
     // waves - were 30 % slower, units of 128 keys 7 %: the address path charges per load instruction) --------------------------------
     // a wave's two chunks of an item (c and c + W_WAVES): both list entries in one LDS round trip, then the four loads
@@ -356,39 +290,73 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         one(ea, c0 < nb, k0, vm0);
         one(eb, c1 < nb, k1, vm1);
     };
-    auto probe2 = [&](u64 k0, u64 k1, u32 vm, u64 he) -> u32 {   // two keys per lane: six lookups in flight
-        const u64 k[2] = {k0, k1};
-        u64 c1[2], c2[2], c3[2];
-        u32 l3[2];
+    // the four keys a lane holds of one chunk: their home buckets are read whole, all reads in flight; then the rare walk for all
+    // four together
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(tkeys);
+    auto probe4 = [&](const u64 (&k)[4], u32 vm, u64 he) -> u32 {
+        uint4 pc[4][NPC];
+        u32 bkt[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            l3[i] = w_l3(k[i]);
-            c1[i] = tkeys[w_l1(k[i])];
-            c2[i] = tkeys[w_l2(k[i])];
-            c3[i] = tkeys[l3[i]];
+        for (int i = 0; i < 4; ++i) {
+            const u32 lo = FJ_HW2(k[i]);
+            bkt[i] = lo & (NBK - 1u);
+            const u32 r = (lo >> NBKLOG) & (NPC - 1u);             // rotation of the pieces: lanes whose buckets share LDS banks start at different pieces
+            const unsigned char* bp = tb + ((size_t)bkt[i] << (BSLOG + 3));
+#pragma unroll
+            for (u32 j = 0; j < NPC; ++j) pc[i][j] = *reinterpret_cast<const uint4*>(bp + (((j ^ r) & (NPC - 1u)) << 4));
         }
         __builtin_amdgcn_sched_barrier(0);
+        u32 fm = 0, cm = 0;                                        // per lane: key i found / key i walks on
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 lo = FJ_HW2(k[i]), hi = FJ_HW1(k[i]);
+            const u32 r = (lo >> NBKLOG) & (NPC - 1u);
+            bool f = false;
+#pragma unroll
+            for (u32 j = 0; j < NPC; ++j) {
+                const u64 e0 = ((u64)pc[i][j].y << 32) | pc[i][j].x, e1 = ((u64)pc[i][j].w << 32) | pc[i][j].z;
+                f |= (e0 == k[i]) | (e1 == k[i]);
+            }
+            // the bucket's LAST slot (piece NPC - 1, read as piece (NPC - 1) ^ r of this lane's order): an entry of the partition in place = full
+            u32 last_hi = pc[i][0].w;
+#pragma unroll
+            for (u32 j = 1; j < NPC; ++j) last_hi = (((NPC - 1u) ^ r) == j) ? pc[i][j].w : last_hi;
+            const bool c = !f && (((last_hi ^ hi) & pmask) == 0u) && ((vm >> i) & 1u);
+            fm |= f ? 1u << i : 0u;
+            cm |= c ? 1u << i : 0u;
+        }
+        if (__ballot(cm != 0)) {
+            u32 step = 0;
+            do {
+                ++step;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!((cm >> i) & 1u)) continue;
+                    bkt[i] = (bkt[i] + 1u) & (NBK - 1u);
+                    const unsigned char* bp = tb + ((size_t)bkt[i] << (BSLOG + 3));
+                    bool f = false; u32 last_hi = 0;
+#pragma unroll
+                    for (u32 j = 0; j < NPC; ++j) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(bp + (j << 4));
+                        const u64 e0 = ((u64)q.y << 32) | q.x, e1 = ((u64)q.w << 32) | q.z;
+                        f |= (e0 == k[i]) | (e1 == k[i]);
+                        last_hi = q.w;
+                    }
+                    if (f) fm |= 1u << i;
+                    if (f || (((last_hi ^ FJ_HW1(k[i])) & pmask) != 0u)) cm &= ~(1u << i);
+                }
+            } while (__ballot(cm != 0) && step < W_MAXWALK);
+        }
         u32 hits = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bool found = (c1[i] == k[i]) | (c2[i] == k[i]) | (c3[i] == k[i]);
-            // a key beyond l3 sits behind three occupied slots: walk on only where all three are taken by other keys
-            bool walk = !found && c1[i] != FJ_EMPTY_KEY && c2[i] != FJ_EMPTY_KEY && c3[i] != FJ_EMPTY_KEY && ((vm >> i) & 1u) && k[i] != FJ_EMPTY_KEY;
-            if (__ballot(walk)) {
-                u32 s = l3[i];
-                for (u32 step = 0; step < W_MAXWALK && __ballot(walk); ++step) {
-                    s = (s + 1) & (WS - 1);
-                    if (walk) { const u64 c = tkeys[s]; if (c == k[i]) { found = true; walk = false; } else if (c == FJ_EMPTY_KEY) walk = false; }
-                }
-            }
-            const u64 hit = __ballot(found);
-            const u64 ise = __ballot(k[i] == FJ_EMPTY_KEY);        // the empty marker is never stored in the table
+        for (int i = 0; i < 4; ++i) {
+            const u64 hit = __ballot((fm >> i) & 1u);
+            const u64 ise = __ballot(k[i] == FJ_EMPTY_KEY);        // the empty marker is never stored in the table (and equals its initial fill)
             const u64 ok = __ballot((vm >> i) & 1u);
             hits += (u32)__popcll(ok & ((hit & ~ise) | (ise & he)));
         }
         return hits;
     };
-    auto probe4 = [&](const u64 (&k)[4], u32 vm, u64 he) -> u32 { return probe2(k[0], k[1], vm, he) + probe2(k[2], k[3], vm >> 2, he); };
 
     // a partition of more than 32 build chunks / 8192 build keys is not offered to the table at all: its items are marked for the
     // host's retry ladder like any partition the table cannot hold (no rarely-taken loads inside the loop: they would make every
@@ -400,16 +368,16 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     if (DENSE && tid < w.nsrc) { hdr->lo_off[tid] = w.lo_off[tid]; hdr->mid_off[tid] = w.mid_off[tid]; hdr->offs_off[tid] = w.offs_off[tid]; }
     if (tid < 5) store_items(tid, fetch_items(tid));
     if (tid == 0) { hdr->cnt = 0; hdr->has_empty[0] = hdr->has_empty[1] = 0; hdr->full[0] = hdr->full[1] = 0; }
-    reset_table();
-    for (u32 i = tid; i < 2 * (WS / 32); i += WNT) bits0[i] = 0;
+    fill_table(FJ_EMPTY_KEY);
+    zero_fill_counts();
     __syncthreads();
     if (tid < 4) store_boff(tid, fetch_boff(tid));
     __syncthreads();
     // descriptor fields kept in scalar registers, rotated every iteration: probe chunks of items k .. k+2, build chunks of k+1, k+2
     u32 ns0 = ring(0, 1), ns1 = ring(1, 1), ns2 = ring(2, 1), nbc1 = ring(1, 5), nbc2 = ring(2, 5), part2 = ring(2, 2);
-    // grouped deals: partition ids of items k+1 (part1) and k+2 (part2) ride along; sameA / sameB: the item whose build keys
-    // bkA / bkB would hold finds its partition's table in place (its predecessor built it)
-    u32 part1 = grouped ? ring(1, 2) : 0u;
+    // partition ids of items k+1 (part1) and k+2 (part2) ride along (the last partition's special case; grouped deals); sameA /
+    // sameB: the item whose build keys bkA / bkB would hold finds its partition's table in place (its predecessor built it)
+    u32 part1 = ring(1, 2);
     bool sameA = grouped && 1 < nmine && part1 == ring(0, 2), sameB = false;
     u32* sl_k = meta, * sl_k1 = meta + W_STRIDE, * sl_k2 = meta + 2 * W_STRIDE, * sl_k3 = meta + 3 * W_STRIDE;
     {
@@ -420,20 +388,18 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         request(1, ns1, nbc1, ring(1, 0), ring(1, 2), ring(1, 4), mp, mb, mb2); park(sl_k1, mp, mb, mb2);
         request(2, ns2, nbc2, ring(2, 0), ring(2, 2), ring(2, 4), mp, mb, mb2); park(sl_k2, mp, mb, mb2);
     }
+    if (is_last_part(ring(0, 2))) fill_table(W_POISON2);
     __syncthreads();
     u64 bkA[8], bkB[8];
     RawBuild rawB;                                                 // DENSE: the planes of the batch bkB stands for
     u32 topB = 0;
     u32 bokA = 0, bokB = 0, amA = 0, amB = 0;
-    u32 slots[8], am_cur = 0;                                      // of the item in the table (this thread's keys)
     {
         const u32 nbc0 = ring(0, 5), tot0 = DENSE ? dense_total(sl_k) : 0u;
         const uint4 ud[2] = {unit_desc(sl_k, 0), unit_desc(sl_k, 1)};
         load_build(sl_k, ring(0, 2), 0, nbc0 < W_META_B ? nbc0 : W_META_B, tot0, ud, bkA, rawB, bokA, amA);
         if constexpr (DENSE) assemble(rawB, top_of(ring(0, 2)), bkA);
-        claim(bits0, bkA, bokA, amA, 0, slots);
-        store_keys(bkA, slots, amA);
-        am_cur = amA;
+        insert(bkA, bokA, amA, 0);
         if (is_big(nbc0, tot0)) hdr->full[0] = 1;
     }
     u64 ka[4], kb[4];
@@ -458,11 +424,10 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
 #define W_STAMP(i) do { } while (0)
 #endif
     for (u32 k = 0; k < nmine; ++k) {
-        // at entry: the table holds item k (this thread's keys of it: slots[], am_cur), bitmap k&1 marks them; ka/kb = first probe
-        // chunks of item k; bkA = first build batch of item k+1 (tot1 keys if DENSE); ring slots sl_k, sl_k1, sl_k2 hold the entries of
-        // items k, k+1, k+2; descriptors complete up to k+3, the item-table part of k+4 is in the ring
+        // at entry: the table holds item k (flags of parity k & 1); ka/kb = first probe chunks of item k; bkA = first build batch of
+        // item k+1 (tot1 units if DENSE); ring slots sl_k, sl_k1, sl_k2 hold the entries of items k, k+1, k+2; descriptors complete
+        // up to k+3, the item-table part of k+4 is in the ring
         const u32 par = k & 1u, parn = par ^ 1u;
-        u32* bitsn = bits0 + parn * (WS / 32);
         // ---- 1. requests: descriptor parts (one thread), entries of k+3, build keys of k+2 ----
         uint4 it5 = make_uint4(0, 0, 0, 0); uint2 bo4 = make_uint2(0, 0);
         // everything the first phases read from LDS in ONE batch - descriptor of item k+3, the flags of the table in place, (DENSE) the
@@ -486,7 +451,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         if (!sameB) { load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, ud2, bkB, rawB, bokB, amB); topB = DENSE ? top_of(part2) : 0u; }
         else { bokB = 0; amB = 0; }
         W_STAMP(0);
-        // ---- 2a. probe item k; then its successor's first probe chunks are requested into the same registers ----
+        // ---- 2. P: the fill counts are cleared for the next insert (no lookup reads them); probe item k; then its successor's first
+        // probe chunks are requested into the same registers ----
+        zero_fill_counts();
         const bool full = __builtin_amdgcn_readfirstlane(par ? flg.w : flg.z) != 0 || ns0 > 2 * W_WAVES;      // (an item longer than 32 probe chunks - a host-side bug - goes to the retry ladder)
         const u64 he = __builtin_amdgcn_readfirstlane(par ? flg.y : flg.x) ? ~0ull : 0ull;
         u32 wave_hits = 0;
@@ -499,21 +466,14 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             load_chunks2(sl_k1, nbn, ka, va, kb, vb);
         }
         W_STAMP(1);
-        // ---- 2b. claims of item k+1 on the other bitmap (other waves are still probing: the round trips overlap their lookups) ----
-        u32 nslots[8];
-        if (!sameA) {
-            claim(bitsn, bkA, bokA, amA, parn, nslots);
-            if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
-        }
-        W_STAMP(2);
         // ---- 3. park what was requested ----
         park(sl_k3, mp, mb, mb2);
         if (tid == 0) { store_boff(k + 4, bo4); store_items(k + 5, it5); }
         if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
+        W_STAMP(2);
+        __syncthreads();                                         // A: every wave is done with the table in place; the fill counts are zero
         W_STAMP(3);
-        __syncthreads();                                         // A: every wave is done with the table and with bitmap parn
-        W_STAMP(4);
-        // ---- 4. item k's result; the table is emptied by the owners of its keys; bitmap `par` is cleared for item k+2 ----
+        // ---- 4. I: item k's result; item k+1 goes in ----
         if (tid == 0) {
             const u32 cnt = skip ? 0u : hdr->cnt;
             if (sameA) { hdr->has_empty[parn] = hdr->has_empty[par]; hdr->full[parn] = hdr->full[par]; }      // the table stays: so do its flags
@@ -522,28 +482,22 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             a.part_count[id_of(k)] = full ? FJ_ITEM_RETRY : cnt;
             if (cnt) atomicAdd(a.total, (unsigned long long)cnt);
         }
-        if (!sameA) clear_slots(slots, am_cur);
-        if (tid < WS / 32) bits0[par * (WS / 32) + tid] = 0;
-        W_STAMP(5);
-        __syncthreads();                                         // B
-        // ---- 5. item k+1 goes in ----
-        if (!sameA) store_keys(bkA, nslots, amA);
-        W_STAMP(6);
-        __syncthreads();                                         // C
-        W_STAMP(7);
-        // ---- 6. rotate ----
         if (!sameA) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) slots[j] = nslots[j];
-            am_cur = amA;
+            if (k + 1 < nmine && is_last_part(part1)) { fill_table(W_POISON2); __syncthreads(); }     // (uniform; once per launch at most)
+            insert(bkA, bokA, amA, parn);
+            if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
         }
+        W_STAMP(4);
+        __syncthreads();                                         // B
+        W_STAMP(5);
+        // ---- 5. rotate ----
         if constexpr (DENSE) assemble(rawB, topB, bkA);          // (the loads were issued at the top of the iteration: they are in)
         else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bkA[j] = bkB[j];
         }
         bokA = bokB; amA = amB; tot1 = tot2; sameA = sameB;
-        ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part1 = part2; part2 = (DENSE || grouped) ? part3 : 0u;
+        ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part1 = part2; part2 = part3;
         u32* t = sl_k; sl_k = sl_k1; sl_k1 = sl_k2; sl_k2 = sl_k3; sl_k3 = t;
     }
 #ifdef FJ_LAB
@@ -553,7 +507,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
 
 }  // namespace
 
-u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + 2 * (WS / 8) + 4 * W_STRIDE * 4 + 80); }
+u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + NBK * 4 + 4 * W_STRIDE * 4 + 80); }
 
 // counting join over the final chunk sets with the 16384-slot table: a.items / a.nitems_dev / a.part_count / a.total / a.err as
 // for fj_launch_lds_join.  dense: the build side comes from w (build-broadcast wire format).
@@ -561,9 +515,9 @@ hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w
     if (!a.probe.list || !a.items || (!dense && !a.build.list) || a.want_dups) return hipErrorInvalidValue;
     if (dense && (w.nsrc == 0 || w.nsrc > FJ_WIDE_MAXSRC || !w.base || (w.mid_bytes != 2 && w.mid_bytes != 4) || w.bits > 32)) return hipErrorInvalidValue;
     if (w.group_log > 6) return hipErrorInvalidValue;
+    if (w.pmask == 0 || a.nparts == 0) return hipErrorInvalidValue;   // (stale table entries are told from live ones by their partition bits: the plan has some)
     const u32 lds = fj_wide_lds_bytes();
-    if (w.group_log && !dense) return hipErrorInvalidValue;        // (chunk-list build sides come with <= 32 probe chunks per partition: fj_plan.hip wide_join_planned)
-    auto kern = !dense ? fj_count_join_wide<0, false>
+    auto kern = !dense ? (w.group_log ? fj_count_join_wide<0, true> : fj_count_join_wide<0, false>)
               : w.mid_bytes == 2 ? (w.group_log ? fj_count_join_wide<2, true> : fj_count_join_wide<2, false>)
                                  : (w.group_log ? fj_count_join_wide<4, true> : fj_count_join_wide<4, false>);
     hipError_t e = fj_set_max_lds_once(reinterpret_cast<const void*>(kern), lds);

@@ -306,6 +306,7 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     const bool wide = pit.item_tc_max == 32 && !materialize && !ja.dbg && !ja.dbg_flags && ja.probe.list && ja.build.list && ja.items;
     if (wide) {
         FjWideArgs wa{};
+        wa.pmask = fj_wide_pmask(plan.bits, top_bits);
         FjLdsJoinArgs jw = ja;
 #ifdef FJ_LAB
         if (getenv("FJ_WIDE_STAMPS") && stamps_begin(&jw.dbg, s)) return 1;      // (diagnostic: where a workgroup's time goes, per pipeline stage)
@@ -319,8 +320,8 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
             double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (u32 g = 0; g < grid && g < 4096; ++g) for (int i = 0; i < 8; ++i) acc[i] += (double)h[g * 8 + i] * 0.01;
             const double per = (double)std::min<u32>(grid, 4096) * ((double)nitems / grid);
-            fprintf(stderr, "[FJ_WIDE_STAMPS] us per item (thread 0): requests %.3f  probe %.3f  claims %.3f  park %.3f  barA %.3f  clear %.3f  barB+store %.3f  barC %.3f\n",
-                    acc[0] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per, acc[5] / per, acc[6] / per, acc[7] / per);
+            fprintf(stderr, "[FJ_WIDE_STAMPS] us per item (thread 0): requests %.3f  probe %.3f  park %.3f  barA %.3f  insert %.3f  barB %.3f  rotate %.3f\n",
+                    acc[0] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per, acc[5] / per, acc[6] / per);
         }
     } else
     HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item, options().persistent_min_items));
