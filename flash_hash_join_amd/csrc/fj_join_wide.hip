@@ -16,8 +16,9 @@
 //     probe phase.  "This bucket is full" is read off the entry in its last slot: it belongs to the partition in place (same
 //     partition bits as the probe key, FjWideArgs::pmask) exactly if the bucket's BS-th key went in (a stale same-partition
 //     entry - the same partition rebuilt by this workgroup - can only make a lookup walk one bucket further than it had to);
-//     the table starts out filled with FJ_EMPTY_KEY, which reads as a key of the LAST partition: before that partition goes
-//     in, the table is filled once more with a key no probe key of it can equal;
+//     the table starts out filled with FJ_EMPTY_KEY (all ones), a key of the LAST partition - no probe key of any other partition
+//     can equal it; before the last partition goes in, the table is filled once more, with a key of the FIRST partition.  So
+//     every 64-bit value is a legal key on both sides and no value is handled out of band;
 //   * an item is two phases and two barriers: P (probe item k; zero the fill counts; requests and prefetches as before) | barrier
 //     | I (insert item k+1: its keys have been in registers for an iteration) | barrier.  Round 5 overlapped its claims with the
 //     probe and then paid a clear phase, a store phase and three barriers;
@@ -53,13 +54,14 @@ constexpr u32 W_UNITS = 32;               // DENSE: 256-slot load units per item
 constexpr u32 W_STRIDE = W_META_P + 4 * W_UNITS + 4;
 constexpr u32 W_MAXWALK = 64;             // full buckets a key walks past before the table counts as full (insert) / the lookup gives up
 constexpr u32 W_WAVES = WNT / 64;
+constexpr u32 W_NOSLOT = 0xFFFFFFFFu;
 // what the table is filled with before the LAST partition goes in: a key of the first partition (high word 0), so no probe key of
 // the last partition - whose partition bits are all ones - can equal it
 constexpr u64 W_POISON2 = 0x00000000FFFFFFFFull;
 
 struct WHdr {
     u32 cnt, pad0[3];
-    u32 has_empty[2], full[2];             // per parity of the item whose keys are / go in the table
+    u32 unused0[2], full[2];               // full: per parity of the item whose keys are / go in the table
     u32 dring[8][8];                       // item descriptors: {probe list pos, probe chunks, partition, item id, b0, nbc, -, -}
     u64 lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC], offs_off[FJ_WIDE_MAXSRC];
 };
@@ -72,9 +74,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WHdr* hdr = reinterpret_cast<WHdr*>(smem);
     u64* tkeys = reinterpret_cast<u64*>(smem + sizeof(WHdr));
-    u32* fill = reinterpret_cast<u32*>(tkeys + WS);                // [NBK] keys that asked for a slot of the bucket
+    u32* fill = reinterpret_cast<u32*>(tkeys + WS);                // [2][NBK / 2]: per parity of the item, keys that asked for a slot of the bucket (16 bits per bucket, two buckets per word)
     u32* meta = fill + NBK;                                        // [4][W_STRIDE]: ring of staged list entries
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the wave id in a SCALAR register: what hangs on it - which chunks and units a wave owns - is then scalar work)
     const u32 pmask = w.pmask;
 
     u32 item_lo = 0, item_hi = *a.nitems_dev;
@@ -193,8 +195,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
                 const u32 kk = in ? k0 : (have ? ua0 : 0u);
                 raw.lo[i] = *reinterpret_cast<const uint4*>(w.base + ((u64)ulo << 4) + (u64)kk * 4);
                 if constexpr (DENSE) raw.mid[i] = *reinterpret_cast<const midv_t*>(w.base + ((u64)umid << 4) + (u64)kk * (u64)MIDB);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (in && k0 + j >= ub && k0 + j < ue) bok |= 1u << (4 * i + j);
+                // the lane's keys k0 .. k0 + 3 that lie in [ub, ue): bits [first, end) of a nibble
+                const u32 bfirst = ub > k0 ? ub - k0 : 0u, bend = ue > k0 ? (ue - k0 < 4u ? ue - k0 : 4u) : 0u;      // (bfirst <= 3: the unit starts at ub & ~3)
+                if (in) bok |= (((1u << bend) - 1u) & ~((1u << bfirst) - 1u)) << (4 * i);
                 if (have) am |= 0xFu << (4 * i);
             }
         } else {
@@ -218,86 +221,114 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         am = __builtin_amdgcn_readfirstlane(am);
     };
 
-    // ---- insert a batch: one returning atomic add per key on its home bucket's fill count, one store; the few keys whose bucket
-    // was full walk on, all of a thread's stragglers together (one more round trip per step whatever the wave holds) --------------
-    auto insert = [&](const u64 (&bk)[8], u32 bok, u32 am, u32 par) {
-        u32 bkt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, old[8] = {BS, BS, BS, BS, BS, BS, BS, BS};
-        u32 vm = bok;
+    // ---- slots for a batch: one returning atomic add per key on its home bucket's fill count (the count array of the item's parity:
+    // the table itself is not touched, so this runs WHILE the item in place is probed - claim_issue in front of the lookups,
+    // claim_resolve behind them, the round trip in between is free); the few keys whose bucket was full walk on, all of a thread's
+    // stragglers together.  sl[j] = the slot key j will be stored in once the table is free (W_NOSLOT: none) ----------------------
+    auto fill_add = [&](u32* f, u32 b) -> u32 { return (atomicAdd(&f[b >> 1], 1u << ((b & 1u) << 4)) >> ((b & 1u) << 4)) & 0xFFFFu; };
+    auto claim_issue = [&](u32* f, const u64 (&bk)[8], u32 bok, u32 am, u32 (&old)[8]) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            if (!((am >> (4 * g)) & 0xFu)) { vm &= ~(0xFu << (4 * g)); continue; }       // (wave-uniform)
 #pragma unroll
-            for (int j = 4 * g; j < 4 * g + 4; ++j) {
-                if (bk[j] == FJ_EMPTY_KEY) { if ((vm >> j) & 1u) hdr->has_empty[par] = 1; vm &= ~(1u << j); }    // never stored: a flag stands for it
-                bkt[j] = FJ_HW2(bk[j]) & (NBK - 1u);
-                old[j] = BS;
-                if ((vm >> j) & 1u) old[j] = atomicAdd(&fill[bkt[j]], 1u);
-            }
+            for (int j = 4 * g; j < 4 * g + 4; ++j) old[j] = BS;
+            if (!((am >> (4 * g)) & 0xFu)) continue;               // (wave-uniform)
+#pragma unroll
+            for (int j = 4 * g; j < 4 * g + 4; ++j)
+                if ((bok >> j) & 1u) old[j] = fill_add(f, FJ_HW2(bk[j]) & (NBK - 1u));
         }
+    };
+    auto claim_resolve = [&](u32* f, const u64 (&bk)[8], u32 bok, u32 am, u32 par, const u32 (&old)[8], u32 (&sl)[8]) {
         u32 pend = 0;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int j = 4 * g; j < 4 * g + 4; ++j) sl[j] = W_NOSLOT;
             if (!((am >> (4 * g)) & 0xFu)) continue;
 #pragma unroll
             for (int j = 4 * g; j < 4 * g + 4; ++j) {
-                if (!((vm >> j) & 1u)) continue;
-                if (old[j] < BS) tkeys[(bkt[j] << BSLOG) + old[j]] = bk[j];
+                if (!((bok >> j) & 1u)) continue;
+                if (old[j] < BS) sl[j] = ((FJ_HW2(bk[j]) & (NBK - 1u)) << BSLOG) + old[j];
                 else pend |= 1u << j;
             }
         }
         if (__ballot(pend != 0)) {
-            u32 step = 0;
+            // stragglers (0.35 % of the keys at load 0.23): a lane's pending keys one after the other, each walking bucket by bucket
+            u32 failed = 0;
             do {
-                ++step;
+                // the lane's first pending key, picked with bit masks (a chain of selects on the key index becomes an indexed array in
+                // scratch memory: eight stores per item whether or not anything is pending)
+                const u32 low = pend & (0u - pend);                // its bit alone
+                u32 b = 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    old[j] = BS;
-                    if ((pend >> j) & 1u) { bkt[j] = (bkt[j] + 1u) & (NBK - 1u); old[j] = atomicAdd(&fill[bkt[j]], 1u); }
-                }
+                for (int t = 0; t < 8; ++t) b |= (FJ_HW2(bk[t]) & (NBK - 1u)) & (0u - ((low >> t) & 1u));
+                u32 got = W_NOSLOT, step = 0;
+                bool c = pend != 0;
+                do {
+                    ++step;
+                    if (c) {
+                        b = (b + 1u) & (NBK - 1u);
+                        const u32 o = fill_add(f, b);
+                        if (o < BS) { got = (b << BSLOG) + o; c = false; }
+                    }
+                } while (__ballot(c) && step < W_MAXWALK);
+                if (pend != 0 && got == W_NOSLOT) failed = 1;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (((pend >> j) & 1u) && old[j] < BS) { tkeys[(bkt[j] << BSLOG) + old[j]] = bk[j]; pend &= ~(1u << j); }
-            } while (__ballot(pend != 0) && step < W_MAXWALK);
-            if (pend) hdr->full[par] = 1;
+                for (int t = 0; t < 8; ++t) sl[t] = ((low >> t) & 1u) ? got : sl[t];
+                pend &= pend - 1u;
+            } while (__ballot(pend != 0));
+            if (failed) hdr->full[par] = 1;
+        }
+    };
+    auto store_keys = [&](const u64 (&bk)[8], const u32 (&sl)[8], u32 am) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (!((am >> (4 * g)) & 0xFu)) continue;
+#pragma unroll
+            for (int j = 4 * g; j < 4 * g + 4; ++j) if (sl[j] != W_NOSLOT) tkeys[sl[j]] = bk[j];
         }
     };
     auto fill_table = [&](u64 v) {
         const ulonglong2 e2 = make_ulonglong2(v, v);
         for (u32 i = tid; i < WS / 2; i += WNT) reinterpret_cast<ulonglong2*>(tkeys)[i] = e2;
     };
-    auto zero_fill_counts = [&]() {
-        for (u32 i = tid; i < NBK / 4; i += WNT) reinterpret_cast<uint4*>(fill)[i] = make_uint4(0, 0, 0, 0);
+    auto zero_fill_counts = [&](u32 par) {                         // one parity: NBK / 2 words
+        for (u32 i = tid; i < NBK / 8; i += WNT) reinterpret_cast<uint4*>(fill + par * (NBK / 2))[i] = make_uint4(0, 0, 0, 0);
     };
     // the partition whose keys' partition bits are all ones - the last one - must not find FJ_EMPTY_KEY (what the table starts out
-    // with: all ones) in a bucket's last slot: every untouched bucket would read as full.  Uniform over the workgroup; rare.
+    // with: all ones) in the table: a probe key could equal it, and every untouched bucket would read as full.  Uniform over the
+    // workgroup; at most once per launch (the last partition's items are the launch's last).
     auto is_last_part = [&](u32 part) -> bool { return part + 1u == a.nparts; };
 
     // ---- probe side: a wave's chunk -> 4 keys per lane (whole chunks per wave: units of 64 keys - 8-byte loads, perfectly balanced
-    // waves - were 30 % slower, units of 128 keys 7 %: the address path charges per load instruction) --------------------------------
-    // a wave's two chunks of an item (c and c + W_WAVES): both list entries in one LDS round trip, then the four loads
-    auto load_chunks2 = [&](const u32* pm, u32 nb, u64 (&k0)[4], u32& vm0, u64 (&k1)[4], u32& vm1) {
+    // waves - were 30 % slower, units of 128 keys 7 %: the address path charges per load instruction; round 6 tried again with the
+    // bucketed table - chunks 16 .. 31 shared by quarters, every wave 4 + 1 keys per lane instead of four waves 8 and twelve 4: 7 %
+    // slower: the kernel is bound by instruction issue, not by its longest wave) ----------------------------------------------------
+    // a wave's two chunks of an item (c and c + W_WAVES): both list entries in one LDS round trip, then the four loads; n0 / n1 = the
+    // keys the chunks hold (wave-uniform; 0: no such chunk).  Lane l holds keys 2l, 2l + 1, 128 + 2l, 129 + 2l of a chunk.
+    auto load_chunks2 = [&](const u32* pm, u32 nb, u64 (&k0)[4], u32& n0, u64 (&k1)[4], u32& n1) {
         const u32 last = nb ? nb - 1 : 0u;
         const u32 c0 = wave, c1 = wave + W_WAVES;
-        const u32 ea = pm[c0 < nb ? c0 : last], eb = pm[c1 < nb ? c1 : last];
-        auto one = [&](u32 e, bool have, u64 (&k)[4], u32& vm) {
-            const u32 cnt = have ? FJ_LIST_CNT(e) : 0u;
+        const u32 ea = __builtin_amdgcn_readfirstlane(pm[c0 < nb ? c0 : last]), eb = __builtin_amdgcn_readfirstlane(pm[c1 < nb ? c1 : last]);
+        auto one = [&](u32 e, bool have, u64 (&k)[4], u32& n) {
+            n = have ? FJ_LIST_CNT(e) : 0u;
             const u64* ck = a.probe.keys + (u64)(nb ? FJ_LIST_ID(e) : 0u) * FJ_CHUNK + (have ? 2 * lane : 0u);
             const u64x2 q0 = *reinterpret_cast<const u64x2*>(ck);
             const u64x2 q1 = *reinterpret_cast<const u64x2*>(ck + (have ? 128 : 0));
             k[0] = q0.x; k[1] = q0.y; k[2] = q1.x; k[3] = q1.y;
-            vm = (2 * lane < cnt ? 1u : 0u) | (2 * lane + 1 < cnt ? 2u : 0u) | (128 + 2 * lane < cnt ? 4u : 0u) | (129 + 2 * lane < cnt ? 8u : 0u);
         };
-        one(ea, c0 < nb, k0, vm0);
-        one(eb, c1 < nb, k1, vm1);
+        one(ea, c0 < nb, k0, n0);
+        one(eb, c1 < nb, k1, n1);
     };
-    // the four keys a lane holds of one chunk: their home buckets are read whole, all reads in flight; then the rare walk for all
-    // four together
+    // the four keys a lane holds of one chunk of n keys: their home buckets are read whole, all reads in flight; found / walks-on are
+    // wave masks in scalar registers (the compares produce them)
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(tkeys);
-    auto probe4 = [&](const u64 (&k)[4], u32 vm, u64 he) -> u32 {
-        uint4 pc[4][NPC];
-        u32 bkt[4];
+    const u32 kidx[4] = {2 * lane, 2 * lane + 1, 128 + 2 * lane, 129 + 2 * lane};
+    auto probe4 = [&](const u64 (&k)[4], u32 n) -> u32 {
+        constexpr int N = 4;
+        uint4 pc[N][NPC];
+        u32 bkt[N];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < N; ++i) {
             const u32 lo = FJ_HW2(k[i]);
             bkt[i] = lo & (NBK - 1u);
             const u32 r = (lo >> NBKLOG) & (NPC - 1u);             // rotation of the pieces: lanes whose buckets share LDS banks start at different pieces
@@ -306,11 +337,12 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             for (u32 j = 0; j < NPC; ++j) pc[i][j] = *reinterpret_cast<const uint4*>(bp + (((j ^ r) & (NPC - 1u)) << 4));
         }
         __builtin_amdgcn_sched_barrier(0);
-        u32 fm = 0, cm = 0;                                        // per lane: key i found / key i walks on
+        u32 hits = 0, cm = 0;                                      // cm: per lane, the keys that must look into the next bucket
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < N; ++i) {
             const u32 lo = FJ_HW2(k[i]), hi = FJ_HW1(k[i]);
             const u32 r = (lo >> NBKLOG) & (NPC - 1u);
+            const bool ok = kidx[i] < n;
             bool f = false;
 #pragma unroll
             for (u32 j = 0; j < NPC; ++j) {
@@ -321,39 +353,40 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             u32 last_hi = pc[i][0].w;
 #pragma unroll
             for (u32 j = 1; j < NPC; ++j) last_hi = (((NPC - 1u) ^ r) == j) ? pc[i][j].w : last_hi;
-            const bool c = !f && (((last_hi ^ hi) & pmask) == 0u) && ((vm >> i) & 1u);
-            fm |= f ? 1u << i : 0u;
+            const bool c = !f && (((last_hi ^ hi) & pmask) == 0u) && ok;
             cm |= c ? 1u << i : 0u;
+            hits += (u32)__popcll(__ballot(f && ok));
         }
+        // the walk (1.5 % of the buckets are full at load 0.23: a lane or two of most chunks): a lane's walking keys one after the other -
+        // only the COUNT of the hits matters, so nothing is handed back per key
         if (__ballot(cm != 0)) {
-            u32 step = 0;
             do {
-                ++step;
+                const u32 low = cm & (0u - cm);
+                u32 klo = 0, khi = 0, b = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (!((cm >> i) & 1u)) continue;
-                    bkt[i] = (bkt[i] + 1u) & (NBK - 1u);
-                    const unsigned char* bp = tb + ((size_t)bkt[i] << (BSLOG + 3));
-                    bool f = false; u32 last_hi = 0;
+                for (int t = 0; t < N; ++t) { const u32 m = 0u - ((low >> t) & 1u); klo |= FJ_HW2(k[t]) & m; khi |= FJ_HW1(k[t]) & m; b |= bkt[t] & m; }
+                const u64 key = ((u64)khi << 32) | klo;
+                bool c = cm != 0, f = false;
+                u32 step = 0;
+                do {
+                    ++step;
+                    if (c) {
+                        b = (b + 1u) & (NBK - 1u);
+                        const unsigned char* bp = tb + ((size_t)b << (BSLOG + 3));
+                        u32 lh = 0;
 #pragma unroll
-                    for (u32 j = 0; j < NPC; ++j) {
-                        const uint4 q = *reinterpret_cast<const uint4*>(bp + (j << 4));
-                        const u64 e0 = ((u64)q.y << 32) | q.x, e1 = ((u64)q.w << 32) | q.z;
-                        f |= (e0 == k[i]) | (e1 == k[i]);
-                        last_hi = q.w;
+                        for (u32 j = 0; j < NPC; ++j) {
+                            const uint4 q = *reinterpret_cast<const uint4*>(bp + (j << 4));
+                            const u64 e0 = ((u64)q.y << 32) | q.x, e1 = ((u64)q.w << 32) | q.z;
+                            f |= (e0 == key) | (e1 == key);
+                            lh = q.w;
+                        }
+                        c = !f && (((lh ^ khi) & pmask) == 0u);
                     }
-                    if (f) fm |= 1u << i;
-                    if (f || (((last_hi ^ FJ_HW1(k[i])) & pmask) != 0u)) cm &= ~(1u << i);
-                }
-            } while (__ballot(cm != 0) && step < W_MAXWALK);
-        }
-        u32 hits = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u64 hit = __ballot((fm >> i) & 1u);
-            const u64 ise = __ballot(k[i] == FJ_EMPTY_KEY);        // the empty marker is never stored in the table (and equals its initial fill)
-            const u64 ok = __ballot((vm >> i) & 1u);
-            hits += (u32)__popcll(ok & ((hit & ~ise) | (ise & he)));
+                } while (__ballot(c) && step < W_MAXWALK);
+                hits += (u32)__popcll(__ballot(f));
+                cm &= cm - 1u;
+            } while (__ballot(cm != 0));
         }
         return hits;
     };
@@ -367,9 +400,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     // ---- prologue (synchronous): descriptors 0..4, entries of items 0..2, item 0 built, probe keys of item 0, build keys of item 1
     if (DENSE && tid < w.nsrc) { hdr->lo_off[tid] = w.lo_off[tid]; hdr->mid_off[tid] = w.mid_off[tid]; hdr->offs_off[tid] = w.offs_off[tid]; }
     if (tid < 5) store_items(tid, fetch_items(tid));
-    if (tid == 0) { hdr->cnt = 0; hdr->has_empty[0] = hdr->has_empty[1] = 0; hdr->full[0] = hdr->full[1] = 0; }
+    if (tid == 0) { hdr->cnt = 0; hdr->unused0[0] = hdr->unused0[1] = 0; hdr->full[0] = hdr->full[1] = 0; }
     fill_table(FJ_EMPTY_KEY);
-    zero_fill_counts();
+    zero_fill_counts(0); zero_fill_counts(1);
     __syncthreads();
     if (tid < 4) store_boff(tid, fetch_boff(tid));
     __syncthreads();
@@ -399,14 +432,17 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         const uint4 ud[2] = {unit_desc(sl_k, 0), unit_desc(sl_k, 1)};
         load_build(sl_k, ring(0, 2), 0, nbc0 < W_META_B ? nbc0 : W_META_B, tot0, ud, bkA, rawB, bokA, amA);
         if constexpr (DENSE) assemble(rawB, top_of(ring(0, 2)), bkA);
-        insert(bkA, bokA, amA, 0);
+        u32 old[8], sl[8];
+        claim_issue(fill, bkA, bokA, amA, old);
+        claim_resolve(fill, bkA, bokA, amA, 0, old, sl);
+        store_keys(bkA, sl, amA);
         if (is_big(nbc0, tot0)) hdr->full[0] = 1;
     }
     u64 ka[4], kb[4];
-    u32 va = 0, vb = 0;
+    u32 na = 0, nbk = 0;                                           // keys in the two probe chunks this wave holds
     {
         const u32 nb = ns0 < W_META_P ? ns0 : W_META_P;
-        load_chunks2(sl_k, nb, ka, va, kb, vb);
+        load_chunks2(sl_k, nb, ka, na, kb, nbk);
     }
     u32 tot1 = DENSE ? dense_total(sl_k1) : 0u;
     if (!sameA) {
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         const u32* rq3 = hdr->dring[(k + 3) & 7];
         const uint4 rq_a = *reinterpret_cast<const uint4*>(rq3);          // {probe list pos, probe chunks, partition, item id}
         const uint2 rq_b = *reinterpret_cast<const uint2*>(rq3 + 4);      // {first build-list entry, build chunks}
-        const uint4 flg = *reinterpret_cast<const uint4*>(hdr->has_empty);     // has_empty[2], full[2]
+        const uint4 flg = *reinterpret_cast<const uint4*>(hdr->unused0);       // -, -, full[2]
         const u32 part4w = DENSE ? 0u : hdr->dring[(k + 4) & 7][2];      // (thread 0's build-list offsets of item k+4 hang on it)
         const u32 tot2w = DENSE ? sl_k2[W_META_P + 4 * W_UNITS] : 0u;
         uint4 ud2[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
@@ -451,41 +487,46 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         if (!sameB) { load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, ud2, bkB, rawB, bokB, amB); topB = DENSE ? top_of(part2) : 0u; }
         else { bokB = 0; amB = 0; }
         W_STAMP(0);
-        // ---- 2. P: the fill counts are cleared for the next insert (no lookup reads them); probe item k; then its successor's first
-        // probe chunks are requested into the same registers ----
-        zero_fill_counts();
+        // ---- 2. P: slots for item k+1 are requested on its parity's fill counts (no lookup reads them; the table is not touched); item
+        // k is probed; then its successor's first probe chunks are requested into the same registers; the requests' answers are
+        // taken, stragglers placed; the fill counts of item k's parity are cleared for item k+2 ----
+        u32* fill_n = fill + parn * (NBK / 2);
+        u32 old[8], nslots[8];
+        if (!sameA) claim_issue(fill_n, bkA, bokA, amA, old);
+        zero_fill_counts(par);
         const bool full = __builtin_amdgcn_readfirstlane(par ? flg.w : flg.z) != 0 || ns0 > 2 * W_WAVES;      // (an item longer than 32 probe chunks - a host-side bug - goes to the retry ladder)
-        const u64 he = __builtin_amdgcn_readfirstlane(par ? flg.y : flg.x) ? ~0ull : 0ull;
         u32 wave_hits = 0;
         const bool skip = full || ns0 == 0;
-        const u32 nb = ns0 < 2 * W_WAVES ? ns0 : 2 * W_WAVES;      // (items of this kernel have at most 32 probe chunks: the host cuts them so)
-        if (!skip && wave < nb) wave_hits += probe4(ka, va, he);
-        if (!skip && wave + W_WAVES < nb) wave_hits += probe4(kb, vb, he);
+        if (!skip && na) wave_hits += probe4(ka, na);
+        if (!skip && nbk) wave_hits += probe4(kb, nbk);
         {
             const u32 nbn = ns1 < W_META_P ? ns1 : W_META_P;
-            load_chunks2(sl_k1, nbn, ka, va, kb, vb);
+            load_chunks2(sl_k1, nbn, ka, na, kb, nbk);
         }
         W_STAMP(1);
+        if (!sameA) {
+            claim_resolve(fill_n, bkA, bokA, amA, parn, old, nslots);
+            if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
+        }
         // ---- 3. park what was requested ----
         park(sl_k3, mp, mb, mb2);
         if (tid == 0) { store_boff(k + 4, bo4); store_items(k + 5, it5); }
         if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
         W_STAMP(2);
-        __syncthreads();                                         // A: every wave is done with the table in place; the fill counts are zero
+        __syncthreads();                                         // A: every wave is done with the table in place; item k+1's slots are settled
         W_STAMP(3);
-        // ---- 4. I: item k's result; item k+1 goes in ----
-        if (tid == 0) {
+        // ---- 4. I: item k's result (one lane of the LAST wave: it holds the fewest probe chunks); item k+1 goes in: plain stores ----
+        if (tid == WNT - 64) {
             const u32 cnt = skip ? 0u : hdr->cnt;
-            if (sameA) { hdr->has_empty[parn] = hdr->has_empty[par]; hdr->full[parn] = hdr->full[par]; }      // the table stays: so do its flags
-            hdr->cnt = 0; hdr->has_empty[par] = 0; hdr->full[par] = 0;
+            if (sameA) hdr->full[parn] = hdr->full[par];            // the table stays: so does its verdict
+            hdr->cnt = 0; hdr->full[par] = 0;
             if (full) atomicOr(a.err, FJ_STAT_RETRY);            // the table could not hold the partition: redone with the tagged table
             a.part_count[id_of(k)] = full ? FJ_ITEM_RETRY : cnt;
             if (cnt) atomicAdd(a.total, (unsigned long long)cnt);
         }
         if (!sameA) {
             if (k + 1 < nmine && is_last_part(part1)) { fill_table(W_POISON2); __syncthreads(); }     // (uniform; once per launch at most)
-            insert(bkA, bokA, amA, parn);
-            if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
+            store_keys(bkA, nslots, amA);
         }
         W_STAMP(4);
         __syncthreads();                                         // B
@@ -507,7 +548,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
 
 }  // namespace
 
-u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + NBK * 4 + 4 * W_STRIDE * 4 + 80); }
+u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + NBK * 4 + 4 * W_STRIDE * 4 + 80); }     // (NBK * 4: two parities of NBK 16-bit counts)
 
 // counting join over the final chunk sets with the 16384-slot table: a.items / a.nitems_dev / a.part_count / a.total / a.err as
 // for fj_launch_lds_join.  dense: the build side comes from w (build-broadcast wire format).
@@ -515,7 +556,7 @@ hipError_t fj_launch_count_join_wide(const FjLdsJoinArgs& a, const FjWideArgs& w
     if (!a.probe.list || !a.items || (!dense && !a.build.list) || a.want_dups) return hipErrorInvalidValue;
     if (dense && (w.nsrc == 0 || w.nsrc > FJ_WIDE_MAXSRC || !w.base || (w.mid_bytes != 2 && w.mid_bytes != 4) || w.bits > 32)) return hipErrorInvalidValue;
     if (w.group_log > 6) return hipErrorInvalidValue;
-    if (w.pmask == 0 || a.nparts == 0) return hipErrorInvalidValue;   // (stale table entries are told from live ones by their partition bits: the plan has some)
+    if (w.pmask == 0 || a.nparts < 2) return hipErrorInvalidValue;    // (stale table entries are told from live ones by their partition bits: the plan has some)
     const u32 lds = fj_wide_lds_bytes();
     auto kern = !dense ? (w.group_log ? fj_count_join_wide<0, true> : fj_count_join_wide<0, false>)
               : w.mid_bytes == 2 ? (w.group_log ? fj_count_join_wide<2, true> : fj_count_join_wide<2, false>)

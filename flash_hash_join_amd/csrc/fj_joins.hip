@@ -319,7 +319,9 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
             HIPCHK(hipMemcpy(h.data(), jw.dbg, h.size() * 8, hipMemcpyDeviceToHost));
             double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (u32 g = 0; g < grid && g < 4096; ++g) for (int i = 0; i < 8; ++i) acc[i] += (double)h[g * 8 + i] * 0.01;
-            const double per = (double)std::min<u32>(grid, 4096) * ((double)nitems / grid);
+            u32 nit = 0;
+            HIPCHK(hipMemcpy(&nit, jw.nitems_dev, 4, hipMemcpyDeviceToHost));           // (nitems is the table's capacity)
+            const double per = (double)std::min<u32>(grid, 4096) * ((double)nit / grid);
             fprintf(stderr, "[FJ_WIDE_STAMPS] us per item (thread 0): requests %.3f  probe %.3f  park %.3f  barA %.3f  insert %.3f  barB %.3f  rotate %.3f\n",
                     acc[0] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per, acc[5] / per, acc[6] / per);
         }
