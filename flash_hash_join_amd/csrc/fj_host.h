@@ -221,7 +221,7 @@ namespace fjh {
 struct Options {
     size_t radix_threshold = 0; int scalar_hbm_table = 0; u32 persistent_min_items = 8192; u32 plan_target_keys = FJ_PART_TARGET_KEYS;
     int bloom_variant = 0, bloom_auto = 1, bloom_auto_max_hit_bp = 2300, mat_single_pass = 1;     // (2300: measured break-even at c4 sizes is 24 % hits, profiles/r03_bloom_threshold.csv)
-    int join_wide = 2;                 // counting joins on the 16384-slot table (fj_join_wide.hip): 0 never, 1 whenever eligible, 2 (default) when the average final partition holds > FJ_WIDE_MIN_KEYS build keys and <= 32 probe chunks
+    int join_wide = 2;                 // counting joins on the bucketed 16384-slot table (fj_join_wide.hip): 0 never, 1 whenever eligible, 2 (default) when at most ~3 probe rows per build row reach the join (wide_join_planned)
     u32 lab_hooks = 0;                 // FJ_HOOK_* bits
     u32 join_items_target = 2048;      // work items the join of a plan with few partitions is cut into (tuning knob)
     Options();                         // initial values: FJ_OPTIONS="name=value,name=value" (the names of fj_set_option), the ONE environment variable behind all of them
@@ -240,7 +240,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s);
 int pass_launch(fj_ctx* c, PassIter& it, const u64* keys, const u64* vals, size_t n, hipStream_t s, int* ev_cursor);
 bool bloom_stage_follows(const PassIter& it, int level);
 void join_item_geometry(u64 nparts, size_t np, u64 chunk_bound, u32* tc, u64* max_items);
-bool wide_join_planned(bool materialize, size_t nb, size_t np, int bits);
+bool wide_join_planned(bool materialize, size_t nb, size_t np_eff, int bits);
 int level_finish(fj_ctx* c, PassIter& it, bool final_level, hipStream_t s);
 int pass_complete(fj_ctx* c, PassIter& it, hipStream_t s);
 int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s);

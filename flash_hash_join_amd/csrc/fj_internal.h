@@ -180,10 +180,9 @@ hipError_t fj_launch_lds_join(const FjLdsJoinArgs& a, bool materialize, hipStrea
 // the single-pass materialising join over chunk lists (a.out_cursor != nullptr; unique build keys: duplicates are reported, FJ_STAT_DUPS)
 hipError_t fj_launch_emit_single(const FjLdsJoinArgs& a, hipStream_t s, u32* next_item);
 // ---- counting join with a 16384-slot table, one 1024-thread workgroup per CU (csrc/fj_join_wide.hip) ----
-// for partitions whose build side is not thin against the probe side (> FJ_WIDE_MIN_KEYS build keys on average), and for the
-// multi-GPU build-broadcast form, whose build side arrives as dense per-partition runs from every rank (DENSE)
+// for joins whose build side is not small against the probe side (wide_join_planned, fj_plan.hip), and for the multi-GPU
+// build-broadcast form, whose build side arrives as dense per-partition runs from every rank (DENSE)
 #define FJ_WIDE_MAXSRC 16u
-#define FJ_WIDE_MIN_KEYS 3400u
 struct FjWideArgs {
     const u32* toff; u32 part_lo, part_hi;       // toff != nullptr: only the items of partitions [part_lo, part_hi) (toff = first item of every partition)
     // DENSE build side: source s keeps, at byte offsets into base, an offset table u32[nparts + 1] (keys before partition p), the keys'

@@ -59,6 +59,13 @@ constexpr u32 W_NOSLOT = 0xFFFFFFFFu;
 // the last partition - whose partition bits are all ones - can equal it
 constexpr u64 W_POISON2 = 0x00000000FFFFFFFFull;
 
+// a key's home: hash word 2's low bits name one of the table's WS / 2 16-byte PIECES - the bucket (the bits above the piece-in-bucket
+// bits) and the piece a lookup reads first (the order of a bucket's pieces is rotated per key, so that the lanes of a wave whose
+// buckets share LDS banks start at different pieces): the first address is one AND and one shift
+constexpr u32 NPCLOG = BSLOG - 1;
+__device__ __forceinline__ u32 w_bucket(u64 h) { return (FJ_HW2(h) >> NPCLOG) & (NBK - 1u); }
+__device__ __forceinline__ u32 w_piece0(u64 h) { return FJ_HW2(h) & (WS / 2u - 1u); }
+
 struct WHdr {
     u32 cnt, pad0[3];
     u32 unused0[2], full[2];               // full: per parity of the item whose keys are / go in the table
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             if (!((am >> (4 * g)) & 0xFu)) continue;               // (wave-uniform)
 #pragma unroll
             for (int j = 4 * g; j < 4 * g + 4; ++j)
-                if ((bok >> j) & 1u) old[j] = fill_add(f, FJ_HW2(bk[j]) & (NBK - 1u));
+                if ((bok >> j) & 1u) old[j] = fill_add(f, w_bucket(bk[j]));
         }
     };
     auto claim_resolve = [&](u32* f, const u64 (&bk)[8], u32 bok, u32 am, u32 par, const u32 (&old)[8], u32 (&sl)[8]) {
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
 #pragma unroll
             for (int j = 4 * g; j < 4 * g + 4; ++j) {
                 if (!((bok >> j) & 1u)) continue;
-                if (old[j] < BS) sl[j] = ((FJ_HW2(bk[j]) & (NBK - 1u)) << BSLOG) + old[j];
+                if (old[j] < BS) sl[j] = (w_bucket(bk[j]) << BSLOG) + old[j];
                 else pend |= 1u << j;
             }
         }
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
                 const u32 low = pend & (0u - pend);                // its bit alone
                 u32 b = 0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) b |= (FJ_HW2(bk[t]) & (NBK - 1u)) & (0u - ((low >> t) & 1u));
+                for (int t = 0; t < 8; ++t) b |= w_bucket(bk[t]) & (0u - ((low >> t) & 1u));
                 u32 got = W_NOSLOT, step = 0;
                 bool c = pend != 0;
                 do {
@@ -329,19 +336,17 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         u32 bkt[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const u32 lo = FJ_HW2(k[i]);
-            bkt[i] = lo & (NBK - 1u);
-            const u32 r = (lo >> NBKLOG) & (NPC - 1u);             // rotation of the pieces: lanes whose buckets share LDS banks start at different pieces
-            const unsigned char* bp = tb + ((size_t)bkt[i] << (BSLOG + 3));
+            const u32 p0 = w_piece0(k[i]);
+            bkt[i] = p0 >> NPCLOG;
 #pragma unroll
-            for (u32 j = 0; j < NPC; ++j) pc[i][j] = *reinterpret_cast<const uint4*>(bp + (((j ^ r) & (NPC - 1u)) << 4));
+            for (u32 j = 0; j < NPC; ++j) pc[i][j] = *reinterpret_cast<const uint4*>(tb + ((p0 ^ j) << 4));     // piece (r ^ j) of the bucket, r = p0 & (NPC - 1)
         }
         __builtin_amdgcn_sched_barrier(0);
         u32 hits = 0, cm = 0;                                      // cm: per lane, the keys that must look into the next bucket
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const u32 lo = FJ_HW2(k[i]), hi = FJ_HW1(k[i]);
-            const u32 r = (lo >> NBKLOG) & (NPC - 1u);
+            const u32 hi = FJ_HW1(k[i]);
+            const u32 r = FJ_HW2(k[i]) & (NPC - 1u);
             const bool ok = kidx[i] < n;
             bool f = false;
 #pragma unroll
@@ -350,12 +355,17 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
                 f |= (e0 == k[i]) | (e1 == k[i]);
             }
             // the bucket's LAST slot (piece NPC - 1, read as piece (NPC - 1) ^ r of this lane's order): an entry of the partition in place = full
-            u32 last_hi = pc[i][0].w;
+            // (bitwise operators on the flags: && would put every key's test into a branch of its own)
+            u32 last_hi;
+            if constexpr (NPC == 2) last_hi = r ? pc[i][0].w : pc[i][1].w;
+            else {
+                last_hi = pc[i][0].w;
 #pragma unroll
-            for (u32 j = 1; j < NPC; ++j) last_hi = (((NPC - 1u) ^ r) == j) ? pc[i][j].w : last_hi;
-            const bool c = !f && (((last_hi ^ hi) & pmask) == 0u) && ok;
+                for (u32 j = 1; j < NPC; ++j) last_hi = (((NPC - 1u) ^ r) == j) ? pc[i][j].w : last_hi;
+            }
+            const bool c = (!f) & (((last_hi ^ hi) & pmask) == 0u) & ok;
             cm |= c ? 1u << i : 0u;
-            hits += (u32)__popcll(__ballot(f && ok));
+            hits += (u32)__popcll(__ballot(f & ok));
         }
         // the walk (1.5 % of the buckets are full at load 0.23: a lane or two of most chunks): a lane's walking keys one after the other -
         // only the COUNT of the hits matters, so nothing is handed back per key

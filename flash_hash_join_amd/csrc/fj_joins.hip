@@ -307,6 +307,8 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
     if (wide) {
         FjWideArgs wa{};
         wa.pmask = fj_wide_pmask(plan.bits, top_bits);
+        // a partition's probe side cut into several items (items hold <= 32 chunks): dealt in runs of 8, a run's items of one partition share one table build
+        wa.group_log = np / ((size_t)1 << plan.bits) > 7000 ? 3u : 0u;
         FjLdsJoinArgs jw = ja;
 #ifdef FJ_LAB
         if (getenv("FJ_WIDE_STAMPS") && stamps_begin(&jw.dbg, s)) return 1;      // (diagnostic: where a workgroup's time goes, per pipeline stage)
@@ -322,8 +324,8 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
             u32 nit = 0;
             HIPCHK(hipMemcpy(&nit, jw.nitems_dev, 4, hipMemcpyDeviceToHost));           // (nitems is the table's capacity)
             const double per = (double)std::min<u32>(grid, 4096) * ((double)nit / grid);
-            fprintf(stderr, "[FJ_WIDE_STAMPS] us per item (thread 0): requests %.3f  probe %.3f  park %.3f  barA %.3f  insert %.3f  barB %.3f  rotate %.3f\n",
-                    acc[0] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per, acc[5] / per, acc[6] / per);
+            fprintf(stderr, "[FJ_WIDE_STAMPS] us per item (thread 0): rotate+requests %.3f  claim_issue+zero %.3f  barB %.3f  probe %.3f  resolve+park %.3f  barA %.3f  stores %.3f\n",
+                    acc[0] / per, acc[5] / per, acc[6] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per);
         }
     } else
     HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item, options().persistent_min_items));
@@ -414,7 +416,13 @@ int join_radix(fj_ctx* c, int materialize, int bloom, const u64* bk, const u64* 
     }
     pass_init(pit, 1, false, np, pplan, top_bits);
     pit.want_items = true;
-    if (plan.bloom_level == 0 && wide_join_planned(materialize != 0, nb, np, plan.bits)) pit.item_tc_max = 32;
+    {
+        // probe rows that will reach the join: behind the filter the sampled hit rate + what the filter lets through (~10 % of the misses);
+        // a filter that was asked for by name (no sample) is taken to be there for a reason: 15 %
+        size_t np_eff = np;
+        if (plan.bloom_level > 0) np_eff = (size_t)((double)np * (t->sampled_hit_bp >= 0 ? std::min(10000, t->sampled_hit_bp + 1000) : 1500) / 10000.0);
+        if (wide_join_planned(materialize != 0, nb, np_eff, plan.bits)) pit.item_tc_max = 32;
+    }
     // bloom precheck: the probe side's level `bloom_level` is filtered against the build side's same level
     if (plan.bloom_level > 0) pit.bloom_build = &bit.saved;
     if (run_passes(c, pit, pk, nullptr, s, &ja.probe, &evc)) return 1;

@@ -10,7 +10,7 @@ def _rand(rng, n):
 
 def make_case(name):
     """Returns (build_keys, build_values, probe_keys) as uint64 arrays."""
-    seed = {n: i + 1 for i, n in enumerate(CASES)}[name]
+    seed = {n: i + 1 for i, n in enumerate(CASES + BIG_CASES)}[name]
     rng = np.random.default_rng(1000 + seed)
     if name == "tiny":
         bk = np.array([5, 1, 9, 0, 2**64 - 1], dtype=np.uint64)
@@ -56,10 +56,19 @@ def make_case(name):
         bk = np.unique(_rand(rng, 70001))[:65537]
         bv = _rand(rng, bk.size)
         pk = np.concatenate([rng.choice(bk, 33333), _rand(rng, 44444)])[:77777 - 2]
+    elif name == "big_two_pass_wide":         # 21M x 50M rows: a two-pass plan and <= 3 probe rows per build row (the bucketed wide join kernel by default)
+        rng = np.random.default_rng(77)
+        bk = np.unique(_rand(rng, 21_000_000))
+        bv = bk * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)
+        pk = np.concatenate([rng.choice(bk, 25_000_000), _rand(rng, 25_000_000)])
+        rng.shuffle(pk)
     else:
         raise KeyError(name)
     return bk, bv, pk
 
+
+# cases of tens of millions of rows: count + pair digest only, run once (not under every dispatch mode)
+BIG_CASES = ["big_two_pass_wide"]
 
 CASES = ["tiny", "small_unique_50", "mid_unique_50", "two_pass_unique_5", "dup_build_same_value",
          "dup_probe_all_hit", "all_miss", "extreme_keys", "sequential_keys", "ragged_sizes"]

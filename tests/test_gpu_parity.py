@@ -73,6 +73,54 @@ def test_all_twelve_functions_match_golden_vectors(fj, oracle, name, scalar_mode
         assert _digest(oracle, k, v) == g["pairs_sha256"], fn
 
 
+def test_big_golden_case_two_pass_plan_and_the_wide_join_kernel(fj, oracle):
+    """A committed fixture of 21M x 50M rows (tests/golden/golden_joins.json: count and pair digest by the C restatement AND the
+    NumPy oracle, tests/golden/make_golden.py): a two-pass plan and the bucketed wide join kernel meet a golden vector, not only
+    the generator's closed form.  Counting functions under the default dispatch, with the wide kernel forced on and off; pairs once."""
+    from golden_inputs import BIG_CASES
+    for name in BIG_CASES:
+        g = _golden()[name]
+        bk, bv, pk = make_case(name)
+        assert bk.size == g["nb"] and pk.size == g["np"]
+        for wide in (2, 1, 0):
+            fj.set_option("join_wide", wide)
+            try:
+                for fn in ("hash_join_count_radix", "adaptive_join_count", "hash_join_count_radix_bloom"):
+                    n, _ = getattr(fj, fn)(bk, bv, pk)
+                    assert n == g["count"], (name, fn, wide, n, g["count"])
+                    lt = fj.last_timings()
+                    assert lt["passes"] == 2 and lt["fell_back"] == 0 and lt["lds_retries"] == 0, lt
+            finally:
+                fj.set_option("join_wide", 2)
+        n, _, k, v = fj.hash_join_radix(bk, bv, pk, return_arrays=True)
+        assert n == g["count"] and _digest(oracle, k, v) == g["pairs_sha256"]
+
+
+def test_bench_line_at_one_gpu_is_self_consistent(fj):
+    """`python bench.py --steps 3` (N = 1, the headline configuration) prints ONE JSON line whose per-kernel accounting adds up:
+    every kernel's fraction of the HBM peak is <= 1, and the timed kernels' launch time x launches per step does not exceed the
+    step (they run one after the other on one stream)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-entry"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["config"]["bench_workload"] == "c3" and d["dtype"] == "int64" and d["vs_baseline"] is None
+    assert d["config"]["build_rows_total"] == 100_000_000 and d["config"]["probe_rows_total"] == 1_000_000_000
+    rows = d["roofline_kernels"]
+    assert rows and all(0 < r["frac"] <= 1.0 for r in rows), rows
+    kernel_ms = sum(r["avg_launch_ms"] * r["launches_per_step"] for r in rows)
+    assert kernel_ms <= d["ms_per_step"] * 1.001, (kernel_ms, d["ms_per_step"])
+    assert kernel_ms >= 0.8 * d["ms_per_step"], (kernel_ms, d["ms_per_step"])      # ... and they ARE the step: nothing big goes untimed
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == rows[0]["kernel"] and r["frac"] == rows[0]["frac"] and 0 < r["frac"] <= 1.0
+    assert abs(d["value"] - 1e9 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+
+
 def test_against_c_oracle_on_fresh_random_inputs(fj, oracle, scalar_mode):
     rng = np.random.default_rng(2024)
     for nb, npk in [(1, 1), (2, 3), (255, 1000), (4096, 50000), (4097, 50000), (30000, 1), (123457, 654321)]:
@@ -886,6 +934,8 @@ def test_shuffled_stream_recovers_from_an_oversized_partition(fj):
     (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom", 0),         # BASELINE config 4 as named
     (100_000_000, 1_000_000_000, 500, "hash_join_count_bloom", 1),         # ... non-partitioned HBM table + bloom precheck
     (1_000_000, 10_000_000, 5000, "adaptive_join_count", 0),               # BASELINE config 1 sizes on the device
+    (1_000_000, 10_000_000, 5000, "hash_join_count", 0),                   # ... and through the function config 1 names ("flash_join scalar path")
+    (1_000_000, 10_000_000, 5000, "hash_join_count", 1),                   # ... literally: one table, linear probing
     (300_000_000, 300_000_000, 5000, "hash_join_count_radix", 0),          # 17 radix bits: an 8-bit and a 9-bit pass
     (800_000_000, 200_000_000, 5000, "hash_join_count_radix", 0),          # 18 bits (9 + 9): the replicated build side of 8 GPUs
     (50_000_000, 3_900_000_000, 2500, "hash_join_count_radix", 0),         # probe side close to the 2^24-chunk directory limit (~4.0e9 rows)
