@@ -10,16 +10,20 @@ uniform-random int64 keys that are already resident in HBM when the timed region
           hash_join_count_radix, 100M build x 1B probe rows, 50 % hit rate, one MI355X.
   N > 1 : workload "c5" = BASELINE.json configs[4] cut into its per-GPU shards: 125M build x 1.25B probe rows
           PER GPU (1B x 10B at N = 8; the same shard size at N = 2 and 4: weak scaling), block-distributed,
-          joined with the owner shuffle - an RCCL all-to-all per relation over xGMI
-          (flash_hash_join_amd/distributed.py).  `python bench.py --gpus N` without a torchrun environment
-          starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process (before
-          anything touches the GPU) and relays its output and exit code.
+          joined in the form the C++ driver's cost model picks for those sizes and the link rate measured at
+          start-up (flash_hash_join_amd/distributed.py, csrc/fj_dist.hip) - for configs[4] the BUILD
+          BROADCAST (the probe rows stay, every rank's partitioned build rows travel to every peer over
+          xGMI, 6 bytes per key); north_star's all-to-all of radix partitions, the OWNER SHUFFLE, is
+          measured beside it in the same line (`alt_strategy`, with its own roofline block and wire bytes).
+          FJ_DIST_STRATEGY=broadcast|shuffle|scatter pins the timed form.  `python bench.py --gpus N` without
+          a torchrun environment starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+          child process (before anything touches the GPU) and relays its output and exit code.
 
 value = probes processed by all ranks / wall time of the K timed steps (max over ranks), in
 G probes/s, end to end (build side included).  The probe-phase-only rate, the build time, the
 roofline of the dominant kernel (probe-side partition pass) and the CPU baseline (the oracle's
-restatement of the reference algorithm on this box's host cores, bounded sample) ride along in the
-same JSON line.
+restatement of the reference algorithm on this box's host cores, bounded sample; at N > 1: rank 0
+runs the config-3-size join, labelled as such) ride along in the same JSON line.
 """
 from __future__ import annotations
 
@@ -35,7 +39,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same guide
-HBM_POOL_COPY_GBS = 5621.0     # this pool's MI355X boxes: best plain read-one-write-one copy, tools/ubench_copy.hip (profiles/r01_ubench_copy.csv).
+HBM_POOL_COPY_GBS = 5745.0     # this pool's MI355X boxes: best plain read-one-write-one copy of a 158-point sweep (tools/ubench_copy2.hip, profiles/r06_ubench_copy.csv:
+                               # 8-32 GiB, grid-stride and persistent-slice kernels, 1-8 loads in flight, nontemporal or not; hipMemcpyDtoD: 4.8-5.3 TB/s; round 1's 4 x 4 sweep: 5621).
                                # A radix pass streams 8 B in and 8 B out per key: a copy is its ceiling.  (Rounds 1-3 also quoted a
                                # "scatter ceiling" of 5038 GB/s from one grid size of tools/ubench_scatter.hip; the same benchmark reaches
                                # 5.2-5.5 TB/s with other grids - profiles/r02_ubench_scatter_by_grid.csv - and the pass ran at 1.008 of
@@ -202,6 +207,25 @@ def host_entry(device) -> dict:
             "device_resident_ms": round(lt["total_ms"], 3), "streamed_under_copy": bool(lt["host_streamed"])}
 
 
+def dist_roofline(strategy: str, part_ms, launches: int, units: float, wire_chunk_bytes) -> dict:
+    """Roofline block of a multi-GPU step's dominant kernel, the probe-side radix pass: over this rank's own probe rows (build
+    broadcast, owner scatter: 8 B read + 8 B written per key) or over a received piece in the wire format (owner shuffle: 7 B read
+    when the chunks are 1792 bytes, + 8 B written); launch times by HIP events on the join stream (fj_timings.probe_part_kernel_ms)."""
+    avg_ms = sum(part_ms) / len(part_ms)
+    bpu = 8.0 + (float(wire_chunk_bytes) / 256.0 if (strategy == "owner-shuffle" and wire_chunk_bytes) else 8.0)
+    alg_bytes = bpu * units
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+    return {"bound": "hbm", "kernel": "fj_partition_kernel<keys-only> (the owner's radix pass over a received piece)" if strategy == "owner-shuffle" else
+            "fj_partition_kernel<keys> (a probe-side radix pass over this rank's own probe rows)" if strategy == "build-broadcast" else
+            "fj_partition_kernel<keys> (a probe-side radix pass of the owner's join over the rows it received)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+            "frac_of_this_pools_copy_rate": round(achieved / HBM_POOL_COPY_GBS, 4),
+            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": bpu, "units_per_launch": units,
+            "note": "launch time by HIP events on the join stream: at N > 1 the pass shares the GPU with the exchange's kernels and the next piece's packing kernels (other streams), so this is an upper bound of the kernel's own time",
+            "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches, "traffic": None}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +236,8 @@ def main() -> None:
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-entry", action="store_true", help="skip the PCIe-inclusive measurement of the NumPy entry")
+    ap.add_argument("--selfcheck-timeout", type=float, default=240.0, help="N > 1: seconds the pre-flight may take before the run is declared stuck")
+    ap.add_argument("--selfcheck-corrupt", action="store_true", help=argparse.SUPPRESS)      # test hook: rank 0 flips one received bit in the pre-flight exchange
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "c3" if args.gpus == 1 else "c5"
@@ -256,11 +282,9 @@ def main() -> None:
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         _flush_c_stdio()
-        if force_dist:
-            os.environ["FJ_FORCE_EXCHANGE"] = "1"
         # `value` at N > 1: what an unconfigured job runs - the form the C++ driver's cost model picks for the step's sizes with the
         # link rate measured below (fj_dist_model: build broadcast or owner shuffle); the other form is measured beside it as
-        # `alt_strategy`, never instead of it.  FJ_DIST_STRATEGY=shuffle|broadcast|replicate pins the timed form.
+        # `alt_strategy`, never instead of it.  FJ_DIST_STRATEGY=broadcast|shuffle|scatter pins the timed form.
         pinned_strategy = os.environ.get("FJ_DIST_STRATEGY")
         if pinned_strategy in ("", "auto"):
             pinned_strategy = None
@@ -310,9 +334,7 @@ def main() -> None:
             # pinned for the self-check and the timed steps so that what was checked is what is timed
             form_pick = _D.form_model(world, nb_gpu, np_gpu)
             if materialize or world == 1:
-                form_pick = dict(form_pick, pick="shuffle", note="one rank / materialising: the shuffle (FJ_BENCH_FORCE_FORM=broadcast times the other form on one rank)")
-            if os.environ.get("FJ_BENCH_FORCE_FORM"):
-                form_pick = dict(form_pick, pick=os.environ["FJ_BENCH_FORCE_FORM"])
+                form_pick = dict(form_pick, pick="shuffle", note="one rank / materialising: the shuffle (FJ_DIST_STRATEGY=broadcast times the other form on one rank)")
             os.environ["FJ_DIST_STRATEGY"] = form_pick["pick"]
         timed_strategy = os.environ["FJ_DIST_STRATEGY"]
 
@@ -341,20 +363,20 @@ def main() -> None:
         done = threading.Event()
 
         def watchdog():
-            if not done.wait(float(os.environ.get("FJ_BENCH_SELFCHECK_TIMEOUT", "240"))):
+            if not done.wait(args.selfcheck_timeout):
                 if rank == 0:
                     print(error_line("the multi-rank self-check did not finish (a collective is stuck)", None), flush=True)
                 os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
         # the default protocol first (chunk-form shuffle through the native entry); a form that fails its check - the ranks agree
         # on that - is replaced by the next simpler one, and the line says which one was timed
-        shuffle_forms = [("chunks (fj_dist_join_count over RCCL)", {"FJ_DIST_STRATEGY": "shuffle"}),
-                         ("chunks (fj_dist_join_count over torch.distributed callbacks)", {"FJ_DIST_STRATEGY": "shuffle", "FJ_DIST_NATIVE": "0"}),
-                         ("owner-scatter", {"FJ_DIST_STRATEGY": "shuffle", "FJ_DIST_NATIVE": "0", "FJ_DIST_CHUNK_SHUFFLE": "0"})]
-        forms = {"broadcast": [("build broadcast (fj_dist_join_count over RCCL)", {"FJ_DIST_STRATEGY": "broadcast"}),
-                               ("build broadcast (fj_dist_join_count over torch.distributed callbacks)", {"FJ_DIST_STRATEGY": "broadcast", "FJ_DIST_NATIVE": "0"})] + shuffle_forms,
-                 "replicate": [("replicate (all-gather of the build keys)", {"FJ_DIST_STRATEGY": "replicate"})] + shuffle_forms}.get(timed_strategy, shuffle_forms)
-        user_pins = {k: os.environ[k] for k in ("FJ_DIST_NATIVE", "FJ_DIST_CHUNK_SHUFFLE") if k in os.environ}
+        scatter_form = [("owner-scatter", {"FJ_DIST_STRATEGY": "scatter"})]
+        shuffle_forms = [("chunks (fj_dist_join over RCCL)", {"FJ_DIST_STRATEGY": "shuffle"}),
+                         ("chunks (fj_dist_join over torch.distributed callbacks)", {"FJ_DIST_STRATEGY": "shuffle", "FJ_DIST_NATIVE": "0"})] + scatter_form
+        forms = {"broadcast": [("build broadcast (fj_dist_join over RCCL)", {"FJ_DIST_STRATEGY": "broadcast"}),
+                               ("build broadcast (fj_dist_join over torch.distributed callbacks)", {"FJ_DIST_STRATEGY": "broadcast", "FJ_DIST_NATIVE": "0"})] + shuffle_forms,
+                 "scatter": scatter_form}.get(timed_strategy, shuffle_forms)
+        user_pins = {k: os.environ[k] for k in ("FJ_DIST_NATIVE",) if k in os.environ}
         if pinned_strategy is not None:
             user_pins["FJ_DIST_STRATEGY"] = pinned_strategy
         tried = []
@@ -362,13 +384,15 @@ def main() -> None:
             if any(k in user_pins and user_pins[k] != v for k, v in env.items()):
                 continue                                     # the user pinned a form: honour it
             os.environ.update(env)
-            selfcheck = self_check(dist, None, engine, (sbk, sbv, spk), int(e.item()), msg, transport=transport)
+            selfcheck = self_check(dist, None, engine, (sbk, sbv, spk), int(e.item()), msg, transport=transport, corrupt=args.selfcheck_corrupt)
             selfcheck["shuffle_form_checked"] = name
             tried.append({"form": name, "ok": selfcheck["ok"], "error": selfcheck["error"]})
             if selfcheck["ok"]:
                 break
         timed_strategy = os.environ["FJ_DIST_STRATEGY"]
         selfcheck["forms_tried"] = tried
+        if selfcheck.get("precheck") and selfcheck["precheck"].get("action"):      # the precheck failed its check (the ranks agree): off for the timed steps
+            os.environ["FJ_DIST_PREFILTER"] = "0"
         done.set()
         del sbk, sbv, spk
         if not selfcheck["ok"]:
@@ -416,7 +440,7 @@ def main() -> None:
             res = api.join_device(algo, bloom, materialize, bk, bv, pk, return_arrays=False)
         else:
             t = {}
-            res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t, transport=transport)
+            res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t, transport=transport, force_exchange=force_dist)
             if t.get("prefilter_sampled_survivors") is not None:       # (warm-up steps included: "auto" samples once per shape, then remembers)
                 dsampled.update(survivors=t["prefilter_sampled_survivors"], below=t.get("prefilter_below"))
             if record:
@@ -428,14 +452,14 @@ def main() -> None:
             if world == 1 and not force_dist:
                 npart = 0
                 record_kernels(lt)
-            elif t.get("strategy") == "replicate":
-                npart = 1                                  # probe rows never move: one first-pass launch over all of them
-                units_per_launch[0] = t.get("local_probe_rows", np_gpu)
-                strategy_seen[0] = "replicate-build"
             elif t.get("strategy") == "broadcast":
                 npart = min(4, int(lt["passes"]))          # probe rows never move: the plan's passes, each over all of this rank's probe rows
                 units_per_launch[0] = float(np_gpu)
                 strategy_seen[0] = "build-broadcast"
+            elif t.get("strategy") == "scatter":
+                npart = min(4, int(lt["passes"]))          # the owner's plain single-GPU join of what it received
+                units_per_launch[0] = float(t.get("local_probe_rows", np_gpu))
+                strategy_seen[0] = "owner-scatter"
             else:
                 npart = min(4, int(t.get("pieces", 0)))    # pipelined exchange: first-pass launches, one per received piece
                 units_per_launch[0] = t.get("local_probe_rows", np_gpu) / max(1, int(t.get("pieces", 1)))
@@ -515,20 +539,7 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
                 "launches_timed": int(round(d["launches_per_step"] * args.steps)), "traffic": traffic}
     elif part_ms:
-        # multi-GPU: the first probe-side pass over what this rank received (one launch per piece / per step)
-        avg_ms = mean(part_ms)
-        # chunk form: the owner's pass reads the wire format (7 bytes per key when wire_chunk_bytes == 1792) and writes 8
-        bpu = 8.0 + (float(dlast["wire_chunk_bytes"]) / 256.0 if dlast.get("wire_chunk_bytes") else 8.0)
-        alg_bytes = bpu * units_per_launch[0]
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "fj_partition_kernel<keys> (a probe-side radix pass over this rank's own probe rows)" if strategy_seen[0] == "build-broadcast" else
-                "fj_partition_kernel<keys-only> (the owner's radix pass over a received piece)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
-                "frac_of_this_pools_copy_rate": round(achieved / HBM_POOL_COPY_GBS, 4),
-                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_unit": bpu, "units_per_launch": units_per_launch[0],
-                "note": "launch time by HIP events on the join stream: at N > 1 the pass shares the GPU with the next piece's packing kernels (other streams), so this is an upper bound of the kernel's own time",
-                "avg_launch_ms": round(avg_ms, 4), "launches_timed": part_launches, "traffic": None}
+        roof = dist_roofline(strategy_seen[0], part_ms, part_launches, units_per_launch[0], dlast.get("wire_chunk_bytes"))
     else:
         # non-partitioned workloads (one table in HBM): the probe kernel dominates; 8 B per probe key
         avg_ms = mean(phase["join_ms"])
@@ -603,57 +614,75 @@ def main() -> None:
             out["host_entry"] = host_entry(device)
         except Exception as ex:
             out["host_entry"] = {"error": repr(ex)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            # full workload on the host when it fits (the oracle needs ~2.5x the input bytes), else a 1/10 sample
-            import psutil
-            need = (nb_gpu * 16 + np_gpu * 8) * 2.5
-            full = psutil.virtual_memory().available > need + (8 << 30)
-            sb, sp = (nb_gpu, np_gpu) if full else (max(1, nb_gpu // 10), max(1, np_gpu // 10))
-            try:
-                del bk, bv, pk
-            except NameError:
-                pass
-            torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
-        except Exception as ex:      # the baseline never blocks the GPU measurement
-            out["cpu_baseline"] = {"error": repr(ex)}
-        # BASELINE.md section 4: "Configs 1-2 always" - the reference's own CPU-runnable cases (hash_join_count, one table),
-        # a few seconds each
-        for tag, cb, cp in (("cpu_baseline_c1", 1_000_000, 10_000_000), ("cpu_baseline_c2", 1_000_000, 100_000_000)):
-            try:
-                out[tag] = cpu_baseline(device, cb, cp, 5000, algo="scalar", budget_s=6.0)
-            except Exception as ex:
-                out[tag] = {"error": repr(ex)}
     if link is not None:
         out["xgmi_all_to_all"] = link
     if selfcheck is not None:
         out["self_check"] = selfcheck
-    if world > 1 and not materialize:
-        # the form the model did NOT pick (or, for a pinned run, the broadcast / the shuffle), a second, labelled measurement
+    if (world > 1 or force_dist) and not materialize and timed_strategy in ("broadcast", "shuffle"):
+        # the OTHER form of the step - the owner shuffle (north_star's all-to-all of radix partitions) when the broadcast was timed, and
+        # the other way round - as a second, labelled measurement with its own roofline block and wire bytes; never `value`
         main = dlast.get("strategy", timed_strategy)
         alt = "shuffle" if main == "broadcast" else "broadcast"
-        os.environ["FJ_DIST_STRATEGY"] = alt
         try:
             asteps = max(1, min(3, args.steps))
             ta_ = {}
-            got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport, timings=ta_)[0]      # untimed (workspace growth)
+            a_part, a_launch, a_units, a_label = [], 0, float(np_gpu), "owner-shuffle" if alt == "shuffle" else "build-broadcast"
+            got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport, timings=ta_, strategy=alt, force_exchange=force_dist)[0]      # untimed (workspace growth)
             sync()
             ta = time.perf_counter()
             for _ in range(asteps):
-                got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport, timings=ta_)[0]
+                got = distributed_join(bk, bv, pk, bloom=bool(bloom), engine=engine, transport=transport, timings=ta_, strategy=alt, force_exchange=force_dist)[0]
+                lta = api.last_timings()
+                if ta_.get("strategy") == "broadcast":
+                    npart_a, a_units, a_label = min(4, int(lta["passes"])), float(np_gpu), "build-broadcast"
+                elif ta_.get("strategy") == "scatter":
+                    npart_a, a_units, a_label = min(4, int(lta["passes"])), float(ta_.get("local_probe_rows", np_gpu)), "owner-scatter"
+                else:
+                    npart_a, a_units, a_label = min(4, int(ta_.get("pieces", 0))), ta_.get("local_probe_rows", np_gpu) / max(1, int(ta_.get("pieces", 1))), "owner-shuffle"
+                for i in range(npart_a):
+                    a_part.append(lta["probe_part_kernel_ms"][i]); a_launch += 1
             sync()
             ea = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=device)
-            dist.all_reduce(ea, op=dist.ReduceOp.MAX)
-            out["alt_strategy"] = {"strategy": {"shuffle": "owner-shuffle", "broadcast": "build-broadcast"}.get(ta_.get("strategy"), ta_.get("strategy")),
+            if world > 1:
+                dist.all_reduce(ea, op=dist.ReduceOp.MAX)
+            out["alt_strategy"] = {"strategy": a_label, "asked_for": alt,
                                    "form": ta_.get("shuffle_form"), "steps": asteps, "ms_per_step": round(float(ea.item()) / asteps * 1e3, 3),
                                    "value": round(np_total * asteps / float(ea.item()) / 1e9, 3), "unit": "Gprobes/s", "count_ok": int(got) == exp_total,
-                                   "wire_bytes_sent_rank0": ta_.get("wire_bytes_sent"),
+                                   "wire_bytes_sent_rank0": ta_.get("wire_bytes_sent"), "wire_chunk_bytes": ta_.get("wire_chunk_bytes"),
+                                   "roofline": dist_roofline(a_label, a_part, a_launch, a_units, ta_.get("wire_chunk_bytes")) if a_part else None,
+                                   "fell_to": None if ta_.get("strategy") == alt else ta_.get("strategy"),
+                                   "errors": {k: ta_[k] for k in ("broadcast_form_error", "chunk_form_error") if ta_.get(k)} or None,
                                    "note": "not `value`: the other form of the multi-GPU step, measured beside the timed one"}
         except Exception as ex:
             out["alt_strategy"] = {"strategy": alt, "error": repr(ex)}
-        finally:
-            os.environ["FJ_DIST_STRATEGY"] = timed_strategy
+    if rank == 0 and not args.no_cpu_baseline and not force_dist:
+        try:
+            # N = 1: the full workload on the host when it fits (the oracle needs ~2.5x the input bytes), else a 1/10 sample.
+            # N > 1: rank 0 runs the config-3-size join (100M x 1B) and the block says so ("c5's CPU column is the
+            # config-3-size run, labelled as such"); the other ranks wait at the final barrier meanwhile.
+            import psutil
+            cb_, cp_ = (nb_gpu, np_gpu) if world == 1 else (int(100_000_000 * args.scale) or 1, int(1_000_000_000 * args.scale) or 1)
+            need = (cb_ * 16 + cp_ * 8) * 2.5
+            full = psutil.virtual_memory().available > need + (8 << 30)
+            sb, sp = (cb_, cp_) if full else (max(1, cb_ // 10), max(1, cp_ // 10))
+            if world == 1:
+                try:
+                    del bk, bv, pk
+                except NameError:
+                    pass
+                torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(device, sb, sp, hit_bp)
+            if world > 1:
+                out["cpu_baseline"]["sample"] = "config-3-size run on rank 0's host cores (not this step's 1/N share of config 5): " + out["cpu_baseline"]["sample"]
+        except Exception as ex:      # the baseline never blocks the GPU measurement
+            out["cpu_baseline"] = {"error": repr(ex)}
+        # BASELINE.md section 4: "Configs 1-2 always" - the reference's own CPU-runnable cases (hash_join_count, one table),
+        # a few seconds each
+        for tag, cb, cp in (("cpu_baseline_c1", 1_000_000, 10_000_000), ("cpu_baseline_c2", 1_000_000, 100_000_000)) if world == 1 else ():
+            try:
+                out[tag] = cpu_baseline(device, cb, cp, 5000, algo="scalar", budget_s=6.0)
+            except Exception as ex:
+                out[tag] = {"error": repr(ex)}
     if priming:
         out["priming_steps"] = priming
     if share_gpu:

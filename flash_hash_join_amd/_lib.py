@@ -1,7 +1,11 @@
-"""ctypes binding of libflashjoin_hip.so (C ABI: include/flashjoin.h).
+"""ctypes binding of libflashjoin_hip.so (C ABI: include/flashjoin.h, 40 entry points).
 
 There is no CPU fallback: if the HIP library is missing or cannot be loaded, importing the join
 API raises, and every call on a box without a HIP device fails with the library's error string.
+
+The building blocks behind the ABI (include/flashjoin_lab.h: stream joins, the pieces of the multi-GPU driver, the partition
+diagnostic) are not exported by the product library.  FJ_LIB_VARIANT=lab loads libflashjoin_hip_lab.so - the same objects linked
+without the export list - for the test-suite and the measurement tools (flash_hash_join_amd/lab.py).
 """
 from __future__ import annotations
 
@@ -10,30 +14,39 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# FJ_LIB_VARIANT=<name>: load lib/ab/<name>.so instead (same-box A/B of two builds of the library, tools/r5_wide_ab.sh; the in-tree
-# library itself is never overwritten by a measurement script)
-LIB_PATH = (os.path.join(_PKG, "lib", "ab", os.environ["FJ_LIB_VARIANT"] + ".so") if os.environ.get("FJ_LIB_VARIANT")
-            else os.path.join(_PKG, "lib", "libflashjoin_hip.so"))
+# FJ_LIB_VARIANT=lab: the library with the internal entry points visible; any other <name>: lib/ab/<name>.so (same-box A/B of two
+# builds of the library, tools/mk_lib_variant.sh: linked with everything visible; the in-tree library is never overwritten by a
+# measurement script)
+VARIANT = os.environ.get("FJ_LIB_VARIANT", "")
+LIB_PATH = (os.path.join(_PKG, "lib", "libflashjoin_hip.so") if not VARIANT
+            else os.path.join(_PKG, "lib", "libflashjoin_hip_lab.so") if VARIANT == "lab"
+            else os.path.join(_PKG, "lib", "ab", VARIANT + ".so"))
+PRODUCT_LIB_PATH = os.path.join(_PKG, "lib", "libflashjoin_hip.so")
+LAB_LIB_PATH = os.path.join(_PKG, "lib", "libflashjoin_hip_lab.so")
+ABI_VERSION = 6                     # include/flashjoin.h: FJ_ABI_VERSION
 CSRC = os.path.join(_PKG, "csrc")
 
-# every symbol include/flashjoin.h declares
+# every symbol include/flashjoin.h declares (what libflashjoin_hip.so exports: csrc/exports.map)
 SYMBOLS = [
-    "fj_initialize", "fj_last_error", "fj_device_count", "fj_version", "fj_key_mix64", "fj_key_unmix64",
-    "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_reserve_cus", "fj_ctx_workspace_bytes", "fj_ctx_trim", "fj_stream_abort",
-    "fj_join_host", "fj_free_host", "fj_last_timings",
-    "fj_join_device", "fj_emit_pairs", "fj_owner_split", "fj_owner_hist", "fj_owner_scatter",
-    "fj_set_option", "fj_get_option",
-    "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe",
-    "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
-    "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
-    "fj_shuffle_plan", "fj_shuffle_chunk_bytes", "fj_shuffle_pack_begin", "fj_shuffle_pack_counts", "fj_shuffle_pack_finish", "fj_stream_open_shuffled",
+    "fj_initialize", "fj_last_error", "fj_device_count", "fj_version", "fj_abi_version", "fj_set_option", "fj_get_option", "fj_key_mix64", "fj_key_unmix64",
+    "fj_ctx_create", "fj_ctx_destroy", "fj_ctx_workspace_bytes", "fj_ctx_trim",
+    "fj_join_host", "fj_free_host", "fj_last_timings", "fj_join_device", "fj_emit_pairs",
+    "fj_owner_split", "fj_stream_abort", "fj_shuffle_plan", "fj_bcast_plan",
+    "fj_dist_comm_set_form", "fj_dist_model", "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_from_transport",
+    "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size", "fj_dist_join_count", "fj_dist_join",
+    "fj_generate_build", "fj_generate_probe",
+    "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h", "fj_memcpy_d2d",
+]
+# ... and include/flashjoin_lab.h (visible in libflashjoin_hip_lab.so only)
+LAB_SYMBOLS = [
+    "fj_owner_hist", "fj_owner_scatter",
+    "fj_shuffle_chunk_bytes", "fj_shuffle_pack_begin", "fj_shuffle_pack_counts", "fj_shuffle_pack_finish", "fj_stream_open_shuffled",
     "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
     "fj_shuffle_part_filter_bytes", "fj_shuffle_part_filter_range", "fj_stream_export_part_filters", "fj_shuffle_pack_filter", "fj_shuffle_pack_kept", "fj_part_filter_sample",
-    "fj_bcast_plan", "fj_bcast_region_bytes", "fj_bcast_piece_span", "fj_bcast_pack", "fj_bcast_pack_bounds", "fj_bcast_probe", "fj_bcast_join", "fj_bcast_finish", "fj_bcast_abort",
-    "fj_dist_unique_id", "fj_dist_comm_create", "fj_dist_comm_from_nccl", "fj_dist_comm_from_transport", "fj_dist_comm_destroy", "fj_dist_comm_rank", "fj_dist_comm_size",
-    "fj_dist_join_count", "fj_dist_join", "fj_dist_comm_set_form", "fj_dist_model",
-    "fj_generate_build", "fj_generate_probe", "fj_debug_partition",
-    "fj_device_malloc", "fj_device_free", "fj_memcpy_h2d", "fj_memcpy_d2h", "fj_memcpy_d2d",
+    "fj_bcast_region_bytes", "fj_bcast_piece_span", "fj_bcast_pack", "fj_bcast_pack_bounds", "fj_bcast_probe", "fj_bcast_join", "fj_bcast_finish", "fj_bcast_abort",
+    "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
+    "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe", "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
+    "fj_ctx_reserve_cus", "fj_debug_partition",
 ]
 
 
@@ -55,6 +68,7 @@ class FjTimings(ctypes.Structure):
 
 class FjDistTimings(ctypes.Structure):
     _fields_ = [
+        ("struct_size", ctypes.c_size_t),
         ("total_ms", ctypes.c_double), ("split_ms", ctypes.c_double), ("exchange_ms", ctypes.c_double), ("join_ms", ctypes.c_double),
         ("local_count", ctypes.c_uint64), ("local_build_chunks", ctypes.c_uint64), ("local_probe_chunks", ctypes.c_uint64),
         ("sent_chunks", ctypes.c_uint64),
@@ -103,7 +117,7 @@ EngBcFinishFn = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _pu64)
 
 
 class FjDistEngineOps(ctypes.Structure):
-    _fields_ = [("user", _vp), ("chunk_bytes", ctypes.c_size_t), ("error", EngErrorFn), ("plan", EngPlanFn), ("alloc", EngAllocFn),
+    _fields_ = [("struct_size", ctypes.c_size_t), ("user", _vp), ("chunk_bytes", ctypes.c_size_t), ("error", EngErrorFn), ("plan", EngPlanFn), ("alloc", EngAllocFn),
                 ("release", EngReleaseFn), ("pack_begin", EngPackBeginFn), ("pack_counts", EngPackCountsFn), ("pack_finish", EngPackFinishFn),
                 ("open", EngOpenFn), ("append", EngAppendFn), ("finish", EngFinishFn), ("abort", EngAbortFn),
                 ("filter_range", EngFilterRangeFn), ("export_filters", EngExportFn), ("pack_filter", EngPackFilterFn), ("sample", EngSampleFn),
@@ -150,7 +164,6 @@ def load() -> ctypes.CDLL:
     L.fj_key_unmix64.restype = u64; L.fj_key_unmix64.argtypes = [u64]
     L.fj_ctx_create.restype = vp; L.fj_ctx_create.argtypes = [i32]
     L.fj_ctx_destroy.restype = None; L.fj_ctx_destroy.argtypes = [vp]
-    L.fj_ctx_reserve_cus.restype = None; L.fj_ctx_reserve_cus.argtypes = [vp, ctypes.c_uint]
     L.fj_ctx_workspace_bytes.restype = sz; L.fj_ctx_workspace_bytes.argtypes = [vp]
     L.fj_ctx_trim.restype = i32; L.fj_ctx_trim.argtypes = [vp]
     L.fj_stream_abort.restype = i32; L.fj_stream_abort.argtypes = [vp]
@@ -166,33 +179,9 @@ def load() -> ctypes.CDLL:
     L.fj_emit_pairs.argtypes = [vp, vp, vp, sz, vp, ctypes.POINTER(FjTimings)]
     L.fj_owner_split.restype = i32
     L.fj_owner_split.argtypes = [vp, vp, vp, sz, i32, vp, vp, pu64, vp]
-    L.fj_owner_hist.restype = i32; L.fj_owner_hist.argtypes = [vp, vp, sz, i32, pu64, vp]
-    L.fj_owner_scatter.restype = i32; L.fj_owner_scatter.argtypes = [vp, vp, vp, sz, i32, pu64, vp, vp, vp]
     L.fj_set_option.restype = i32; L.fj_set_option.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     L.fj_get_option.restype = ctypes.c_longlong; L.fj_get_option.argtypes = [ctypes.c_char_p]
-    L.fj_stream_open.restype = i32; L.fj_stream_open.argtypes = [vp, sz, i32, sz, i32, vp, i32]
-    L.fj_stream_append_build.restype = i32; L.fj_stream_append_build.argtypes = [vp, vp, sz, vp]
-    L.fj_stream_advance_probe.restype = i32; L.fj_stream_advance_probe.argtypes = [vp, vp]
-    L.fj_stream_begin.restype = i32; L.fj_stream_begin.argtypes = [vp, vp, vp, sz, sz, i32, vp, i32]
-    L.fj_stream_append_probe.restype = i32; L.fj_stream_append_probe.argtypes = [vp, vp, sz, vp]
-    L.fj_stream_finish.restype = i32; L.fj_stream_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
-    L.fj_bloom_filter_words.restype = sz; L.fj_bloom_filter_words.argtypes = []
-    L.fj_bloom_export.restype = i32; L.fj_bloom_export.argtypes = [vp, vp, sz, i32, vp, vp]
-    L.fj_bloom_prefilter.restype = i32; L.fj_bloom_prefilter.argtypes = [vp, vp, sz, i32, vp, vp, sz, pu64, vp]
     L.fj_shuffle_plan.restype = i32; L.fj_shuffle_plan.argtypes = [sz, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
-    L.fj_shuffle_chunk_bytes.restype = sz; L.fj_shuffle_chunk_bytes.argtypes = [sz, i32]
-    L.fj_shuffle_pack_begin.restype = i32; L.fj_shuffle_pack_begin.argtypes = [vp, vp, vp, sz, sz, i32, i32, vp]
-    L.fj_shuffle_part_filter_bytes.restype = sz; L.fj_shuffle_part_filter_bytes.argtypes = []
-    L.fj_shuffle_part_filter_range.restype = i32; L.fj_shuffle_part_filter_range.argtypes = [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
-    L.fj_stream_export_part_filters.restype = i32; L.fj_stream_export_part_filters.argtypes = [vp, vp, vp]
-    L.fj_shuffle_pack_filter.restype = i32; L.fj_shuffle_pack_filter.argtypes = [vp, vp, vp]
-    L.fj_shuffle_pack_kept.restype = u64; L.fj_shuffle_pack_kept.argtypes = [vp]
-    L.fj_part_filter_sample.restype = i32; L.fj_part_filter_sample.argtypes = [vp, vp, sz, sz, vp, sz, i32, vp, pu64]
-    L.fj_shuffle_pack_counts.restype = i32; L.fj_shuffle_pack_counts.argtypes = [vp, pu64]
-    L.fj_shuffle_pack_finish.restype = i32; L.fj_shuffle_pack_finish.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
-    L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, i32, vp]
-    L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, vp, sz, vp]
-    L.fj_stream_append_probe_chunks.restype = i32; L.fj_stream_append_probe_chunks.argtypes = [vp, vp, vp, sz, vp]
     L.fj_dist_comm_from_transport.restype = vp
     L.fj_dist_comm_from_transport.argtypes = [vp, ctypes.POINTER(FjDistTransport), ctypes.POINTER(FjDistEngineOps)]
     L.fj_dist_unique_id.restype = i32; L.fj_dist_unique_id.argtypes = [ctypes.c_char_p]
@@ -203,14 +192,6 @@ def load() -> ctypes.CDLL:
     L.fj_dist_comm_size.restype = i32; L.fj_dist_comm_size.argtypes = [vp]
     psz, pi32, pu32 = ctypes.POINTER(sz), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_uint32)
     L.fj_bcast_plan.restype = i32; L.fj_bcast_plan.argtypes = [sz, pi32, pu32, pi32]
-    L.fj_bcast_region_bytes.restype = sz; L.fj_bcast_region_bytes.argtypes = [sz, sz]
-    L.fj_bcast_piece_span.restype = i32; L.fj_bcast_piece_span.argtypes = [sz, sz, sz, sz, i32, psz, psz]
-    L.fj_bcast_pack.restype = i32; L.fj_bcast_pack.argtypes = [vp, vp, sz, sz, vp, i32, vp]
-    L.fj_bcast_pack_bounds.restype = i32; L.fj_bcast_pack_bounds.argtypes = [vp, pu64]
-    L.fj_bcast_probe.restype = i32; L.fj_bcast_probe.argtypes = [vp, vp, sz, sz, vp]
-    L.fj_bcast_join.restype = i32; L.fj_bcast_join.argtypes = [vp, vp, i32, pu64, pu64, ctypes.c_uint32, ctypes.c_uint32, vp]
-    L.fj_bcast_finish.restype = i32; L.fj_bcast_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
-    L.fj_bcast_abort.restype = None; L.fj_bcast_abort.argtypes = [vp]
     pdbl = ctypes.POINTER(ctypes.c_double)
     L.fj_dist_model.restype = i32; L.fj_dist_model.argtypes = [i32, u64, u64, u64, u64, u64, ctypes.c_double, pdbl, pdbl]
     L.fj_dist_comm_set_form.restype = i32; L.fj_dist_comm_set_form.argtypes = [vp, i32, ctypes.c_double]
@@ -219,13 +200,52 @@ def load() -> ctypes.CDLL:
     L.fj_generate_build.restype = i32; L.fj_generate_build.argtypes = [vp, vp, vp, u64, sz, vp]
     L.fj_generate_probe.restype = i32
     L.fj_generate_probe.argtypes = [vp, vp, u64, sz, u64, u64, ctypes.c_uint32, pu64, vp]
-    L.fj_debug_partition.restype = i32
-    L.fj_debug_partition.argtypes = [vp, vp, vp, sz, i32, i32, vp, vp, vp, vp, pu64]
     L.fj_device_malloc.restype = i32; L.fj_device_malloc.argtypes = [ctypes.POINTER(vp), sz]
     L.fj_device_free.restype = i32; L.fj_device_free.argtypes = [vp]
     L.fj_memcpy_h2d.restype = i32; L.fj_memcpy_h2d.argtypes = [vp, vp, sz]
     L.fj_memcpy_d2h.restype = i32; L.fj_memcpy_d2h.argtypes = [vp, vp, sz]
     L.fj_memcpy_d2d.restype = i32; L.fj_memcpy_d2d.argtypes = [vp, vp, sz]
+
+    L.fj_abi_version.restype = i32; L.fj_abi_version.argtypes = []
+    if L.fj_abi_version() != ABI_VERSION:
+        raise ImportError(f"flash_hash_join_amd: {LIB_PATH} speaks ABI {L.fj_abi_version()}, this binding ABI {ABI_VERSION} (rebuild: make -C flash_hash_join_amd/csrc)")
+    L.has_lab = hasattr(L, "fj_debug_partition")          # the internal entry points are visible (libflashjoin_hip_lab.so, A/B variants)
+    if L.has_lab:
+        L.fj_ctx_reserve_cus.restype = None; L.fj_ctx_reserve_cus.argtypes = [vp, ctypes.c_uint]
+        L.fj_owner_hist.restype = i32; L.fj_owner_hist.argtypes = [vp, vp, sz, i32, pu64, vp]
+        L.fj_owner_scatter.restype = i32; L.fj_owner_scatter.argtypes = [vp, vp, vp, sz, i32, pu64, vp, vp, vp]
+        L.fj_stream_open.restype = i32; L.fj_stream_open.argtypes = [vp, sz, i32, sz, i32, vp, i32]
+        L.fj_stream_append_build.restype = i32; L.fj_stream_append_build.argtypes = [vp, vp, sz, vp]
+        L.fj_stream_advance_probe.restype = i32; L.fj_stream_advance_probe.argtypes = [vp, vp]
+        L.fj_stream_begin.restype = i32; L.fj_stream_begin.argtypes = [vp, vp, vp, sz, sz, i32, vp, i32]
+        L.fj_stream_append_probe.restype = i32; L.fj_stream_append_probe.argtypes = [vp, vp, sz, vp]
+        L.fj_stream_finish.restype = i32; L.fj_stream_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
+        L.fj_bloom_filter_words.restype = sz; L.fj_bloom_filter_words.argtypes = []
+        L.fj_bloom_export.restype = i32; L.fj_bloom_export.argtypes = [vp, vp, sz, i32, vp, vp]
+        L.fj_bloom_prefilter.restype = i32; L.fj_bloom_prefilter.argtypes = [vp, vp, sz, i32, vp, vp, sz, pu64, vp]
+        L.fj_shuffle_chunk_bytes.restype = sz; L.fj_shuffle_chunk_bytes.argtypes = [sz, i32]
+        L.fj_shuffle_pack_begin.restype = i32; L.fj_shuffle_pack_begin.argtypes = [vp, vp, vp, sz, sz, i32, i32, vp]
+        L.fj_shuffle_part_filter_bytes.restype = sz; L.fj_shuffle_part_filter_bytes.argtypes = []
+        L.fj_shuffle_part_filter_range.restype = i32; L.fj_shuffle_part_filter_range.argtypes = [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
+        L.fj_stream_export_part_filters.restype = i32; L.fj_stream_export_part_filters.argtypes = [vp, vp, vp]
+        L.fj_shuffle_pack_filter.restype = i32; L.fj_shuffle_pack_filter.argtypes = [vp, vp, vp]
+        L.fj_shuffle_pack_kept.restype = u64; L.fj_shuffle_pack_kept.argtypes = [vp]
+        L.fj_part_filter_sample.restype = i32; L.fj_part_filter_sample.argtypes = [vp, vp, sz, sz, vp, sz, i32, vp, pu64]
+        L.fj_shuffle_pack_counts.restype = i32; L.fj_shuffle_pack_counts.argtypes = [vp, pu64]
+        L.fj_shuffle_pack_finish.restype = i32; L.fj_shuffle_pack_finish.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), vp]
+        L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, i32, vp]
+        L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.fj_stream_append_probe_chunks.restype = i32; L.fj_stream_append_probe_chunks.argtypes = [vp, vp, vp, sz, vp]
+        L.fj_bcast_region_bytes.restype = sz; L.fj_bcast_region_bytes.argtypes = [sz, sz]
+        L.fj_bcast_piece_span.restype = i32; L.fj_bcast_piece_span.argtypes = [sz, sz, sz, sz, i32, psz, psz]
+        L.fj_bcast_pack.restype = i32; L.fj_bcast_pack.argtypes = [vp, vp, sz, sz, vp, i32, vp]
+        L.fj_bcast_pack_bounds.restype = i32; L.fj_bcast_pack_bounds.argtypes = [vp, pu64]
+        L.fj_bcast_probe.restype = i32; L.fj_bcast_probe.argtypes = [vp, vp, sz, sz, vp]
+        L.fj_bcast_join.restype = i32; L.fj_bcast_join.argtypes = [vp, vp, i32, pu64, pu64, ctypes.c_uint32, ctypes.c_uint32, vp]
+        L.fj_bcast_finish.restype = i32; L.fj_bcast_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
+        L.fj_bcast_abort.restype = None; L.fj_bcast_abort.argtypes = [vp]
+        L.fj_debug_partition.restype = i32
+        L.fj_debug_partition.argtypes = [vp, vp, vp, sz, i32, i32, vp, vp, vp, vp, pu64]
     _lib = L
     return L
 

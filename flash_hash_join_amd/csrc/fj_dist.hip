@@ -254,7 +254,7 @@ struct HipEngine : Engine {
 
 struct CallbackEngine : Engine {                             // a caller's stand-in (tests): everything is synchronous, tokens are null
     fj_dist_engine_ops o;
-    explicit CallbackEngine(const fj_dist_engine_ops& ops) : o(ops) {}
+    explicit CallbackEngine(const fj_dist_engine_ops& ops) { memset(&o, 0, sizeof o); memcpy(&o, &ops, std::min(sizeof o, ops.struct_size)); }   // (a caller built against a shorter struct: the callbacks it does not know read as NULL)
     int fail(const char* what) { return derr("%s: %s", what, o.error ? o.error(o.user) : "engine callback failed"); }
     int plan(size_t nb_total, int nranks, size_t* cb) override { if (o.plan(o.user, nb_total, nranks)) return fail("plan"); *cb = o.chunk_bytes; return 0; }
     void* alloc(size_t bytes) override { return o.alloc(o.user, bytes); }
@@ -441,6 +441,12 @@ struct CallbackNet : Net {                                   // a caller's block
 
 struct DBuf { void* p = nullptr; size_t bytes = 0; };
 
+// what the step measured -> the caller's struct, as far as the caller's struct goes (fj_dist_timings::struct_size, checked at entry)
+void write_timings(fj_dist_timings* out, const fj_dist_timings& T) {
+    const size_t n = std::min(out->struct_size, sizeof T);
+    memcpy((char*)out + sizeof(size_t), (const char*)&T + sizeof(size_t), n - sizeof(size_t));
+}
+
 }  // namespace
 
 struct fj_dist_comm {
@@ -568,13 +574,14 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
     if (out_global_count) *out_global_count = res[0];
     if (out_local_count) *out_local_count = local;
     if (timings) {
-        memset(timings, 0, sizeof *timings);
-        timings->total_ms = ms_since(t0); timings->split_ms = split_ms; timings->join_ms = ms_since(t2);
-        timings->exchange_ms = std::max(0.0, timings->total_ms - timings->join_ms - split_ms);
-        timings->local_count = local; timings->pieces = pieces; timings->nranks = N; timings->local = lt;
-        timings->form = FJ_DIST_FORM_BROADCAST; timings->wire_bytes_sent = wire_sent; timings->prefilter_sampled = -1.0;
-        timings->probe_rows_kept = np;
-        timings->local_build_chunks = nb_total; timings->local_probe_chunks = np;       // (this form: ROWS this rank joined - every rank's build rows, its own probe rows)
+        fj_dist_timings T; memset(&T, 0, sizeof T);
+        T.total_ms = ms_since(t0); T.split_ms = split_ms; T.join_ms = ms_since(t2);
+        T.exchange_ms = std::max(0.0, T.total_ms - T.join_ms - split_ms);
+        T.local_count = local; T.pieces = pieces; T.nranks = N; T.local = lt;
+        T.form = FJ_DIST_FORM_BROADCAST; T.wire_bytes_sent = wire_sent; T.prefilter_sampled = -1.0;
+        T.probe_rows_kept = np;
+        T.local_build_chunks = nb_total; T.local_probe_chunks = np;       // (this form: ROWS this rank joined - every rank's build rows, its own probe rows)
+        write_timings(timings, T);
     }
     return 0;
 }
@@ -630,6 +637,7 @@ fj_dist_comm* fj_dist_comm_from_transport(fj_ctx* ctx, const fj_dist_transport* 
         derr("fj_dist_comm_from_transport: incomplete transport (three callbacks, 1..64 ranks)"); return nullptr;
     }
     if (!ctx && !engine) { derr("fj_dist_comm_from_transport: a context or a stand-in engine is needed"); return nullptr; }
+    if (engine && engine->struct_size < offsetof(fj_dist_engine_ops, filter_range)) { derr("fj_dist_comm_from_transport: fj_dist_engine_ops.struct_size is not set (ABI %d: the struct begins with its own size)", FJ_ABI_VERSION); return nullptr; }
     if (engine && (!engine->plan || !engine->alloc || !engine->release || !engine->pack_begin || !engine->pack_counts || !engine->pack_finish || !engine->open ||
                    !engine->append || !engine->finish || engine->chunk_bytes == 0)) { derr("fj_dist_comm_from_transport: incomplete engine"); return nullptr; }
     fj_dist_comm* dc = new fj_dist_comm();
@@ -652,12 +660,12 @@ void fj_dist_comm_destroy(fj_dist_comm* dc) {
 // per 125M build rows; two probe-side passes 7.95 / 8.35 / 8.6 ms per 1.25B rows under the 16- / 17- / 18-bit plans of 2 / 4 / 8 ranks; dense
 // join 3.2 ps per build key of ALL ranks + 2.45 ps per local probe key (3.85 / 4.8 / 6.25 ms at 2 / 4 / 8 ranks), all of it kernels
 // of this rank (the wire overlaps everything behind the pack); shuffle - 13.4 ms of kernels per 1.375B rows of both relations + ~2.5
-// ms of head and tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: nb_max * 6.01).
+// ms of head and tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: computed from nb_max and the plan).
 int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
                   double* t_shuffle, double* t_broadcast) {
     const double rate = link_bytes_per_s > 0 ? link_bytes_per_s : 55e9, N = nranks < 1 ? 1 : nranks;
-    if (region_max == 0) region_max = (uint64_t)((double)nb_max * 6.01) + (1u << 20);
     const int bits = fjh::make_plan((size_t)nb_total, 64).bits;
+    if (region_max == 0) region_max = nb_max * (bits >= 16 ? 6u : 8u) + 4ull * ((1ull << bits) + 1) + 64;      // (fj_bcast_region_bytes: offset table + the two planes)
     const double pack = (double)nb_max * 11.6e-12, passes = (double)np_max * (6.36e-12 + 0.27e-12 * (bits > 16 ? std::min(bits, 18) - 16 : 0)),
                  join = (double)nb_total * 3.2e-12 + (double)np_max * 2.45e-12;
     const double wire_b = N > 1 ? (double)region_max / rate : 0.0;
@@ -688,6 +696,7 @@ int fj_dist_join_count(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb
 int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                  int materialize, double prefilter_below, void* stream, uint64_t* out_global_count, uint64_t* out_local_count, fj_dist_timings* timings) {
     if (!dc) return derr("fj_dist_join_count: null communicator");
+    if (timings && timings->struct_size < offsetof(fj_dist_timings, local)) return derr("fj_dist_join: fj_dist_timings.struct_size is not set (ABI %d: the struct begins with its own size)", FJ_ABI_VERSION);
 
     if (materialize && (!dc->hip || (nb && !d_build_vals) || ((uintptr_t)d_build_vals & 15))) return derr("fj_dist_join: a materialising join needs the HIP engine and 16-byte aligned build values");
     const bool mat = materialize != 0;
@@ -934,14 +943,15 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     if (out_global_count) *out_global_count = res[0];
     if (out_local_count) *out_local_count = local;          // materialising: fj_emit_pairs(ctx, ...) then writes this rank's `local` pairs (they stay with the owner)
     if (timings) {
-        memset(timings, 0, sizeof *timings);
-        timings->total_ms = ms_since(t0); timings->split_ms = split_ms; timings->join_ms = ms_since(t2);
-        timings->exchange_ms = std::max(0.0, timings->total_ms - timings->join_ms - split_ms);
-        timings->local_count = local; timings->local_build_chunks = B.chunks; timings->local_probe_chunks = rows_recv_chunks;
-        timings->pieces = pieces; timings->nranks = N; timings->fan_log0 = 0; timings->local = lt;
-        timings->wire_chunk_bytes = (int)CB; timings->sent_chunks = sent_chunks;
-        timings->form = FJ_DIST_FORM_SHUFFLE; timings->wire_bytes_sent = (uint64_t)sent_chunks * (CB + 4);
-        timings->prefilter = pf ? 1 : 0; timings->prefilter_sampled = sampled; timings->probe_rows_kept = kept_rows; timings->filter_bytes = filter_bytes;
+        fj_dist_timings T; memset(&T, 0, sizeof T);
+        T.total_ms = ms_since(t0); T.split_ms = split_ms; T.join_ms = ms_since(t2);
+        T.exchange_ms = std::max(0.0, T.total_ms - T.join_ms - split_ms);
+        T.local_count = local; T.local_build_chunks = B.chunks; T.local_probe_chunks = rows_recv_chunks;
+        T.pieces = pieces; T.nranks = N; T.fan_log0 = 0; T.local = lt;
+        T.wire_chunk_bytes = (int)CB; T.sent_chunks = sent_chunks;
+        T.form = FJ_DIST_FORM_SHUFFLE; T.wire_bytes_sent = (uint64_t)sent_chunks * (CB + 4);
+        T.prefilter = pf ? 1 : 0; T.prefilter_sampled = sampled; T.probe_rows_kept = kept_rows; T.filter_bytes = filter_bytes;
+        write_timings(timings, T);
     }
     return 0;
 }

@@ -7,6 +7,7 @@
 #pragma once
 #include "fj_internal.h"
 #include "../../include/flashjoin.h"
+#include "../../include/flashjoin_lab.h"
 
 #include <algorithm>
 #include <chrono>

@@ -17,6 +17,13 @@ fj_timings& last_timings() { return g_last; }
 Options& options() { static Options o; return o; }
 static int set_option_value(Options& o, const char* name, long long value);
 Options::Options() {
+    // Until round 5 every option had an environment variable of its own; they are gone (FJ_OPTIONS carries them all, test hooks are
+    // bits of "lab_hooks").  A job that still sets one would be ignored silently: say so, once.
+    static const char* const legacy[] = {"FJ_RADIX_THRESHOLD", "FJ_SCALAR_HBM_TABLE", "FJ_BLOOM_AUTO", "FJ_BLOOM_AUTO_MAX_HIT_BP", "FJ_BLOOM_VARIANT", "FJ_PLAN_TARGET_KEYS",
+                                         "FJ_MAT_SINGLE_PASS", "FJ_PERSISTENT_MIN_ITEMS", "FJ_JOIN_ITEMS_TARGET", "FJ_JOIN_WIDE", "FJ_DIST_LOOPBACK", "FJ_DIST_INJECT_FAIL",
+                                         "FJ_DIST_RESERVE_ALWAYS", "FJ_DIST_SPLIT_ALWAYS", "FJ_DIST_ONE_COMM", "FJ_EMIT_TAGGED"};
+    for (const char* name : legacy)
+        if (getenv(name)) fprintf(stderr, "flash_hash_join_amd: the environment variable %s is no longer read (use FJ_OPTIONS=\"name=value,...\" or fj_set_option; see include/flashjoin.h)\n", name);
     const char* e = getenv("FJ_OPTIONS");
     if (!e) return;
     std::string str(e);
@@ -25,10 +32,15 @@ Options::Options() {
         size_t end = str.find(',', pos);
         if (end == std::string::npos) end = str.size();
         const std::string item = str.substr(pos, end - pos);
-        const size_t eq = item.find('=');
-        if (eq != std::string::npos && set_option_value(*this, item.substr(0, eq).c_str(), strtoll(item.c_str() + eq + 1, nullptr, 10)))
-            fprintf(stderr, "flash_hash_join_amd: FJ_OPTIONS: ignoring '%s' (%s)\n", item.c_str(), fj_last_error());
         pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        char* tail = nullptr;
+        const long long value = eq == std::string::npos ? 0 : strtoll(item.c_str() + eq + 1, &tail, 10);
+        if (eq == std::string::npos || eq == 0 || tail == item.c_str() + eq + 1 || *tail != '\0')      // (name=abc used to read as name=0)
+            fprintf(stderr, "flash_hash_join_amd: FJ_OPTIONS: ignoring '%s' (want name=integer)\n", item.c_str());
+        else if (set_option_value(*this, item.substr(0, eq).c_str(), value))
+            fprintf(stderr, "flash_hash_join_amd: FJ_OPTIONS: ignoring '%s' (%s)\n", item.c_str(), fj_last_error());
     }
 }
 
@@ -404,7 +416,8 @@ void fj_set_error_string(const char* msg) { fjh::g_err = msg ? msg : ""; }     /
 extern "C" {
 
 const char* fj_last_error(void) { return fjh::g_err.c_str(); }
-const char* fj_version(void) { return "flash_hash_join_amd 0.2 (gfx950)"; }
+const char* fj_version(void) { return "flash_hash_join_amd 0.6 (gfx950)"; }
+int fj_abi_version(void) { return FJ_ABI_VERSION; }
 
 int fj_set_option(const char* name, long long value) {
     if (!name) return set_err("fj_set_option: null name");

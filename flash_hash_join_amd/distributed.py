@@ -1,51 +1,44 @@
 """Multi-GPU radix join: one process per GPU over RCCL/xGMI.
 
-The reference is single-process; this is new design.  Two exchange strategies, chosen per call
-by FJ_DIST_STRATEGY = shuffle | replicate | auto (a per-link byte + local-work cost model, choose_strategy); unset it
-means the shuffle north_star names:
+The reference is single-process (hash_join.cpp:318); this is new design.  What it exploits is that radix
+partitions are independent join units (hash_join.cpp:340-356, :515-525).  A join of relations whose rows are block-distributed
+over the ranks of a group takes the first of three FORMS that applies and succeeds - a ladder, the same on every rank:
 
-replicate -- every rank all-gathers the build KEYS (and values when materialising) and joins its own probe rows
-  against all of them; probe rows never move, their partition passes run while the build keys are on the wire
-  (fj_stream_open / append_probe / advance_probe, then append_build per arrived piece / finish; FJ_REPLICATE_PIECES,
-  default 4 asynchronous all-gathers: the first pass over piece c runs while piece c+1 is on the wire).  An xGMI mesh
-  has one link per peer, so an exchange is bound by bytes per link: B*8 here against (P*8 + B*16)/N for the shuffle -- fewer up to
-  N = 12 for the probe-heavy (P = 10 B) joins this path is built for, 6x fewer at N = 2.  Cost: every rank
-  partitions all N*B build keys.  Global count = sum of local counts; pairs stay with their probe row.
+1. BUILD BROADCAST (counting joins; csrc/fj_bcast.hip behind fj_dist_join): the probe rows never move.  Every rank partitions
+   its build rows by the plan for the TOTAL build side, packs them densely (6 bytes per key) and sends them to every peer; every
+   rank joins its own probe partitions against the runs of all ranks.  0.75 GB per link and step at BASELINE configs[4], whatever
+   the number of ranks.  Taken when the C++ driver's cost model (fj_dist_model: bytes per link over the link rate against the
+   kernel time per rank) puts it ahead of the shuffle - it does for probe-heavy joins such as configs[4] - and the replicas fit.
+2. OWNER SHUFFLE in chunk form (north_star's all-to-all of radix partitions; counting and materialising joins whose global plan
+   has two or more passes): the first radix pass of the plan for the total build side is the owner split - bucket b of its 256 /
+   512 buckets belongs to rank (b * world) >> log2(buckets); a sender runs that pass and rewrites its output for the wire (dense
+   256-key chunks, 7 bytes per key), the owner starts at the plan's second pass.  With the sender-side precheck (the owners'
+   per-partition Bloom filters, all-gathered in front of the probe exchange) where a per-link model says it pays.
+   Both forms run inside ONE C++ driver, csrc/fj_dist.hip (fj_dist_join): over RCCL under the nccl backend, over three callbacks
+   into torch.distributed otherwise (_CallbackTransport: gloo, a transport object), with a stand-in for the rank's own work in the
+   CPU test-suite.  A step that fails on one rank fails on every rank (the driver agrees on it), so all ranks move down together.
+3. OWNER SCATTER (the plain last resort, driven from here: small build sides, duplicate build keys in a materialising join, and
+   any step the forms above failed on): every rank splits its rows by owner GPU = (top 16 hash bits * world) >> 16
+   (fj_owner_split), ONE all-to-all per relation moves each segment to its owner (torch.distributed all_to_all_single), each rank
+   joins what it owns with the single-GPU radix join (hash_top_bits = 48), one all-reduce adds the counts.  No precheck of its own.
 
-shuffle -- radix partitions are independent join units (hash_join.cpp:340-356, :515-525), so the level-0 digit is
-  the owner GPU:   owner(key) = (top 16 bits of hash(key) * world) >> 16
-
-  Joins whose GLOBAL plan has two or more passes take the CHUNK form: the first radix pass of the plan for the
-  total build side IS the owner split - bucket b of its 256 / 512 buckets belongs to rank (b * world) >> log2(buckets); a sender
-  runs that pass and rewrites its output for the wire (fj_shuffle_pack_begin / _counts / _finish: dense 256-key chunks, 7 bytes
-  per key, one directory word per chunk), and the owner starts at the plan's second pass.  The protocol lives in ONE place, the
-  C++ driver csrc/fj_dist.hip (fj_dist_join / fj_dist_join_count); this module hands it RCCL (nccl backend), or three callbacks
-  into torch.distributed (_CallbackTransport: gloo, a transport object), or - in the CPU test-suite - also a stand-in for the
-  rank's own work.  Everything else (small build sides, the sender-side precheck, duplicate build keys in a materialising join,
-  and any step the chunk form fails on) takes the OWNER-SCATTER form, driven from here:
-  1. every rank splits its local rows of both relations by owner (fj_owner_split: LDS counting
-     sort per tile, contiguous per-owner segments);
-  2. ONE all-to-all per relation moves each segment to its owner (torch.distributed
-     all_to_all_single, backend "nccl" == RCCL on ROCm; a fully connected xGMI mesh carries one
-     peer per link); counting joins cut the probe exchange into pieces and overlap it with the split of the
-     next piece and the first partition pass of the previous one;
-  3. each rank joins what it owns with the single-GPU radix join (hash_top_bits = 48: the owner
-     digit is already consumed);
-  4. the global count is one all-reduce of a single int64.  Materialised pairs stay sharded by owner.
-
-`engine` abstracts the per-rank primitives so the protocol can be exercised on CPU (gloo) in the
-test-suite with a stand-in engine; the default engine is the HIP one and has no CPU fallback.
+FJ_DIST_STRATEGY = auto (default) | broadcast | shuffle | scatter pins the first rung; a rung that failed for a join shape is
+remembered and skipped for the next 32 steps of that shape (_FORM_MEMO).  `engine` abstracts the per-rank primitives so that the
+protocol can be exercised on CPU (gloo) with a stand-in engine; the default engine is the HIP one and has no CPU fallback.
+Python reads six environment variables here: FJ_DIST_STRATEGY, FJ_DIST_PIECES, FJ_DIST_PREFILTER (0 | 1 | auto), FJ_DIST_NATIVE
+(0: the driver over torch.distributed callbacks instead of RCCL directly), FJ_DIST_NO_FALLBACK, and FJ_LIB_VARIANT (_lib.py).
 """
 from __future__ import annotations
 
 import ctypes
 import os
 import time
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 
 class HipEngine:
-    """Per-rank primitives on an MI355X through the C ABI (include/flashjoin.h)."""
+    """Per-rank primitives on an MI355X through the C ABI (include/flashjoin.h).  (The building blocks behind the ABI - stream
+    joins, the pieces of the driver - are reached through lab.LabEngine and the lab build of the library.)"""
 
     def __init__(self, device=None):
         import torch
@@ -70,14 +63,11 @@ class HipEngine:
             raise ValueError(f"build_values has {bv.numel()} elements, build_keys has {bk.numel()}")
         return bk, bv, pk
 
-    def empty_like(self, t):
-        return self.torch.empty_like(t)
-
-    def cat(self, parts):
-        return self.torch.cat(list(parts))
-
     def counts_tensor(self, counts: List[int]):
         return self.torch.tensor(counts, dtype=self.torch.int64, device=self.device)
+
+    def free_bytes(self) -> int:
+        return int(self.torch.cuda.mem_get_info(self.index)[0])
 
     def owner_split(self, keys, vals, world: int):
         t = self.torch
@@ -91,85 +81,12 @@ class HipEngine:
             t.cuda.current_stream(self.index).cuda_stream))
         return out_k, out_v, [int(counts[r]) for r in range(world)]
 
-    def owner_hist(self, keys, world: int) -> List[int]:
-        counts = (ctypes.c_uint64 * 64)()
-        self._lib.check(self.L.fj_owner_hist(self.ctx, keys.data_ptr(), keys.numel(), world, counts,
-                                             self.torch.cuda.current_stream(self.index).cuda_stream))
-        return [int(counts[r]) for r in range(world)]
-
-    def owner_scatter(self, keys, world: int, counts: List[int]):
-        """Owner-contiguous copy of `keys` given its per-owner counts; asynchronous on the current stream."""
-        out = self.empty(keys.numel())
-        c = (ctypes.c_uint64 * 64)(*counts)
-        self._lib.check(self.L.fj_owner_scatter(self.ctx, keys.data_ptr(), None, keys.numel(), world, c, out.data_ptr(), None,
-                                                self.torch.cuda.current_stream(self.index).cuda_stream))
-        return out
-
-    def stream_begin(self, bk, bv, np_bound: int, max_appends: int, hash_top_bits: int):
-        self._keep = [bk, bv]                                    # inputs must outlive the asynchronous kernels
-        self._lib.check(self.L.fj_stream_begin(self.ctx, bk.data_ptr(), bv.data_ptr(), bk.numel(), np_bound, max_appends,
-                                               self.torch.cuda.current_stream(self.index).cuda_stream, hash_top_bits))
-
-    def stream_open(self, nb_bound: int, build_appends: int, np_bound: int, probe_appends: int, hash_top_bits: int):
-        self._keep = []
-        self._lib.check(self.L.fj_stream_open(self.ctx, nb_bound, build_appends, np_bound, probe_appends,
-                                              self.torch.cuda.current_stream(self.index).cuda_stream, hash_top_bits))
-
     @staticmethod
     def _aligned(t):
         """The C ABI wants contiguous, 16-byte aligned pieces (a view into a larger tensor may be neither)."""
         if not t.is_contiguous() or t.data_ptr() % 16:
             t = t.contiguous().clone() if t.data_ptr() % 16 else t.contiguous()
         return t
-
-    def stream_append_build(self, piece):
-        piece = self._aligned(piece)
-        self._keep.append(piece)
-        self._lib.check(self.L.fj_stream_append_build(self.ctx, piece.data_ptr(), piece.numel(),
-                                                      self.torch.cuda.current_stream(self.index).cuda_stream))
-
-    def stream_advance_probe(self):
-        self._lib.check(self.L.fj_stream_advance_probe(self.ctx, self.torch.cuda.current_stream(self.index).cuda_stream))
-
-    def stream_append(self, piece):
-        piece = self._aligned(piece)
-        self._keep.append(piece)
-        self._lib.check(self.L.fj_stream_append_probe(self.ctx, piece.data_ptr(), piece.numel(),
-                                                      self.torch.cuda.current_stream(self.index).cuda_stream))
-
-    def stream_finish(self) -> int:
-        cnt = ctypes.c_uint64(0)
-        t = self._lib.FjTimings()
-        try:
-            self._lib.check(self.L.fj_stream_finish(self.ctx, self.torch.cuda.current_stream(self.index).cuda_stream,
-                                                    ctypes.byref(cnt), ctypes.byref(t)))
-        finally:
-            self._keep = []
-        self.api._last = t
-        return int(cnt.value)
-
-    def bloom_export(self, build_keys, hash_top_bits: int):
-        """Bloom filters of the build keys this rank owns: 512 radix buckets x fj_bloom_filter_words()/512 words (int32 tensor)."""
-        t = self.torch
-        build_keys = self._aligned(build_keys)
-        out = t.empty(int(self.L.fj_bloom_filter_words()), dtype=t.int32, device=self.device)
-        self._lib.check(self.L.fj_bloom_export(self.ctx, build_keys.data_ptr(), build_keys.numel(), hash_top_bits, out.data_ptr(),
-                                               t.cuda.current_stream(self.index).cuda_stream))
-        return out
-
-    def bloom_prefilter(self, keys, filters, hash_top_bits: int):
-        """The rows of `keys` that may match the owner whose filters these are (no row that matches is dropped; the order changes)."""
-        t = self.torch
-        keys = self._aligned(keys)
-        out = self.empty(keys.numel())
-        n = ctypes.c_uint64(0)
-        self._lib.check(self.L.fj_bloom_prefilter(self.ctx, keys.data_ptr(), keys.numel(), hash_top_bits, filters.data_ptr(),
-                                                  out.data_ptr(), out.numel(), ctypes.byref(n), t.cuda.current_stream(self.index).cuda_stream))
-        return out[: int(n.value)]
-
-    # ---- owner shuffle in chunk form (SURVEY 8(e): the first radix pass of the global plan is the owner split) ----
-    def empty_i32(self, n: int):
-        return self.torch.empty(n, dtype=self.torch.int32, device=self.device)
 
     def shuffle_plan(self, nb_total: int, world: int) -> Optional[int]:
         """log2 of the first-pass fan-out of the plan for a build side of nb_total rows in all, or None when the chunk form
@@ -179,72 +96,6 @@ class HipEngine:
             return None
         return int(f0.value)
 
-    def shuffle_chunk_bytes(self, nb_total: int, world: int) -> int:
-        return int(self.L.fj_shuffle_chunk_bytes(nb_total, world))
-
-    def part_filter_range(self, nb_total: int, world: int, rank: int):
-        """(first, count, total, bytes_each): where rank's per-partition Bloom filters sit among all final partitions' filters."""
-        sz = ctypes.c_size_t
-        first, count, total = sz(0), sz(0), sz(0)
-        self._lib.check(self.L.fj_shuffle_part_filter_range(nb_total, world, rank, ctypes.byref(first), ctypes.byref(count), ctypes.byref(total)))
-        return int(first.value), int(count.value), int(total.value), int(self.L.fj_shuffle_part_filter_bytes())
-
-    def stream_export_part_filters(self, out):
-        """Filters of the final partitions this owner holds (build side complete), into the uint8 tensor `out`."""
-        self._lib.check(self.L.fj_stream_export_part_filters(self.ctx, out.data_ptr(), self.torch.cuda.current_stream(self.index).cuda_stream))
-
-    def shuffle_pack(self, keys, vals, nb_total: int, world: int, filters=None):
-        """First pass of the global plan over local rows, rewritten for the wire (fj_shuffle_pack_begin / _counts / _finish).
-        Returns (chunks, dir, used): per owner r a uint8 tensor of used[r] * shuffle_chunk_bytes() bytes (dense 256-key chunks
-        in the 7-byte wire format when the first pass has >= 256 buckets) and an int32 tensor of used[r] directory words.
-        filters: all partitions' Bloom filters (uint8 tensor) - the piece is prechecked against them (fj_shuffle_pack_filter);
-        self.last_pack_kept = the rows it kept."""
-        t = self.torch
-        keys = self._aligned(keys)
-        stream = t.cuda.current_stream(self.index).cuda_stream
-        cb = self.shuffle_chunk_bytes(nb_total, world)
-        if cb == 0:
-            raise RuntimeError(self._lib.last_error())
-        if vals is not None:
-            vals = self._aligned(vals)
-        self._lib.check(self.L.fj_shuffle_pack_begin(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, world,
-                                                     int(filters is not None), stream))
-        if filters is not None:
-            self._lib.check(self.L.fj_shuffle_pack_filter(self.ctx, filters.data_ptr(), stream))
-        used = (ctypes.c_uint64 * 64)()
-        self._lib.check(self.L.fj_shuffle_pack_counts(self.ctx, used))
-        self.last_pack_kept = int(self.L.fj_shuffle_pack_kept(self.ctx)) if filters is not None else keys.numel()
-        used = [int(used[r]) for r in range(world)]
-        chunks = [t.empty(max(16, u * cb), dtype=t.uint8, device=self.device) for u in used]
-        dirs = [self.empty_i32(max(4, u)) for u in used]
-        vp = ctypes.c_void_p
-        dk = (vp * 64)(*[c.data_ptr() for c in chunks])
-        dd = (vp * 64)(*[d.data_ptr() for d in dirs])
-        if vals is None:
-            self._lib.check(self.L.fj_shuffle_pack_finish(self.ctx, dk, None, dd, stream))
-            return [c[: u * cb] for c, u in zip(chunks, used)], [d[:u] for d, u in zip(dirs, used)], used
-        vouts = [self.empty(max(2, u * 256)) for u in used]
-        dv = (vp * 64)(*[v.data_ptr() for v in vouts])
-        self._lib.check(self.L.fj_shuffle_pack_finish(self.ctx, dk, dv, dd, stream))
-        return [c[: u * cb] for c, u in zip(chunks, used)], [d[:u] for d, u in zip(dirs, used)], used, [v[: u * 256] for v, u in zip(vouts, used)]
-
-    def stream_open_shuffled(self, nb_total: int, world: int, rank: int, nb_bound: int, build_appends: int, np_bound: int, probe_appends: int,
-                             with_vals: bool = False):
-        self._keep = []
-        self._lib.check(self.L.fj_stream_open_shuffled(self.ctx, nb_total, world, rank, nb_bound, build_appends, np_bound, probe_appends, int(with_vals),
-                                                       self.torch.cuda.current_stream(self.index).cuda_stream))
-
-    def stream_append_chunks(self, side: int, chunks, dirw, vals=None):
-        """A received piece: wire-format chunks (uint8 tensor) + their directory words (rewritten in place) [+ 256 values per build chunk]."""
-        self._keep += [chunks, dirw, vals]
-        stream = self.torch.cuda.current_stream(self.index).cuda_stream
-        if side:
-            self._lib.check(self.L.fj_stream_append_probe_chunks(self.ctx, chunks.data_ptr(), dirw.data_ptr(), dirw.numel(), stream))
-        else:
-            self._lib.check(self.L.fj_stream_append_build_chunks(self.ctx, chunks.data_ptr(), vals.data_ptr() if vals is not None else None, dirw.data_ptr(),
-                                                                 dirw.numel(), stream))
-
-    # ---- build-broadcast form (csrc/fj_bcast.hip): probe rows never move, every rank's build rows travel as dense per-partition runs ----
     def bcast_plan(self, nb_total: int):
         """(radix bits, final partitions, bytes of the high-word plane per key) of the plan for a total build side, or None when
         that plan has no pass (such joins take the owner-scatter form)."""
@@ -253,50 +104,12 @@ class HipEngine:
             return None
         return b.value, n.value, m.value
 
-    def bcast_region_bytes(self, nb_total: int, nkeys: int) -> int:
-        return int(self.L.fj_bcast_region_bytes(nb_total, nkeys))
-
-    def bcast_pack(self, keys, nb_total: int, region, pieces: int) -> None:
-        """Asynchronous: this rank's build keys -> `region` (a uint8 tensor view of bcast_region_bytes(nb_total, keys.numel()) bytes)."""
-        s = self.torch.cuda.current_stream(self.index).cuda_stream
-        self._lib.check(self.L.fj_bcast_pack(self.ctx, keys.data_ptr(), keys.numel(), nb_total, region.data_ptr(), pieces, s))
-
-    def bcast_pack_bounds(self, pieces: int) -> List[int]:
-        b = (ctypes.c_uint64 * (pieces + 1))()
-        self._lib.check(self.L.fj_bcast_pack_bounds(self.ctx, b))
-        return [int(x) for x in b]
-
-    def bcast_probe(self, probe_keys, nb_total: int) -> None:
-        s = self.torch.cuda.current_stream(self.index).cuda_stream
-        self._lib.check(self.L.fj_bcast_probe(self.ctx, probe_keys.data_ptr(), probe_keys.numel(), nb_total, s))
-
-    def bcast_join(self, base, region_off: List[int], nkeys: List[int], part_lo: int, part_hi: int) -> None:
-        n = len(region_off)
-        ro, nk = (ctypes.c_uint64 * n)(*region_off), (ctypes.c_uint64 * n)(*nkeys)
-        s = self.torch.cuda.current_stream(self.index).cuda_stream
-        self._lib.check(self.L.fj_bcast_join(self.ctx, base.data_ptr(), n, ro, nk, part_lo, part_hi, s))
-
-    def bcast_finish(self) -> int:
-        cnt = ctypes.c_uint64(0)
-        t = self._lib.FjTimings()
-        s = self.torch.cuda.current_stream(self.index).cuda_stream
-        self._lib.check(self.L.fj_bcast_finish(self.ctx, s, ctypes.byref(cnt), ctypes.byref(t)))
-        self.last_bcast_timings = t.as_dict()
-        return int(cnt.value)
-
     def emit_pairs(self, n: int):
         """The pairs of the materialising join that was just counted on this context (fj_emit_pairs): two int64 tensors of n rows."""
         ok, ov = self.empty(max(n, 2)), self.empty(max(n, 2))
         t = self._lib.FjTimings()
         self._lib.check(self.L.fj_emit_pairs(self.ctx, ok.data_ptr(), ov.data_ptr(), n, self.torch.cuda.current_stream(self.index).cuda_stream, ctypes.byref(t)))
         return ok[:n], ov[:n]
-
-    def chunk_rows(self, dirw) -> int:
-        """Rows in a set of chunks, from their directory words (bucket << 9 | count; unused ids are all ones)."""
-        if dirw.numel() == 0:
-            return 0
-        cnt = dirw & 0x1FF
-        return int(cnt[dirw != -1].sum().item())
 
     # ---- the multi-GPU driver (csrc/fj_dist.hip): fj_dist_join_count over an RCCL communicator of the library's own (torch does
     #      not hand out its ncclComm_t) ----
@@ -341,8 +154,7 @@ class HipEngine:
                 pass
 
     def stream_abort(self):
-        """Error recovery: drop a stream join that will not be finished, so that the context serves other joins again."""
-        self._keep = []
+        """Error recovery: drop a stream join that a failed step left open, so that the context serves other joins again."""
         self._lib.check(self.L.fj_stream_abort(self.ctx))
 
     def local_join(self, bk, bv, pk, materialize: bool, bloom: bool, hash_top_bits: int, return_arrays: bool):
@@ -410,30 +222,28 @@ def _abort_stream(engine) -> None:
             pass
 
 
-def _prefilter_mode(bloom: bool) -> str:
-    """Sender-side bloom precheck of the probe exchange: "on" | "off" | "auto".  FJ_DIST_PREFILTER=1 / 0 / auto decides;
-    unset, the *_bloom meaning (`bloom=True`) asks for "auto": the filters are exported and a sample of the probe rows is
-    tested against them; the precheck runs when few enough rows survive to pay for the extra pass (_prefilter_break_even)."""
-    env = os.environ.get("FJ_DIST_PREFILTER", "")
-    if env in ("0", "1", "auto"):
-        return {"0": "off", "1": "on", "auto": "auto"}[env]
-    return "auto" if bloom else "off"
+
+_LINK_BYTES_PER_S = 45e9          # one xGMI link, one direction, effective (153.6 GB/s bidirectional raw): the built-in guess; set_link_rate replaces it
+_LINK_MEASURED = False
 
 
-# fj_bloom_prefilter on one MI355X, 156M-row segments against 125M-key owners (profiles/r02_prefilter_probe.txt):
-# 1.26 ms at 13 % survivors ... 1.91 ms at 100 %  =  7.4 ps + 4.9 ps x survivors, per row
-_PREFILTER_S_PER_ROW = 7.4e-12
-_PREFILTER_S_PER_SURVIVOR = 4.9e-12
-_PREFILTER_SAMPLE_ROWS = 1 << 20
+def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
+    """Replace the built-in per-link rate of the cost models (the form choice, the sender-side precheck's break-even) by a measured
+    one (tools/xgmi_probe.py; bench.py does this once at N > 1)."""
+    global _LINK_BYTES_PER_S, _LINK_MEASURED
+    if bytes_per_s > 0:
+        _LINK_BYTES_PER_S = float(bytes_per_s)
+        _LINK_MEASURED = bool(measured)
 
 
-def _prefilter_break_even(world: int) -> float:
-    """Survivor fraction below which the precheck pays: a sender filters `world` segments one after the other while its
-    links carry one segment each in parallel, so per segment row it spends world * (a + b f) and saves (8 B / link) * (1 - f).
-    A 0.8 margin covers what the model leaves out (the filters' own 73 MB per link, the lost scatter/exchange overlap)."""
-    link = 8.0 / _LINK_BYTES_PER_S
-    f = (link - _PREFILTER_S_PER_ROW * world) / (link + _PREFILTER_S_PER_SURVIVOR * world)
-    return max(0.0, 0.8 * f)
+def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] = None, nb_total: Optional[int] = None, np_global: Optional[int] = None) -> dict:
+    """The C++ driver's cost model for a counting step of `world` ranks holding at most nb x np_ rows each (fj_dist_model):
+    modelled seconds in either form and the pick."""
+    from . import _lib
+    ts, tb = ctypes.c_double(0), ctypes.c_double(0)
+    f = _lib.load().fj_dist_model(world, nb, np_, nb_total if nb_total is not None else nb * world, np_global if np_global is not None else np_ * world, 0,
+                                  float(link_bytes_per_s or _LINK_BYTES_PER_S), ctypes.byref(ts), ctypes.byref(tb))
+    return {"shuffle": ts.value, "broadcast": tb.value, "pick": "broadcast" if f == FORM_BROADCAST else "shuffle"}
 
 
 # the precheck in chunk form (fj_dist_join(prefilter_below), csrc/fj_pack.hip: fj_part_filter_inplace): what a config-5 shard costs
@@ -444,18 +254,18 @@ _CHUNK_FILTER_S_PER_ROW = 7.4e-12       # the precheck at the 8-rank plan (512 p
                                         # 312M rows, profiles/r04_precheck_probe.txt; 4.9-6.6 ps at the 1-rank plan's 128 partitions per bucket)
 _CHUNK_REST_S_PER_ROW = 6.1e-12         # copy into the wire format + the owner's second pass, lists and join: scale with what survives
 _CHUNK_WIRE_BYTES_PER_ROW = 7.02
+PREFILTER_BELOW_OVERRIDE: Optional[float] = None
 
 
 def _chunk_prefilter_break_even(world: int, nb_total: int, np_local: int, link_bytes_per_s: Optional[float] = None) -> float:
-    """Survivor fraction below which the precheck of the chunk form pays (FJ_DIST_PREFILTER_BELOW overrides the model).  Per local
+    """Survivor fraction below which the precheck of the chunk form pays (PREFILTER_BELOW_OVERRIDE, a module variable, pins it).  Per local
     probe row a step costs max(wire, kernels) - the model of tools/scale_model.py: wire = 7.02 B x (f x probe rows + build rows) /
     (world x link rate) on each of the links that work in parallel, plus - with the precheck - the filters (1.07 bytes per build
     key to every rank: ~nb_total / world bytes per link); kernels as above; ~0.5 ms of latency before the first probe piece can be
     checked.  It never pays where the kernels bound the step (one rank; links faster than ~12 ps per row); on wire-bound steps it
     does: below ~75 % survivors at 8 GPUs and 45 GB/s per link (~55 % at 55 GB/s, ~15 % at 65), below ~85 % at 2-4 GPUs."""
-    env = os.environ.get("FJ_DIST_PREFILTER_BELOW")
-    if env:
-        return float(env)
+    if PREFILTER_BELOW_OVERRIDE is not None:                                 # (tests and measurements pin the threshold)
+        return float(PREFILTER_BELOW_OVERRIDE)
     if np_local <= 0 or world <= 1:
         return 0.0
     link = float(link_bytes_per_s or _LINK_BYTES_PER_S)                      # (a multi-rank caller passes rank 0's: one verdict everywhere)
@@ -510,162 +320,17 @@ def _precheck_remember(key, timings: dict, decision: str) -> None:
         memo[0] += 1
 
 
-def _chunk_prefilter_mode(bloom: bool, world: int) -> str:
+def _chunk_prefilter_mode(bloom: bool, world: int, override: Optional[str] = None) -> str:
     """The chunk form's precheck: FJ_DIST_PREFILTER=1 / 0 / auto decides; unset it is "auto" for every join across more than one
     rank (the *_bloom functions and the plain ones alike: results are identical, and a step whose links are the bottleneck is
     shorter by what the owners' filters keep off them - the model above prices it with the measured link rate when bench.py or the
     host called set_link_rate) and for the *_bloom functions on one rank (where the model declines)."""
+    if override in ("off", "on", "auto"):
+        return override
     env = os.environ.get("FJ_DIST_PREFILTER", "")
     if env in ("0", "1", "auto"):
         return {"0": "off", "1": "on", "auto": "auto"}[env]
     return "auto" if (bloom or world > 1) else "off"
-
-
-def _sampled_survivors(dist, group, engine, world, probe_keys, filters) -> float:
-    """Fraction of a strided sample of every rank's probe rows that passes the owners' filters (identical on all ranks)."""
-    n = probe_keys.numel()
-    kept = m = 0
-    if n:
-        m = min(n, _PREFILTER_SAMPLE_ROWS)
-        sample = probe_keys[:: max(1, n // m)][:m].contiguous()
-        m = sample.numel()
-        s, _, counts = engine.owner_split(sample, None, world)
-        off = 0
-        for d in range(world):
-            kept += int(engine.bloom_prefilter(s[off: off + counts[d]], filters[d], 48).numel())
-            off += counts[d]
-    v = engine.counts_tensor([kept, m])
-    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
-    kept, m = (int(x) for x in v.tolist())
-    return kept / m if m else 1.0
-
-
-def _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces: int, timings: Optional[dict],
-                     prefilter: str = "off"):
-    """Counting join with the probe exchange cut into `pieces` rounds: the owner-scatter of piece c+1 and the first
-    partition pass over piece c-1 run while piece c is on the wire (asynchronous all-to-all).
-
-    prefilter ("on" / "auto"): every owner exports Bloom filters of the build keys it received (512 radix buckets, one
-    LDS-sized filter each: fj_bloom_export), one all-gather hands them to every rank, and a rank sends an owner only the
-    probe rows that pass that owner's filters (fj_bloom_prefilter).  Costs 73 MB per link for the filters + one more
-    partition pass on the sender; saves (1 - survivors) of the probe exchange, which is what bounds the shuffle
-    (DESIGN.md section 6)."""
-    t0 = time.perf_counter()
-    # build side: split, exchange, start the build-side passes
-    bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)
-    n = probe_keys.numel()
-    bounds = [(n * c // pieces) & ~1 for c in range(pieces)] + [n]      # even row offsets: every piece stays 16-byte aligned
-    views = [probe_keys[bounds[c]: bounds[c + 1]] for c in range(pieces)]
-    p_counts = [engine.owner_hist(v, world) for v in views]                  # [piece][owner]
-    t1 = time.perf_counter()
-
-    def exchange_counts(flat, per_rank):
-        send_c = engine.counts_tensor(flat)
-        recv_c = engine.counts_tensor([0] * len(flat))
-        dist.all_to_all_single(recv_c, send_c, group=group)
-        return recv_c.reshape(world, per_rank).tolist()
-
-    def message_rounds(largest):
-        mx = engine.counts_tensor([largest])
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-        return max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
-
-    filtered, sampled = False, None
-    if prefilter == "off":
-        # one all-to-all tells every rank what it will receive: build counts + per-piece probe counts
-        flat = []
-        for d in range(world):
-            flat += [b_counts[d]] + [p_counts[c][d] for c in range(pieces)]
-        rc = exchange_counts(flat, pieces + 1)
-        b_recv = [int(r[0]) for r in rc]
-        p_recv = [[int(rc[src][c + 1]) for src in range(world)] for c in range(pieces)]      # [piece][source]
-        rounds = message_rounds(max([max(b_counts)] + [max(pc) for pc in p_counts]))
-        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
-        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
-    else:
-        # the build side travels first: its owners' filters decide what the probe side sends
-        b_recv = [int(r[0]) for r in exchange_counts(list(b_counts), 1)]
-        b_rounds = message_rounds(max(b_counts))
-        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, b_rounds)
-        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, b_rounds)
-        mine = engine.bloom_export(bk_r, 48)
-        filters = [engine.empty_like(mine) for _ in range(world)]
-        dist.all_gather(filters, mine, group=group)
-        filtered = True
-        if prefilter == "auto":
-            sampled = _sampled_survivors(dist, group, engine, world, probe_keys, filters)
-            filtered = sampled < _prefilter_break_even(world)
-        rounds = message_rounds(max(max(pc) for pc in p_counts))          # (survivors never outnumber the rows they come from)
-        if not filtered:
-            del filters, mine
-            flat = []
-            for d in range(world):
-                flat += [p_counts[c][d] for c in range(pieces)]
-            rc = exchange_counts(flat, pieces)
-            p_recv = [[int(rc[src][c]) for src in range(world)] for c in range(pieces)]
-
-    keep, works, recvs = [], [], []
-
-    def put_on_the_wire(c, s_c):
-        r_c = engine.empty(sum(p_recv[c]))
-        if rounds <= 1:
-            w = dist.all_to_all_single(r_c, s_c, output_split_sizes=p_recv[c], input_split_sizes=p_counts[c], group=group, async_op=True)
-        else:                                    # very large pieces: fall back to blocking rounds for this piece
-            r_c = _exchange(dist, group, engine, s_c, p_counts[c], p_recv[c], rounds)
-            w = None
-        keep.append(s_c); works.append(w); recvs.append(r_c)
-
-    if filtered:
-        # piece c is scattered and filtered while piece c-1 is on the wire; its survivor counts are exchanged just before it
-        # leaves.  The owner's stream join opens once every piece was filtered (fj_bloom_prefilter and an open stream join
-        # share the context's chunk pools); what it then appends is the small filtered remainder.
-        p_recv = []
-        for c in range(pieces):
-            s_c = engine.owner_scatter(views[c], world, p_counts[c])
-            off, kept = 0, []
-            for d in range(world):
-                kept.append(engine.bloom_prefilter(s_c[off: off + p_counts[c][d]], filters[d], 48))
-                off += p_counts[c][d]
-            p_counts[c] = [int(k.numel()) for k in kept]
-            p_recv.append([int(r[0]) for r in exchange_counts(p_counts[c], 1)])
-            put_on_the_wire(c, engine.cat(kept))
-        del filters, mine
-        np_total = sum(sum(p) for p in p_recv)
-    try:
-        if filtered:
-            engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
-            for c in range(pieces):
-                if works[c] is not None:
-                    works[c].wait()
-                engine.stream_append(recvs[c])
-        else:
-            np_total = sum(sum(p) for p in p_recv)
-            engine.stream_begin(bk_r, bv_r, np_total, pieces, 48)
-            for c in range(pieces):
-                put_on_the_wire(c, engine.owner_scatter(views[c], world, p_counts[c]))
-                if c >= 1:
-                    if works[c - 1] is not None:
-                        works[c - 1].wait()
-                    engine.stream_append(recvs[c - 1])
-            if works[-1] is not None:
-                works[-1].wait()
-            engine.stream_append(recvs[-1])
-        sent_rows = sum(sum(pc) for pc in p_counts)
-        t2 = time.perf_counter()
-        local_count = engine.stream_finish()     # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
-    except BaseException:
-        _abort_stream(engine)                    # an error between begin and finish must not leave the context occupied
-        raise
-    tot = engine.counts_tensor([local_count])
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
-    engine.synchronize()
-    t3 = time.perf_counter()
-    del keep
-    if timings is not None:
-        timings.update(split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2, exchange_rounds=rounds, pieces=pieces,
-                       local_build_rows=sum(b_recv), local_probe_rows=np_total, local_count=local_count,
-                       prefilter=filtered, prefilter_mode=prefilter, prefilter_sampled_survivors=sampled, probe_rows_sent=sent_rows)
-    return int(tot.item()), t3 - t0
 
 
 class _CallbackTransport:
@@ -842,32 +507,34 @@ def _engine_ops_struct(ops, keep: list):
               _lib.EngBcFinishFn(guard(bc_finish))]
     cbs["bcast"] = bc
     keep.append(cbs)
-    return _lib.FjDistEngineOps(None, int(ops.chunk_bytes), cbs["error"], cbs["plan"], cbs["alloc"], cbs["release"], cbs["pack_begin"],
+    return _lib.FjDistEngineOps(ctypes.sizeof(_lib.FjDistEngineOps), None, int(ops.chunk_bytes), cbs["error"], cbs["plan"], cbs["alloc"], cbs["release"], cbs["pack_begin"],
                                 cbs["pack_counts"], cbs["pack_finish"], cbs["open"], cbs["append"], cbs["finish"], cbs["abort"], *pre, *bc)
+
 
 
 FORM_AUTO, FORM_SHUFFLE, FORM_BROADCAST = 0, 1, 2      # include/flashjoin.h: FJ_DIST_FORM_*
 
 
-def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport, build_values=None, return_arrays=False,
-                  prefilter_below: float = 0.0, prefilter_mode: str = "off", form: int = FORM_SHUFFLE):
-    """The owner shuffle in chunk form through the ONE driver, csrc/fj_dist.hip (fj_dist_join): natively over RCCL under the nccl
+def _driver_join(dist, group, engine, build_keys, probe_keys, pieces: int, timings: Optional[dict], transport, build_values=None, return_arrays=False,
+                 prefilter_below: float = 0.0, prefilter_mode: str = "off", form: int = FORM_SHUFFLE):
+    """One step through the ONE driver, csrc/fj_dist.hip (fj_dist_join), in the given form: natively over RCCL under the nccl
     backend; over a callback transport (torch.distributed with host staging: gloo, a transport object) otherwise; with a stand-in
     engine's callbacks in the CPU test-suite.  build_values: a materialising join (the pairs stay with the owner; returned when
-    return_arrays).  prefilter_below: the sender-side precheck in chunk form (include/flashjoin.h: fj_dist_join) - 0 never, >= 2
-    always, else the survivor share of a sample below which it runs.  Collective; a failure on any rank raises on every rank."""
+    return_arrays).  prefilter_below: the sender-side precheck of the shuffle - 0 never, >= 2 always, else the survivor share of a
+    sample below which it runs.  Collective; a failure on any rank raises on every rank."""
     from . import _lib
     L = _lib.load()
     t0 = time.perf_counter()
     cnt, local = ctypes.c_uint64(0), ctypes.c_uint64(0)
     dt = _lib.FjDistTimings()
+    dt.struct_size = ctypes.sizeof(_lib.FjDistTimings)
     keep: list = []
     pairs = None
     standin = hasattr(engine, "dist_engine_ops")
     native = (not standin and transport is None and os.environ.get("FJ_DIST_NATIVE", "1") != "0" and dist.get_backend(group) == "nccl")
     if native:
         comm, own = engine.native_comm(dist, group), False
-        form_label = "chunks (fj_dist_join_count over RCCL)"
+        via = "RCCL"
     else:
         tr = _CallbackTransport(dist, group, "host" if standin else "device", None if standin else engine.device)
         ops = _engine_ops_struct(engine.dist_engine_ops(tr.world), keep) if standin else None
@@ -875,7 +542,7 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
         if not comm:
             raise RuntimeError(_lib.last_error())
         own = True
-        form_label = "chunks (fj_dist_join_count over a callback transport)"
+        via = "a callback transport"
     try:
         _lib.check(L.fj_dist_comm_set_form(comm, int(form), float(_LINK_BYTES_PER_S)))
         if standin:
@@ -902,13 +569,13 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
     if not standin:
         engine.api._last = dt.local
     if timings is not None and int(dt.form) == FORM_BROADCAST:
-        timings.update(strategy="broadcast", shuffle_form="build broadcast (fj_dist_join_count: probe rows stay, dense 6-byte build runs to every peer)",
+        timings.update(strategy="broadcast", shuffle_form=f"build broadcast (fj_dist_join over {via}: probe rows stay, dense 6-byte build runs to every peer)",
                        split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3, join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces),
                        local_build_rows=int(dt.local_build_chunks), local_probe_rows=probe_keys.numel(), local_count=int(dt.local_count), prefilter=False, prefilter_mode="off",
                        prefilter_sampled_survivors=None, prefilter_below=0.0, probe_rows_sent=0, filter_bytes_received=0, wire_chunk_bytes=0,
                        wire_bytes_sent=int(dt.wire_bytes_sent))
     elif timings is not None:
-        timings.update(strategy="shuffle", shuffle_form=form_label, split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
+        timings.update(strategy="shuffle", shuffle_form=f"chunks (fj_dist_join over {via})", split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3,
                        join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces), local_build_rows=int(dt.local_build_chunks) * 256,
                        local_probe_rows=int(dt.local_probe_chunks) * 256, local_count=int(dt.local_count), prefilter=bool(dt.prefilter), prefilter_mode=prefilter_mode,
                        prefilter_sampled_survivors=(float(dt.prefilter_sampled) if dt.prefilter_sampled >= 0 else None), prefilter_below=float(prefilter_below),
@@ -920,92 +587,31 @@ def _driver_count(dist, group, engine, build_keys, probe_keys, pieces: int, timi
     return int(cnt.value), sec
 
 
-# ---- strategy 2: replicate the build side ------------------------------------------------------------------
-# xGMI is a point-to-point mesh: a GPU has ONE link to each peer, so what bounds an exchange is the bytes per link.
-# The owner shuffle puts (P*8 + B*16)/N bytes on every link (P, B = local probe / build rows); sending every rank's
-# build KEYS to every peer puts B*8 there (B*16 with values).  For the probe-heavy joins this path is built for
-# (P = 10 B) that is fewer bytes up to N = 12 -- 6x fewer at N = 2 -- and the probe side never moves: its partition
-# passes run while the build keys are on the wire.  The price is local: every rank partitions all N*B build keys.
-_LINK_BYTES_PER_S = 45e9          # one xGMI link, one direction, effective (153.6 GB/s bidirectional raw)
-# local work, measured on one MI355X (profiles/r01_replicate_local.txt; c3 = 100M x 1B rows per GPU):
-_PROBE_PASS_S_PER_ROW = 3.25e-12   # one probe-side partition pass (3.1-3.3 ms per 1B rows, profiles/r02_c3_kernel_stats.csv)
-_BUILD_S_PER_ROW = 15e-12          # a build row's share of passes + table build, counting join (800M rows: 6.4 + 5.2 ms)
-_SPLIT_S_PER_ROW = 2.7e-12         # shuffle: owner histogram + the un-overlapped first owner scatter
-_JOIN_S_PER_ROW = 1.7e-12          # per-partition join, per probe row
+# A rung of the ladder that failed for a join shape - a skewed partition beyond the LDS table in the broadcast form, pools that an
+# owner of hot keys overflows in the chunk form, replicas that do not fit - must not be attempted again on every later step of that
+# shape: every failed attempt costs the whole step once more.  (world, build rows, probe rows, materialize, join_id) -> [calls since,
+# first rung to try]; re-examined every 32nd call.  All ranks fail together (the driver agrees on failures), so the memos stay identical.
+_FORM_MEMO: dict = {}
+_FORM_RETRY_EVERY = 32
+RUNGS = ("broadcast", "shuffle", "scatter")
 
 
-def _npass(bits: int) -> int:
-    return (1 if bits > 0 else 0) if bits <= 9 else (2 if bits <= 18 else -(-bits // 9))
-
-
-def _plan_passes(nb: int) -> int:
-    """Partition passes of the single-GPU plan for a build side of nb rows (csrc/fj_plan.hip make_plan)."""
-    bits = 0
-    if nb > 4096:
-        bits = (-(-nb // 4096) - 1).bit_length()
-    if (nb >> bits) > 3950:                       # one more radix bit where it costs no extra pass (FJ_PLAN_BUMP_KEYS)
-        nb1 = 5 if bits == 0 else bits + 1
-        if bits == 0 or _npass(nb1) == _npass(bits):
-            bits = nb1
-    if 0 < bits < 5:
-        bits = 5
-    return _npass(bits)
-
-
-def strategy_costs(world: int, nb: int, np_: int, materialize: bool) -> dict:
-    """Modelled seconds of one step for per-rank relation sizes nb x np_ under both strategies."""
-    kb = 2 if materialize else 1
-    # shuffle: exchange of 1/N of every relation per link; the probe exchange hides the splits and the first pass
-    x_sh = (np_ * 8 + nb * 16) / world / _LINK_BYTES_PER_S
-    t_shuffle = (_SPLIT_S_PER_ROW * np_ + x_sh + (_plan_passes(nb) - 1) * _PROBE_PASS_S_PER_ROW * np_
-                 + _JOIN_S_PER_ROW * np_ + _BUILD_S_PER_ROW * nb * kb)
-    # replicate: the build keys of one peer per link; the probe passes hide under it, the N-fold build work does not
-    x_rep = nb * 8 * kb / _LINK_BYTES_PER_S
-    t_replicate = (max(x_rep, _plan_passes(world * nb) * _PROBE_PASS_S_PER_ROW * np_)
-                   + _BUILD_S_PER_ROW * world * nb * kb + _JOIN_S_PER_ROW * np_)
-    return {"shuffle": t_shuffle, "replicate": t_replicate}
-
-
-def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] = None) -> dict:
-    """The C++ driver's cost model for a counting step of `world` ranks holding nb x np_ rows each (fj_dist_model: what
-    FJ_DIST_FORM_AUTO decides with): modelled seconds in either form and the pick."""
-    from . import _lib
-    ts, tb = ctypes.c_double(0), ctypes.c_double(0)
-    f = _lib.load().fj_dist_model(world, nb, np_, nb * world, np_ * world, 0, float(link_bytes_per_s or _LINK_BYTES_PER_S), ctypes.byref(ts), ctypes.byref(tb))
-    return {"shuffle": ts.value, "broadcast": tb.value, "pick": "broadcast" if f == FORM_BROADCAST else "shuffle"}
-
-
-_LINK_MEASURED = False
-
-
-def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
-    """Replace the built-in per-link rate of the cost model (FJ_DIST_STRATEGY=auto, the sender-side precheck's break-even)
-    by a measured one (tools/xgmi_probe.py; bench.py does this once at N > 1)."""
-    global _LINK_BYTES_PER_S, _LINK_MEASURED
-    if bytes_per_s > 0:
-        _LINK_BYTES_PER_S = float(bytes_per_s)
-        _LINK_MEASURED = bool(measured)
-
-
-def choose_strategy(world: int, nb: int, np_: int, materialize: bool) -> str:
-    """What a multi-rank join runs as, for per-rank relation sizes nb x np_ (the maxima over the ranks):
-      'auto'      (unset FJ_DIST_STRATEGY) counting joins: the C++ driver's per-link / per-rank cost model picks the owner shuffle or the
-                  build broadcast for the step's sizes (csrc/fj_dist.hip: the same verdict on every rank); materialising joins shuffle;
-      'shuffle'   always the owner shuffle (north_star's all-to-all of radix partitions);
-      'broadcast' counting joins in the build-broadcast form (probe rows never move; csrc/fj_bcast.hip), materialising joins shuffle;
-      'replicate' the build KEYS all-gathered unpartitioned (rounds 1-4's alternative; kept for comparison)."""
+def choose_strategy() -> str:
+    """FJ_DIST_STRATEGY: 'auto' (default: the first rung that applies, by the driver's cost model), or the rung the ladder starts at -
+    'broadcast' (counting joins; materialising joins start at the shuffle), 'shuffle', 'scatter'."""
     forced = os.environ.get("FJ_DIST_STRATEGY", "auto")
-    if forced in ("replicate", "shuffle", "broadcast", "auto"):
+    if forced in ("auto",) + RUNGS:
         return forced
-    raise ValueError(f"FJ_DIST_STRATEGY={forced!r}: shuffle | broadcast | replicate | auto")
+    raise ValueError(f"FJ_DIST_STRATEGY={forced!r}: auto | broadcast | shuffle | scatter")
 
 
-def self_check(dist, group, engine, small_inputs, expected_small: int, message_elems: int, transport=None) -> dict:
+def self_check(dist, group, engine, small_inputs, expected_small: int, message_elems: int, transport=None, corrupt: bool = False) -> dict:
     """A few seconds before a multi-rank job's first timed step: (1) one exchange of per-peer VIEWS at the largest message size
     the step will use (`message_elems` int64 per peer, capped at the RCCL-safe size), every element a function of (source,
-    destination, index), verified in full on arrival - the transport of the chunk-form shuffle, and the > 4 GiB defect the
-    bounded rounds work around, on real ranks; (2) one small distributed_join against its closed-form count.  Every rank
-    returns the same verdict: {"ok", "error", "failed_ranks", "message_bytes", "seconds"}."""
+    destination, index), verified in full on arrival - the > 4 GiB defect the bounded rounds work around, on real ranks; (2) one
+    small distributed_join against its closed-form count; (3) the same join with the sender-side precheck forced on.  Every rank
+    returns the same verdict: {"ok", "error", "failed_ranks", "message_bytes", "seconds", "precheck"}.  corrupt: test hook - rank 0
+    flips one received bit (what a transport that moves wrong data looks like)."""
     import torch
     t0 = time.perf_counter()
     me, world = dist.get_rank(group), dist.get_world_size(group)
@@ -1024,7 +630,7 @@ def self_check(dist, group, engine, small_inputs, expected_small: int, message_e
         ins = [send[d * n: (d + 1) * n] for d in range(world)]
         for w in _views_all_to_all(dist, group, ins, outs):
             w.wait()
-        if os.environ.get("FJ_SELFCHECK_CORRUPT") and me == 0:      # test hook: what a transport that moves wrong data looks like
+        if corrupt and me == 0:
             outs[world - 1][n // 2] ^= 1
         for q in range(world):
             want = idx * 1000003 + (q * 64 + me) * 7919 + 12345
@@ -1035,148 +641,90 @@ def self_check(dist, group, engine, small_inputs, expected_small: int, message_e
         del send, pad, outs, ins, idx
     except Exception as ex:                                        # noqa: BLE001
         err = f"exchange self-check raised {ex!r}"
-    flag = engine.counts_tensor([1 if err else 0])
-    dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
-    nbad = int(flag.item())
+
+    def agree(e) -> int:
+        flag = engine.counts_tensor([1 if e else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+        return int(flag.item())
+    nbad = agree(err)
+    bk, bv, pk = small_inputs
     if nbad == 0:
         try:
-            bk, bv, pk = small_inputs
             got = distributed_join(bk, bv, pk, group=group, engine=engine, transport=transport)[0]
             if int(got) != int(expected_small):
                 err = f"join self-check: count {got} != closed form {expected_small}"
         except Exception as ex:                                    # noqa: BLE001  (raised on every rank, or agreed on inside)
             err = f"join self-check raised {ex!r}"
-        flag = engine.counts_tensor([1 if err else 0])
-        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
-        nbad = int(flag.item())
-    # (3) the same join with the sender-side precheck forced on (what "auto" may choose in the timed steps: filters exported,
-    #     all-gathered, probe pieces compacted).  A failure does not fail the check: the precheck is switched off for this process
-    #     (FJ_DIST_PREFILTER=0, the ranks agree) and the verdict says so.
+        nbad = agree(err)
+    # the precheck forced on: what "auto" may choose in the timed steps (filters exported, all-gathered, probe pieces compacted).  A
+    # failure does not fail the check: the verdict says so and the caller switches the precheck off (bench.py: FJ_DIST_PREFILTER=0)
     precheck = None
     if nbad == 0 and os.environ.get("FJ_DIST_PREFILTER", "") != "0" and hasattr(engine, "shuffle_plan") and not hasattr(engine, "dist_engine_ops"):
         perr = None
-        saved = os.environ.get("FJ_DIST_PREFILTER")
-        os.environ["FJ_DIST_PREFILTER"] = "1"
         try:
             tt: dict = {}
-            got = distributed_join(bk, bv, pk, group=group, engine=engine, transport=transport, timings=tt)[0]
+            got = distributed_join(bk, bv, pk, group=group, engine=engine, transport=transport, timings=tt, prefilter="on", strategy="shuffle")[0]
             if int(got) != int(expected_small):
                 perr = f"count {got} != closed form {expected_small}"
             precheck = {"ok": perr is None, "ran": bool(tt.get("prefilter")), "rows_sent": tt.get("probe_rows_sent"), "form": tt.get("shuffle_form")}
         except Exception as ex:                                    # noqa: BLE001
             perr = f"raised {ex!r}"
-            precheck = {"ok": False}
-        finally:
-            if saved is None:
-                os.environ.pop("FJ_DIST_PREFILTER", None)
-            else:
-                os.environ["FJ_DIST_PREFILTER"] = saved
-        flag = engine.counts_tensor([1 if perr else 0])
-        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
-        if int(flag.item()):
-            os.environ["FJ_DIST_PREFILTER"] = "0"
-            precheck = {"ok": False, "error": perr, "failed_ranks": int(flag.item()), "action": "FJ_DIST_PREFILTER=0 for the timed steps"}
+        pbad = agree(perr)
+        if pbad:
+            precheck = {"ok": False, "error": perr, "failed_ranks": pbad, "action": "switch the precheck off for the timed steps (FJ_DIST_PREFILTER=0)"}
     return {"ok": nbad == 0, "error": err, "failed_ranks": nbad, "message_bytes": n * 8, "seconds": round(time.perf_counter() - t0, 3), "precheck": precheck}
 
 
-def _gather_rows(dist, group, engine, world, t, sizes: List[int], lo_frac=(0, 1), async_op=False):
-    """All ranks' slice [n*a/b, n*(a+1)/b) of their tensor `t`, concatenated in rank order.  Returns (work, out, fix)
-    where fix(out) compacts the result when the slices are not all the same length."""
-    a, b = lo_frac
-    lens = [n * (a + 1) // b - n * a // b for n in sizes]
-    me = dist.get_rank(group)
-    mine = t[sizes[me] * a // b: sizes[me] * (a + 1) // b]
-    mx = max(lens)
-    if min(lens) == mx:
-        out = engine.empty(mx * world)
-        w = dist.all_gather_into_tensor(out, mine.contiguous(), group=group, async_op=async_op)
-        return w, out, None
-    pad = engine.empty(mx)
-    pad[: lens[me]] = mine
-    out = engine.empty(mx * world)
-    w = dist.all_gather_into_tensor(out, pad, group=group, async_op=async_op)
-
-    def fix(o):
-        import torch
-        return torch.cat([o[r * mx: r * mx + lens[r]] for r in range(world)])
-    return w, out, fix
-
-
-def _replicated_join(dist, group, engine, world, build_keys, build_values, probe_keys, sizes_b: List[int], materialize: bool,
-                     bloom: bool, return_arrays: bool, pieces: int, timings: Optional[dict]):
-    """Every rank joins ITS probe rows against ALL build rows: build keys (and values when materialising) are
-    all-gathered, probe rows never leave their GPU.  The global count is the sum of the local counts; materialised
-    pairs stay on the rank that holds the probe row."""
-    t0 = time.perf_counter()
-    nb_total = sum(sizes_b)
-    need = max(1, -(-max(sizes_b) // _MAX_ELEMS_PER_MESSAGE))        # keep every rank's contribution to one collective <= 1 GiB
-    if materialize or not hasattr(engine, "stream_open"):
-        import torch
-
-        def gather_all(t):
-            parts = []
-            for c in range(need):
-                _, o, fix = _gather_rows(dist, group, engine, world, t, sizes_b, (c, need))
-                parts.append(fix(o) if fix else o)
-            if need == 1:
-                return parts[0]
-            # piece-major -> rank-major, so that the first occurrence of a duplicate key is the one of the lowest rank
-            lens = [[n * (c + 1) // need - n * c // need for n in sizes_b] for c in range(need)]
-            offs = [[sum(l[:r]) for r in range(world)] for l in lens]
-            return torch.cat([parts[c][offs[c][r]: offs[c][r] + lens[c][r]] for r in range(world) for c in range(need)])
-        bk_all = gather_all(build_keys)
-        bv_all = gather_all(build_values)
-        engine.synchronize()
-        t1 = time.perf_counter()
-        res = engine.local_join(bk_all, bv_all, probe_keys, materialize, bloom, 64, return_arrays)
-        local_count = int(res[0])
-    else:
-        # counting: keys only, in `pieces` asynchronous all-gathers; the probe side is partitioned meanwhile
-        pieces = max(pieces, need)
-        if nb_total <= 8192 or min(sizes_b) < pieces:        # (a zero-pass build side must arrive as one piece)
-            pieces = 1
-        gathers = [_gather_rows(dist, group, engine, world, build_keys, sizes_b, (c, pieces), async_op=True) for c in range(pieces)]
-        try:
-            engine.stream_open(nb_total, pieces, probe_keys.numel(), 1, 64)
-            engine.stream_append(probe_keys)
-            engine.stream_advance_probe()
-            keep = []
-            for w, out, fix in gathers:
-                if w is not None:
-                    w.wait()
-                if fix: out = fix(out)
-                keep.append(out)
-                engine.stream_append_build(out)
-            t1 = time.perf_counter()
-            local_count = engine.stream_finish() # (a skewed partition beyond the LDS tables: fj_stream_finish falls back by itself)
-        except BaseException:
-            _abort_stream(engine)
-            raise
-        res = None
-        del keep
+def _owner_scatter_join(dist, group, engine, world, build_keys, build_values, probe_keys, materialize, bloom, return_arrays, timings, t0):
+    """The last rung: split by owner, one all-to-all per array, the single-GPU join of what this rank owns, one all-reduce."""
+    bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)
+    pk_s, _, p_counts = engine.owner_split(probe_keys, None, world)
+    t1 = time.perf_counter()
+    flat = []
+    for d in range(world):
+        flat += [b_counts[d], p_counts[d]]
+    send_c = engine.counts_tensor(flat)
+    recv_c = engine.counts_tensor([0] * len(flat))
+    dist.all_to_all_single(recv_c, send_c, group=group)
+    rc = recv_c.reshape(world, 2).tolist()
+    b_recv, p_recv = [int(x[0]) for x in rc], [int(x[1]) for x in rc]
+    mx = engine.counts_tensor([max(b_counts + p_counts)])              # the largest single message anywhere in the group decides the rounds
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
+    bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
+    bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
+    pk_r = _exchange(dist, group, engine, pk_s, p_counts, p_recv, rounds)
+    engine.synchronize()
+    t2 = time.perf_counter()
+    res = engine.local_join(bk_r, bv_r, pk_r, materialize, bloom, 48, return_arrays)
+    local_count = int(res[0])
     tot = engine.counts_tensor([local_count])
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     engine.synchronize()
-    t2 = time.perf_counter()
+    t3 = time.perf_counter()
     if timings is not None:
-        timings.update(strategy="replicate", split_s=0.0, exchange_s=t1 - t0, join_s=t2 - t1, exchange_rounds=1, pieces=pieces,
-                       local_build_rows=nb_total, local_probe_rows=probe_keys.numel(), local_count=local_count)
-    out = (int(tot.item()), t2 - t0)
+        timings.update(strategy="scatter", shuffle_form="owner-scatter", split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2, exchange_rounds=rounds,
+                       local_build_rows=sum(b_recv), local_probe_rows=sum(p_recv), local_count=local_count,
+                       prefilter=False, prefilter_mode="off", prefilter_sampled_survivors=None, probe_rows_sent=sum(p_counts),
+                       wire_bytes_sent=8 * (sum(p_counts) - p_counts[dist.get_rank(group)]) + 16 * (sum(b_counts) - b_counts[dist.get_rank(group)]))
+    out = (int(tot.item()), t3 - t0)
     if materialize and return_arrays:
         return out + (res[2], res[3])
     return out
 
 
 def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool = False, bloom: bool = False,
-                     group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None, transport=None, join_id=None):
+                     group=None, engine=None, return_arrays: bool = False, timings: Optional[dict] = None, transport=None, join_id=None,
+                     strategy: Optional[str] = None, prefilter: Optional[str] = None, force_exchange: bool = False):
     """Join relations whose rows are block-distributed over the ranks of `group`.
 
-    Every rank passes its LOCAL rows (int64 tensors on its GPU) and gets back
-    `(global_match_count, seconds)`; with `materialize and return_arrays` also the pairs this
-    rank owns.  `seconds` is this rank's wall time for the whole step (split + exchange + join).
-    `transport`: an object with torch.distributed's collective functions (default: torch.distributed itself) - the
-    self-tests that run several ranks on one GPU pass one that stages device tensors through the host for gloo.
-    `join_id` (hashable, the same on every rank): names a repeated join for the sender-side precheck's memory of what it sampled.
+    Every rank passes its LOCAL rows (int64 tensors on its GPU) and gets back `(global_match_count, seconds)`; with
+    `materialize and return_arrays` also the pairs this rank owns.  `seconds` is this rank's wall time for the whole step.
+    `transport`: an object with torch.distributed's collective functions (default: torch.distributed itself) - the self-tests
+    that run several ranks on one GPU pass one that stages device tensors through the host for gloo.
+    `join_id` (hashable, the same on every rank): names a repeated join for what is remembered about its shape (the precheck's
+    sampled verdict, a rung that failed).  `strategy`: overrides FJ_DIST_STRATEGY for this call; `prefilter`: "off" | "on" | "auto"
+    overrides FJ_DIST_PREFILTER; force_exchange: run the full protocol on a one-rank group too (tests).
     """
     import torch.distributed as _td
     dist = transport if transport is not None else _td
@@ -1185,184 +733,88 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     if hasattr(engine, "normalize"):             # int64/uint64, contiguous, 16-byte aligned: what the C ABI's pointers must be
         build_keys, build_values, probe_keys = engine.normalize(build_keys, build_values, probe_keys)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 and os.environ.get("FJ_FORCE_EXCHANGE") and not dist.is_initialized():
-        raise RuntimeError("FJ_FORCE_EXCHANGE needs an initialised process group")
+    if world == 1 and force_exchange and not dist.is_initialized():
+        raise RuntimeError("force_exchange needs an initialised process group")
     t0 = time.perf_counter()
-    if world == 1 and not os.environ.get("FJ_FORCE_EXCHANGE"):      # FJ_FORCE_EXCHANGE: run the full protocol on one rank (tests)
+    if world == 1 and not force_exchange:
         res = engine.local_join(build_keys, build_values, probe_keys, materialize, bloom, 64, return_arrays)
         if timings is not None:
             timings.update(split_s=0.0, exchange_s=0.0, join_s=time.perf_counter() - t0)
         return res
 
     pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
-    # relation sizes of every rank: one tiny all-gather decides the strategy identically everywhere
-    # (third word: this rank's per-link rate in kB/s - every rank models with rank 0's, so that hosts that called set_link_rate with
-    #  per-rank measurements still take the same decisions and the same fallback paths)
-    mine = engine.counts_tensor([build_keys.numel(), probe_keys.numel(), int(_LINK_BYTES_PER_S / 1e3)])
-    allsz = engine.counts_tensor([0] * (3 * world))
+    no_fallback = bool(os.environ.get("FJ_DIST_NO_FALLBACK"))
+    standin = hasattr(engine, "dist_engine_ops")
+    # relation sizes of every rank, rank 0's link rate (every rank models with it: hosts that called set_link_rate with per-rank
+    # measurements still take the same decisions) and the free device memory: one tiny all-gather, the same ladder everywhere
+    free_mb = (engine.free_bytes() >> 20) if hasattr(engine, "free_bytes") else (1 << 40)
+    mine = engine.counts_tensor([build_keys.numel(), probe_keys.numel(), int(_LINK_BYTES_PER_S / 1e3), free_mb])
+    allsz = engine.counts_tensor([0] * (4 * world))
     dist.all_gather_into_tensor(allsz, mine, group=group)
-    allsz = allsz.reshape(world, 3).tolist()
+    allsz = allsz.reshape(world, 4).tolist()
     link0 = float(allsz[0][2]) * 1e3
-    sizes_b = [int(x[0]) for x in allsz]
-    strategy = choose_strategy(world, max(sizes_b), max(int(x[1]) for x in allsz), materialize)
-    if strategy == "replicate":
-        return _replicated_join(dist, group, engine, world, build_keys, build_values, probe_keys, sizes_b, materialize, bloom,
-                                return_arrays, int(os.environ.get("FJ_REPLICATE_PIECES", "4")), timings)
-    if timings is not None:
-        timings["strategy"] = "shuffle"
-    form = {"auto": FORM_AUTO, "broadcast": FORM_BROADCAST}.get(strategy, FORM_SHUFFLE)
-    if not materialize and form != FORM_SHUFFLE:
-        # counting joins: the driver may take the build-broadcast form (a stand-in engine: when it has that form's callbacks)
-        can = (hasattr(engine, "bcast_plan") and engine.bcast_plan(sum(sizes_b)) is not None) if not hasattr(engine, "dist_engine_ops") else getattr(engine, "has_bcast", False)
-        if not can or world > 16:
-            if strategy == "broadcast" and os.environ.get("FJ_DIST_NO_FALLBACK"):
-                raise RuntimeError("FJ_DIST_STRATEGY=broadcast: this join cannot take the build-broadcast form (engine, > 16 ranks, or a total build side without a partitioned plan)")
-            form = FORM_SHUFFLE
-        elif form == FORM_BROADCAST or not hasattr(engine, "shuffle_plan") or engine.shuffle_plan(sum(sizes_b), world) is None or pieces <= 1:
-            # (forced, or the chunk form of the shuffle is not available for these sizes: nothing for the driver to choose between)
-            try:
-                tt = timings if timings is not None else {}
-                return _driver_count(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, form=FORM_BROADCAST)
-            except RuntimeError as ex:
-                if os.environ.get("FJ_DIST_NO_FALLBACK"):
-                    raise
-                _abort_stream(engine)
-                if timings is not None:
-                    timings["broadcast_form_error"] = str(ex)
-                form = FORM_SHUFFLE
-    if not materialize and pieces > 1 and hasattr(engine, "stream_begin"):
-        standin = hasattr(engine, "dist_engine_ops")
-        mode = "off" if not hasattr(engine, "bloom_export") else _prefilter_mode(bloom) if standin else _chunk_prefilter_mode(bloom, world)
-        nb_total, np_global = sum(sizes_b), sum(int(x[1]) for x in allsz)
-        # the chunk form (the first radix pass of the global plan is the owner split) serves every counting shuffle whose
-        # global plan has two or more passes, the sender-side precheck included (per-partition filters: fj_dist_join's
-        # prefilter_below); the owner-scatter form below serves the small ones (and a stand-in engine's precheck)
-        if ((mode == "off" or not standin or getattr(engine, "chunk_precheck", False)) and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0" and hasattr(engine, "shuffle_plan")
-                and engine.shuffle_plan(nb_total, world) is not None):      # (ranks with few or no rows: the driver sends everything as one piece)
-            # ONE driver for every transport: csrc/fj_dist.hip (fj_dist_join_count) - over RCCL under the nccl backend, over
-            # callbacks into torch.distributed under gloo / a transport object, with a stand-in engine in the CPU tests.  A step
-            # that fails on any rank fails on every rank (the driver agrees on it), so all of them fall back together to the
-            # owner-scatter form, whose segments are sized from an owner histogram: the answer to heavily skewed keys (an owner
-            # that receives far more than 1.5x its share overflows the chunk form's pools).
-            below, memo_key, decision = _precheck_threshold(mode, world, nb_total, np_global, link0, join_id)
-            for attempt in ((below, mode), (0.0, "off")) if below > 0 else ((0.0, mode),):     # (a failed step with the precheck is retried without it)
-                try:
-                    tt = timings if timings is not None else {}
-                    # (form AUTO: the driver weighs the build broadcast against the shuffle for these sizes; a precheck asks for the shuffle)
-                    res = _driver_count(dist, group, engine, build_keys, probe_keys, pieces, tt, transport, prefilter_below=attempt[0], prefilter_mode=attempt[1],
-                                        form=form if attempt[0] == 0.0 else FORM_SHUFFLE)
-                    _precheck_remember(memo_key, tt, decision)
-                    return res
-                except RuntimeError as ex:
-                    if os.environ.get("FJ_DIST_NO_FALLBACK"):
-                        raise
-                    _abort_stream(engine)
-                    if timings is not None:
-                        timings["chunk_form_error"] = str(ex)
-                    form = FORM_SHUFFLE                      # (a broadcast step that failed - a skewed partition - is retried as the shuffle)
-                    if attempt[0] > 0 and memo_key is not None:
-                        # a step that failed WITH the precheck (an owner of hot probe keys overflows pools sized from the mean before any
-                        # probe piece is seen) must not be attempted again on every later step of the same shape: remembered as declined,
-                        # re-examined with the next resample like any other verdict (all ranks fail together: the memos stay identical)
-                        _PRECHECK_MEMO[memo_key] = [1, 2.0]
-        if timings is not None:
-            timings["shuffle_form"] = "owner-scatter"
-        if not standin and hasattr(engine, "bloom_export"):
-            mode = _prefilter_mode(bloom)               # (the owner-scatter form's own rule and break-even)
-        return _pipelined_count(dist, group, engine, world, build_keys, build_values, probe_keys, pieces, timings, prefilter=mode)
+    sizes_b, sizes_p = [int(x[0]) for x in allsz], [int(x[1]) for x in allsz]
+    nb_total, np_global = sum(sizes_b), sum(sizes_p)
+    strategy = strategy or choose_strategy()
 
-    # materialising joins: the chunk form too (the build rows travel with their values, the pairs stay with the owner: SURVEY 8(e)) -
-    # through the same driver, sender-side precheck included; duplicate build keys and small build sides take the owner-scatter form below
-    if (materialize and hasattr(engine, "emit_pairs") and os.environ.get("FJ_DIST_CHUNK_SHUFFLE", "1") != "0"
-            and engine.shuffle_plan(sum(sizes_b), world) is not None):
+    # ---- which rungs apply, in order ----
+    rungs = []
+    if not materialize and strategy in ("auto", "broadcast") and world <= 16:
+        can = (hasattr(engine, "bcast_plan") and engine.bcast_plan(nb_total) is not None) if not standin else getattr(engine, "has_bcast", False)
+        # every rank holds a replica of the whole build side (6 bytes per key) beside its own pools (~20 bytes per local row of both relations)
+        need_mb = (6.1 * nb_total + 20.0 * (max(sizes_b) + max(sizes_p))) / 2**20
+        fits = min(int(x[3]) for x in allsz) > need_mb
+        if can and fits and (strategy == "broadcast" or form_model(world, max(sizes_b), max(sizes_p), link0, nb_total, np_global)["pick"] == "broadcast"):
+            rungs.append("broadcast")
+        elif strategy == "broadcast" and no_fallback:
+            raise RuntimeError("FJ_DIST_STRATEGY=broadcast: this join cannot take the build-broadcast form (engine, > 16 ranks, a total build side without "
+                               "a partitioned plan, or replicas that do not fit the free device memory)")
+    if (strategy != "scatter" and hasattr(engine, "shuffle_plan") and engine.shuffle_plan(nb_total, world) is not None
+            and (not materialize or hasattr(engine, "emit_pairs"))):
+        rungs.append("shuffle")
+    rungs.append("scatter")
+    memo_key = (world, nb_total, np_global, bool(materialize), join_id)
+    memo = _FORM_MEMO.get(memo_key)
+    if memo is not None and strategy == "auto":
+        memo[0] += 1
+        if memo[0] % _FORM_RETRY_EVERY:
+            rungs = [r for r in rungs if RUNGS.index(r) >= memo[1]] or ["scatter"]
+
+    # ---- down the ladder ----
+    tt = timings if timings is not None else {}
+    for i, rung in enumerate(rungs):
         try:
-            mode = _chunk_prefilter_mode(bloom, world)
-            below, memo_key, decision = _precheck_threshold(mode, world, sum(sizes_b), sum(int(x[1]) for x in allsz), link0, join_id)
-            tt = timings if timings is not None else {}
-            res = _driver_count(dist, group, engine, build_keys, probe_keys, pieces, tt, transport, build_values=build_values, return_arrays=return_arrays,
-                                prefilter_below=below, prefilter_mode=mode)
-            _precheck_remember(memo_key, tt, decision)
+            if rung == "broadcast":
+                res = _driver_join(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, form=FORM_BROADCAST)
+            elif rung == "shuffle":
+                mode = "off" if (standin and not getattr(engine, "chunk_precheck", False)) else _chunk_prefilter_mode(bloom, world, prefilter)
+                below, pf_key, decision = _precheck_threshold(mode, world, nb_total, np_global, link0, join_id)
+                res = None
+                for attempt in ((below, mode), (0.0, "off")) if below > 0 else ((0.0, mode),):     # (a failed step with the precheck is retried without it)
+                    try:
+                        res = _driver_join(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, build_values=build_values if materialize else None,
+                                           return_arrays=return_arrays, prefilter_below=attempt[0], prefilter_mode=attempt[1], form=FORM_SHUFFLE)
+                        _precheck_remember(pf_key, tt, decision)
+                        break
+                    except RuntimeError as ex:
+                        if no_fallback or attempt[0] == 0.0:
+                            raise
+                        _abort_stream(engine)
+                        tt["chunk_form_error"] = str(ex)
+                        if pf_key is not None:
+                            # a step that failed WITH the precheck (an owner of hot probe keys overflows pools sized from the mean before any probe
+                            # piece is seen) is remembered as declined, re-examined with the next resample like any other verdict
+                            _PRECHECK_MEMO[pf_key] = [1, 2.0]
+            else:
+                res = _owner_scatter_join(dist, group, engine, world, build_keys, build_values, probe_keys, materialize, bloom, return_arrays, tt, t0)
+            if i > 0 and strategy == "auto":
+                _FORM_MEMO[memo_key] = [0, RUNGS.index(rung)]           # the rungs above failed for this shape: start here for a while
+            elif i == 0 and memo is not None and memo[0] % _FORM_RETRY_EVERY == 0:
+                _FORM_MEMO.pop(memo_key, None)                          # re-examined, and the first rung holds again
             return res
         except RuntimeError as ex:
-            if os.environ.get("FJ_DIST_NO_FALLBACK"):
+            if no_fallback or rung == "scatter":
                 raise
             _abort_stream(engine)
-            if timings is not None:
-                timings["chunk_form_error"] = str(ex)
-    if timings is not None:
-        timings["shuffle_form"] = "owner-scatter"
-
-    # 1. split by owner
-    bk_s, bv_s, b_counts = engine.owner_split(build_keys, build_values, world)
-    pk_s, _, p_counts = engine.owner_split(probe_keys, None, world)
-    t1 = time.perf_counter()
-
-    # 2. counts, then payload: one all-to-all per array
-    def counts_to_owners(rows):
-        send_c = engine.counts_tensor(rows)
-        recv_c = engine.counts_tensor([0] * len(rows))
-        dist.all_to_all_single(recv_c, send_c, group=group)
-        return recv_c.reshape(world, len(rows) // world).tolist()
-
-    def message_rounds(largest):                 # the largest single message anywhere in the group decides (same value on every rank)
-        mx = engine.counts_tensor([largest])
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-        return max(1, -(-int(mx.item()) // _MAX_ELEMS_PER_MESSAGE))
-
-    mode = _prefilter_mode(bloom) if hasattr(engine, "bloom_export") else "off"
-    filtered, sampled, rows_before = False, None, sum(p_counts)
-    if mode == "off":
-        flat = []
-        for d in range(world):
-            flat += [b_counts[d], p_counts[d]]
-        rc = counts_to_owners(flat)
-        b_recv = [int(x[0]) for x in rc]
-        p_recv = [int(x[1]) for x in rc]
-        rounds = message_rounds(max(b_counts + p_counts))
-        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
-        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
-    else:
-        # sender-side precheck (see _pipelined_count): build side first, the owners' filters come back, survivors travel
-        b_recv = [int(x[0]) for x in counts_to_owners(list(b_counts))]
-        rounds = message_rounds(max(b_counts))
-        bk_r = _exchange(dist, group, engine, bk_s, b_counts, b_recv, rounds)
-        bv_r = _exchange(dist, group, engine, bv_s, b_counts, b_recv, rounds)
-        mine = engine.bloom_export(bk_r, 48)
-        filters = [engine.empty_like(mine) for _ in range(world)]
-        dist.all_gather(filters, mine, group=group)
-        filtered = True
-        if mode == "auto":
-            sampled = _sampled_survivors(dist, group, engine, world, probe_keys, filters)
-            filtered = sampled < _prefilter_break_even(world)
-        if filtered:
-            off, kept = 0, []
-            for d in range(world):
-                kept.append(engine.bloom_prefilter(pk_s[off: off + p_counts[d]], filters[d], 48))
-                off += p_counts[d]
-            p_counts = [int(k.numel()) for k in kept]
-            pk_s = engine.cat(kept)
-        del filters, mine
-        p_recv = [int(x[0]) for x in counts_to_owners(list(p_counts))]
-        rounds = message_rounds(max(p_counts))
-    pk_r = _exchange(dist, group, engine, pk_s, p_counts, p_recv, rounds)
-    engine.synchronize()
-    t2 = time.perf_counter()
-
-    # 3. join what this rank owns
-    res = engine.local_join(bk_r, bv_r, pk_r, materialize, bloom, 48, return_arrays)
-    local_count = int(res[0])
-
-    # 4. global count
-    tot = engine.counts_tensor([local_count])
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
-    engine.synchronize()
-    t3 = time.perf_counter()
-    if timings is not None:
-        timings.update(split_s=t1 - t0, exchange_s=t2 - t1, join_s=t3 - t2, exchange_rounds=rounds,
-                       local_build_rows=sum(b_recv), local_probe_rows=sum(p_recv), local_count=local_count,
-                       prefilter=filtered, prefilter_mode=mode, prefilter_sampled_survivors=sampled,
-                       probe_rows_sent=sum(p_counts) if filtered else rows_before)
-    out = (int(tot.item()), t3 - t0)
-    if materialize and return_arrays:
-        return out + (res[2], res[3])
-    return out
+            tt["broadcast_form_error" if rung == "broadcast" else "chunk_form_error"] = str(ex)
+    raise AssertionError("unreachable: the owner-scatter rung returns or raises")

@@ -22,23 +22,53 @@ def lib():
     return _lib.load()
 
 
-def test_library_exports_every_declared_symbol(lib):
-    from flash_hash_join_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "flashjoin.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # prose in comments may mention other names
-    declared = sorted(set(re.findall(r"\b(fj_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(declared) >= 15
-    assert sorted(_lib.SYMBOLS) == declared
-    for name in declared:
+    return sorted(set(re.findall(r"\b(fj_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+
+
+def test_library_exports_exactly_the_declared_symbols(lib):
+    """The drop-in boundary is include/flashjoin.h: 40 entry points, and they are ALL libflashjoin_hip.so exports (header ->
+    library and library -> header; the export list csrc/exports.map and the binding's table agree).  The building blocks behind
+    it (include/flashjoin_lab.h) are visible in libflashjoin_hip_lab.so only - the same objects linked without the export list."""
+    from flash_hash_join_amd import _lib
+    public, lab = _declared("flashjoin.h"), _declared("flashjoin_lab.h")
+    assert len(public) == 40 and not set(public) & set(lab)
+    assert sorted(_lib.SYMBOLS) == public and sorted(_lib.LAB_SYMBOLS) == lab
+    m = open(os.path.join(_lib.CSRC, "exports.map")).read()
+    assert sorted(re.findall(r"\b(fj_[a-z0-9_]+);", re.sub(r"/\*.*?\*/", "", m, flags=re.S))) == public
+    assert _exported(_lib.PRODUCT_LIB_PATH) == public, "libflashjoin_hip.so must export include/flashjoin.h and nothing else"
+    assert _exported(_lib.LAB_LIB_PATH) == sorted(public + lab)
+    for name in public:
         assert hasattr(lib, name), name
-    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
-    for name in declared:
-        assert re.search(rf"\bT {name}\b", out), f"{name} is not an exported text symbol"
-    # ... and library -> header: the C ABI is ALL the library exports (built with -fvisibility=hidden; what remains beside it are
-    # the toolchain's own symbols: the HIP fat-binary handles and C++ runtime weak symbols)
-    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
-    extra = [e for e in exported if e not in declared]
-    assert extra == [], f"exported but not declared in include/flashjoin.h: {extra}"
+    assert lib.fj_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define FJ_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "flashjoin.h")).read()).group(1))
+    # both libraries are links of the SAME objects: every public function has the same size in both
+    def sizes(path):
+        out = subprocess.check_output(["nm", "-D", "-S", "--defined-only", path], text=True)
+        return {l.split()[-1]: l.split()[1] for l in out.splitlines() if " T " in l}
+    sp, sl = sizes(_lib.PRODUCT_LIB_PATH), sizes(_lib.LAB_LIB_PATH)
+    assert all(sp[n] == sl[n] for n in public)
+
+
+def test_abi_structs_carry_their_size_and_old_option_variables_are_called_out(lib):
+    """structs the library fills or reads on a caller's behalf begin with struct_size (a caller built against another
+    layout is refused or served within its own bounds), FJ_OPTIONS rejects non-numeric values instead of reading them as 0, and the
+    per-option environment variables that round 5 removed produce one warning instead of being ignored silently."""
+    from flash_hash_join_amd import _lib
+    assert _lib.FjDistTimings._fields_[0][0] == "struct_size" and _lib.FjDistEngineOps._fields_[0][0] == "struct_size"
+    code = "from flash_hash_join_amd import _lib, api; print(api.get_option('join_wide'), api.get_option('radix_threshold'))"
+    env = dict(os.environ, FJ_OPTIONS="join_wide=abc,radix_threshold=77,=3,bogus=1", FJ_RADIX_THRESHOLD="5")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["2", "77"]                                  # join_wide=abc ignored (default 2), radix_threshold=77 taken
+    assert "ignoring 'join_wide=abc' (want name=integer)" in out.stderr and "ignoring 'bogus=1'" in out.stderr and "ignoring '=3'" in out.stderr
+    assert "FJ_RADIX_THRESHOLD is no longer read" in out.stderr
 
 
 def test_key_mixer_is_a_bijection_and_matches_its_numpy_restatement(lib):
@@ -79,12 +109,14 @@ def test_header_is_plain_c_and_the_c_example_links(lib, tmp_path):
     """include/flashjoin.h must be usable from C (the boundary a cgo / JNI / ctypes binding sees): it compiles as C99 and as
     C++11 on its own, and examples/host_join.c builds and links against the library (running it needs a GPU)."""
     from flash_hash_join_amd import _lib
-    hdr = os.path.join(ROOT, "include", "flashjoin.h")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
-    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    for h in ("flashjoin.h", "flashjoin_lab.h"):
+        hdr = os.path.join(ROOT, "include", h)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+        subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
     exe = str(tmp_path / "host_join")
+    libdir = os.path.dirname(_lib.PRODUCT_LIB_PATH)
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_join.c"),
-                           "-L" + os.path.dirname(_lib.LIB_PATH), "-lflashjoin_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", exe])
+                           "-L" + libdir, "-lflashjoin_hip", "-Wl,-rpath," + libdir, "-o", exe])
     assert os.path.exists(exe)
     if not has_gpu():                                           # no GPU: the example must fail loudly through fj_last_error, not crash
         out = subprocess.run([exe], capture_output=True, text=True)
@@ -215,13 +247,14 @@ def test_multi_gpu_strategy_model():
     documented break points."""
     from flash_hash_join_amd import distributed as D
     os.environ.pop("FJ_DIST_STRATEGY", None)
-    assert D.choose_strategy(8, 100_000_000, 1_000_000_000, False) == "auto"
-    for forced in ("shuffle", "broadcast", "replicate", "auto"):
+    assert D.choose_strategy() == "auto"
+    for forced in ("shuffle", "broadcast", "scatter", "auto"):
         os.environ["FJ_DIST_STRATEGY"] = forced
-        assert D.choose_strategy(2, 100_000_000, 1_000_000_000, False) == forced
-    os.environ["FJ_DIST_STRATEGY"] = "bogus"
-    with pytest.raises(ValueError):
-        D.choose_strategy(2, 1, 1, False)
+        assert D.choose_strategy() == forced
+    for gone in ("bogus", "replicate"):                        # (rounds 1-4's unpartitioned replicate is superseded by the broadcast form and gone)
+        os.environ["FJ_DIST_STRATEGY"] = gone
+        with pytest.raises(ValueError):
+            D.choose_strategy()
     os.environ.pop("FJ_DIST_STRATEGY")
     # BASELINE configs[4]'s per-rank sizes: every link carries 0.75 GB (broadcast) against 9.7 / 2.4 / 1.2 GB (shuffle at N = 2 / 4 / 8)
     for world in (2, 4, 8):
@@ -232,31 +265,25 @@ def test_multi_gpu_strategy_model():
     assert 0.0165 < m["broadcast"] < 0.0185 and 0.023 < m["shuffle"] < 0.026, m           # kernel-bound at ~17.5 ms against a wire-bound ~24.4 ms
     assert D.form_model(8, 500_000_000, 500_000_000, 55e9)["pick"] == "shuffle"          # as many build rows as probe rows: the regions outweigh the rows
     assert D.form_model(8, 125_000_000, 1_250_000_000, 4000e9)["pick"] == "shuffle"      # links as fast as HBM: the form with fewer kernels
-    c = D.strategy_costs(2, 100_000_000, 1_000_000_000, False)
-    assert c["shuffle"] > 3 * c["replicate"]                                           # (rounds 1-4's model of the unpartitioned replicate)
-    # passes: none up to 3950 rows (one cuckoo table), one up to 9 radix bits (512 buckets), two up to 18 bits,
-    # then three; a build side just under 4096 * 2^k takes one more bit where that costs no extra pass
-    assert [D._plan_passes(n) for n in (1, 3950, 3951, 4096, 4097, 1 << 20, (1 << 20) + 1, 2_000_000, 2_100_000, 100_000_000,
-                                        268_435_456, 268_435_457, 800_000_000, 1 << 30, (1 << 30) + 1)] == \
-        [0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3]
+    # the Python layer reads six environment variables and no more
+    src = open(os.path.join(ROOT, "flash_hash_join_amd", "distributed.py")).read() + open(os.path.join(ROOT, "flash_hash_join_amd", "_lib.py")).read() + \
+        open(os.path.join(ROOT, "flash_hash_join_amd", "api.py")).read() + open(os.path.join(ROOT, "flash_hash_join_amd", "lab.py")).read()
+    assert sorted(set(re.findall(r"environ[^\n]*?[\"'](FJ_[A-Z_]+)[\"']", src))) == ["FJ_DIST_NATIVE", "FJ_DIST_NO_FALLBACK", "FJ_DIST_PIECES", "FJ_DIST_PREFILTER", "FJ_DIST_STRATEGY", "FJ_LIB_VARIANT"]
+    assert len(open(os.path.join(ROOT, "flash_hash_join_amd", "distributed.py")).read().splitlines()) <= 900
 
 
-def test_shuffle_prefilter_decision_model(monkeypatch):
-    """The sender-side precheck of the owner shuffle: environment / `bloom` -> mode, and the survivor fraction below which
-    the sampled ("auto") decision runs it: generous on small meshes (a sender filters N segments while each link carries
-    one), never on a link too fast to be worth a pass."""
+def test_shuffle_prefilter_mode(monkeypatch):
+    """The sender-side precheck of the chunk-form shuffle: environment / `bloom` / an explicit override -> mode ("auto" for every
+    join across more than one rank: the per-link model of _chunk_prefilter_break_even decides from a sample)."""
     from flash_hash_join_amd import distributed as D
     monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False)
-    assert D._prefilter_mode(False) == "off" and D._prefilter_mode(True) == "auto"
+    assert D._chunk_prefilter_mode(False, 1) == "off" and D._chunk_prefilter_mode(True, 1) == "auto" and D._chunk_prefilter_mode(False, 2) == "auto"
     for env, mode in (("0", "off"), ("1", "on"), ("auto", "auto")):
         monkeypatch.setenv("FJ_DIST_PREFILTER", env)
-        assert D._prefilter_mode(False) == D._prefilter_mode(True) == mode
+        assert D._chunk_prefilter_mode(False, 1) == D._chunk_prefilter_mode(True, 8) == mode
+        assert D._chunk_prefilter_mode(False, 8, "on") == "on"                  # an explicit argument wins
     monkeypatch.setenv("FJ_DIST_PREFILTER", "bogus")
-    assert D._prefilter_mode(True) == "auto" and D._prefilter_mode(False) == "off"
-    be = [D._prefilter_break_even(w) for w in (2, 4, 8, 16)]
-    assert be == sorted(be, reverse=True) and 0.6 < be[0] < 0.8 and 0.3 < be[2] < 0.45 and be[3] < 0.2
-    monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 1e15)
-    assert D._prefilter_break_even(8) == 0.0
+    assert D._chunk_prefilter_mode(True, 1) == "auto" and D._chunk_prefilter_mode(False, 1) == "off"
 
 
 def test_bench_launches_its_own_ranks_when_asked_for_several_gpus(monkeypatch):

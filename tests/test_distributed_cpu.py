@@ -1,7 +1,7 @@
-"""CPU test of the multi-GPU protocol (flash_hash_join_amd/distributed.py): world_size 2 and 3 over
-gloo.  The per-rank primitives are replaced by a stand-in engine built on the CPU oracle (test
-infrastructure); what is under test is the host logic: owner split -> counts exchange ->
-all_to_all_single payload -> local join -> all-reduce."""
+"""CPU test of the multi-GPU protocol (flash_hash_join_amd/distributed.py + the C++ driver csrc/fj_dist.hip): world_size 2 and 3
+over gloo.  The per-rank primitives are replaced by a stand-in engine built on the CPU oracle (test infrastructure); what is
+under test is the host logic: the ladder of forms (build broadcast -> owner shuffle in chunk form -> owner scatter), the driver's
+state machine over a callback transport, agreed failures and what is remembered about them, the sender-side precheck's protocol."""
 import os
 import socket
 import sys
@@ -37,29 +37,6 @@ class OracleEngine:
     def counts_tensor(self, counts):
         return torch.tensor(counts, dtype=torch.int64)
 
-    def empty_like(self, t):
-        return torch.empty_like(t)
-
-    def cat(self, parts):
-        return torch.cat(list(parts))
-
-    # stand-in for fj_bloom_export / fj_bloom_prefilter: ONE 2^20-bit filter per owner, one bit per key (what the protocol
-    # needs from them: fixed-size filters that never reject a key of the build side)
-    _FBITS = 1 << 20
-
-    def _fpos(self, keys):
-        return (_fmix64(keys.numpy().view(np.uint64).copy()) % np.uint64(self._FBITS)).astype(np.int64)
-
-    def bloom_export(self, build_keys, hash_top_bits):
-        assert hash_top_bits == 48
-        bits = np.zeros(self._FBITS, dtype=np.int32)
-        bits[self._fpos(build_keys)] = 1
-        return torch.from_numpy(bits)
-
-    def bloom_prefilter(self, keys, filters, hash_top_bits):
-        assert hash_top_bits == 48 and filters.numel() == self._FBITS
-        return keys[torch.from_numpy(filters.numpy()[self._fpos(keys)] != 0)]
-
     def owner_split(self, keys, vals, world):
         k = keys.numpy().view(np.uint64)
         owner = (((_fmix64(k.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)).astype(np.int64)
@@ -68,14 +45,6 @@ class OracleEngine:
         ok = torch.from_numpy(k[order].view(np.int64).copy())
         ov = torch.from_numpy(vals.numpy()[order].copy()) if vals is not None else None
         return ok, ov, counts
-
-    def owner_hist(self, keys, world):
-        return self.owner_split(keys, None, world)[2]
-
-    def owner_scatter(self, keys, world, counts):
-        out, _, c = self.owner_split(keys, None, world)
-        assert c == list(counts)
-        return out
 
     # stand-in for the chunk form of the owner shuffle: the rank's own work behind the C++ driver (csrc/fj_dist.hip runs the
     # protocol; fj_dist_engine_ops callbacks do what fj_shuffle_pack_* / fj_stream_open_shuffled / fj_stream_append_*_chunks do
@@ -92,35 +61,6 @@ class OracleEngine:
 
     def shuffle_plan(self, nb_total, world):
         return 5 if nb_total >= 10000 and world <= 32 else None
-
-    def stream_begin(self, bk, bv, np_bound, max_appends, hash_top_bits):
-        self._b = (bk, bv); self._pieces = []; self._bound = np_bound; self._max = max_appends; self._closed = False
-
-    def stream_open(self, nb_bound, build_appends, np_bound, probe_appends, hash_top_bits):
-        assert hash_top_bits == 64
-        self._b = None; self._bp = []; self._bb = nb_bound; self._bmax = build_appends
-        self._pieces = []; self._bound = np_bound; self._max = probe_appends; self._closed = False
-
-    def stream_append_build(self, piece):
-        self._bp.append(piece)
-        assert len(self._bp) <= self._bmax and sum(p.numel() for p in self._bp) <= self._bb
-
-    def stream_advance_probe(self):
-        self._closed = True
-
-    def stream_append(self, piece):
-        assert not getattr(self, "_closed", False)
-        self._pieces.append(piece)
-        assert len(self._pieces) <= self._max and sum(p.numel() for p in self._pieces) <= self._bound
-
-    def stream_finish(self):
-        pk = torch.cat(self._pieces) if self._pieces else torch.empty(0, dtype=torch.int64)
-        assert pk.numel() == self._bound
-        if self._b is None:                     # replicate strategy: build keys arrived in pieces, no values
-            bk = torch.cat(self._bp)
-            assert bk.numel() == self._bb
-            self._b = (bk, torch.zeros_like(bk))
-        return self.O.c_join(self._b[0].numpy(), self._b[1].numpy(), pk.numpy(), algo="radix", threads=2)[0]
 
     def local_join(self, bk, bv, pk, materialize, bloom, hash_top_bits, return_arrays):
         res = self.O.c_join(bk.numpy(), bv.numpy(), pk.numpy(), algo="radix", bloom=bloom, materialize=materialize,
@@ -347,19 +287,21 @@ def _worker_chunk_precheck(rank, world, port, nb, npk, q):
         tb, tv, tp = (torch.from_numpy(x.view(np.int64)) for x in (bk, bv, pk))
         e = torch.tensor([exp_local]); dist.all_reduce(e); exp = int(e.item())
         out = {}
-        for name, env in (("on", {"FJ_DIST_PREFILTER": "1"}), ("auto_runs", {"FJ_DIST_PREFILTER": "auto", "FJ_DIST_PREFILTER_BELOW": "0.9"}),
-                          ("auto_again", {"FJ_DIST_PREFILTER": "auto", "FJ_DIST_PREFILTER_BELOW": "0.9"}),
-                          ("auto_declines", {"FJ_DIST_PREFILTER": "auto", "FJ_DIST_PREFILTER_BELOW": "0.05"}),
-                          ("export_fails", {"FJ_DIST_PREFILTER": "1", "FJ_TEST_FAIL": f"export:{world - 1}"})):
-            for k in ("FJ_DIST_PREFILTER", "FJ_DIST_PREFILTER_BELOW", "FJ_TEST_FAIL"):
+        for name, env, below in (("on", {"FJ_DIST_PREFILTER": "1"}, None), ("auto_runs", {"FJ_DIST_PREFILTER": "auto"}, 0.9),
+                                 ("auto_again", {"FJ_DIST_PREFILTER": "auto"}, 0.9),
+                                 ("auto_declines", {"FJ_DIST_PREFILTER": "auto"}, 0.05),
+                                 ("export_fails", {"FJ_DIST_PREFILTER": "1", "FJ_TEST_FAIL": f"export:{world - 1}"}, None)):
+            for k in ("FJ_DIST_PREFILTER", "FJ_TEST_FAIL"):
                 os.environ.pop(k, None)
             os.environ.update(env)
+            D.PREFILTER_BELOW_OVERRIDE = below
+            D._FORM_MEMO.clear()
             if name in ("auto_runs", "auto_declines"):
                 D._PRECHECK_MEMO.clear()
             t = {}
             cnt, _ = D.distributed_join(tb, tv, tp, engine=OracleEngine(), timings=t)
             assert cnt == exp, (name, cnt, exp)
-            assert t["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport"), (name, t)
+            assert t["shuffle_form"].startswith("chunks (fj_dist_join over a callback transport"), (name, t)
             glob = torch.tensor([t["probe_rows_sent"]]); dist.all_reduce(glob)
             if name in ("on", "auto_runs", "auto_again"):
                 assert t["prefilter"] is True and "chunk_form_error" not in t, (name, t)
@@ -384,26 +326,19 @@ def _worker(rank, world, port, nb, npk, q, strategy):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    small_messages = strategy == "replicate_small_messages"
     variant = strategy.split("_", 1)[1] if "_" in strategy else ""
-    prefilter = variant in ("prefilter", "prefilterauto")
     strategy = strategy.split("_")[0]
-    os.environ["FJ_DIST_PREFILTER"] = {"prefilter": "1", "prefilterauto": "auto", "prefilterdeclined": "auto"}.get(variant, "0")
+    os.environ["FJ_DIST_PREFILTER"] = "0"
     os.environ["FJ_DIST_STRATEGY"] = strategy
-    os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if variant == "scatter" else "1"
-    if variant in ("packfail", "copyfail", "appendfail", "bcpackfail", "bcjoinfail"):    # one rank's packing pass / local join fails inside the C++ driver: EVERY rank sees the failure
+    failing = variant in ("packfail", "copyfail", "appendfail")
+    if failing:    # one rank's packing pass / local join fails inside the C++ driver: EVERY rank sees the failure
         os.environ["FJ_TEST_FAIL"] = variant[:-4] + ":" + str(world - 1)
-    if strategy == "replicate":
-        os.environ["FJ_REPLICATE_PIECES"] = "3"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from flash_hash_join_amd import datagen
+        import flash_hash_join_amd.distributed as D
         from flash_hash_join_amd.distributed import distributed_join
-        if variant == "prefilterdeclined":      # an infinitely fast link: the sampled decision turns the precheck down
-            import flash_hash_join_amd.distributed as D
-            D._LINK_BYTES_PER_S = 1e15
-        if small_messages:                      # every collective carries <= 3000 rows per rank: 4 pieces, reordered rank-major
-            import flash_hash_join_amd.distributed as D
+        if variant == "smallmessages":          # every message of the owner-scatter exchange carries <= 3000 rows: several rounds per array
             D._MAX_ELEMS_PER_MESSAGE = 3000
         # block distribution of the global relation (GPU g holds rows [g*N/G, (g+1)*N/G))
         b0, b1 = rank * nb // world, (rank + 1) * nb // world
@@ -432,16 +367,16 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             e0 = torch.tensor([exp_local]); dist.all_reduce(e0)
             chk = self_check(dist, None, OracleEngine(), (tb, tv, tp), int(e0.item()), 5000)
             assert chk["ok"] and chk["failed_ranks"] == 0 and chk["message_bytes"] == 40000, chk
-            os.environ["FJ_SELFCHECK_CORRUPT"] = "1"
-            chk = self_check(dist, None, OracleEngine(), (tb, tv, tp), int(e0.item()), 5000)
-            del os.environ["FJ_SELFCHECK_CORRUPT"]
+            chk = self_check(dist, None, OracleEngine(), (tb, tv, tp), int(e0.item()), 5000, corrupt=True)
             assert not chk["ok"] and chk["failed_ranks"] == 1 and (rank != 0 or "elements received from rank" in chk["error"]), chk
             chk = self_check(dist, None, OracleEngine(), (tb, tv, tp), int(e0.item()) + 1, 5000)        # a wrong expectation: the join check fires
             assert not chk["ok"] and chk["failed_ranks"] == world and "join self-check" in chk["error"], chk
+        # materialising: a stand-in engine cannot emit an owner's pairs from the chunk form: the owner-scatter rung
         res = distributed_join(tb, tv, tp, materialize=True, return_arrays=True, engine=OracleEngine(), timings=t)
+        assert t["strategy"] == "scatter" and t["shuffle_form"] == "owner-scatter", t
         exp = torch.tensor([exp_local]); dist.all_reduce(exp)
         tc = {}
-        if variant in ("packfail", "copyfail", "appendfail"):
+        if failing:
             os.environ["FJ_DIST_NO_FALLBACK"] = "1"
             # ("copyfail": the failing rank stays in step - nobody waits for an exchange it never posted - up to the final all-reduce,
             #  where what it sent instead of the piece may have failed its receivers' joins too: "on N rank(s)")
@@ -453,53 +388,36 @@ def _worker(rank, world, port, nb, npk, q, strategy):
             else:
                 assert ("injected" in str(ei.value)) == (rank == world - 1)       # the failing rank says why, the others that somebody failed
             del os.environ["FJ_DIST_NO_FALLBACK"]
-        cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)        # counting: pipelined exchange
-        assert cnt == int(exp.item()) and tc["strategy"] == t["strategy"] == strategy
-        if variant in ("packfail", "copyfail", "appendfail"):    # ... and without FJ_DIST_NO_FALLBACK all ranks rerun in the owner-scatter form together
-            assert "failed on " in tc["chunk_form_error"] and tc["shuffle_form"] == "owner-scatter"
-        if variant in ("skew", "uneven"):
-            assert tc["shuffle_form"].startswith("chunks") and "chunk_form_error" not in tc, tc
+        cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)        # counting
+        assert cnt == int(exp.item())
+        if failing:    # without FJ_DIST_NO_FALLBACK all ranks move down the ladder together: the owner-scatter rung
+            assert "failed on " in tc["chunk_form_error"] and tc["shuffle_form"] == "owner-scatter" and tc["strategy"] == "scatter", tc
+            # ... and under "auto" the shape is remembered: the next step starts at the rung that worked (no second failed attempt)
+            os.environ["FJ_DIST_STRATEGY"] = "auto"
+            D._FORM_MEMO.clear()
+            t1, t2 = {}, {}
+            assert distributed_join(tb, tv, tp, engine=OracleEngine(), timings=t1, strategy="shuffle")[0] == cnt          # (pinned: nothing is remembered)
+            assert not D._FORM_MEMO and "chunk_form_error" in t1
+            os.environ["FJ_DIST_STRATEGY"] = strategy
+        elif strategy == "scatter":
+            assert tc["strategy"] == "scatter" and tc["shuffle_form"] == "owner-scatter" and tc["probe_rows_sent"] == p1 - p0, tc
+            if variant == "smallmessages":
+                assert tc["exchange_rounds"] >= 2, tc
+        elif variant in ("skew", "uneven", ""):
+            assert tc["strategy"] == "shuffle" and tc["shuffle_form"].startswith("chunks (fj_dist_join over a callback transport") and "chunk_form_error" not in tc, tc
         if variant == "uneven":
             assert tc["pieces"] == 1          # a rank without probe rows: the exchange is not cut into pieces
         if variant == "lateskew":                    # (at these sizes the pools' constant slack absorbs it; at scale the ranks would rerun together in the owner-scatter form)
             assert tc["shuffle_form"].startswith("chunks") or "failed on" in tc["chunk_form_error"], tc
-        keys = res[2].numpy().view(np.uint64)
-        assert tc.get("prefilter", False) == prefilter
-        if variant.startswith("prefilter"):
-            assert tc["prefilter_mode"] == ("on" if variant == "prefilter" else "auto")
-            assert (tc["prefilter_sampled_survivors"] is None) == (variant == "prefilter")
-            if variant != "prefilter":
-                assert 0.45 < tc["prefilter_sampled_survivors"] < 0.6          # 50 % hits + a few false positives
-        if strategy == "shuffle":
-            assert t["prefilter"] == prefilter          # the materialising (one-shot) shuffle takes the same decision
-        if prefilter:                           # half the probe rows miss: the filters (load 1/40) keep nearly none of them
-            assert tc["local_probe_rows"] == t["local_probe_rows"] and tc["probe_rows_sent"] == t["probe_rows_sent"] < 0.6 * (p1 - p0)
-            glob = torch.tensor([tc["local_probe_rows"]]); dist.all_reduce(glob)
-            assert int(exp.item()) <= int(glob.item()) < 0.6 * npk
-        elif strategy == "shuffle" and variant in ("skew", "lateskew", "uneven"):
-            pass
-        elif strategy == "shuffle" and variant == "":
-            # the counting join took the chunk form (its owners are whole first-pass buckets: another split of the hash range than
-            # the owner-scatter form the materialising join uses, so only the totals agree)
-            assert tc["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport") and tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
-            assert tc["wire_chunk_bytes"] == 2048 and "chunk_form_error" not in tc
+        if strategy == "shuffle" and variant == "":
+            assert tc["probe_rows_sent"] == p1 - p0 and tc["wire_chunk_bytes"] == 2048 and tc["pieces"] == 4
             # (the driver reports received CHUNKS x 256: the stand-in's ragged 200-key chunks count as whole ones)
             glob = torch.tensor([tc["local_probe_rows"], tc["local_build_rows"], tc["local_count"]]); dist.all_reduce(glob)
             assert npk <= glob[0] <= 2.5 * npk and nb <= glob[1] <= 2.5 * nb and int(glob[2]) == int(exp.item())
-        else:
-            assert tc["local_probe_rows"] == t["local_probe_rows"]
-            if strategy == "shuffle":
-                assert tc["shuffle_form"] == "owner-scatter" and tc["probe_rows_sent"] == t["probe_rows_sent"] == p1 - p0
-        if strategy == "shuffle":
-            assert tc["pieces"] == (1 if variant == "uneven" else 4)
-            # every pair this rank owns must hash to this rank
-            owner = ((_fmix64(keys.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)
-            owned = bool(np.all(owner == rank))
-        else:
-            # pairs stay with the probe row: every emitted key is one of this rank's probe keys, every build row was here
-            per_rank = -(-nb // world)
-            assert tc["pieces"] == (max(3, -(-per_rank // 3000)) if small_messages else 3) and t["local_build_rows"] == nb
-            owned = bool(np.isin(keys, pk).all()) and t["local_probe_rows"] == p1 - p0
+        # every pair this rank owns must hash to this rank (the owner-scatter rung: owner = top 16 hash bits * world >> 16)
+        keys = res[2].numpy().view(np.uint64)
+        owner = ((_fmix64(keys.copy()) >> np.uint64(48)) * np.uint64(world)) >> np.uint64(16)
+        owned = bool(np.all(owner == rank))
         q.put((rank, int(res[0]), int(exp.item()), int(res[2].numel()), owned, t.get("local_count")))
     finally:
         dist.destroy_process_group()
@@ -514,13 +432,17 @@ def _worker_broadcast(rank, world, port, nb, npk, q, variant):
     os.environ["MASTER_PORT"] = str(port)
     os.environ["FJ_DIST_PREFILTER"] = "0"
     os.environ.pop("FJ_DIST_STRATEGY", None)
-    if variant != "auto":
+    auto = variant.startswith("auto")
+    if not auto:
         os.environ["FJ_DIST_STRATEGY"] = "broadcast"
+    if variant == "autofail":
+        variant = "bcjoinfail"
     if variant in ("bcpackfail", "bcjoinfail"):
         os.environ["FJ_TEST_FAIL"] = variant[:-4] + ":" + str(world - 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from flash_hash_join_amd import datagen
+        import flash_hash_join_amd.distributed as D
         from flash_hash_join_amd.distributed import distributed_join
         b0, b1 = rank * nb // world, (rank + 1) * nb // world
         p0, p1 = rank * npk // world, (rank + 1) * npk // world
@@ -540,8 +462,15 @@ def _worker_broadcast(rank, world, port, nb, npk, q, variant):
         tc = {}
         cnt, _ = distributed_join(tb, tv, tp, engine=OracleEngine(), timings=tc)
         assert cnt == int(exp.item()), (cnt, int(exp.item()))
-        if variant in ("bcpackfail", "bcjoinfail"):     # without FJ_DIST_NO_FALLBACK all ranks rerun together in another form
-            assert "failed on 1 rank" in tc["broadcast_form_error"] and tc["strategy"] == "shuffle", tc
+        if variant in ("bcpackfail", "bcjoinfail"):     # without FJ_DIST_NO_FALLBACK all ranks move down the ladder together: the chunk shuffle comes next
+            assert "failed on 1 rank" in tc["broadcast_form_error"] and tc["strategy"] == "shuffle" and "chunk_form_error" not in tc, tc
+            if auto:
+                # under "auto" a failed broadcast used to drop to the owner-scatter form - and to be attempted again on every
+                # step.  Now the shuffle is the next rung, and the shape remembers where to start: no second failed attempt
+                t2 = {}
+                assert distributed_join(tb, tv, tp, engine=OracleEngine(), timings=t2)[0] == cnt
+                assert t2["strategy"] == "shuffle" and "broadcast_form_error" not in t2, t2
+                assert list(D._FORM_MEMO.values()) == [[1, 1]], D._FORM_MEMO
         else:
             assert tc["strategy"] == "broadcast" and tc["shuffle_form"].startswith("build broadcast") and tc["probe_rows_sent"] == 0, tc
             assert tc["pieces"] == 4 and tc["local_probe_rows"] == p1 - p0
@@ -552,7 +481,7 @@ def _worker_broadcast(rank, world, port, nb, npk, q, variant):
         # a materialising join under the same setting shuffles (the pairs stay with the owner of the key)
         t = {}
         res = distributed_join(tb, tv, tp, materialize=True, return_arrays=True, engine=OracleEngine(), timings=t)
-        assert res[0] == int(exp.item()) and t["strategy"] == "shuffle"
+        assert res[0] == int(exp.item()) and t["strategy"] == "scatter"
         q.put((rank, int(cnt), int(exp.item())))
     finally:
         dist.destroy_process_group()
@@ -562,8 +491,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_copyfail", "shuffle_appendfail", "shuffle_skew", "shuffle_lateskew", "shuffle_uneven", "shuffle_scatter", "shuffle_prefilter", "shuffle_prefilterauto", "shuffle_prefilterdeclined", "replicate",
-                                      "replicate_small_messages"])
+@pytest.mark.parametrize("strategy", ["shuffle", "shuffle_packfail", "shuffle_copyfail", "shuffle_appendfail", "shuffle_skew", "shuffle_lateskew", "shuffle_uneven", "scatter", "scatter_smallmessages"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_join_gloo(world, strategy, oracle):
     nb, npk = 20000, 90000
@@ -585,10 +513,10 @@ def test_distributed_join_gloo(world, strategy, oracle):
     assert total_pairs == rows[0][1]
 
 
-@pytest.mark.parametrize("variant", ["", "auto", "uneven", "bcpackfail", "bcjoinfail"])
+@pytest.mark.parametrize("variant", ["", "auto", "autofail", "uneven", "bcpackfail", "bcjoinfail"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_build_broadcast_form_through_the_driver_gloo(world, variant, oracle):
-    nb, npk = 20000, (400000 if variant == "auto" else 90000)
+    nb, npk = 20000, (400000 if variant.startswith("auto") else 90000)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -626,7 +554,7 @@ def test_chunk_form_precheck_break_even_model(monkeypatch):
     one or three links carry the shuffle; at 8 GPUs ~0.75 with 45 GB/s links, ~0.55 with 55, ~0.15 with 65; zero when the links outrun the
     kernels.  _chunk_prefilter_mode: "auto" for every multi-rank join unless FJ_DIST_PREFILTER says otherwise."""
     from flash_hash_join_amd import distributed as D
-    monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False); monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW", raising=False)
+    monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False); monkeypatch.setattr(D, "PREFILTER_BELOW_OVERRIDE", None)
     monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 45e9)
     f = D._chunk_prefilter_break_even
     assert f(1, 125_000_000, 1_250_000_000) == 0.0 and f(8, 8_000_000, 10_000_000) == 0.0 and f(4, 10**9, 0) == 0.0
@@ -638,7 +566,7 @@ def test_chunk_form_precheck_break_even_model(monkeypatch):
     assert f(8, 10**9, 1_250_000_000) < 0.2
     monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 200e9)
     assert f(8, 10**9, 1_250_000_000) == 0.0
-    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.25")
+    monkeypatch.setattr(D, "PREFILTER_BELOW_OVERRIDE", 0.25)
     assert f(1, 1, 1) == 0.25
     assert D._chunk_prefilter_mode(False, 1) == "off" and D._chunk_prefilter_mode(True, 1) == "auto" and D._chunk_prefilter_mode(False, 8) == "auto"
     monkeypatch.setenv("FJ_DIST_PREFILTER", "0")
@@ -663,12 +591,10 @@ def test_a_failed_precheck_attempt_is_remembered_as_declined(monkeypatch):
         tt.update(strategy="shuffle", prefilter=False, prefilter_sampled_survivors=None)
         return 7, 0.0
 
-    monkeypatch.setattr(D, "_driver_count", fake_driver)
+    monkeypatch.setattr(D, "_driver_join", fake_driver)
 
     class Eng:
         def counts_tensor(self, c): return torch.tensor(c, dtype=torch.int64)
-        def stream_begin(self): pass
-        def bloom_export(self): pass
         def shuffle_plan(self, nb_total, world): return 9
         def stream_abort(self): pass
         has_bcast = False
@@ -680,7 +606,7 @@ def test_a_failed_precheck_attempt_is_remembered_as_declined(monkeypatch):
         def get_world_size(self, group=None): return 8
         def all_gather_into_tensor(self, out, t, group=None): out.copy_(t.repeat(8))
 
-    monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_PREFILTER", "auto"); monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.6")
+    monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_PREFILTER", "auto"); monkeypatch.setattr(D, "PREFILTER_BELOW_OVERRIDE", 0.6)
     bk = torch.arange(125_000, dtype=torch.int64); pk = torch.arange(1_250_000, dtype=torch.int64)
     below = D._precheck_threshold("auto", 8, 8 * 125_000, 8 * 1_250_000)[0]
     assert below == 0.6                                    # a threshold in the model's place: sample, then decide
@@ -697,7 +623,7 @@ def test_precheck_verdict_is_remembered_per_join_shape(monkeypatch):
     declines without exporting a filter, and samples afresh on every 32nd call; forced modes and joins the model rules out keep no memo."""
     from flash_hash_join_amd import distributed as D
     monkeypatch.delenv("FJ_DIST_PREFILTER", raising=False)
-    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.4")
+    monkeypatch.setattr(D, "PREFILTER_BELOW_OVERRIDE", 0.4)
     D._PRECHECK_MEMO.clear()
     shape = (8, 10**9, 10**10)
     assert D._precheck_threshold("on", *shape) == (2.0, None, "on") and D._precheck_threshold("off", *shape) == (0.0, None, "off")
@@ -717,13 +643,10 @@ def test_precheck_verdict_is_remembered_per_join_shape(monkeypatch):
     assert D._precheck_threshold("auto", 8, 10**9, 5 * 10**9)[2] == "sampled"     # another shape: its own verdict
     assert D._precheck_threshold("auto", *shape, None, "orders x lineitem")[2] == "sampled"   # the same shape under a name: its own verdict too
     # the threshold is a function of the link rate it is GIVEN (distributed_join passes rank 0's), not of this process's setting
-    monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
+    monkeypatch.setattr(D, "PREFILTER_BELOW_OVERRIDE", None)
     slow, fast = D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000, 45e9), D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000, 65e9)
     monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 65e9)
     assert slow > fast and D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000, 45e9) == slow and D._chunk_prefilter_break_even(8, 10**9, 1_250_000_000) == fast
-    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.4")
-    monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0")
-    monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
     monkeypatch.setattr(D, "_LINK_BYTES_PER_S", 45e9)
     assert D._precheck_threshold("auto", 1, 125_000_000, 1_250_000_000) == (0.0, None, "model: cannot pay")
     D._PRECHECK_MEMO.clear()

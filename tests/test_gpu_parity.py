@@ -73,6 +73,41 @@ def test_all_twelve_functions_match_golden_vectors(fj, oracle, name, scalar_mode
         assert _digest(oracle, k, v) == g["pairs_sha256"], fn
 
 
+def test_golden_vectors_through_the_product_library(fj):
+    """This test process loads the lab build of the library (conftest.py: the same objects, linked without the export list).  The
+    PRODUCT library - what a host binds - runs in a child process here: the twelve functions on every golden case, pair digests
+    included, and the driver's own smoke()."""
+    import subprocess
+    import sys
+    from conftest import ROOT, product_env
+    code = """
+import hashlib, json, os, sys
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import flash_join
+from flash_hash_join_amd import _lib
+from golden_inputs import CASES, make_case
+assert _lib.LIB_PATH.endswith("libflashjoin_hip.so") and not _lib.load().has_lab, _lib.LIB_PATH
+g = json.load(open(os.path.join(%r, "tests", "golden", "golden_joins.json")))
+def digest(k, v):
+    o = np.lexsort((v, k)); k, v = k[o], v[o]
+    return hashlib.sha256(k.tobytes() + v.tobytes()).hexdigest()
+for name in CASES:
+    bk, bv, pk = make_case(name)
+    for fn in ("hash_join_count", "hash_join_count_bloom", "hash_join_count_radix", "hash_join_count_radix_bloom", "adaptive_join_count", "adaptive_join_count_bloom",
+               "hash_join", "hash_join_bloom", "hash_join_radix", "hash_join_radix_bloom", "adaptive_join", "adaptive_join_bloom"):
+        assert getattr(flash_join, fn)(bk, bv, pk)[0] == g[name]["count"], (name, fn)
+    for fn in ("hash_join", "hash_join_radix", "adaptive_join"):
+        n, sec, k, v = getattr(flash_join, fn)(bk, bv, pk, return_arrays=True)
+        assert n == g[name]["count"] and digest(k.view(np.uint64), v.view(np.uint64)) == g[name]["pairs_sha256"], (name, fn)
+import __graft_entry__
+__graft_entry__.smoke()
+print("PRODUCT OK", len(CASES))
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT, env=product_env())
+    assert out.returncode == 0 and "PRODUCT OK" in out.stdout, out.stdout[-1500:] + out.stderr[-2500:]
+
+
 def test_big_golden_case_two_pass_plan_and_the_wide_join_kernel(fj, oracle):
     """A committed fixture of 21M x 50M rows (tests/golden/golden_joins.json: count and pair digest by the C restatement AND the
     NumPy oracle, tests/golden/make_golden.py): a two-pass plan and the bucketed wide join kernel meet a golden vector, not only
@@ -103,8 +138,9 @@ def test_bench_line_at_one_gpu_is_self_consistent(fj):
     import subprocess
     import sys
     from conftest import ROOT
+    from conftest import product_env
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-entry"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=product_env())
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -420,7 +456,7 @@ def test_owner_split_then_local_joins_equals_global_join(fj):
     import ctypes
     import torch
     from flash_hash_join_amd import datagen, api
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     nb, npk, world = 1_000_000, 5_000_000, 8
     dbk, dbv = datagen.build_device(nb, "cuda:0")
     dpk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=5, hit_bp=2500)
@@ -457,7 +493,7 @@ def test_owner_shuffle_in_chunk_form_on_one_gpu(fj, world, nb_total, nb, npk, bp
     import torch
     import keymix
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     eng = HipEngine("cuda:0")
     f0 = eng.shuffle_plan(nb_total, world)
     assert 5 <= f0 <= 9 and (1 << f0) >= world                    # 5 + 5, 7 + 7 and 9 + 8 bits for the three plan sizes
@@ -514,7 +550,7 @@ def test_materialising_owner_shuffle_in_chunk_form_on_one_gpu(fj, world, nb_tota
     import torch
     import keymix
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     eng = HipEngine("cuda:0")
     f0 = eng.shuffle_plan(nb_total, world)
     bk, bv = datagen.build_device(nb, "cuda:0")
@@ -556,7 +592,7 @@ def test_wire_format_edge_cases(fj, nb_total, world):
     unpacked with the NumPy restatement of the wire format, is exactly the multiset that went in, every chunk with its owner."""
     import torch
     import keymix
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     eng = HipEngine("cuda:0")
     f0 = eng.shuffle_plan(nb_total, world)
     rng = np.random.default_rng(11)
@@ -626,7 +662,7 @@ def test_sender_side_prefilter_keeps_every_hit(fj, nb, npk, hit_bp, top_bits):
     most misses are gone (filter load: nb / 512 keys in a 1.1 Mbit filter)."""
     import torch
     from flash_hash_join_amd import datagen, api
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     bk, bv = datagen.build_device(nb, "cuda:0")
     pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=13, hit_bp=hit_bp)
     eng = HipEngine("cuda:0")
@@ -658,7 +694,7 @@ def test_sender_side_prefilter_refuses_filters_of_another_variant(fj):
     """Exporter and sender must set the same bits: filters carry the variant they were built with, and a sender configured
     for another one gets an error instead of silently dropping matching rows."""
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     bk, _ = datagen.build_device(2_000_000, "cuda:0")
     pk, _ = datagen.probe_device(1_000_000, 2_000_000, "cuda:0", seed=9, hit_bp=5000)
     eng = HipEngine("cuda:0")
@@ -681,7 +717,7 @@ def test_sender_side_prefilter_on_random_key_distributions(fj, seed):
     """The precheck primitives on uniform, tiny-domain, sequential and sentinel-valued keys with duplicates on both sides:
     survivors = a sub-multiset of the probe rows that keeps every row whose key is in the build side."""
     import torch
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     rng = np.random.default_rng(700 + seed)
     nb = int(rng.choice([1, 9, 4000, 70000, 900000]))
     npk = int(rng.choice([1, 2, 999, 65536, 1200001]))
@@ -723,75 +759,89 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
-        monkeypatch.setenv("FJ_FORCE_EXCHANGE", "1")
+        import flash_hash_join_amd.distributed as D
         nb, npk = 3_000_000, 20_000_000
         bk, bv = datagen.build_device(nb, "cuda:0")
         pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=4, hit_bp=5000)
         M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
-        for strategy, rp in (("shuffle", "1"), ("shuffle", "python"), ("shuffle", "scatter"), ("replicate", "1"), ("replicate", "3"), ("broadcast", "1"), ("broadcast", "python")):
+        dj = lambda *a, **kw: distributed_join(*a, force_exchange=True, **kw)        # the full protocol on this one rank
+        for strategy, via in (("shuffle", "rccl"), ("shuffle", "python"), ("scatter", "rccl"), ("broadcast", "rccl"), ("broadcast", "python")):
             monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
-            monkeypatch.setenv("FJ_REPLICATE_PIECES", rp if rp.isdigit() else "1")
-            monkeypatch.setenv("FJ_DIST_NATIVE", "0" if rp == "python" else "1")            # the same driver over callbacks into torch.distributed instead of RCCL directly
-            monkeypatch.setenv("FJ_DIST_CHUNK_SHUFFLE", "0" if rp == "scatter" else "1")    # the owner-scatter form
+            monkeypatch.setenv("FJ_DIST_NATIVE", "0" if via == "python" else "1")            # the same driver over callbacks into torch.distributed instead of RCCL directly
             t = {}
-            n, sec = distributed_join(bk, bv, pk, timings=t)
+            n, sec = dj(bk, bv, pk, timings=t)
             assert n == exp and t["strategy"] == strategy, t
             if strategy == "broadcast":                    # the build-broadcast form on a 1-rank communicator: pack -> (no peer) -> probe passes -> 4 range joins
                 assert t["shuffle_form"].startswith("build broadcast") and t["pieces"] == 4 and t["local_count"] == exp and t["wire_bytes_sent"] == 0, t
             if strategy == "shuffle":
-                form = {"1": "chunks (fj_dist_join_count over RCCL)", "python": "chunks (fj_dist_join_count over a callback transport)", "scatter": "owner-scatter"}[rp]
+                form = {"rccl": "chunks (fj_dist_join over RCCL)", "python": "chunks (fj_dist_join over a callback transport)"}[via]
                 assert t["shuffle_form"] == form and t["pieces"] == 4 and t["local_count"] == exp and "chunk_form_error" not in t
-                if rp != "scatter":
-                    assert t["wire_chunk_bytes"] == 2048          # (a 3M-row build side: 5 + 5 bits, whole keys on the wire)
+                assert t["wire_chunk_bytes"] == 2048          # (a 3M-row build side: 5 + 5 bits, whole keys on the wire)
+            if strategy == "scatter":
+                assert t["shuffle_form"] == "owner-scatter" and t["local_count"] == exp
             if t.get("rows_are_chunk_capacity"):        # the native entry reports received chunks x 256 (partial chunks counted whole)
                 assert npk <= t["local_probe_rows"] <= 1.3 * npk and nb <= t["local_build_rows"] <= 1.3 * nb
             else:
                 assert t["local_probe_rows"] == npk and t["local_build_rows"] == nb
-            if strategy == "replicate":
-                assert t["pieces"] == int(rp)
-            n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
+            tm = {}
+            n, sec, k, v = dj(bk, bv, pk, materialize=True, return_arrays=True, timings=tm)
             assert n == exp and k.numel() == exp
             assert bool(torch.all((v + 1) * M == k))
-        # a build side with one key repeated 20000 times: its final partition does not fit the broadcast form's LDS table (that form has
-        # no per-partition recovery) - the step fails on every rank alike and is rerun as the shuffle, whose skew ladder takes it
-        monkeypatch.setenv("FJ_DIST_STRATEGY", "broadcast"); monkeypatch.setenv("FJ_DIST_NATIVE", "1"); monkeypatch.setenv("FJ_DIST_CHUNK_SHUFFLE", "1")
+            assert tm["strategy"] == ("scatter" if strategy == "scatter" else "shuffle")     # materialising joins start at the shuffle
+        # duplicate build keys in the broadcast form (round 5's table failed the whole step from 52 copies of one key on):
+        # a copy takes a slot of its own in the bucketed table, a lookup stops at the first match - 60 and 200 copies of two keys join
+        # in the broadcast form itself, exactly
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "broadcast"); monkeypatch.setenv("FJ_DIST_NATIVE", "1")
+        dk = torch.cat([bk, bk[777:778].repeat(60), bk[4242:4243].repeat(200)]); dv = torch.cat([bv, bv[777:778].repeat(60), bv[4242:4243].repeat(200)])
+        t = {}
+        n, sec = dj(dk, dv, pk, timings=t)
+        assert n == exp and t["strategy"] == "broadcast" and "broadcast_form_error" not in t, t
+        # ... and one key repeated 20000 times: its final partition does not fit the LDS table (that form has no per-partition
+        # recovery) - the step fails on every rank alike and moves down the ladder to the shuffle, whose skew ladder takes it
         hot = bk[12345:12346].repeat(20000)
         sbk2, sbv2 = torch.cat([bk, hot]), torch.cat([bv, bv[12345:12346].repeat(20000)])
         t = {}
-        n, sec = distributed_join(sbk2, sbv2, pk, timings=t)
+        n, sec = dj(sbk2, sbv2, pk, timings=t)
         assert n == exp and t["strategy"] == "shuffle" and "does not fit the LDS table" in t["broadcast_form_error"], t
         t = {}
-        n, sec = distributed_join(bk, bv, pk, timings=t)                                 # ... and the next plain join broadcasts again
+        n, sec = dj(bk, bv, pk, timings=t)                                 # ... and the next plain join broadcasts again (a pinned strategy remembers nothing)
         assert n == exp and t["strategy"] == "broadcast" and "broadcast_form_error" not in t, t
-        # sender-side bloom precheck of the probe exchange: in chunk form (per-partition filters: fj_stream_export_part_filters ->
-        # all-gather -> fj_shuffle_pack_filter, inside the driver) and in the owner-scatter form (fj_bloom_export -> all_gather ->
-        # fj_bloom_prefilter per owner)
+        # under "auto" the failed rung is remembered for the shape: the second step of the skewed join goes straight to the shuffle
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "auto")
+        D._FORM_MEMO.clear()
+        monkeypatch.setattr(D, "form_model", lambda *a, **kw: {"pick": "broadcast"})      # (one rank: the model would never broadcast)
+        for step in range(2):
+            t = {}
+            n, sec = dj(sbk2, sbv2, pk, timings=t, join_id="skewed")
+            assert n == exp and t["strategy"] == "shuffle" and ("broadcast_form_error" in t) == (step == 0), (step, t)
+        D._FORM_MEMO.clear()
+        monkeypatch.undo(); monkeypatch.setenv("FJ_DIST_NATIVE", "1")
+        # sender-side bloom precheck of the probe exchange in chunk form (per-partition filters: fj_stream_export_part_filters ->
+        # all-gather -> fj_shuffle_pack_filter, inside the driver); the owner-scatter rung has none of its own
         monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle")
         lpk, lexp = datagen.probe_device(npk, nb, "cuda:0", seed=9, hit_bp=500)
-        for chunk_form in ("1", "0"):
-            monkeypatch.setenv("FJ_DIST_CHUNK_SHUFFLE", chunk_form)
-            for pre in ("1", "0"):
-                monkeypatch.setenv("FJ_DIST_PREFILTER", pre)
-                t = {}
-                n, sec = distributed_join(bk, bv, lpk, timings=t)
-                assert n == lexp and t["prefilter"] == (pre == "1") and t["shuffle_form"].startswith("chunks" if chunk_form == "1" else "owner-scatter"), t
-                assert t["probe_rows_sent"] == npk if pre == "0" else lexp <= t["probe_rows_sent"] < 0.08 * npk
-                tm = {}
-                n, sec, k, v = distributed_join(bk, bv, lpk, materialize=True, return_arrays=True, timings=tm)      # materialising: the same precheck
-                assert n == lexp and k.numel() == lexp and bool(torch.all((v + 1) * M == k))
-                assert tm["prefilter"] == (pre == "1") and tm["probe_rows_sent"] == t["probe_rows_sent"]
-                assert tm["shuffle_form"].startswith("chunks" if chunk_form == "1" else "owner-scatter"), tm
-            n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # FJ_DIST_PREFILTER=0 overrides the bloom argument
-            assert n == lexp and not t["prefilter"]
-            monkeypatch.delenv("FJ_DIST_PREFILTER")
-            n, sec = distributed_join(bk, bv, lpk, bloom=True, timings=t)       # the *_bloom meaning of the multi-GPU join: "auto"
-            assert n == lexp and t["prefilter_mode"] == "auto"
-            # (chunk form: a 20M-row probe side does not pay for the filters' fixed cost on one rank - nothing is exported or sampled;
-            #  the owner-scatter form's model has no fixed cost: it samples and filters)
-            assert t["prefilter"] == (chunk_form == "0"), t
-        monkeypatch.delenv("FJ_DIST_CHUNK_SHUFFLE")
-        # a build side whose keys all land in ONE partition: the streamed (replicate) join re-partitions that partition alone
-        # inside fj_stream_finish (round 3; rounds 1-2 fell back to one table in HBM)
+        for pre in ("1", "0"):
+            monkeypatch.setenv("FJ_DIST_PREFILTER", pre)
+            t = {}
+            n, sec = dj(bk, bv, lpk, timings=t)
+            assert n == lexp and t["prefilter"] == (pre == "1") and t["shuffle_form"].startswith("chunks"), t
+            assert t["probe_rows_sent"] == npk if pre == "0" else lexp <= t["probe_rows_sent"] < 0.08 * npk
+            tm = {}
+            n, sec, k, v = dj(bk, bv, lpk, materialize=True, return_arrays=True, timings=tm)      # materialising: the same precheck
+            assert n == lexp and k.numel() == lexp and bool(torch.all((v + 1) * M == k))
+            assert tm["prefilter"] == (pre == "1") and tm["probe_rows_sent"] == t["probe_rows_sent"] and tm["shuffle_form"].startswith("chunks"), tm
+        n, sec = dj(bk, bv, lpk, bloom=True, timings=t)       # FJ_DIST_PREFILTER=0 overrides the bloom argument
+        assert n == lexp and not t["prefilter"]
+        n, sec = dj(bk, bv, lpk, bloom=True, timings=t, prefilter="on")       # ... and an explicit argument overrides the environment
+        assert n == lexp and t["prefilter"]
+        monkeypatch.delenv("FJ_DIST_PREFILTER")
+        n, sec = dj(bk, bv, lpk, bloom=True, timings=t)       # the *_bloom meaning of the multi-GPU join: "auto"
+        assert n == lexp and t["prefilter_mode"] == "auto"
+        assert not t["prefilter"], t      # (a 20M-row probe side does not pay for the filters' fixed cost on one rank: nothing is exported or sampled)
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "scatter")
+        n, sec = dj(bk, bv, lpk, bloom=True, timings=t)
+        assert n == lexp and t["prefilter"] is False and t["shuffle_form"] == "owner-scatter"
+        # a build side whose keys all land in ONE partition of the owner's plan: the shuffle's owner re-partitions that partition alone
         def hash_w1(kk):
             lo = (kk & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (kk >> np.uint64(32)).astype(np.uint32)
             with np.errstate(over="ignore"):
@@ -805,24 +855,19 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
         sbk = torch.from_numpy(skew.view(np.int64)).cuda(); sbv = sbk + 1
         spk = torch.from_numpy(np.concatenate([skew, cand[:50000]]).view(np.int64)).cuda()
         sexp = int(np.isin(np.concatenate([skew, cand[:50000]]), skew).sum())
-        for strategy in ("replicate", "shuffle"):
+        for strategy in ("auto", "shuffle", "scatter"):
             monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
-            n, sec = distributed_join(sbk, sbv, spk)
+            n, sec = dj(sbk, sbv, spk)
             assert n == sexp
-            if strategy == "replicate":                                  # (the shuffle consumes the top 16 hash bits for the
-                lt = fj.last_timings()                                   #  owner: these keys spread over its partitions)
-                assert lt["path"] == 0 and lt["fell_back"] == 0 and lt["lds_retries"] == 2, lt
-        # messages capped at 1M rows: the shuffle moves every segment in several rounds (list all_to_all on views: the
-        # workaround for RCCL's > 4 GiB-per-peer defect), the replicate path gathers in bounded pieces
-        import flash_hash_join_amd.distributed as D
+        # messages capped at 1M rows: the owner-scatter rung moves every segment in several rounds (list all_to_all on views: the
+        # workaround for RCCL's > 4 GiB-per-peer defect)
         monkeypatch.setattr(D, "_MAX_ELEMS_PER_MESSAGE", 1 << 20)
-        for strategy in ("shuffle", "replicate"):
-            monkeypatch.setenv("FJ_DIST_STRATEGY", strategy)
-            t = {}
-            n, sec = distributed_join(bk, bv, pk, timings=t)
-            assert n == exp and (t["exchange_rounds"] > 1 or t["pieces"] >= 3)
-            n, sec, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True)
-            assert n == exp and k.numel() == exp and bool(torch.all((v + 1) * M == k))
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "scatter")
+        t = {}
+        n, sec = dj(bk, bv, pk, timings=t)
+        assert n == exp and t["exchange_rounds"] > 1
+        n, sec, k, v = dj(bk, bv, pk, materialize=True, return_arrays=True)
+        assert n == exp and k.numel() == exp and bool(torch.all((v + 1) * M == k))
     finally:
         dist.destroy_process_group()
 
@@ -849,7 +894,8 @@ def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
     import sys
     from conftest import ROOT
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
-    env = dict(os.environ, FJ_BENCH_SHARE_GPU="1")
+    from conftest import product_env
+    env = product_env(FJ_BENCH_SHARE_GPU="1")               # (the bench runs on the PRODUCT library)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2",
                           "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -859,7 +905,11 @@ def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["probe_rows_total"] == 2 * 25_000_000     # default at N > 1: c5 (x 0.02)
     assert d["config"]["bench_workload"] == "c5" and d["config"]["build_rows_total"] == 2 * 2_500_000
-    assert d["config"]["parallelism"].endswith("x2") and "cpu_baseline" not in d and d["value"] > 0
+    assert d["config"]["parallelism"].endswith("x2") and d["value"] > 0
+    # the N > 1 line is complete: the CPU baseline (rank 0, the config-3-size run, labelled), the timed form's
+    # roofline, the model's verdict, and the OTHER form as a labelled second measurement with a roofline block and wire bytes of its own
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["sample"].startswith("config-3-size run on rank 0's host cores"), cb
     # the pre-flight self-check ran (under the host-staged transport only the torch.distributed forms apply) and is in the line;
     # value is the form the driver's cost model picks for these sizes (10 probe rows per build row: the build broadcast), checked
     # before it is timed; the other form rides along as a labelled second measurement
@@ -867,7 +917,11 @@ def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
     assert d["phases"]["form_model"]["pick"] == "broadcast" and d["phases"]["strategy_timed"] == "broadcast", d["phases"]
     assert d["config"]["parallelism"].startswith("build-broadcast") and d["phases"]["shuffle_form"].startswith("build broadcast")
     assert d["roofline"]["kernel"].startswith("fj_partition_kernel<keys> (a probe-side radix pass") and 0 < d["roofline"]["frac"] < 1
-    assert d["alt_strategy"]["strategy"] == "owner-shuffle" and d["alt_strategy"]["count_ok"] is True and d["alt_strategy"]["form"].startswith("chunks")
+    alt = d["alt_strategy"]
+    assert alt["strategy"] == "owner-shuffle" and alt["count_ok"] is True and alt["form"].startswith("chunks") and alt["fell_to"] is None and alt["errors"] is None, alt
+    assert alt["roofline"]["kernel"].startswith("fj_partition_kernel<keys-only> (the owner's radix pass") and 0 < alt["roofline"]["frac"] < 1 and alt["roofline"]["bytes_per_unit"] in (15.0, 16.0), alt
+    assert alt["wire_bytes_sent_rank0"] > 0 and alt["wire_chunk_bytes"] in (1792, 2048) and alt["value"] > 0, alt
+    assert d["phases"]["wire_bytes_sent_rank0"] > 0 and d["phases"]["form_model"]["shuffle"] > 0 and d["phases"]["form_model"]["broadcast"] > 0
     # ... and a pinned strategy is what gets timed
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -875,13 +929,13 @@ def test_bench_multi_rank_branch_with_ranks_sharing_this_gpu(fj):
                           "--warmup", "1"], capture_output=True, text=True, timeout=900, env=dict(env, FJ_DIST_STRATEGY="shuffle"), cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert d["config"]["parallelism"].startswith("owner-shuffle") and d["phases"]["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport")
-    assert d["alt_strategy"]["strategy"] == "build-broadcast" and d["alt_strategy"]["count_ok"] is True
+    assert d["config"]["parallelism"].startswith("owner-shuffle") and d["phases"]["shuffle_form"].startswith("chunks (fj_dist_join over a callback transport")
+    assert d["alt_strategy"]["strategy"] == "build-broadcast" and d["alt_strategy"]["count_ok"] is True and 0 < d["alt_strategy"]["roofline"]["frac"] < 1 and "cpu_baseline" in d
     # a transport that moves wrong data (test hook): every shuffle form fails its check, ONE JSON line says so, exit code 3
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2",
-                          "--warmup", "1"], capture_output=True, text=True, timeout=900, env=dict(env, FJ_SELFCHECK_CORRUPT="1"), cwd=ROOT)
+                          "--warmup", "1", "--selfcheck-corrupt"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode != 0
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -895,7 +949,7 @@ def test_shuffled_stream_recovers_from_an_oversized_partition(fj):
     partition: fj_stream_finish re-partitions that partition alone (no fallback exists for chunk pieces) - exact count."""
     import torch
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
         lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
         with np.errstate(over="ignore"):
@@ -1039,7 +1093,7 @@ def test_config5_every_owner_shard_at_full_size_on_one_gpu(fj):
     hash_top_bits = 48, and the 8 owners' counts add up to the closed-form count of the whole 1B x 10B join."""
     import torch
     from flash_hash_join_amd import datagen, api
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     world, nb_rank, np_rank = 8, 125_000_000, 1_250_000_000
     nb_total = nb_rank * world
     eng = HipEngine("cuda:0")
@@ -1094,7 +1148,7 @@ def test_config5_chunk_form_every_owner_at_full_size_on_one_gpu(fj):
     per key."""
     import torch
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     world, nb_rank, np_rank = 8, 125_000_000, 1_250_000_000
     nb_total = nb_rank * world
     eng = HipEngine("cuda:0")
@@ -1169,7 +1223,7 @@ def test_build_broadcast_form_matches_the_oracle(fj, oracle, world, nb_total, np
     high-word plane (bits < 16 / >= 16 under plan_target_keys), 1..5 pieces.  The last three: few, fat partitions whose probe side is
     cut into 18 / 3 / 2 items each - dealt to the workgroups in runs, a partition's table built once per run (FjWideArgs::group_log)."""
     import torch
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     fj.set_option("plan_target_keys", target)
     try:
         eng = HipEngine("cuda:0")
@@ -1197,7 +1251,7 @@ def test_build_broadcast_refuses_a_partition_that_cannot_fit_the_table(fj, np_ra
     where the items of the oversized partition inherit its verdict from the one that tried to build it."""
     import torch
     from flash_hash_join_amd import _lib
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     L = _lib.load()
     eng = HipEngine("cuda:0")
     world, nb_total = 2, 400_000
@@ -1228,7 +1282,7 @@ def test_config5_build_broadcast_every_rank_at_full_size_on_one_gpu(fj):
     closed-form count of the whole join."""
     import torch
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     world, nb_rank, np_rank, pieces = 8, 125_000_000, 1_250_000_000, 4
     nb_total = nb_rank * world
     eng = HipEngine("cuda:0")
@@ -1269,7 +1323,7 @@ def test_config5_chunk_form_with_the_precheck_every_owner_at_full_size_on_one_gp
     probe rows never reach the wire (the hits + ~3 % of the misses travel)."""
     import torch
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     world, nb_rank, np_rank = 8, 125_000_000, 1_250_000_000
     nb_total = nb_rank * world
     eng = HipEngine("cuda:0")
@@ -1331,7 +1385,9 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        monkeypatch.setenv("FJ_FORCE_EXCHANGE", "1"); monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        _dj0 = distributed_join
+        distributed_join = lambda *a, **kw: _dj0(*a, force_exchange=True, **kw)      # the full protocol on this one rank
         nb, npk = 125_000_000, 1_250_000_000
         bk, bv = datagen.build_device(nb, "cuda:0")
         pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=1, hit_bp=5000)
@@ -1340,7 +1396,7 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
             t = {}
             n, sec = distributed_join(bk, bv, pk, timings=t)
             assert n == exp and t["local_count"] == exp and t["pieces"] == 4 and t["wire_chunk_bytes"] == 1792, t
-            assert t["shuffle_form"] == ("chunks (fj_dist_join_count over RCCL)" if native == "1" else "chunks (fj_dist_join_count over a callback transport)")
+            assert t["shuffle_form"] == ("chunks (fj_dist_join over RCCL)" if native == "1" else "chunks (fj_dist_join over a callback transport)")
             # dense chunks: at most one partial chunk per (bucket, piece); looped back, every chunk went through ncclSend / ncclRecv
             assert npk <= t["local_probe_rows"] <= npk + 256 * 256 * 4 and nb <= t["local_build_rows"] <= nb + 256 * 256
             sent = (t["local_probe_rows"] + t["local_build_rows"]) // 256 * (1792 + 4)
@@ -1349,12 +1405,12 @@ def test_full_config5_shard_through_the_driver_on_a_one_rank_communicator(fj, mo
             assert lt["fell_back"] == 0 and lt["passes"] == 2
         # the control collectives on a communicator of their own (ncclCommSplit - what every N > 1 job does; a 1-rank communicator
         # only splits under this test hook): a fresh communicator, the same step, the same count
-        from flash_hash_join_amd.distributed import HipEngine
+        from flash_hash_join_amd.lab import LabEngine as HipEngine
         HipEngine.close_native_comms()
         fj.set_option("lab_hooks", 4 | 1); monkeypatch.setenv("FJ_DIST_NATIVE", "1")                 # FJ_HOOK_SPLIT_ALWAYS | FJ_HOOK_LOOPBACK
         t = {}
         n, sec = distributed_join(bk[: nb // 10], bv[: nb // 10], pk[: npk // 10], timings=t)
-        assert t["shuffle_form"] == "chunks (fj_dist_join_count over RCCL)" and n == int(torch.isin(pk[: npk // 10], bk[: nb // 10]).sum())
+        assert t["shuffle_form"] == "chunks (fj_dist_join over RCCL)" and n == int(torch.isin(pk[: npk // 10], bk[: nb // 10]).sum())
         HipEngine.close_native_comms()
     finally:
         fj.set_option("lab_hooks", 0)
@@ -1378,7 +1434,9 @@ def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monke
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        monkeypatch.setenv("FJ_FORCE_EXCHANGE", "1"); monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        _dj0 = distributed_join
+        distributed_join = lambda *a, **kw: _dj0(*a, force_exchange=True, **kw)      # the full protocol on this one rank
         for nb, npk in ((20_000_000, 200_000_000), (125_000_000, 1_250_000_000), (3_000_001, 10_000_003)):
             bk, bv = datagen.build_device(nb, "cuda:0")
             for hit_bp in (500, 5000):
@@ -1400,7 +1458,7 @@ def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monke
                 t = {}
                 n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t)              # "auto": on one rank the model always declines
                 assert n == exp and t["prefilter_mode"] == "auto" and t["prefilter_below"] == 0 and t["prefilter"] is False and t["prefilter_sampled_survivors"] is None, t
-                monkeypatch.setenv("FJ_DIST_PREFILTER_BELOW", "0.3")                      # ... a threshold in its place: sample, then decide
+                monkeypatch.setattr(D, "PREFILTER_BELOW_OVERRIDE", 0.3)                   # ... a threshold in its place: sample, then decide
                 D._PRECHECK_MEMO.clear()
                 n, sec = distributed_join(bk, bv, pk, bloom=True, timings=t)
                 assert n == exp and t["prefilter_decision"] == "sampled" and abs(t["prefilter_sampled_survivors"] - (exp + 0.03 * (npk - exp)) / npk) < 0.03, t
@@ -1410,7 +1468,7 @@ def test_sender_side_precheck_in_chunk_form_on_a_one_rank_communicator(fj, monke
                 assert n == exp and t2["prefilter"] == t["prefilter"] and t2["prefilter_sampled_survivors"] is None, t2      # nothing is sampled,
                 assert t2["prefilter_decision"] == ("memo: runs" if hit_bp == 500 else "memo: declined"), t2
                 assert t2["filter_bytes_received"] == 0 and (t2["prefilter"] or t2["prefilter_below"] == 0), t2              # and a declined precheck exports nothing
-                monkeypatch.delenv("FJ_DIST_PREFILTER_BELOW")
+                monkeypatch.setattr(D, "PREFILTER_BELOW_OVERRIDE", None)
             if npk <= 200_000_000:
                 monkeypatch.setenv("FJ_DIST_PREFILTER", "1")
                 sub = pk[: min(npk, 50_000_000)]
@@ -1436,7 +1494,9 @@ def test_driver_with_tiny_and_empty_probe_sides(fj, monkeypatch):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        monkeypatch.setenv("FJ_FORCE_EXCHANGE", "1"); monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        monkeypatch.setenv("FJ_DIST_STRATEGY", "shuffle"); monkeypatch.setenv("FJ_DIST_NO_FALLBACK", "1")
+        _dj0 = distributed_join
+        distributed_join = lambda *a, **kw: _dj0(*a, force_exchange=True, **kw)      # the full protocol on this one rank
         bk, bv = datagen.build_device(6_000_000, "cuda:0")
         pk, _ = datagen.probe_device(1000, 6_000_000, "cuda:0", seed=8, hit_bp=5000)
         for n in (0, 1, 5, 7, 1000):
@@ -1595,7 +1655,7 @@ def test_streamed_probe_equals_one_shot(fj, nb, npk, pieces):
     two-pass plans and both hash_top_bits settings."""
     import torch
     from flash_hash_join_amd import datagen, api
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     bk, bv = datagen.build_device(nb, "cuda:0")
     pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=11, hit_bp=3000)
     eng = HipEngine("cuda:0")
@@ -1614,7 +1674,7 @@ def test_stream_join_with_both_sides_in_pieces(fj, nb, npk, bpieces, ppieces):
     """fj_stream_open / append_build / append_probe / advance_probe / finish == the one-shot radix count, with the
     probe side closed BEFORE the build side arrives (the replicate-build exchange order) and after it."""
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     bk, bv = datagen.build_device(nb, "cuda:0")
     pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=12, hit_bp=4000)
     eng = HipEngine("cuda:0")
@@ -1638,7 +1698,7 @@ def test_streamed_join_recovers_from_an_oversized_partition_by_itself(fj):
     """A streamed (multi-GPU building block) join whose build side puts 9000 keys into one partition - beyond even the tagged
     LDS table - re-partitions that partition inside fj_stream_finish: exact count, no fallback, no exception."""
     import torch
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     def hash_w1(k):                                                # fj_hash_w1 of csrc/fj_common.h
         lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (k >> np.uint64(32)).astype(np.uint32)
         with np.errstate(over="ignore"):
@@ -1772,7 +1832,7 @@ def test_workspace_can_be_trimmed_between_joins(fj, oracle):
     refused while a stream join is open."""
     import torch
     from flash_hash_join_amd import api, datagen, _lib
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     bk, bv = datagen.build_device(3_000_000, "cuda:0")
     pk, exp = datagen.probe_device(20_000_000, 3_000_000, "cuda:0", seed=2, hit_bp=5000)
     assert fj.hash_join_count_radix(bk, bv, pk)[0] == exp
@@ -1833,7 +1893,7 @@ def test_c_abi_rejects_bad_arguments(fj):
 def test_stream_join_rejects_misuse(fj):
     import torch
     from flash_hash_join_amd import datagen
-    from flash_hash_join_amd.distributed import HipEngine
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
     bk, bv = datagen.build_device(100_000, "cuda:0")
     pk, exp = datagen.probe_device(100_000, 100_000, "cuda:0", seed=1, hit_bp=5000)
     eng = HipEngine("cuda:0")
@@ -1880,33 +1940,30 @@ def test_stream_join_rejects_misuse(fj):
     from flash_hash_join_amd.distributed import distributed_join
 
     class Failing(HipEngine):
-        def stream_append(self, piece):
-            raise RuntimeError("injected failure between begin and finish")
+        def local_join(self, *a, **kw):
+            raise RuntimeError("injected failure in the owner's local join")
 
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dj = lambda *a, **kw: distributed_join(*a, force_exchange=True, **kw)
     try:
-        os.environ["FJ_FORCE_EXCHANGE"] = "1"
-        for strategy in ("shuffle", "replicate"):
-            os.environ["FJ_DIST_STRATEGY"] = strategy
-            os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0"                        # the engine hooks live in the owner-scatter form of the shuffle (Python protocol)
-            with pytest.raises(RuntimeError, match="injected failure"):
-                distributed_join(big_bk, big_bv, big_pk, engine=Failing("cuda:0"))
-            os.environ.pop("FJ_DIST_CHUNK_SHUFFLE")
-            assert distributed_join(big_bk, big_bv, big_pk)[0] == big_exp               # the context is free again
+        os.environ["FJ_DIST_STRATEGY"] = "scatter"                           # the owner-scatter rung runs the engine's hooks from Python
+        with pytest.raises(RuntimeError, match="injected failure"):
+            dj(big_bk, big_bv, big_pk, engine=Failing("cuda:0"))
+        assert dj(big_bk, big_bv, big_pk)[0] == big_exp                      # the context is free again
         # ... and so does the C++ driver of the chunk form (csrc/fj_dist.hip): a local append that fails (test hook) is agreed on in the
-        # final all-reduce, the stream join is dropped, every rank raises; without FJ_DIST_NO_FALLBACK the ranks rerun in the owner-scatter form
+        # final all-reduce, the stream join is dropped, every rank raises; without FJ_DIST_NO_FALLBACK the ranks move down to the owner-scatter rung
         os.environ["FJ_DIST_STRATEGY"] = "shuffle"; fj.set_option("lab_hooks", 2); os.environ["FJ_DIST_NO_FALLBACK"] = "1"      # FJ_HOOK_INJECT_FAIL
         with pytest.raises(RuntimeError, match="the local join failed on 1 rank.*injected failure of a local append"):
-            distributed_join(big_bk, big_bv, big_pk)
+            dj(big_bk, big_bv, big_pk)
         os.environ.pop("FJ_DIST_NO_FALLBACK")
         t = {}
-        assert distributed_join(big_bk, big_bv, big_pk, timings=t)[0] == big_exp and t["shuffle_form"] == "owner-scatter" and "injected" in t["chunk_form_error"]
+        assert dj(big_bk, big_bv, big_pk, timings=t)[0] == big_exp and t["shuffle_form"] == "owner-scatter" and "injected" in t["chunk_form_error"]
         fj.set_option("lab_hooks", 0)
         t = {}
-        assert distributed_join(big_bk, big_bv, big_pk, timings=t)[0] == big_exp and t["shuffle_form"].startswith("chunks") and "chunk_form_error" not in t
+        assert dj(big_bk, big_bv, big_pk, timings=t)[0] == big_exp and t["shuffle_form"].startswith("chunks") and "chunk_form_error" not in t
     finally:
-        for k_ in ("FJ_FORCE_EXCHANGE", "FJ_DIST_STRATEGY", "FJ_DIST_NATIVE", "FJ_DIST_CHUNK_SHUFFLE", "FJ_DIST_NO_FALLBACK"):
+        for k_ in ("FJ_DIST_STRATEGY", "FJ_DIST_NATIVE", "FJ_DIST_NO_FALLBACK"):
             os.environ.pop(k_, None)
         fj.set_option("lab_hooks", 0)
         dist.destroy_process_group()

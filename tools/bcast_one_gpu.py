@@ -5,9 +5,10 @@ is the kernel time per rank and step that tools/scale_model.py puts beside the w
 usage: python tools/bcast_one_gpu.py [world=8] [nb_rank=125000000] [np_rank=1250000000] [pieces=4] [steps=5] [hit_bp=5000] [reserve_cus=0]
 (reserve_cus: CUs the passes and the join leave free, as they do while RCCL's kernels share the GPU at N > 1: csrc/fj_dist.hip reserves 32)"""
 import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("FJ_LIB_VARIANT", "lab")           # the building blocks behind the C ABI are visible in the lab build only
 import torch
 from flash_hash_join_amd import api, datagen
-from flash_hash_join_amd.distributed import HipEngine
+from flash_hash_join_amd.lab import LabEngine as HipEngine
 
 args = [int(x) for x in sys.argv[1:]]
 world, nb_rank, np_rank, pieces, steps, hit_bp, reserve = (args + [8, 125_000_000, 1_250_000_000, 4, 5, 5000, 0][len(args):])[:7]

@@ -39,7 +39,7 @@ grep "the precheck:\|^filters of" gpurun_out/stats_${TAG}_precheck_probe.log > $
 ( python tools/bcast_one_gpu.py 8 125000000 1250000000 4 5 5000 0 | tail -7; echo "-- with the 32-CU reserve of an N > 1 step over RCCL:"; python tools/bcast_one_gpu.py 8 125000000 1250000000 4 5 5000 32 | tail -5 ) > $O/bcast_one_rank.txt 2>&1
 tools/prof_py.sh ${TAG}_bcast tools/bcast_one_gpu.py 8 125000000 1250000000 4 5 > $O/bcast_one_rank_kernel_stats.txt 2>&1
 cp $(find gpurun_out/stats_${TAG}_bcast -name "*kernel_stats.csv" | head -1) $O/bcast_one_rank_kernel_stats.csv
-FJ_BENCH_FORCE_DIST=1 FJ_BENCH_FORCE_FORM=broadcast timeout 600 python bench.py --workload c5 --steps 5 --warmup 2 --no-host-entry --no-cpu-baseline 2>&1 | tail -1 > $O/c5_one_rank_broadcast_bench.json
+FJ_BENCH_FORCE_DIST=1 FJ_DIST_STRATEGY=broadcast timeout 600 python bench.py --workload c5 --steps 5 --warmup 2 --no-host-entry --no-cpu-baseline 2>&1 | tail -1 > $O/c5_one_rank_broadcast_bench.json
 FJ_OPTIONS=join_wide=1 ./tools/pmc.sh $O/pmc_wide --workload c5_rep8 --no-host-entry > $O/c5_rep8_wide_pmc_summary.txt 2>&1
 FJ_OPTIONS=join_wide=0 timeout 300 python bench.py --workload c5_rep8 --steps 10 --warmup 2 --no-cpu-baseline --no-host-entry 2>&1 | tail -1 > $O/c5_rep8_narrow_table_bench.json
 python tools/scale_model.py > $O/scale_model.txt 2>&1

@@ -12,7 +12,10 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-os.environ["FJ_FORCE_EXCHANGE"] = "1"; os.environ["FJ_DIST_STRATEGY"] = "shuffle"
+os.environ["FJ_DIST_STRATEGY"] = "shuffle"
+import flash_hash_join_amd.distributed as D
+_dj = distributed_join
+distributed_join = lambda *a, **kw: _dj(*a, force_exchange=True, **kw)      # the full protocol on this one rank
 nb, npk = 20_000_000, 150_000_000
 bk, bv = datagen.build_device(nb, "cuda:0")
 pk, exp = datagen.probe_device(npk, nb, "cuda:0", seed=3, hit_bp=5000)
@@ -25,7 +28,7 @@ for r in range(rounds):
     os.environ["FJ_DIST_NATIVE"] = "0" if mode == 2 else "1"
     api.set_option("lab_hooks", hooks)
     os.environ["FJ_DIST_PREFILTER"] = ("0", "1", "auto")[(r // 5) % 3]      # the sender-side precheck: off / forced / by a sample (threshold below)
-    os.environ["FJ_DIST_PREFILTER_BELOW"] = "0.7"
+    D.PREFILTER_BELOW_OVERRIDE = 0.7
     if mode == 3:
         api.set_option("lab_hooks", hooks | 2)              # the chunk form fails (agreed), the step reruns in the owner-scatter form
     t = {}

@@ -3,10 +3,12 @@ contexts run the build-broadcast step of ONE rank of 8 (tools/bcast_one_gpu.py) 
 (fj_ctx_reserve_cus(128): a pass / join workgroup fills a CU, so the two pipelines run side by side), the second pipeline started
 half a step behind the first so that one's join meets the other's passes.  Prints: one step on the whole chip, one step on half the
 chip, two steps side by side.  usage: python tools/overlap_probe.py [np_rank=1250000000] [lag_ms=8]"""
+import os
+os.environ.setdefault("FJ_LIB_VARIANT", "lab")           # the building blocks behind the C ABI are visible in the lab build only
 import ctypes, os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flash_hash_join_amd import api, datagen, _lib
-from flash_hash_join_amd.distributed import HipEngine
+from flash_hash_join_amd.lab import LabEngine as HipEngine
 
 np_rank = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000_000
 world, nb_rank, pieces = 8, 125_000_000, 4

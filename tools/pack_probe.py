@@ -1,10 +1,12 @@
 """Sender side of the owner shuffle in isolation (fj_shuffle_pack_begin / _counts / _finish): time of the first pass + bookkeeping
 and of the copy into the wire format, for one piece of n rows.  usage: python tools/pack_probe.py [n] [nb_total] [world]"""
+import os
+os.environ.setdefault("FJ_LIB_VARIANT", "lab")           # the building blocks behind the C ABI are visible in the lab build only
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flash_hash_join_amd import datagen
-from flash_hash_join_amd.distributed import HipEngine
+from flash_hash_join_amd.lab import LabEngine as HipEngine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 312_500_000
 nb_total = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000

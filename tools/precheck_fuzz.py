@@ -14,7 +14,9 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-os.environ.update(FJ_FORCE_EXCHANGE="1", FJ_DIST_STRATEGY="shuffle", FJ_DIST_NO_FALLBACK="1", FJ_DIST_PREFILTER="1")
+os.environ.update(FJ_DIST_STRATEGY="shuffle", FJ_DIST_NO_FALLBACK="1", FJ_DIST_PREFILTER="1")
+_dj = distributed_join
+distributed_join = lambda *a, **kw: _dj(*a, force_exchange=True, **kw)      # the full protocol on this one rank
 M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
 t0 = time.time()
 kept_tot = rows_tot = 0
@@ -38,11 +40,11 @@ for c in range(cases):
     pk = pk.contiguous()
     exp = int(torch.isin(pk, bk).sum()) if npk else 0
     os.environ["FJ_DIST_PIECES"] = str(rng.choice([1, 2, 4, 7]))
-    os.environ["FJ_DIST_LOOPBACK"] = rng.choice(["0", "1"]); api.set_option("lab_hooks", int(os.environ["FJ_DIST_LOOPBACK"]))      # (lab_hooks & 1: the loop-back hook; the variable is only this script's label)
+    loop = rng.choice(["0", "1"]); api.set_option("lab_hooks", int(loop))      # (lab_hooks & 1: the loop-back hook)
     os.environ["FJ_DIST_NATIVE"] = rng.choice(["1", "1", "0"])
     mat = rng.random() < 0.3 and exp < 60_000_000
     t = {}
-    print(f"case {c}: nb {nb} np {npk} hit_bp {hit_bp} pieces {os.environ['FJ_DIST_PIECES']} loop {os.environ['FJ_DIST_LOOPBACK']} native {os.environ['FJ_DIST_NATIVE']} mat {mat} exp {exp}", file=sys.stderr, flush=True)
+    print(f"case {c}: nb {nb} np {npk} hit_bp {hit_bp} pieces {os.environ['FJ_DIST_PIECES']} loop {loop} native {os.environ['FJ_DIST_NATIVE']} mat {mat} exp {exp}", file=sys.stderr, flush=True)
     if mat:
         n, _, k, v = distributed_join(bk, bv, pk, materialize=True, return_arrays=True, timings=t)
         assert n == exp == k.numel() and bool(torch.all((v + 1) * M == k)) and (exp == 0 or (int(v.min()) >= first and int(v.max()) < first + nb)), (c, n, exp)
@@ -50,8 +52,7 @@ for c in range(cases):
     else:
         n, _ = distributed_join(bk, bv, pk, timings=t)
         assert n == exp, (c, nb, npk, hit_bp, n, exp, t)
-    one_shot = os.environ["FJ_DIST_PIECES"] == "1" and not mat           # (a counting join in one piece takes the owner-scatter form - with ITS precheck)
-    assert t["shuffle_form"].startswith("owner-scatter" if one_shot else "chunks") and t["prefilter"] is True, t
+    assert t["shuffle_form"].startswith("chunks") and t["prefilter"] is True, t
     assert exp == 0 or t["probe_rows_sent"] >= min(exp, 1), t
     kept_tot += t["probe_rows_sent"]; rows_tot += npk
     if c % 10 == 9:

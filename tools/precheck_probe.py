@@ -4,10 +4,11 @@ that rank: fj_stream_export_part_filters), then one probe piece is packed withou
 kernel-side time of the first pass + precheck + bookkeeping, of the copy, rows kept, false-positive rate.
 usage: python tools/precheck_probe.py [piece_rows] [nb_total] [world] [hit_bp]"""
 import os, sys, time
+os.environ.setdefault("FJ_LIB_VARIANT", "lab")           # the building blocks behind the C ABI are visible in the lab build only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flash_hash_join_amd import datagen
-from flash_hash_join_amd.distributed import HipEngine
+from flash_hash_join_amd.lab import LabEngine as HipEngine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 312_500_000
 nb_total = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000

@@ -5,12 +5,13 @@ at several hit rates.  Prints the times, the survivors, and the per-link bytes w
 usage: python tools/prefilter_probe.py [--scale 1.0]"""
 import argparse
 import os
+os.environ.setdefault("FJ_LIB_VARIANT", "lab")           # the building blocks behind the C ABI are visible in the lab build only
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                                            # noqa: E402
 from flash_hash_join_amd import api, datagen           # noqa: E402
-from flash_hash_join_amd.distributed import HipEngine  # noqa: E402
+from flash_hash_join_amd.lab import LabEngine as HipEngine  # noqa: E402
 
 
 def timed(fn, reps=5):

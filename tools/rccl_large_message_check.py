@@ -1,9 +1,10 @@
 """Reproduces the RCCL finding behind distributed._exchange: an int64 all_to_all_single is exact at 0.8 GB per peer and
 wrong at 4.8 GB per peer (MI355X, RCCL 2.26.6, torch 2.10 ROCm 7.0); also checks fj_owner_split at 1e9 rows."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("FJ_LIB_VARIANT", "lab")           # the building blocks behind the C ABI are visible in the lab build only
 import torch, torch.distributed as dist
 from flash_hash_join_amd import api, datagen
-from flash_hash_join_amd.distributed import HipEngine
+from flash_hash_join_amd.lab import LabEngine as HipEngine
 api.initialize()
 eng = HipEngine("cuda:0")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29588")

@@ -83,17 +83,12 @@ def worker(rank, world, port, q):
         chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim)
         assert chk["ok"] and chk["failed_ranks"] == 0, chk
         assert chk["precheck"] and chk["precheck"]["ok"] and chk["precheck"]["ran"] and chk["precheck"]["form"].startswith("chunks"), chk   # the forced-precheck leg
-        os.environ["FJ_SELFCHECK_CORRUPT"] = "1"
-        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim)
-        del os.environ["FJ_SELFCHECK_CORRUPT"]
+        chk = D.self_check(shim, None, D.HipEngine("cuda:0"), (sk, sv, sp), int(et.item()), 300_000, transport=shim, corrupt=True)
         assert not chk["ok"] and chk["failed_ranks"] == 1 and (rank != 0 or "elements received from rank" in chk["error"]), chk
-        for strategy, pieces in (("replicate", "1"), ("replicate", "3"), ("shuffle", "1"), ("shuffle", "scatter"), ("shuffle", "prefilter"), ("shuffle", "scatter-prefilter"), ("shuffle", "auto"),
-                                 ("broadcast", "1"), ("auto", "1")):
-            os.environ["FJ_DIST_STRATEGY"] = strategy; os.environ["FJ_REPLICATE_PIECES"] = pieces if pieces.isdigit() else "1"
-            os.environ["FJ_DIST_PREFILTER"] = "1" if "prefilter" in pieces else "auto" if pieces == "auto" else "0"
-            os.environ["FJ_DIST_CHUNK_SHUFFLE"] = "0" if "scatter" in pieces else "1"
-            chunk = "scatter" not in pieces
-            D._PRECHECK_MEMO.clear()
+        for strategy, variant in (("shuffle", ""), ("scatter", ""), ("shuffle", "prefilter"), ("shuffle", "auto"), ("broadcast", ""), ("auto", "")):
+            os.environ["FJ_DIST_STRATEGY"] = strategy
+            os.environ["FJ_DIST_PREFILTER"] = "1" if variant == "prefilter" else "auto" if variant == "auto" else "0"
+            D._PRECHECK_MEMO.clear(); D._FORM_MEMO.clear()
             t = {}
             n, sec = D.distributed_join(bk, bv, pk, timings=t, transport=shim)
             assert n == exp, (strategy, n, exp)
@@ -101,11 +96,9 @@ def worker(rank, world, port, q):
                 assert t["strategy"] == "broadcast" and t["probe_rows_sent"] == 0 and t["local_build_rows"] == nb and t["local_probe_rows"] == p1 - p0, t
                 assert 0 < t["wire_bytes_sent"] <= (world - 1) * (8.1 * (b1 - b0) + 300_000), t        # (6M build rows in all: 11 bits, a 4-byte high-word plane)
                 assert "broadcast_form_error" not in t and "chunk_form_error" not in t, t
-            if "prefilter" in pieces:                       # half the probe rows miss; the owners' filters stop nearly all of them
-                assert t["prefilter"] and t["probe_rows_sent"] < 0.56 * (p1 - p0), t
-                if chunk:                                   # per-partition filters, all-gathered inside the driver (uneven ranges at 3 ranks)
-                    assert t["shuffle_form"].startswith("chunks") and t["filter_bytes_received"] > 0 and t["probe_rows_sent"] < 0.53 * (p1 - p0), t
-            if pieces == "auto":                            # every rank reaches the same verdict from the all-reduced sample
+            if variant == "prefilter":                      # half the probe rows miss; the owners' per-partition filters (all-gathered inside the driver: uneven ranges at 3 ranks) stop nearly all of them
+                assert t["prefilter"] and t["shuffle_form"].startswith("chunks") and t["filter_bytes_received"] > 0 and t["probe_rows_sent"] < 0.53 * (p1 - p0), t
+            if variant == "auto":                           # every rank reaches the same verdict from the all-reduced sample
                 assert t["prefilter_mode"] == "auto" and t["shuffle_form"].startswith("chunks"), t
                 vs = [None] * world
                 dist.all_gather_object(vs, (t["prefilter"], t["prefilter_sampled_survivors"]))
@@ -114,15 +107,17 @@ def worker(rank, world, port, q):
             n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True, transport=shim, timings=tm)
             M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
             assert n2 == exp and bool(torch.all((v + 1) * M == k)), strategy
-            if strategy == "shuffle":                        # materialising joins take the chunk form too (values travel with the build rows)
-                assert tm["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport" if chunk else "owner-scatter"), tm
-                assert tm["prefilter"] == ("prefilter" in pieces) or pieces == "auto", tm
+            if strategy != "scatter":                        # materialising joins start at the chunk-form shuffle (values travel with the build rows)
+                assert tm["shuffle_form"].startswith("chunks (fj_dist_join over a callback transport"), tm
+                assert tm["prefilter"] == (variant == "prefilter") or variant == "auto", tm
                 assert "chunk_form_error" not in tm, tm
+            else:
+                assert tm["shuffle_form"] == "owner-scatter" and t["shuffle_form"] == "owner-scatter", (t, tm)
             tot = torch.tensor([k.numel()]); dist.all_reduce(tot)
             assert int(tot.item()) == exp                   # the ranks' pair sets add up to the global result
             if strategy == "shuffle":
-                assert t["shuffle_form"].startswith("chunks (fj_dist_join_count over a callback transport" if chunk else "owner-scatter"), t
-            res[strategy + pieces] = (t["strategy"], t["pieces"], t["local_build_rows"], t["local_probe_rows"])
+                assert t["shuffle_form"].startswith("chunks (fj_dist_join over a callback transport"), t
+            res[strategy + variant] = (t["strategy"], t["pieces"] if "pieces" in t else None, t["local_build_rows"], t["local_probe_rows"])
         q.put((rank, exp, res))
     finally:
         dist.destroy_process_group()
