@@ -583,7 +583,9 @@ def main() -> None:
                        # what rank 0 put on its links per step (chunks + directory words; its own share never travels) and per key sent
                        "wire_chunk_bytes": dlast.get("wire_chunk_bytes"), "wire_bytes_sent_rank0": dlast.get("wire_bytes_sent"),
                        "chunk_form_error": dlast.get("chunk_form_error"), "broadcast_form_error": dlast.get("broadcast_form_error"),
-                       "strategy_timed": dlast.get("strategy"), "form_model": form_pick})
+                       "strategy_timed": dlast.get("strategy"), "form_model": form_pick,
+                       # what the passes left to the transport's kernels in the last timed step, and the measurements behind that choice
+                       "cu_reserve": dlast.get("cu_reserve")})
 
     out = {
         "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",

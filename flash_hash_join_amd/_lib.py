@@ -76,6 +76,7 @@ class FjDistTimings(ctypes.Structure):
         ("prefilter", ctypes.c_int), ("prefilter_sampled", ctypes.c_double), ("probe_rows_kept", ctypes.c_uint64), ("filter_bytes", ctypes.c_uint64),
         ("form", ctypes.c_int), ("form_reserved", ctypes.c_int), ("wire_bytes_sent", ctypes.c_uint64),
         ("local", FjTimings),
+        ("reserve_cus", ctypes.c_int), ("reserve_how", ctypes.c_int), ("reserve_with_ms", ctypes.c_double), ("reserve_without_ms", ctypes.c_double),
     ]
 
 

@@ -141,7 +141,7 @@ struct Engine {
     virtual int finish(uint64_t* count, fj_timings* lt) = 0;
     virtual void abort() = 0;
     virtual int drain() = 0;                                                    // everything this engine enqueued has finished
-    virtual void reserve(bool) {}                                               // leave room for the transport's own kernels (HIP engine over RCCL)
+    virtual void reserve(unsigned) {}                                           // leave n CUs to the transport's own kernels (HIP engine over RCCL); 0: none
     // ---- build-broadcast form (csrc/fj_bcast.hip) ----
     virtual bool has_bcast() const { return false; }
     virtual size_t bc_region_bytes(size_t, size_t) { return 0; }               // 0: no such plan
@@ -223,15 +223,11 @@ struct HipEngine : Engine {
     int finish(uint64_t* count, fj_timings* lt) override { return fj_stream_finish(ctx, js, count, lt); }
     void abort() override { (void)fj_stream_abort(ctx); }
     int drain() override { DHIP(hipStreamSynchronize(ps)); DHIP(hipStreamSynchronize(js)); return 0; }
-    // RCCL's kernels are resident for the length of an exchange: the partition passes (one persistent workgroup per CU, static
-    // tile shares) leave them room - see fj_ctx_reserve_cus.  FJ_DIST_RESERVE_CUS (default 32) CUs while a step over RCCL with more
-    // than one rank runs (FJ_DIST_RESERVE_ALWAYS: also on one rank - a test and measurement hook).  Not measured on a multi-GPU box:
-    // a hedge whose price is bounded (the passes run ~14 % slower in a regime where the wire is the bottleneck) against a cliff
-    // (a pass that does not get every CU takes twice as long).
-    void reserve(bool on) override {
-        static const unsigned n = getenv("FJ_DIST_RESERVE_CUS") ? (unsigned)atoi(getenv("FJ_DIST_RESERVE_CUS")) : 32u;
-        fj_ctx_reserve_cus(ctx, on ? n : 0u);
-    }
+    // RCCL's kernels are resident for the length of an exchange: the partition passes and the wide join (one persistent workgroup per
+    // CU, static tile shares) can leave them room - fj_ctx_reserve_cus.  How many CUs, if any, is measured per communicator
+    // (reserve_for_step below): a pass that does not get every CU it was launched for takes twice as long, a pass launched on 224
+    // CUs runs ~10 % slower than on 256.
+    void reserve(unsigned n) override { fj_ctx_reserve_cus(ctx, n); }
     bool has_bcast() const override { return true; }
     size_t bc_region_bytes(size_t nb_total, size_t nkeys) override { return fj_bcast_region_bytes(nb_total, nkeys); }
     int bc_span(size_t nb_total, size_t nkeys, size_t lo, size_t hi, int part, size_t* off, size_t* bytes) override { return fj_bcast_piece_span(nb_total, nkeys, lo, hi, part, off, bytes); }
@@ -458,6 +454,9 @@ struct fj_dist_comm {
     DBuf filt;                                              // every final partition's Bloom filter (sender-side precheck)
     DBuf bcast;                                             // build-broadcast form: the regions of all ranks, rank after rank
     int form = FJ_DIST_FORM_AUTO; double link_rate = 0.0;   // fj_dist_comm_set_form
+    // the CU reserve, measured: successful steps so far; this rank's probe-side pass time (ms) of the step that ran with / without it
+    // (per join shape: a step of other sizes - a pre-flight check in front of the real joins - starts the measurement afresh)
+    int rs_step = 0; double rs_with_ms = 0.0, rs_without_ms = 0.0; unsigned long long rs_nb = 0, rs_np = 0;
     int grow(DBuf& b, size_t bytes) {
         if (bytes == 0) bytes = 16;
         if (b.bytes >= bytes) return 0;
@@ -475,6 +474,27 @@ struct fj_dist_comm {
     }
 };
 
+// CUs the step's passes and joins leave to the transport (and how the number came about: fj_dist_timings::reserve_how).  tot_with /
+// tot_without: every rank's measured pass time summed (the same on every rank: they travelled in the step's first all-gather).
+static constexpr unsigned RESERVE_CUS = 32;
+static unsigned reserve_for_step(const fj_dist_comm* dc, bool applies, double tot_with, double tot_without, int* how) {
+    *how = 0;
+    if (!applies) return 0;
+    if (const char* e = getenv("FJ_DIST_RESERVE_CUS")) { *how = 1; return (unsigned)atoi(e); }
+    if (dc->rs_step <= 1) { *how = 2; return RESERVE_CUS; }            // step 0 (pools grow, communicators connect) and the measuring step WITH the reserve
+    if (dc->rs_step == 2) { *how = 2; return 0; }                      // the measuring step WITHOUT it
+    *how = 3;
+    return tot_with > 0 && tot_without > 0 && tot_without < tot_with ? 0u : RESERVE_CUS;
+}
+static void reserve_account(fj_dist_comm* dc, const fj_timings& lt, int how) {         // after a successful step
+    double ms = 0;
+    for (int i = 0; i < 4; ++i) ms += lt.probe_part_kernel_ms[i];
+    if (how == 2 && dc->rs_step == 1) dc->rs_with_ms = ms;             // (only measuring steps measure: a pinned reserve records nothing)
+    if (how == 2 && dc->rs_step == 2) dc->rs_without_ms = ms;
+    ++dc->rs_step;
+}
+
+
 // ---- the step in its BUILD-BROADCAST form ----------------------------------------------------------------------------------------
 // The probe rows never move.  Every rank packs its build rows into its region (fj_bcast_pack: both passes of the plan for the
 // TOTAL build side, then one run per final partition, 6 bytes per key), queues both passes over its own probe rows behind that,
@@ -484,7 +504,7 @@ struct fj_dist_comm {
 // agreement on the buffers; a rank-local failure is agreed on like in the shuffle form.
 static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                            const std::vector<uint64_t>& nb_of, unsigned long long nb_total, uint64_t* out_global_count, uint64_t* out_local_count,
-                           fj_dist_timings* timings) {
+                           fj_dist_timings* timings, unsigned reserve_n, int reserve_how, double tot_with, double tot_without) {
     Net& net = *dc->net; Engine& eng = *dc->eng;
     const int N = net.nranks, me = net.rank;
     const auto t0 = std::chrono::steady_clock::now();
@@ -495,9 +515,9 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
     std::vector<uint64_t> roff(N + 1, 0);
     for (int r = 0; r < N; ++r) roff[r + 1] = roff[r] + ((eng.bc_region_bytes(nb_total, (size_t)nb_of[r]) + 255) & ~(size_t)255);
     net.begin_step();
-    const bool reserve = net.shares_the_gpu() && (N > 1 || (fj_get_option("lab_hooks") & FJ_HOOK_RESERVE_ALWAYS));
-    struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(false); } } reserve_guard{eng, reserve};
-    if (reserve) eng.reserve(true);
+    const bool reserve = reserve_n > 0;
+    struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(0); } } reserve_guard{eng, reserve};
+    if (reserve) eng.reserve(reserve_n);
     bool begun = false;
     auto bail = [&](const std::string& why) { (void)net.drain(); (void)eng.drain(); if (begun) eng.bc_abort(); return derr("%s", why.c_str()); };
 
@@ -557,7 +577,7 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
         if (net.exchange(3, sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, q)) return bail(fj_last_error());
         if (failed.empty()) {
             // (the last range's join starts when the last piece has landed: the transport's kernels are gone from this GPU by then)
-            if (reserve && q + 1 == pieces) eng.reserve(false);
+            if (reserve && q + 1 == pieces) eng.reserve(0);
             const uint32_t plo = (uint32_t)(((uint64_t)nparts * q) / pieces), phi = (uint32_t)(((uint64_t)nparts * (q + 1)) / pieces);
             guarded(eng.bc_join(base, N, roff.data(), nb_of.data(), plo, phi, done ? done : packed));
         }
@@ -573,8 +593,10 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
     if (res[1]) return derr("fj_dist_join_count: the local join failed on %llu rank(s)%s%s", res[1], failed.empty() ? "" : "; this rank: ", failed.c_str());
     if (out_global_count) *out_global_count = res[0];
     if (out_local_count) *out_local_count = local;
+    reserve_account(dc, lt, reserve_how);
     if (timings) {
         fj_dist_timings T; memset(&T, 0, sizeof T);
+        T.reserve_cus = (int)reserve_n; T.reserve_how = reserve_how; T.reserve_with_ms = tot_with; T.reserve_without_ms = tot_without;
         T.total_ms = ms_since(t0); T.split_ms = split_ms; T.join_ms = ms_since(t2);
         T.exchange_ms = std::max(0.0, T.total_ms - T.join_ms - split_ms);
         T.local_count = local; T.pieces = pieces; T.nranks = N; T.local = lt;
@@ -714,21 +736,34 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     auto mark = [&](const char* what) { if (trace) marks.emplace_back(what, ms_since(t0)); };
 
     // relation sizes of every rank: one plan for everybody
-    std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 20));
+    std::vector<unsigned long long> m((size_t)N * std::max(N + 1, 24));
     // (... and one precheck threshold, one form, one link rate, one piece count: rank 0's - what is exchanged, and in how many rounds,
     //  must not depend on the rank)
     {
         const double pb = prefilter_below > 0 ? std::min(prefilter_below, 4.0) : 0.0;
-        const unsigned long long v[5] = {nb, np, (unsigned long long)(pb * 1e9), (unsigned long long)dc->form | ((unsigned long long)pieces << 8),
-                                         (unsigned long long)(dc->link_rate > 0 ? dc->link_rate : 0.0)};
-        if (net.all_gather(v, 5, m.data())) return 1;
+        const unsigned long long v[7] = {nb, np, (unsigned long long)(pb * 1e9), (unsigned long long)dc->form | ((unsigned long long)pieces << 8),
+                                         (unsigned long long)(dc->link_rate > 0 ? dc->link_rate : 0.0),
+                                         (unsigned long long)(dc->rs_with_ms * 1e3), (unsigned long long)(dc->rs_without_ms * 1e3)};      // (this rank's measured pass times, us)
+        if (net.all_gather(v, 7, m.data())) return 1;
     }
     unsigned long long nb_total = 0, np_global = 0, np_min = ~0ull, nb_max = 0, np_max = 0;
     std::vector<uint64_t> nb_of(N);
-    for (int r = 0; r < N; ++r) {
-        nb_of[r] = m[5 * r]; nb_total += m[5 * r]; np_global += m[5 * r + 1]; np_min = std::min(np_min, m[5 * r + 1]);
-        nb_max = std::max(nb_max, m[5 * r]); np_max = std::max(np_max, m[5 * r + 1]);
+    {   // the CU reserve is measured per join shape (sizes are the same on every rank after the all-gather: so is this reset)
+        unsigned long long nbt = 0, npt = 0;
+        for (int r = 0; r < N; ++r) { nbt += m[7 * r]; npt += m[7 * r + 1]; }
+        if (nbt != dc->rs_nb || npt != dc->rs_np) {
+            dc->rs_nb = nbt; dc->rs_np = npt; dc->rs_step = 0; dc->rs_with_ms = dc->rs_without_ms = 0.0;
+            for (int r = 0; r < N; ++r) m[7 * r + 5] = m[7 * r + 6] = 0;       // (what travelled belongs to the previous shape)
+        }
     }
+    double tot_with = 0, tot_without = 0;                     // the ranks' measured probe-side pass times, added up (ms): the CU reserve's evidence
+    for (int r = 0; r < N; ++r) {
+        nb_of[r] = m[7 * r]; nb_total += m[7 * r]; np_global += m[7 * r + 1]; np_min = std::min(np_min, m[7 * r + 1]);
+        nb_max = std::max(nb_max, m[7 * r]); np_max = std::max(np_max, m[7 * r + 1]);
+        tot_with += (double)m[7 * r + 5] * 1e-3; tot_without += (double)m[7 * r + 6] * 1e-3;
+    }
+    int reserve_how = 0;
+    const unsigned reserve_n = reserve_for_step(dc, net.shares_the_gpu() && (N > 1 || (fj_get_option("lab_hooks") & FJ_HOOK_RESERVE_ALWAYS)), tot_with, tot_without, &reserve_how);
     prefilter_below = (double)m[2] * 1e-9;
     pieces = (int)(m[3] >> 8);
     if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: rank 0 asks for %d pieces (1..%d)", pieces, MAX_PIECES);
@@ -746,16 +781,16 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
             bcast = fj_dist_model(N, nb_max, np_max, nb_total, np_global, region_max, link_rate, nullptr, nullptr) == FJ_DIST_FORM_BROADCAST;
         if (form_req == FJ_DIST_FORM_BROADCAST && !can)
             return derr("fj_dist_join_count: the build-broadcast form needs an engine that has it, <= %u ranks and a total build side with a partitioned plan (%llu rows)", FJ_WIDE_MAXSRC, nb_total);
-        if (bcast) return dist_join_bcast(dc, d_build_keys, nb, d_probe_keys, np, pieces, nb_of, nb_total, out_global_count, out_local_count, timings);
+        if (bcast) return dist_join_bcast(dc, d_build_keys, nb, d_probe_keys, np, pieces, nb_of, nb_total, out_global_count, out_local_count, timings, reserve_n, reserve_how, tot_with, tot_without);
     }
     size_t CB = 0;
     if (eng.plan(nb_total, N, &CB)) return 1;                 // (same verdict on every rank: same arguments)
     if (np_min < 2ull * pieces) pieces = 1;
     net.begin_step();
     const bool loop = net.loopback();
-    const bool reserve = net.shares_the_gpu() && (N > 1 || (fj_get_option("lab_hooks") & FJ_HOOK_RESERVE_ALWAYS));
-    struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(false); } } reserve_guard{eng, reserve};
-    if (reserve) eng.reserve(true);
+    const bool reserve = reserve_n > 0;
+    struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(0); } } reserve_guard{eng, reserve};
+    if (reserve) eng.reserve(reserve_n);
 
     std::string failed;                                       // this rank's first local join failure: later engine calls are skipped, collectives go on
     auto guarded = [&](int rc) { if (rc && failed.empty()) failed = fj_last_error(); return rc; };
@@ -942,8 +977,10 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     if (res[1]) return derr("fj_dist_join_count: the local join failed on %llu rank(s)%s%s", res[1], failed.empty() ? "" : "; this rank: ", failed.c_str());
     if (out_global_count) *out_global_count = res[0];
     if (out_local_count) *out_local_count = local;          // materialising: fj_emit_pairs(ctx, ...) then writes this rank's `local` pairs (they stay with the owner)
+    reserve_account(dc, lt, reserve_how);
     if (timings) {
         fj_dist_timings T; memset(&T, 0, sizeof T);
+        T.reserve_cus = (int)reserve_n; T.reserve_how = reserve_how; T.reserve_with_ms = tot_with; T.reserve_without_ms = tot_without;
         T.total_ms = ms_since(t0); T.split_ms = split_ms; T.join_ms = ms_since(t2);
         T.exchange_ms = std::max(0.0, T.total_ms - T.join_ms - split_ms);
         T.local_count = local; T.local_build_chunks = B.chunks; T.local_probe_chunks = rows_recv_chunks;

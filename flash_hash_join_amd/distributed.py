@@ -568,6 +568,11 @@ def _driver_join(dist, group, engine, build_keys, probe_keys, pieces: int, timin
     sec = time.perf_counter() - t0
     if not standin:
         engine.api._last = dt.local
+    if timings is not None:
+        # the CU reserve of the step (fj_dist_timings.reserve_*): how many CUs the passes left to the transport's kernels, how that came
+        # about, and the measurements behind a choice (every rank's probe-side pass time of one step with and one without, added up)
+        timings["cu_reserve"] = {"cus": int(dt.reserve_cus), "how": ("none applies", "pinned (FJ_DIST_RESERVE_CUS)", "measuring step", "chosen from the measurements")[int(dt.reserve_how) & 3],
+                                 "pass_ms_with_32_reserved_all_ranks": round(float(dt.reserve_with_ms), 3), "pass_ms_with_none_all_ranks": round(float(dt.reserve_without_ms), 3)}
     if timings is not None and int(dt.form) == FORM_BROADCAST:
         timings.update(strategy="broadcast", shuffle_form=f"build broadcast (fj_dist_join over {via}: probe rows stay, dense 6-byte build runs to every peer)",
                        split_s=dt.split_ms * 1e-3, exchange_s=dt.exchange_ms * 1e-3, join_s=dt.join_ms * 1e-3, exchange_rounds=1, pieces=int(dt.pieces),

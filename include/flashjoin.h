@@ -211,6 +211,12 @@ int fj_bcast_plan(size_t nb_total, int* bits, uint32_t* nparts, int* mid_bytes);
  *                                 engine == NULL the rank's work runs on ctx's GPU; a stand-in engine (tests) replaces it,
  *                                 then ctx may be NULL and "device" pointers are whatever the stand-in's alloc returns.
  *   (a communicator serves ONE join at a time - it owns the exchange buffers and streams of the step; use one per thread)
+ *   The CU reserve: over RCCL with more than one rank, the transport's send / receive kernels are resident on the GPU for the
+ *   length of an exchange, and the partition passes and the wide join (one persistent workgroup per CU, static tile shares) must not
+ *   find CUs taken.  Whether leaving 32 CUs free beats sharing all 256 is MEASURED per communicator: its second step runs with the
+ *   reserve, its third without, both times the probe-side passes are timed (HIP events, an exchange in flight), the ranks add their
+ *   times up in the next step's first all-gather, and every later step uses the faster setting (fj_dist_timings.reserve_*).
+ *   FJ_DIST_RESERVE_CUS=n pins the number instead.
  *   fj_dist_join_count          - collective.  pieces: rounds of the probe exchange (4 is the measured default).  A build side
  *                                 of less than ~2M rows in all is refused (one-pass plan: join it on one GPU).
  *   fj_dist_join                - the same step, optionally materialising (materialize != 0: the build rows travel with their
@@ -239,6 +245,12 @@ typedef struct fj_dist_timings {
     int form_reserved;
     uint64_t wire_bytes_sent;                          /* bytes this rank put on the links (all peers)             */
     fj_timings local;                                  /* device timings of this rank's local join (fj_stream_finish) */
+    /* the CU reserve (below): CUs this step's passes and joins left to the transport's own kernels; how that number came about
+     * (0 = no reserve applies: one rank / a transport without kernels of its own, 1 = pinned by FJ_DIST_RESERVE_CUS, 2 = a measuring
+     * step, 3 = chosen from the measurements); the measurements: this communicator's probe-side pass time per step, summed over the
+     * ranks, with 32 CUs reserved and with none (ms; 0 until measured) */
+    int reserve_cus, reserve_how;
+    double reserve_with_ms, reserve_without_ms;
 } fj_dist_timings;
 typedef struct fj_dist_transport {
     void* user;
