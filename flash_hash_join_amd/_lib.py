@@ -43,7 +43,7 @@ LAB_SYMBOLS = [
     "fj_shuffle_chunk_bytes", "fj_shuffle_pack_begin", "fj_shuffle_pack_counts", "fj_shuffle_pack_finish", "fj_stream_open_shuffled",
     "fj_stream_append_build_chunks", "fj_stream_append_probe_chunks",
     "fj_shuffle_part_filter_bytes", "fj_shuffle_part_filter_range", "fj_stream_export_part_filters", "fj_shuffle_pack_filter", "fj_shuffle_pack_kept", "fj_part_filter_sample",
-    "fj_bcast_region_bytes", "fj_bcast_piece_span", "fj_bcast_pack", "fj_bcast_pack_bounds", "fj_bcast_probe", "fj_bcast_join", "fj_bcast_finish", "fj_bcast_abort",
+    "fj_bcast_region_bytes", "fj_bcast_piece_span", "fj_bcast_pack", "fj_bcast_pack_bounds", "fj_bcast_probe", "fj_bcast_join", "fj_bcast_finish", "fj_bcast_abort", "fj_bcast_emit",
     "fj_bloom_filter_words", "fj_bloom_export", "fj_bloom_prefilter",
     "fj_stream_open", "fj_stream_append_build", "fj_stream_advance_probe", "fj_stream_begin", "fj_stream_append_probe", "fj_stream_finish",
     "fj_ctx_reserve_cus", "fj_debug_partition",
@@ -237,14 +237,15 @@ def load() -> ctypes.CDLL:
         L.fj_stream_open_shuffled.restype = i32; L.fj_stream_open_shuffled.argtypes = [vp, sz, i32, i32, sz, i32, sz, i32, i32, vp]
         L.fj_stream_append_build_chunks.restype = i32; L.fj_stream_append_build_chunks.argtypes = [vp, vp, vp, vp, sz, vp]
         L.fj_stream_append_probe_chunks.restype = i32; L.fj_stream_append_probe_chunks.argtypes = [vp, vp, vp, sz, vp]
-        L.fj_bcast_region_bytes.restype = sz; L.fj_bcast_region_bytes.argtypes = [sz, sz]
+        L.fj_bcast_region_bytes.restype = sz; L.fj_bcast_region_bytes.argtypes = [sz, sz, i32]
         L.fj_bcast_piece_span.restype = i32; L.fj_bcast_piece_span.argtypes = [sz, sz, sz, sz, i32, psz, psz]
-        L.fj_bcast_pack.restype = i32; L.fj_bcast_pack.argtypes = [vp, vp, sz, sz, vp, i32, vp]
+        L.fj_bcast_pack.restype = i32; L.fj_bcast_pack.argtypes = [vp, vp, vp, sz, sz, vp, i32, i32, vp]
         L.fj_bcast_pack_bounds.restype = i32; L.fj_bcast_pack_bounds.argtypes = [vp, pu64]
         L.fj_bcast_probe.restype = i32; L.fj_bcast_probe.argtypes = [vp, vp, sz, sz, vp]
         L.fj_bcast_join.restype = i32; L.fj_bcast_join.argtypes = [vp, vp, i32, pu64, pu64, ctypes.c_uint32, ctypes.c_uint32, vp]
         L.fj_bcast_finish.restype = i32; L.fj_bcast_finish.argtypes = [vp, vp, pu64, ctypes.POINTER(FjTimings)]
         L.fj_bcast_abort.restype = None; L.fj_bcast_abort.argtypes = [vp]
+        L.fj_bcast_emit.restype = i32; L.fj_bcast_emit.argtypes = [vp, vp, vp, sz, vp]
         L.fj_debug_partition.restype = i32
         L.fj_debug_partition.argtypes = [vp, vp, vp, sz, i32, i32, vp, vp, vp, vp, pu64]
     _lib = L

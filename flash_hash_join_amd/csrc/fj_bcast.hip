@@ -182,15 +182,147 @@ __global__ __launch_bounds__(DP_NT) void fj_dense_copy(const u64* __restrict__ k
     if (pos > tile_base) flush(tile_base);
 }
 
-struct Layout { u32 bits, nparts, mid_bytes; size_t lo_off, mid_off, bytes; };
-int layout_of(size_t nb_total, size_t nkeys, Layout* L) {
+
+// materialising joins: one wave per final partition copies its chunks' VALUES to the partition's place in the values plane (same
+// order as fj_dense_copy wrote the keys: chunk after chunk, key after key)
+__global__ __launch_bounds__(DP_NT) void fj_dense_copy_vals(const u64* __restrict__ vals, const u32* __restrict__ boff, const u32* __restrict__ list,
+                                                           u32 nparts, const u32* __restrict__ offs, u64* __restrict__ out) {
+    const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 p = blockIdx.x * (DP_NT / 64) + wv;
+    if (p >= nparts) return;
+    u32 pos = offs[p];
+    for (u32 i = boff[p]; i < boff[p + 1]; ++i) {
+        const u32 e = list[i], cnt = FJ_LIST_CNT(e);
+        const u64* cv = vals + (u64)FJ_LIST_ID(e) * FJ_CHUNK;
+        for (u32 k = lane; k < cnt; k += 64) out[pos + k] = cv[k];
+        pos += cnt;
+    }
+}
+
+// ---- the join of a MATERIALISING build-broadcast step (insert_local + probe_vectorized of one radix partition with the build rows'
+// values, hash_join.cpp:112-128, :153-182, inside _hash_join_radix_materialize, :315-381).  The counting step's kernel
+// (fj_count_join_wide<DENSE>) is a deep software pipeline without room for values; this one is the plain form: one 1024-thread
+// workgroup per CU walks its items; per item the partition's runs of all sources go into an 8192-slot bucketed table (2048 buckets of
+// 4 slots: keys 64 KiB + values 64 KiB of LDS; one returning atomic add on the bucket's fill count per key, a full bucket sends the
+// key to the next one), then the item's probe chunks are looked up.  EMIT = false: counts per item (part_count) and reports
+// duplicate build keys (FJ_STAT_DUPS: a materialising join must emit the FIRST occurrence's value, which only the owner-scatter
+// form can tell) and partitions beyond the table (FJ_STAT_RETRY); EMIT = true: writes the pairs (probe key un-mixed, build value)
+// at out_off[item].  Not a fast path (~2x the counting kernel's time): the pairs' 16 bytes each are what a materialising join costs.
+constexpr u32 DM_NT = 1024, DM_SLOTS = 8192, DM_BS = 4, DM_NBK = DM_SLOTS / DM_BS, DM_MAXWALK = 256;
+struct DenseMatArgs {
+    FjChunkSet probe; const uint4* items; const u32* toff; u32 part_lo, part_hi;
+    const unsigned char* base; u32 nsrc, bits, mid_bytes;
+    u64 offs_off[FJ_WIDE_MAXSRC], lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC], val_off[FJ_WIDE_MAXSRC];
+    u32* part_count; unsigned long long* total; u32* err;
+    const u64* out_off; u64* out_keys; u64* out_vals;
+};
+template <bool EMIT>
+__global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dm_smem[];
+    u64* tkeys = reinterpret_cast<u64*>(dm_smem);
+    u64* tvals = tkeys + DM_SLOTS;
+    u32* fill = reinterpret_cast<u32*>(tvals + (EMIT ? DM_SLOTS : 0));
+    u32* sh = fill + DM_NBK;                                       // [0] hits of the item, [1] table overflow, [2] duplicates, [3] pairs written
+    const u32 tid = threadIdx.x;
+    const u32 item_lo = a.toff[a.part_lo], item_hi = a.toff[a.part_hi];
+    u32 cur_part = 0xFFFFFFFFu;
+    for (u32 it = item_lo + blockIdx.x; it < item_hi; it += gridDim.x) {
+        const uint4 d = a.items[it];                               // {probe list pos, probe chunks, partition, -}
+        const u32 part = d.z;
+        if (tid < 4) sh[tid] = tid == 1 || tid == 2 ? sh[tid] : 0u;
+        if (part != cur_part) {                                    // (items of one partition that follow each other in a workgroup share the table)
+            for (u32 i = tid; i < DM_NBK; i += DM_NT) fill[i] = 0;
+            if (tid == 1 || tid == 2) sh[tid] = 0;
+            __syncthreads();
+            const u32 top = a.bits ? part << (32u - a.bits) : 0u;
+            for (u32 s = 0; s < a.nsrc; ++s) {
+                const u32* offs = reinterpret_cast<const u32*>(a.base + a.offs_off[s]);
+                const u32 b = offs[part], e = offs[part + 1];
+                const u32* lo = reinterpret_cast<const u32*>(a.base + a.lo_off[s]);
+                for (u32 k = b + tid; k < e; k += DM_NT) {
+                    const u32 m = a.mid_bytes == 2 ? (u32)reinterpret_cast<const u16*>(a.base + a.mid_off[s])[k] : reinterpret_cast<const u32*>(a.base + a.mid_off[s])[k];
+                    const u64 key = ((u64)(top | m) << 32) | lo[k];
+                    u32 bk = FJ_HW2(key) & (DM_NBK - 1u), slot = 0xFFFFFFFFu;
+                    for (u32 step = 0; step < DM_MAXWALK; ++step) {
+                        const u32 o = atomicAdd(&fill[bk], 1u);
+                        if (o < DM_BS) { slot = bk * DM_BS + o; break; }
+                        bk = (bk + 1u) & (DM_NBK - 1u);
+                    }
+                    if (slot == 0xFFFFFFFFu) sh[1] = 1;
+                    else { tkeys[slot] = key; if (EMIT) tvals[slot] = reinterpret_cast<const u64*>(a.base + a.val_off[s])[k]; }
+                }
+            }
+            __syncthreads();
+            if (!EMIT) {
+                // duplicate build keys: a key that meets its own value in an EARLIER slot of its bucket chain.  Every thread checks the slots it can reach
+                for (u32 slot = tid; slot < DM_SLOTS; slot += DM_NT) {
+                    const u32 bk = slot / DM_BS, pos = slot % DM_BS;
+                    if (pos >= (fill[bk] < DM_BS ? fill[bk] : DM_BS)) continue;
+                    const u64 key = tkeys[slot];
+                    u32 hb = FJ_HW2(key) & (DM_NBK - 1u);
+                    bool dup = false;
+                    for (u32 step = 0; step < DM_MAXWALK && !dup; ++step) {          // from the key's home bucket up to its own slot
+                        const u32 n = hb == bk ? pos : (fill[hb] < DM_BS ? fill[hb] : DM_BS);
+                        for (u32 j = 0; j < n; ++j) dup |= tkeys[hb * DM_BS + j] == key;
+                        if (hb == bk) break;
+                        hb = (hb + 1u) & (DM_NBK - 1u);
+                    }
+                    if (dup) sh[2] = 1;
+                }
+            }
+            cur_part = part;
+            __syncthreads();
+        } else __syncthreads();
+        const bool bad = sh[1] != 0;
+        u32 my_hits = 0;
+        if (!bad) {
+            for (u32 idx = tid; idx < d.y * FJ_CHUNK; idx += DM_NT) {
+                const u32 e = a.probe.list[d.x + (idx >> FJ_CHUNK_LOG)], k = idx & (FJ_CHUNK - 1u);
+                if (k >= FJ_LIST_CNT(e)) continue;
+                const u64 key = a.probe.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + k];
+                u32 bk = FJ_HW2(key) & (DM_NBK - 1u), hit = 0xFFFFFFFFu;
+                for (u32 step = 0; step < DM_MAXWALK && hit == 0xFFFFFFFFu; ++step) {
+                    const u32 f = fill[bk], n = f < DM_BS ? f : DM_BS;
+                    for (u32 j = 0; j < n; ++j) if (tkeys[bk * DM_BS + j] == key) { hit = bk * DM_BS + j; break; }
+                    if (f <= DM_BS) break;                         // nobody was sent on from this bucket
+                    bk = (bk + 1u) & (DM_NBK - 1u);
+                }
+                if (hit != 0xFFFFFFFFu) {
+                    ++my_hits;
+                    if (EMIT) {
+                        const u32 w = atomicAdd(&sh[3], 1u);
+                        const u64 o = a.out_off[it] + w;
+                        a.out_keys[o] = fj_key_unmix(key); a.out_vals[o] = tvals[hit];
+                    }
+                }
+            }
+        }
+        if (!EMIT) {
+            const u32 wsum = fj_wave_sum(my_hits);
+            if ((tid & 63) == 0 && wsum) atomicAdd(&sh[0], wsum);
+            __syncthreads();
+            if (tid == 0) {
+                a.part_count[it] = bad ? 0u : sh[0];
+                if (bad) atomicOr(a.err, FJ_STAT_RETRY);
+                else if (sh[0]) atomicAdd(a.total, (unsigned long long)sh[0]);
+                if (sh[2]) atomicOr(a.err, FJ_STAT_DUPS);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct Layout { u32 bits, nparts, mid_bytes; size_t lo_off, mid_off, val_off, bytes; };
+// with_vals: the region of a MATERIALISING join carries a fourth part, the build values u64[n] (14 bytes per build row in all)
+int layout_of(size_t nb_total, size_t nkeys, Layout* L, bool with_vals = false) {
     const Plan p = make_plan(nb_total, 64);
     if (p.npass < 1 || p.bits < 5) return set_err("build broadcast: a build side of %zu rows in all needs no partitioning (use the owner-scatter form)", nb_total);
     if (nkeys >= (1ull << 32)) return set_err("build broadcast: %zu build rows on one rank (the offset tables are 32-bit)", nkeys);
     L->bits = (u32)p.bits; L->nparts = 1u << p.bits; L->mid_bytes = 32 - p.bits <= 16 ? 2u : 4u;
     L->lo_off = (((size_t)L->nparts + 1) * 4 + 15) & ~(size_t)15;
     L->mid_off = L->lo_off + ((nkeys * 4 + 15) & ~(size_t)15) + 16;
-    L->bytes = L->mid_off + ((nkeys * L->mid_bytes + 15) & ~(size_t)15) + 16;
+    L->val_off = L->mid_off + ((nkeys * L->mid_bytes + 15) & ~(size_t)15) + 16;
+    L->bytes = with_vals ? L->val_off + ((nkeys * 8 + 15) & ~(size_t)15) + 16 : L->val_off;
     return 0;
 }
 
@@ -207,38 +339,42 @@ int fj_bcast_plan(size_t nb_total, int* bits, uint32_t* nparts, int* mid_bytes) 
     return 0;
 }
 
-size_t fj_bcast_region_bytes(size_t nb_total, size_t nkeys) {
+size_t fj_bcast_region_bytes(size_t nb_total, size_t nkeys, int with_vals) {
     Layout L;
-    return layout_of(nb_total, nkeys, &L) ? 0 : L.bytes;
+    return layout_of(nb_total, nkeys, &L, with_vals != 0) ? 0 : L.bytes;
 }
 
 // where piece q's bytes of a region of `nkeys` keys lie: part 0 = the offset table (travels with piece 0), part 1 = low words,
-// part 2 = high-word plane, of the keys [k_lo, k_hi)
+// part 2 = high-word plane, part 3 = values (regions of materialising joins), of the keys [k_lo, k_hi)
 int fj_bcast_piece_span(size_t nb_total, size_t nkeys, size_t k_lo, size_t k_hi, int part, size_t* offset, size_t* bytes) {
     Layout L;
-    if (layout_of(nb_total, nkeys, &L)) return 1;
-    if (k_lo > k_hi || k_hi > nkeys || part < 0 || part > 2) return set_err("fj_bcast_piece_span: bad range");
+    if (layout_of(nb_total, nkeys, &L, true)) return 1;
+    if (k_lo > k_hi || k_hi > nkeys || part < 0 || part > 3) return set_err("fj_bcast_piece_span: bad range");
     if (part == 0) { *offset = 0; *bytes = ((size_t)L.nparts + 1) * 4; }
     else if (part == 1) { *offset = L.lo_off + k_lo * 4; *bytes = (k_hi - k_lo) * 4; }
-    else { *offset = L.mid_off + k_lo * L.mid_bytes; *bytes = (k_hi - k_lo) * L.mid_bytes; }
+    else if (part == 2) { *offset = L.mid_off + k_lo * L.mid_bytes; *bytes = (k_hi - k_lo) * L.mid_bytes; }
+    else { *offset = L.val_off + k_lo * 8; *bytes = (k_hi - k_lo) * 8; }
     return 0;
 }
 
 // This rank's build rows -> its region (asynchronous on `stream`; starts the step: the plan's scalars are cleared here).
 // pieces: the region will travel in that many pieces of consecutive partitions; fj_bcast_pack_bounds blocks until their key
 // boundaries are known.
-int fj_bcast_pack(fj_ctx* c, const uint64_t* d_keys, size_t nb, size_t nb_total, void* d_region, int pieces, void* stream) {
+int fj_bcast_pack(fj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, size_t nb, size_t nb_total, void* d_region, int pieces, int with_vals_in, void* stream) {
     if (!c) return set_err("fj_bcast_pack: null context");
-    if ((nb && !d_keys) || !d_region || (((uintptr_t)d_keys | (uintptr_t)d_region) & 15)) return set_err("fj_bcast_pack: null or misaligned pointer");
+    if ((nb && !d_keys) || !d_region || (((uintptr_t)d_keys | (uintptr_t)d_vals | (uintptr_t)d_region) & 15)) return set_err("fj_bcast_pack: null or misaligned pointer");
     if (pieces < 1 || pieces > 16) return set_err("fj_bcast_pack: pieces must be 1..16");
     if (c->st.active) return set_err("fj_bcast_pack: a stream join is open on this context");
+    const bool with_vals = with_vals_in != 0;                  // a materialising join: the values travel as a fourth part of the region
+    if (with_vals && nb && !d_vals) return set_err("fj_bcast_pack: a materialising join needs the build values");
     Layout L;
-    if (layout_of(nb_total, nb, &L)) return 1;
+    if (layout_of(nb_total, nb, &L, with_vals)) return 1;
     FJ_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
+    c->pend.valid = false;
     BcastState& bc = c->bc;
     bc = BcastState();
-    bc.nb_total = nb_total; bc.pieces = pieces; bc.plan = make_plan(nb_total, 64);
+    bc.nb_total = nb_total; bc.pieces = pieces; bc.plan = make_plan(nb_total, 64); bc.with_vals = with_vals;
     begin_plan(c);
     HIPCHK(hipEventRecord(c->ev[E_START], s));
     if (clear_plan_scalars(c, s)) return 1;
@@ -249,9 +385,9 @@ int fj_bcast_pack(fj_ctx* c, const uint64_t* d_keys, size_t nb, size_t nb_total,
         HIPCHK(hipMemsetAsync(c->d_sc->bc_bounds, 0, sizeof(c->d_sc->bc_bounds), s));
     } else {
         PassIter it;
-        pass_init(it, 0, false, nb, bc.plan, 64);
+        pass_init(it, 0, with_vals, nb, bc.plan, 64);
         FjChunkSet cs{};
-        if (run_passes(c, it, (const u64*)d_keys, nullptr, s, &cs, nullptr)) return 1;
+        if (run_passes(c, it, (const u64*)d_keys, with_vals ? (const u64*)d_vals : nullptr, s, &cs, nullptr)) return 1;
         if (L.nparts >= 8192u && L.nparts <= (1u << 19)) {
             void* tmp = nullptr;                             // (a slot of the owner shuffle's packing pass: idle in this form)
             if (get_buf(c, W_PK_BKEYS, (size_t)L.nparts * 4, &tmp)) return 1;
@@ -265,6 +401,7 @@ int fj_bcast_pack(fj_ctx* c, const uint64_t* d_keys, size_t nb, size_t nb_total,
         const u32 grid = (L.nparts + DP_NT / 64 - 1) / (DP_NT / 64);
         if (L.mid_bytes == 2) hipLaunchKernelGGL(fj_dense_copy<2>, dim3(grid), dim3(DP_NT), 0, s, cs.keys, cs.boff, cs.list, L.nparts, offs, midmask, (u32*)(reg + L.lo_off), (void*)(reg + L.mid_off));
         else hipLaunchKernelGGL(fj_dense_copy<4>, dim3(grid), dim3(DP_NT), 0, s, cs.keys, cs.boff, cs.list, L.nparts, offs, midmask, (u32*)(reg + L.lo_off), (void*)(reg + L.mid_off));
+        if (with_vals) hipLaunchKernelGGL(fj_dense_copy_vals, dim3(grid), dim3(DP_NT), 0, s, cs.vals, cs.boff, cs.list, L.nparts, offs, (u64*)(reg + L.val_off));
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(c->pk_h, c->d_sc->bc_bounds, (size_t)(pieces + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -314,6 +451,24 @@ int fj_bcast_probe(fj_ctx* c, const uint64_t* d_pk, size_t np, size_t nb_total, 
 
 // join the probe rows of partitions [part_lo, part_hi) against the runs of nsrc sources: source i's region (of nkeys[i] keys,
 // laid out by fj_bcast_pack on its rank) starts region_off[i] bytes into d_base
+static int dense_mat_args(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* region_off, const uint64_t* nkeys, DenseMatArgs* a) {
+    BcastState& bc = c->bc;
+    Layout L0;
+    if (layout_of(bc.nb_total, 0, &L0)) return 1;
+    *a = DenseMatArgs();
+    a->probe = bc.ja.probe; a->items = bc.ja.items; a->toff = bc.pit.toff;
+    a->base = (const unsigned char*)d_base; a->nsrc = (u32)nsrc; a->bits = L0.bits; a->mid_bytes = L0.mid_bytes;
+    for (int i = 0; i < nsrc; ++i) {
+        Layout L;
+        if (layout_of(bc.nb_total, (size_t)nkeys[i], &L, true)) return 1;
+        if (region_off[i] & 15) return set_err("fj_bcast_join: region offsets must be multiples of 16");
+        a->offs_off[i] = region_off[i]; a->lo_off[i] = region_off[i] + L.lo_off; a->mid_off[i] = region_off[i] + L.mid_off; a->val_off[i] = region_off[i] + L.val_off;
+    }
+    a->part_count = bc.ja.part_count; a->total = &c->d_sc->total; a->err = &c->d_sc->err;
+    return 0;
+}
+static u32 dense_mat_lds(bool emit) { return DM_SLOTS * 8 * (emit ? 2 : 1) + DM_NBK * 4 + 16; }
+
 int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* region_off, const uint64_t* nkeys, uint32_t part_lo, uint32_t part_hi, void* stream) {
     if (!c) return set_err("fj_bcast_join: null context");
     BcastState& bc = c->bc;
@@ -324,6 +479,20 @@ int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* regio
     if (part_lo > part_hi || part_hi > L0.nparts) return set_err("fj_bcast_join: partitions [%u, %u) of %u", part_lo, part_hi, L0.nparts);
     if (bc.np == 0 || part_lo == part_hi) return 0;
     FJ_ENTER(c);
+    const u32 cus = c->reserve_cus < c->num_cus ? c->num_cus - c->reserve_cus : 1u;
+    if (bc.with_vals) {
+        // a materialising step: the plain kernel with duplicate detection counts per item; the pairs are written by fj_emit_pairs behind
+        // the step (the regions and the probe partitions stay where they are until then)
+        DenseMatArgs a;
+        if (dense_mat_args(c, d_base, nsrc, region_off, nkeys, &a)) return 1;
+        a.part_lo = part_lo; a.part_hi = part_hi;
+        HIPCHK(fj_set_max_lds_once(reinterpret_cast<const void*>(fj_dense_mat_join<false>), dense_mat_lds(false)));
+        hipLaunchKernelGGL(fj_dense_mat_join<false>, dim3(cus), dim3(DM_NT), dense_mat_lds(false), (hipStream_t)stream, a);
+        HIPCHK(hipGetLastError());
+        bc.mat_base = d_base; bc.mat_nsrc = nsrc;
+        for (int i = 0; i < nsrc; ++i) { bc.mat_off[i] = region_off[i]; bc.mat_nk[i] = nkeys[i]; }
+        return 0;
+    }
     FjWideArgs w{};
     w.toff = bc.pit.toff; w.part_lo = part_lo; w.part_hi = part_hi;
     w.base = (const unsigned char*)d_base; w.nsrc = (u32)nsrc; w.bits = L0.bits; w.mid_bytes = L0.mid_bytes; w.pmask = fj_wide_pmask((int)L0.bits, 64);
@@ -336,8 +505,34 @@ int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* regio
         if (region_off[i] & 15) return set_err("fj_bcast_join: region offsets must be multiples of 16");
         w.offs_off[i] = region_off[i]; w.lo_off[i] = region_off[i] + L.lo_off; w.mid_off[i] = region_off[i] + L.mid_off;
     }
-    const u32 cus = c->reserve_cus < c->num_cus ? c->num_cus - c->reserve_cus : 1u;
     HIPCHK(fj_launch_count_join_wide(bc.ja, w, true, cus, (hipStream_t)stream));
+    return 0;
+}
+
+// the pairs of the materialising step that fj_bcast_finish just counted: (probe key, build value) of this rank's probe rows, out_capacity >= the count
+int fj_bcast_emit(fj_ctx* c, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, void* stream) {
+    if (!c) return set_err("fj_bcast_emit: null context");
+    BcastState& bc = c->bc;
+    if (!bc.mat_ready) return set_err("fj_emit_pairs: no materialising build-broadcast step is pending on this context");
+    if (bc.mat_count > out_capacity) return set_err("fj_emit_pairs: output capacity %zu < %llu pairs", out_capacity, (unsigned long long)bc.mat_count);
+    FJ_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    bc.mat_ready = false;
+    if (bc.mat_count == 0) return 0;
+    if (((uintptr_t)d_out_keys | (uintptr_t)d_out_vals) & 7) return set_err("output buffers must be 8-byte aligned");
+    void* p;
+    if (get_buf(c, W_OUT_OFF, ((size_t)bc.mat_items + 1) * 8, &p)) return 1;
+    HIPCHK(fj_launch_scan_u32_to_u64(bc.ja.part_count, (u64*)p, bc.mat_items, s));
+    DenseMatArgs a;
+    if (dense_mat_args(c, bc.mat_base, bc.mat_nsrc, bc.mat_off, bc.mat_nk, &a)) return 1;
+    Layout L0;
+    if (layout_of(bc.nb_total, 0, &L0)) return 1;
+    a.part_lo = 0; a.part_hi = L0.nparts;
+    a.out_off = (const u64*)p; a.out_keys = d_out_keys; a.out_vals = d_out_vals;
+    HIPCHK(fj_set_max_lds_once(reinterpret_cast<const void*>(fj_dense_mat_join<true>), dense_mat_lds(true)));
+    hipLaunchKernelGGL(fj_dense_mat_join<true>, dim3(c->num_cus), dim3(DM_NT), dense_mat_lds(true), s, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -351,11 +546,14 @@ int fj_bcast_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* ti
     if (read_scalars(c, s)) return 1;
     const u32 err = c->h_sc->err;
     const int npass = bc.plan.npass, bits = bc.plan.bits, evc = bc.evc;
-    bc = BcastState();
+    const bool mat = bc.with_vals;
+    if (!mat || (err & (FJ_ERR_POOL | FJ_STAT_RETRY | FJ_ERR_LDS_FULL | FJ_STAT_DUPS))) bc = BcastState();
+    else { bc.packed = bc.probed = false; bc.mat_ready = true; bc.mat_count = c->h_sc->total; bc.mat_items = bc.pit.items_cap; }      // (the emit reads the regions and the probe partitions where they lie)
     if (err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
     end_plan(c);
     // a final partition beyond the LDS table (> ~8000 build keys in all: build-side skew): the caller takes another form
     if (err & (FJ_STAT_RETRY | FJ_ERR_LDS_FULL)) return set_err("build broadcast: a final partition does not fit the LDS table (skewed build keys)");
+    if (mat && (err & FJ_STAT_DUPS)) return set_err("build broadcast: duplicate build keys in a materialising join (the first occurrence's value is what counts: the owner-scatter form serves them)");
     if (out_count) *out_count = c->h_sc->total;
     fj_timings t; memset(&t, 0, sizeof t);
     t.path = 0; t.passes = npass; t.radix_bits = bits; t.partitions = 1ull << bits; t.sampled_hit_bp = -1;

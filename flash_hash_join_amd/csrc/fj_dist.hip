@@ -144,10 +144,10 @@ struct Engine {
     virtual void reserve(unsigned) {}                                           // leave n CUs to the transport's own kernels (HIP engine over RCCL); 0: none
     // ---- build-broadcast form (csrc/fj_bcast.hip) ----
     virtual bool has_bcast() const { return false; }
-    virtual size_t bc_region_bytes(size_t, size_t) { return 0; }               // 0: no such plan
+    virtual size_t bc_region_bytes(size_t, size_t, bool /*with values*/ = false) { return 0; }               // 0: no such plan
     virtual int bc_span(size_t, size_t, size_t, size_t, int, size_t*, size_t*) { return derr("fj_dist: this engine has no build-broadcast form"); }
     virtual int bc_nparts(size_t, uint32_t*) { return derr("fj_dist: this engine has no build-broadcast form"); }
-    virtual int bc_pack(const void*, size_t, size_t, void*, int, Token*) { return derr("fj_dist: this engine has no build-broadcast form"); }   // asynchronous
+    virtual int bc_pack(const void*, const void* /*values*/, bool /*a materialising join: the values travel*/, size_t, size_t, void*, int, Token*) { return derr("fj_dist: this engine has no build-broadcast form"); }   // asynchronous
     virtual int bc_bounds(int, unsigned long long*) { return derr("fj_dist: this engine has no build-broadcast form"); }                      // blocks
     virtual int bc_probe(const void*, size_t, size_t) { return derr("fj_dist: this engine has no build-broadcast form"); }
     virtual int bc_join(const void*, int, const uint64_t*, const uint64_t*, uint32_t, uint32_t, Token) { return derr("fj_dist: this engine has no build-broadcast form"); }
@@ -229,11 +229,11 @@ struct HipEngine : Engine {
     // CUs runs ~10 % slower than on 256.
     void reserve(unsigned n) override { fj_ctx_reserve_cus(ctx, n); }
     bool has_bcast() const override { return true; }
-    size_t bc_region_bytes(size_t nb_total, size_t nkeys) override { return fj_bcast_region_bytes(nb_total, nkeys); }
+    size_t bc_region_bytes(size_t nb_total, size_t nkeys, bool vals) override { return fj_bcast_region_bytes(nb_total, nkeys, vals ? 1 : 0); }
     int bc_span(size_t nb_total, size_t nkeys, size_t lo, size_t hi, int part, size_t* off, size_t* bytes) override { return fj_bcast_piece_span(nb_total, nkeys, lo, hi, part, off, bytes); }
     int bc_nparts(size_t nb_total, uint32_t* n) override { return fj_bcast_plan(nb_total, nullptr, n, nullptr); }
-    int bc_pack(const void* rows, size_t n, size_t nb_total, void* region, int pieces, Token* packed) override {
-        if (fj_bcast_pack(ctx, (const uint64_t*)rows, n, nb_total, region, pieces, js)) return 1;
+    int bc_pack(const void* rows, const void* vals, bool with_vals, size_t n, size_t nb_total, void* region, int pieces, Token* packed) override {
+        if (fj_bcast_pack(ctx, (const uint64_t*)rows, (const uint64_t*)vals, n, nb_total, region, pieces, with_vals ? 1 : 0, js)) return 1;
         DHIP(hipEventRecord(ev_filt, js));
         *packed = ev_filt;
         return 0;
@@ -287,7 +287,7 @@ struct CallbackEngine : Engine {                             // a caller's stand
     void abort() override { if (o.abort) o.abort(o.user); }
     int drain() override { return 0; }
     bool has_bcast() const override { return o.bc_region_bytes && o.bc_span && o.bc_nparts && o.bc_pack && o.bc_probe && o.bc_join && o.bc_finish; }
-    size_t bc_region_bytes(size_t nb_total, size_t nkeys) override { return has_bcast() ? (size_t)o.bc_region_bytes(o.user, nb_total, nkeys) : 0; }
+    size_t bc_region_bytes(size_t nb_total, size_t nkeys, bool vals) override { return has_bcast() && !vals ? (size_t)o.bc_region_bytes(o.user, nb_total, nkeys) : 0; }      // (a stand-in carries no values)
     int bc_span(size_t nb_total, size_t nkeys, size_t lo, size_t hi, int part, size_t* off, size_t* bytes) override {
         uint64_t a = 0, b = 0;
         if (o.bc_span(o.user, nb_total, nkeys, lo, hi, part, &a, &b)) return fail("bc_span");
@@ -296,7 +296,8 @@ struct CallbackEngine : Engine {                             // a caller's stand
     }
     int bc_nparts(size_t nb_total, uint32_t* n) override { return o.bc_nparts(o.user, nb_total, n) ? fail("bc_nparts") : 0; }
     std::vector<uint64_t> bounds_;
-    int bc_pack(const void* rows, size_t n, size_t nb_total, void* region, int pieces, Token* packed) override {
+    int bc_pack(const void* rows, const void*, bool with_vals, size_t n, size_t nb_total, void* region, int pieces, Token* packed) override {
+        if (with_vals) return derr("fj_dist: the stand-in engine carries no values");
         bounds_.assign((size_t)pieces + 1, 0);
         *packed = nullptr;
         return o.bc_pack(o.user, rows, n, nb_total, region, pieces, bounds_.data()) ? fail("bc_pack") : 0;
@@ -502,7 +503,7 @@ static void reserve_account(fj_dist_comm* dc, const fj_timings& lt, int how) {  
 // piece to every peer (grouped send / recv: one link per peer on an xGMI mesh).  The join of partition range q against the runs of
 // ALL ranks is queued behind piece q's arrival.  One blocking point per step (the bounds), two small control collectives, one
 // agreement on the buffers; a rank-local failure is agreed on like in the shuffle form.
-static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
+static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t* d_build_vals, bool mat, size_t nb, const uint64_t* d_probe_keys, size_t np, int pieces,
                            const std::vector<uint64_t>& nb_of, unsigned long long nb_total, uint64_t* out_global_count, uint64_t* out_local_count,
                            fj_dist_timings* timings, unsigned reserve_n, int reserve_how, double tot_with, double tot_without) {
     Net& net = *dc->net; Engine& eng = *dc->eng;
@@ -513,7 +514,9 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
     if (eng.bc_nparts(nb_total, &nparts)) return 1;
     if ((uint32_t)pieces > nparts) pieces = (int)nparts;
     std::vector<uint64_t> roff(N + 1, 0);
-    for (int r = 0; r < N; ++r) roff[r + 1] = roff[r] + ((eng.bc_region_bytes(nb_total, (size_t)nb_of[r]) + 255) & ~(size_t)255);
+    // (mat: a materialising step - the regions carry the values as a fourth part; a rank without build rows may hold no value pointer)
+    const int nparts_x = mat ? 4 : 3;
+    for (int r = 0; r < N; ++r) roff[r + 1] = roff[r] + ((eng.bc_region_bytes(nb_total, (size_t)nb_of[r], mat) + 255) & ~(size_t)255);
     net.begin_step();
     const bool reserve = reserve_n > 0;
     struct ReserveGuard { Engine& e; bool on; ~ReserveGuard() { if (on) e.reserve(0); } } reserve_guard{eng, reserve};
@@ -531,7 +534,7 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
 
     // pack + probe passes queued; the host then waits for the pack's bounds only
     Token packed = nullptr;
-    bool ok = eng.bc_pack(d_build_keys, nb, nb_total, base + roff[me], pieces, &packed) == 0;
+    bool ok = eng.bc_pack(d_build_keys, d_build_vals, mat, nb, nb_total, base + roff[me], pieces, &packed) == 0;
     begun = ok;
     std::string why = ok ? "" : fj_last_error();
     if (ok && eng.bc_probe(d_probe_keys, np, nb_total)) { ok = false; why = fj_last_error(); }
@@ -550,14 +553,14 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
     std::string failed;
     auto guarded = [&](int rc) { if (rc && failed.empty()) failed = fj_last_error(); return rc; };
     size_t wire_sent = 0;
-    std::vector<const void*> sp(3 * N); std::vector<void*> rp(3 * N); std::vector<size_t> sb(3 * N), rb(3 * N);
+    std::vector<const void*> sp(4 * N); std::vector<void*> rp(4 * N); std::vector<size_t> sb(4 * N), rb(4 * N);
     for (int q = 0; q < pieces; ++q) {
         std::fill(sp.begin(), sp.end(), nullptr); std::fill(rp.begin(), rp.end(), nullptr); std::fill(sb.begin(), sb.end(), 0); std::fill(rb.begin(), rb.end(), 0);
         size_t largest = 0;
         bool spans_ok = true;
         for (int r = 0; r < N; ++r) {
             if (r == me) continue;
-            for (int part = q == 0 ? 0 : 1; part < 3; ++part) {
+            for (int part = q == 0 ? 0 : 1; part < nparts_x; ++part) {
                 size_t off = 0, bytes = 0;
                 spans_ok = spans_ok && eng.bc_span(nb_total, (size_t)nb_of[me], bound(me, q), bound(me, q + 1), part, &off, &bytes) == 0;     // what I send to r
                 sp[part * N + r] = base + roff[me] + off; sb[part * N + r] = bytes; wire_sent += bytes;
@@ -569,12 +572,12 @@ static int dist_join_bcast(fj_dist_comm* dc, const uint64_t* d_build_keys, size_
         }
         if (!spans_ok) return bail(fj_last_error());               // (same arguments on every rank: everybody bails)
         // `largest` must be the same on both ends of every message: the largest piece of ANY region
-        for (int r = 0; r < N; ++r) for (int part = 0; part < 3; ++part) {
+        for (int r = 0; r < N; ++r) for (int part = 0; part < nparts_x; ++part) {
             size_t off = 0, bytes = 0;
             if (eng.bc_span(nb_total, (size_t)nb_of[r], bound(r, q), bound(r, q + 1), part, &off, &bytes) == 0) largest = std::max(largest, bytes);
         }
         Token done = nullptr;
-        if (net.exchange(3, sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, q)) return bail(fj_last_error());
+        if (net.exchange(nparts_x, sp.data(), sb.data(), rp.data(), rb.data(), largest, packed, &done, q)) return bail(fj_last_error());
         if (failed.empty()) {
             // (the last range's join starts when the last piece has landed: the transport's kernels are gone from this GPU by then)
             if (reserve && q + 1 == pieces) eng.reserve(0);
@@ -678,18 +681,19 @@ void fj_dist_comm_destroy(fj_dist_comm* dc) {
 
 // The cost model behind FJ_DIST_FORM_AUTO, as plain arithmetic (also what tools/scale_model.py prints): seconds of one counting step in
 // either form = max(bytes per link / link rate, kernel seconds per rank) + what cannot overlap.  Kernel seconds per row measured on
-// one MI355X at config 5's per-rank sizes (profiles/r05_bcast_one_rank.txt, r04_c5_one_rank_kernel_stats.csv): broadcast - pack 1.45 ms
-// per 125M build rows; two probe-side passes 7.95 / 8.35 / 8.6 ms per 1.25B rows under the 16- / 17- / 18-bit plans of 2 / 4 / 8 ranks; dense
-// join 3.2 ps per build key of ALL ranks + 2.45 ps per local probe key (3.85 / 4.8 / 6.25 ms at 2 / 4 / 8 ranks), all of it kernels
-// of this rank (the wire overlaps everything behind the pack); shuffle - 13.4 ms of kernels per 1.375B rows of both relations + ~2.5
-// ms of head and tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: computed from nb_max and the plan).
+// one MI355X at config 5's per-rank sizes (round 6: profiles/r06_bcast_one_rank_2_4_8.txt; shuffle: r04_c5_one_rank_kernel_stats.csv):
+// broadcast - pack 1.41 ms per 125M build rows; two probe-side passes 7.92 / 8.33 / 8.60 ms per 1.25B rows under the 16- / 17- / 18-bit
+// plans of 2 / 4 / 8 ranks; dense join (the bucketed table) 2.2 ps per build key of ALL ranks + 2.2 ps per local probe key = 3.3 / 3.85 /
+// 4.95 ms modelled, 3.32 / 4.26 / 4.96 measured at 2 / 4 / 8 ranks (round 5's table: 3.85 / 4.8 / 6.2), all of it kernels of this rank
+// (the wire overlaps everything behind the pack); shuffle - 13.4 ms of kernels per 1.375B rows of both relations + ~2.5 ms of head and
+// tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: computed from nb_max and the plan).
 int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
                   double* t_shuffle, double* t_broadcast) {
     const double rate = link_bytes_per_s > 0 ? link_bytes_per_s : 55e9, N = nranks < 1 ? 1 : nranks;
     const int bits = fjh::make_plan((size_t)nb_total, 64).bits;
     if (region_max == 0) region_max = nb_max * (bits >= 16 ? 6u : 8u) + 4ull * ((1ull << bits) + 1) + 64;      // (fj_bcast_region_bytes: offset table + the two planes)
-    const double pack = (double)nb_max * 11.6e-12, passes = (double)np_max * (6.36e-12 + 0.27e-12 * (bits > 16 ? std::min(bits, 18) - 16 : 0)),
-                 join = (double)nb_total * 3.2e-12 + (double)np_max * 2.45e-12;
+    const double pack = (double)nb_max * 11.3e-12, passes = (double)np_max * (6.34e-12 + 0.27e-12 * (bits > 16 ? std::min(bits, 18) - 16 : 0)),
+                 join = (double)nb_total * 2.2e-12 + (double)np_max * 2.2e-12;
     const double wire_b = N > 1 ? (double)region_max / rate : 0.0;
     const double t_b = std::max(wire_b + pack + join / 4.0, pack + passes + join);        // (the last of 4 partition ranges is joined after the wire is done)
     const double rows = (double)nb_max + (double)np_max;
@@ -772,16 +776,16 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     const bool want_pf = prefilter_below > 0;
     if (want_pf && !eng.has_precheck()) return derr("fj_dist_join: this engine has no sender-side precheck");
     // ---- which form (same inputs, hence the same verdict, on every rank) ----
-    if (!mat && !want_pf && form_req != FJ_DIST_FORM_SHUFFLE) {
+    if (!want_pf && form_req != FJ_DIST_FORM_SHUFFLE && (!mat || form_req == FJ_DIST_FORM_BROADCAST)) {      // (a materialising join broadcasts when asked to: the caller's model, distributed.py)
         bool can = eng.has_bcast() && N <= (int)FJ_WIDE_MAXSRC && nb_total > 0;
         size_t region_max = 0;
-        for (int r = 0; can && r < N; ++r) { const size_t b = eng.bc_region_bytes(nb_total, (size_t)nb_of[r]); can = b != 0; region_max = std::max(region_max, b); }
+        for (int r = 0; can && r < N; ++r) { const size_t b = eng.bc_region_bytes(nb_total, (size_t)nb_of[r], mat); can = b != 0; region_max = std::max(region_max, b); }
         bool bcast = can && form_req == FJ_DIST_FORM_BROADCAST;
         if (can && form_req == FJ_DIST_FORM_AUTO && N > 1)
             bcast = fj_dist_model(N, nb_max, np_max, nb_total, np_global, region_max, link_rate, nullptr, nullptr) == FJ_DIST_FORM_BROADCAST;
         if (form_req == FJ_DIST_FORM_BROADCAST && !can)
             return derr("fj_dist_join_count: the build-broadcast form needs an engine that has it, <= %u ranks and a total build side with a partitioned plan (%llu rows)", FJ_WIDE_MAXSRC, nb_total);
-        if (bcast) return dist_join_bcast(dc, d_build_keys, nb, d_probe_keys, np, pieces, nb_of, nb_total, out_global_count, out_local_count, timings, reserve_n, reserve_how, tot_with, tot_without);
+        if (bcast) return dist_join_bcast(dc, d_build_keys, mat ? d_build_vals : nullptr, mat, nb, d_probe_keys, np, pieces, nb_of, nb_total, out_global_count, out_local_count, timings, reserve_n, reserve_how, tot_with, tot_without);
     }
     size_t CB = 0;
     if (eng.plan(nb_total, N, &CB)) return 1;                 // (same verdict on every rank: same arguments)

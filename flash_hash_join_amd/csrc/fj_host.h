@@ -171,6 +171,10 @@ struct BcastState {             // fj_bcast_*: one step of the multi-GPU build-b
     size_t nb_total = 0, nb = 0, np = 0;
     int pieces = 1, evc = 0;
     fjh::Plan plan; fjh::PassIter pit; FjLdsJoinArgs ja{};
+    // a materialising step (the regions carry the build values): counted by fj_bcast_join, the pairs written by fj_emit_pairs afterwards
+    bool with_vals = false, mat_ready = false;
+    const void* mat_base = nullptr; int mat_nsrc = 0; uint64_t mat_off[FJ_WIDE_MAXSRC] = {}, mat_nk[FJ_WIDE_MAXSRC] = {};
+    u64 mat_count = 0; u32 mat_items = 0;
 };
 
 struct fj_ctx {

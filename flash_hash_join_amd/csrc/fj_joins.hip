@@ -543,6 +543,7 @@ int fj_join_device(fj_ctx* c, int algo, int bloom, int materialize,
 
 int fj_emit_pairs(fj_ctx* c, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, void* stream, fj_timings* timings) {
     if (!c) return set_err("fj_emit_pairs: null context");
+    if (c->bc.mat_ready) return fj_bcast_emit(c, d_out_keys, d_out_vals, out_capacity, stream);      // a materialising build-broadcast step (csrc/fj_bcast.hip)
     FJ_ENTER(c);
     fj_timings t = last_timings();
     if (emit_pending(c, d_out_keys, d_out_vals, out_capacity, (hipStream_t)stream, &t)) return 1;

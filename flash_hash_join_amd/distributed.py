@@ -236,14 +236,27 @@ def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
         _LINK_MEASURED = bool(measured)
 
 
-def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] = None, nb_total: Optional[int] = None, np_global: Optional[int] = None) -> dict:
-    """The C++ driver's cost model for a counting step of `world` ranks holding at most nb x np_ rows each (fj_dist_model):
-    modelled seconds in either form and the pick."""
+def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] = None, nb_total: Optional[int] = None, np_global: Optional[int] = None,
+               materialize: bool = False) -> dict:
+    """The C++ driver's cost model for a step of `world` ranks holding at most nb x np_ rows each (fj_dist_model): modelled seconds in
+    either form and the pick.  materialize: the broadcast's regions carry the values too (14 bytes per build row instead of 6) and its
+    join is the plain kernel (csrc/fj_bcast.hip: ~2x the counting kernel's time), the shuffle ships 16 bytes per build row; the pairs
+    are written in either form."""
     from . import _lib
+    nb_total = nb_total if nb_total is not None else nb * world
+    np_global = np_global if np_global is not None else np_ * world
     ts, tb = ctypes.c_double(0), ctypes.c_double(0)
-    f = _lib.load().fj_dist_model(world, nb, np_, nb_total if nb_total is not None else nb * world, np_global if np_global is not None else np_ * world, 0,
-                                  float(link_bytes_per_s or _LINK_BYTES_PER_S), ctypes.byref(ts), ctypes.byref(tb))
-    return {"shuffle": ts.value, "broadcast": tb.value, "pick": "broadcast" if f == FORM_BROADCAST else "shuffle"}
+    region = 0
+    if materialize:
+        bits = max(5, (max(1, -(-nb_total // 4096)) - 1).bit_length()) if nb_total > 4096 else 5
+        region = int(nb * (14 if bits >= 16 else 16) + 4 * ((1 << bits) + 1) + 64)
+    f = _lib.load().fj_dist_model(world, nb, np_, nb_total, np_global, region, float(link_bytes_per_s or _LINK_BYTES_PER_S), ctypes.byref(ts), ctypes.byref(tb))
+    t_s, t_b = ts.value, tb.value
+    if materialize:
+        t_b += 1.0 * (nb_total * 3.2e-12 + np_ * 2.45e-12)                    # the plain join kernel in the counting kernel's place
+        t_s += (16.0 - 7.02) * nb_total / (world * world) / float(link_bytes_per_s or _LINK_BYTES_PER_S) if world > 1 else 0.0     # build rows travel with their values
+        f = FORM_BROADCAST if t_b < t_s else FORM_SHUFFLE
+    return {"shuffle": t_s, "broadcast": t_b, "pick": "broadcast" if f == FORM_BROADCAST else "shuffle"}
 
 
 # the precheck in chunk form (fj_dist_join(prefilter_below), csrc/fj_pack.hip: fj_part_filter_inplace): what a config-5 shard costs
@@ -764,12 +777,13 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
 
     # ---- which rungs apply, in order ----
     rungs = []
-    if not materialize and strategy in ("auto", "broadcast") and world <= 16:
+    if strategy in ("auto", "broadcast") and world <= 16 and (not materialize or (hasattr(engine, "emit_pairs") and not standin)):
         can = (hasattr(engine, "bcast_plan") and engine.bcast_plan(nb_total) is not None) if not standin else getattr(engine, "has_bcast", False)
-        # every rank holds a replica of the whole build side (6 bytes per key) beside its own pools (~20 bytes per local row of both relations)
-        need_mb = (6.1 * nb_total + 20.0 * (max(sizes_b) + max(sizes_p))) / 2**20
+        # every rank holds a replica of the whole build side (6 bytes per key; 14 with the values of a materialising join) beside its
+        # own pools (~20 bytes per local row of both relations)
+        need_mb = ((14.1 if materialize else 6.1) * nb_total + 20.0 * (max(sizes_b) + max(sizes_p))) / 2**20
         fits = min(int(x[3]) for x in allsz) > need_mb
-        if can and fits and (strategy == "broadcast" or form_model(world, max(sizes_b), max(sizes_p), link0, nb_total, np_global)["pick"] == "broadcast"):
+        if can and fits and (strategy == "broadcast" or form_model(world, max(sizes_b), max(sizes_p), link0, nb_total, np_global, materialize=materialize)["pick"] == "broadcast"):
             rungs.append("broadcast")
         elif strategy == "broadcast" and no_fallback:
             raise RuntimeError("FJ_DIST_STRATEGY=broadcast: this join cannot take the build-broadcast form (engine, > 16 ranks, a total build side without "
@@ -790,7 +804,8 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     for i, rung in enumerate(rungs):
         try:
             if rung == "broadcast":
-                res = _driver_join(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, form=FORM_BROADCAST)
+                res = _driver_join(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, build_values=build_values if materialize else None,
+                                   return_arrays=return_arrays, form=FORM_BROADCAST)
             elif rung == "shuffle":
                 mode = "off" if (standin and not getattr(engine, "chunk_precheck", False)) else _chunk_prefilter_mode(bloom, world, prefilter)
                 below, pf_key, decision = _precheck_threshold(mode, world, nb_total, np_global, link0, join_id)

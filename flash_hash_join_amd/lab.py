@@ -168,13 +168,14 @@ class LabEngine(HipEngine):
                                                                  dirw.numel(), stream))
 
     # ---- build-broadcast form (csrc/fj_bcast.hip): probe rows never move, every rank's build rows travel as dense per-partition runs ----
-    def bcast_region_bytes(self, nb_total: int, nkeys: int) -> int:
-        return int(self.L.fj_bcast_region_bytes(nb_total, nkeys))
+    def bcast_region_bytes(self, nb_total: int, nkeys: int, with_vals: bool = False) -> int:
+        return int(self.L.fj_bcast_region_bytes(nb_total, nkeys, int(with_vals)))
 
-    def bcast_pack(self, keys, nb_total: int, region, pieces: int) -> None:
-        """Asynchronous: this rank's build keys -> `region` (a uint8 tensor view of bcast_region_bytes(nb_total, keys.numel()) bytes)."""
+    def bcast_pack(self, keys, nb_total: int, region, pieces: int, vals=None) -> None:
+        """Asynchronous: this rank's build keys (and values: a materialising step) -> `region` (a uint8 tensor view of
+        bcast_region_bytes(nb_total, keys.numel(), vals is not None) bytes)."""
         s = self.torch.cuda.current_stream(self.index).cuda_stream
-        self._lib.check(self.L.fj_bcast_pack(self.ctx, keys.data_ptr(), keys.numel(), nb_total, region.data_ptr(), pieces, s))
+        self._lib.check(self.L.fj_bcast_pack(self.ctx, keys.data_ptr(), vals.data_ptr() if vals is not None else None, keys.numel(), nb_total, region.data_ptr(), pieces, int(vals is not None), s))
 
     def bcast_pack_bounds(self, pieces: int) -> List[int]:
         b = (ctypes.c_uint64 * (pieces + 1))()

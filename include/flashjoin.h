@@ -299,8 +299,10 @@ typedef struct fj_dist_engine_ops {   /* a stand-in for the rank's own work (the
 /* The form a counting step takes (rank 0's setting is used on every rank):
  *   FJ_DIST_FORM_SHUFFLE   - the owner shuffle in chunk form: every row of both relations travels to the owner of its first radix
  *                            digit, 7 bytes per key;
- *   FJ_DIST_FORM_BROADCAST - the build broadcast (fj_bcast_* above): the probe rows stay, every rank's build rows travel to every
- *                            peer, 6 bytes per key; up to 16 ranks, counting joins;
+ *   FJ_DIST_FORM_BROADCAST - the build broadcast (csrc/fj_bcast.hip): the probe rows stay, every rank's build rows travel to every
+ *                            peer, 6 bytes per key; up to 16 ranks.  Materialising joins too (round 6): the values travel as a
+ *                            fourth part (14 bytes per build row) and the pairs stay with the rank that holds the PROBE row
+ *                            (fj_emit_pairs after the step); duplicate build keys are refused (the shuffle forms serve them);
  *   FJ_DIST_FORM_AUTO      - (default) whichever a per-link / per-rank cost model puts ahead for the step's sizes: bytes per link
  *                            over link_bytes_per_s (<= 0: 55e9) against the kernel time per rank measured on one MI355X
  *                            (profiles/r05_scale_model.txt).  Probe-heavy joins (BASELINE configs[4]: 10 probe rows per build row)

@@ -100,15 +100,22 @@ int fj_part_filter_sample(fj_ctx* ctx, const uint64_t* d_raw_keys, size_t n, siz
  *                            d_base (region i of nkeys[i] keys at byte region_off[i]); call once per landed piece
  *   fj_bcast_finish        - blocks; the local match count.  A final partition beyond the LDS table (skewed build keys) is an error:
  *                            the caller takes another form (fj_dist_join does).
+ * MATERIALISING joins (_hash_join_radix_materialize, hash_join.cpp:315-381, across GPUs; round 6): fj_bcast_pack with with_vals = 1
+ * writes the build values as a fourth part of the region (u64[n]: 14 bytes per build row; fj_bcast_region_bytes / _piece_span with
+ * with_vals = 1 / part 3); fj_bcast_join then counts with a plain kernel that also reports duplicate build keys (an error of
+ * fj_bcast_finish: the first occurrence's value is what counts, which only the owner-scatter form can tell); fj_bcast_finish leaves
+ * the regions and the probe partitions in place and fj_emit_pairs (fj_bcast_emit) writes this rank's pairs - (probe key, build value)
+ * of its OWN probe rows: in this form the pairs stay with the probe rows.
  */
-size_t fj_bcast_region_bytes(size_t nb_total, size_t nkeys);
+size_t fj_bcast_region_bytes(size_t nb_total, size_t nkeys, int with_vals);
 int fj_bcast_piece_span(size_t nb_total, size_t nkeys, size_t k_lo, size_t k_hi, int part, size_t* offset, size_t* bytes);
-int fj_bcast_pack(fj_ctx* ctx, const uint64_t* d_build_keys, size_t nb, size_t nb_total, void* d_region, int pieces, void* stream);
+int fj_bcast_pack(fj_ctx* ctx, const uint64_t* d_build_keys, const uint64_t* d_build_vals, size_t nb, size_t nb_total, void* d_region, int pieces, int with_vals, void* stream);
 int fj_bcast_pack_bounds(fj_ctx* ctx, uint64_t* h_bounds);
 int fj_bcast_probe(fj_ctx* ctx, const uint64_t* d_probe_keys, size_t np, size_t nb_total, void* stream);
 int fj_bcast_join(fj_ctx* ctx, const void* d_base, int nsrc, const uint64_t* region_off, const uint64_t* nkeys, uint32_t part_lo, uint32_t part_hi, void* stream);
 int fj_bcast_finish(fj_ctx* ctx, void* stream, uint64_t* out_count, fj_timings* timings);
 void fj_bcast_abort(fj_ctx* ctx);
+int fj_bcast_emit(fj_ctx* ctx, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t out_capacity, void* stream);
 
 /*
  * Sender-side bloom precheck of the owner shuffle (no reference counterpart).  fj_bloom_export: an owner partitions the

@@ -787,7 +787,7 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
             n, sec, k, v = dj(bk, bv, pk, materialize=True, return_arrays=True, timings=tm)
             assert n == exp and k.numel() == exp
             assert bool(torch.all((v + 1) * M == k))
-            assert tm["strategy"] == ("scatter" if strategy == "scatter" else "shuffle")     # materialising joins start at the shuffle
+            assert tm["strategy"] == strategy, tm       # materialising joins take every form too (broadcast: the values travel as a fourth part, the pairs stay with the probe rows)
         # duplicate build keys in the broadcast form (round 5's table failed the whole step from 52 copies of one key on):
         # a copy takes a slot of its own in the bucketed table, a lookup stops at the first match - 60 and 200 copies of two keys join
         # in the broadcast form itself, exactly
@@ -1239,6 +1239,78 @@ def test_build_broadcast_form_matches_the_oracle(fj, oracle, world, nb_total, np
         pks = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.split(pk, cutp)]
         for pieces in (1, 1 + world % 5):
             assert _bcast_emulated(eng, world, bks, pks, int(bk.size), pieces) == exp
+    finally:
+        fj.set_option("plan_target_keys", 4096)
+
+
+@pytest.mark.parametrize("world,nb_total,np_total,target", [(2, 70_000, 300_001, 32), (3, 250_000, 1_000_000, 32), (8, 9_000_000, 12_000_000, 4096),
+                                                              (3, 400_000, 9_000_001, 4096), (4, 40_000, 90_000, 256)])
+def test_build_broadcast_form_materialising_matches_the_oracle(fj, oracle, world, nb_total, np_total, target):
+    """The MATERIALISING build-broadcast step (_hash_join_radix_materialize, hash_join.cpp:315-381, across GPUs; csrc/fj_bcast.hip:
+    the values travel as a fourth part of every region, fj_dense_mat_join counts with duplicate detection, fj_emit_pairs writes every
+    rank's pairs - (probe key, build value) of its OWN probe rows), all ranks played by this GPU: the ranks' pair sets together are
+    the NumPy oracle's pair list, digest for digest; ragged blocks, repeated probe keys, both plane widths, 1 and several pieces.
+    Duplicate build keys across ranks are refused loudly (the first occurrence's value is what counts: the shuffle forms serve them)."""
+    import torch
+    from flash_hash_join_amd.lab import LabEngine
+    fj.set_option("plan_target_keys", target)
+    try:
+        eng = LabEngine("cuda:0")
+        rng = np.random.default_rng(world * 77 + nb_total % 89)
+        bk = np.unique(rng.integers(0, 2**64, size=nb_total, dtype=np.uint64))
+        bv = bk * np.uint64(0x9E3779B97F4A7C15) + np.uint64(3)
+        pk = np.concatenate([rng.choice(bk, np_total // 2), rng.integers(0, 2**64, size=np_total - np_total // 2, dtype=np.uint64)])
+        rng.shuffle(pk)
+        exp, ek, ev = oracle.np_join(bk, bv, pk, return_arrays=True)
+        cutb = sorted(rng.integers(0, bk.size, size=world - 1).tolist()); cutb[0] = 0            # rank 0: no build rows
+        cutp = sorted(rng.integers(0, pk.size, size=world - 1).tolist()); cutp[-1] = pk.size      # last rank: no probe rows
+        bks = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.split(bk, cutb)]
+        bvs = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.split(bv, cutb)]
+        pks = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in np.split(pk, cutp)]
+        sizes = [int(b.numel()) for b in bks]
+        nbt = int(bk.size)
+        bits, nparts, _ = eng.bcast_plan(nbt)
+        for pieces in (1, 1 + world % 4):
+            rbs = [eng.bcast_region_bytes(nbt, n, True) for n in sizes]
+            offs = [sum(rbs[:r]) for r in range(world)]
+            base = torch.empty(sum(rbs), dtype=torch.uint8, device="cuda:0")
+            empty = torch.empty(16, dtype=torch.int64, device="cuda:0")[:0]
+            for r in range(world):                      # what the peers would have sent
+                eng.bcast_pack(bks[r], nbt, base[offs[r]: offs[r] + rbs[r]], pieces, vals=bvs[r])
+                assert eng.bcast_pack_bounds(pieces)[-1] == sizes[r]
+                eng.bcast_probe(empty, nbt)
+                assert eng.bcast_finish() == 0
+            ks, vs, total = [], [], 0
+            for r in range(world):
+                eng.bcast_pack(bks[r], nbt, base[offs[r]: offs[r] + rbs[r]], pieces, vals=bvs[r])
+                eng.bcast_probe(pks[r], nbt)
+                for q in range(pieces):
+                    eng.bcast_join(base, offs, sizes, nparts * q // pieces, nparts * (q + 1) // pieces)
+                n = eng.bcast_finish()
+                k, v = eng.emit_pairs(n)
+                assert k.numel() == n and bool(torch.isin(k, pks[r]).all())          # the pairs stay with the probe rows
+                ks.append(k.cpu().numpy().view(np.uint64)); vs.append(v.cpu().numpy().view(np.uint64)); total += n
+            assert total == exp
+            assert _digest(oracle, np.concatenate(ks), np.concatenate(vs)) == _digest(oracle, ek, ev)
+        # the same key on two ranks: refused
+        dup_b = [torch.cat([bks[-1], bks[1][:3] if world > 1 and sizes[1] >= 3 else bks[-1][:3]])] if sizes[-1] else None
+        if dup_b is not None and world > 1 and sizes[1] >= 3:
+            bks2, bvs2 = bks[:-1] + dup_b, bvs[:-1] + [torch.cat([bvs[-1], bvs[1][:3]])]
+            sizes2 = [int(b.numel()) for b in bks2]
+            nbt2 = sum(sizes2)
+            if eng.bcast_plan(nbt2) is not None and eng.bcast_plan(nbt2)[0] == bits:
+                rbs = [eng.bcast_region_bytes(nbt2, n, True) for n in sizes2]
+                offs = [sum(rbs[:r]) for r in range(world)]
+                base = torch.empty(sum(rbs), dtype=torch.uint8, device="cuda:0")
+                for r in range(world):
+                    eng.bcast_pack(bks2[r], nbt2, base[offs[r]: offs[r] + rbs[r]], 1, vals=bvs2[r])
+                    eng.bcast_pack_bounds(1); eng.bcast_probe(empty, nbt2); eng.bcast_finish()
+                probe_all = torch.cat(pks + [bks[1][:3]])
+                eng.bcast_pack(bks2[0], nbt2, base[offs[0]: offs[0] + rbs[0]], 1, vals=bvs2[0])
+                eng.bcast_probe(probe_all, nbt2)
+                eng.bcast_join(base, offs, sizes2, 0, eng.bcast_plan(nbt2)[1])
+                with pytest.raises(RuntimeError, match="duplicate build keys in a materialising join"):
+                    eng.bcast_finish()
     finally:
         fj.set_option("plan_target_keys", 4096)
 

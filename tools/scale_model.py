@@ -1,13 +1,13 @@
 """The per-link model of DESIGN.md section 6, printed from the arithmetic the C++ driver itself decides with (fj_dist_model, csrc/fj_dist.hip):
 config 5 (125M x 1.25B rows per GPU) on N = 2, 4, 8 GPUs in both forms of the multi-GPU step - the owner shuffle and the build broadcast - for a
 set of link rates: step = max(bytes per link / link rate, kernel seconds per rank) + what cannot overlap.  The kernel seconds are one-GPU
-measurements (profiles/r05_bcast_one_rank.txt: pack, probe-side passes, dense join at the 8-rank plan; profiles/r04_c5_one_rank_kernel_stats.csv:
+measurements (profiles/r06_bcast_one_rank_2_4_8.txt: pack, probe-side passes, dense join at the 2- / 4- / 8-rank plans; profiles/r04_c5_one_rank_kernel_stats.csv:
 the shuffle's step); nothing here was measured on more than one GPU.  usage: python tools/scale_model.py [nb_rank=125000000] [np_rank=1250000000]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flash_hash_join_amd import distributed as D
 
 nb, np_ = (int(x) for x in (sys.argv[1:3] + ["125000000", "1250000000"][len(sys.argv) - 1:])[:2])
-SINGLE_GPU_GPS = 117.6e9               # c3 on one GPU (BENCH_r04.json: 8.503 ms per 1B probes)
+SINGLE_GPU_GPS = 115.1e9               # c3 on one GPU (BENCH_r05.json, the driver's own run: 8.688 ms per 1B probes)
 print(f"{nb} x {np_} rows per rank; one GPU alone: {SINGLE_GPU_GPS / 1e9:.1f} G probes/s (c3)")
 print("%-3s %-10s | %-34s | %-34s | pick" % ("N", "link GB/s", "owner shuffle: ms, G probes/s, x", "build broadcast: ms, G probes/s, x"))
 for n in (2, 4, 8):

@@ -107,7 +107,11 @@ def worker(rank, world, port, q):
             n2, sec, k, v = D.distributed_join(bk, bv, pk, materialize=True, return_arrays=True, transport=shim, timings=tm)
             M = torch.tensor(-7046029254386353131, dtype=torch.int64, device="cuda:0")
             assert n2 == exp and bool(torch.all((v + 1) * M == k)), strategy
-            if strategy != "scatter":                        # materialising joins start at the chunk-form shuffle (values travel with the build rows)
+            if strategy in ("broadcast", "auto"):            # materialising joins take the same form as counting ones: the regions carry the values too
+                assert tm["strategy"] == "broadcast" and tm["shuffle_form"].startswith("build broadcast") and tm["probe_rows_sent"] == 0, tm
+                assert (world - 1) * 14 * (b1 - b0) <= tm["wire_bytes_sent"] <= (world - 1) * (16.1 * (b1 - b0) + 300_000), tm     # (keys 6 - 8 bytes as above + the 8-byte value)
+                assert "broadcast_form_error" not in tm and "chunk_form_error" not in tm, tm
+            elif strategy != "scatter":                      # the chunk-form shuffle (values travel with the build rows)
                 assert tm["shuffle_form"].startswith("chunks (fj_dist_join over a callback transport"), tm
                 assert tm["prefilter"] == (variant == "prefilter") or variant == "auto", tm
                 assert "chunk_form_error" not in tm, tm
