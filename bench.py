@@ -64,6 +64,7 @@ WORKLOADS = {
     # the same shards at config 4's 5 % hit rate through the *_bloom function: at N > 1 the owner shuffle's sender-side
     # precheck decides from a sample whether to filter the probe exchange (distributed._prefilter_mode)
     "c5_bloom": (125_000_000, 1_250_000_000, 500, "hash_join_count_radix_bloom"),
+    "c5_mat": (125_000_000, 1_250_000_000, 5000, "hash_join_radix"),                      # ... materialising (625M pairs per rank)
     # what ONE rank joins locally under the replicate-build multi-GPU strategy at N = 2, 4, 8 (c3 rows per GPU)
     "rep2": (200_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
     "rep4": (400_000_000, 1_000_000_000, 5000, "hash_join_count_radix"),
@@ -332,9 +333,9 @@ def main() -> None:
         if pinned_strategy is None:
             # the driver's model for THIS step's sizes and the measured link rate (every rank computes the same: the rate was agreed on above);
             # pinned for the self-check and the timed steps so that what was checked is what is timed
-            form_pick = _D.form_model(world, nb_gpu, np_gpu)
-            if materialize or world == 1:
-                form_pick = dict(form_pick, pick="shuffle", note="one rank / materialising: the shuffle (FJ_DIST_STRATEGY=broadcast times the other form on one rank)")
+            form_pick = _D.form_model(world, nb_gpu, np_gpu, materialize=bool(materialize))
+            if world == 1:
+                form_pick = dict(form_pick, pick="shuffle", note="one rank: the shuffle (FJ_DIST_STRATEGY=broadcast times the other form on one rank)")
             os.environ["FJ_DIST_STRATEGY"] = form_pick["pick"]
         timed_strategy = os.environ["FJ_DIST_STRATEGY"]
 

@@ -45,4 +45,11 @@ FJ_OPTIONS=join_wide=0 timeout 300 python bench.py --workload c5_rep8 --steps 10
 python tools/scale_model.py > $O/scale_model.txt 2>&1
 # ... and as one rank of 2 and of 4 (16- and 17-bit plans: three and two items per partition, dealt in runs)
 ( for w in 2 4; do python tools/bcast_one_gpu.py $w 125000000 1250000000 4 5 5000 0 2>&1 | grep "^world\|^step"; done ) > $O/bcast_one_rank_of_2_and_4.txt 2>&1
-ls -la $O | head -60
+# round 6: the bucketed wide join by shape (join_wide=0: the narrow-table kernel); the materialising build-broadcast step on one rank
+# beside the same join in the chunk-form shuffle; the measured CU reserve
+TAG=by_shape VARS="-" BC=0 WLS="c3 c4 rep8 c5_rep8" MODES="0 1" bash tools/r6_wide_ab.sh > /dev/null 2>&1; cp gpurun_out/r6_wide_ab_by_shape.txt $O/wide_by_shape.txt
+for st in broadcast shuffle; do
+  FJ_BENCH_FORCE_DIST=1 FJ_DIST_STRATEGY=$st timeout 600 python bench.py --workload c5_mat --steps 5 --warmup 2 --no-host-entry --no-cpu-baseline 2>/dev/null | tail -1 > $O/c5_mat_one_rank_${st}_bench.json
+done
+bash tools/r6_reserve_one_rank.sh > /dev/null 2>&1; cp gpurun_out/r06_cu_reserve_one_rank.txt $O/cu_reserve_one_rank.txt
+ls -la $O | head -80

@@ -24,7 +24,7 @@ if [ -d $D ]; then
   fi
 fi
 for f in pack_probe.txt prefilter_one_rank.txt precheck_probe.txt precheck_probe_kernel_stats.txt dist_one_gpu.txt bcast_one_rank.txt bcast_one_rank_kernel_stats.csv \
-         c5_one_rank_broadcast_bench.json c5_rep8_wide_pmc_summary.txt c5_rep8_narrow_table_bench.json scale_model.txt bcast_one_rank_of_2_and_4.txt; do [ -s $S/$f ] && cp $S/$f profiles/${TAG}_$f; done
+         c5_one_rank_broadcast_bench.json c5_rep8_wide_pmc_summary.txt c5_rep8_narrow_table_bench.json scale_model.txt bcast_one_rank_of_2_and_4.txt wide_by_shape.txt c5_mat_one_rank_broadcast_bench.json c5_mat_one_rank_shuffle_bench.json cu_reserve_one_rank.txt; do [ -s $S/$f ] && cp $S/$f profiles/${TAG}_$f; done
 P=gpurun_out/${TAG}p
 [ -s $P/pf_c5_bloom_kernel_stats.csv ] && cp $P/pf_c5_bloom_kernel_stats.csv profiles/${TAG}_c5_bloom_one_rank_precheck_kernel_stats.csv
 [ -s $P/pf_c5_kernel_stats.csv ] && cp $P/pf_c5_kernel_stats.csv profiles/${TAG}_c5_one_rank_precheck_kernel_stats.csv

@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r04}
 O=gpurun_out/$TAG; mkdir -p $O
-export FJ_OPTIONS=lab_hooks=16      # what an N > 1 step over RCCL does: the partition passes leave FJ_DIST_RESERVE_CUS (32) CUs to RCCL's kernels
+export FJ_OPTIONS=lab_hooks=16 FJ_DIST_RESERVE_CUS=32 FJ_DIST_STRATEGY=shuffle      # the owner shuffle in chunk form, with the 32-CU reserve pinned as in rounds 4-5 (round 6 measures the reserve per communicator: tools/r6_reserve_one_rank.sh)
 FJ_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload c5 --steps 8 --warmup 2 --no-host-entry --no-cpu-baseline 2>$O/c5_one_rank_bench.err | tail -1 > $O/c5_one_rank_bench.json
 python tools/show_bench.py c5_one_rank < $O/c5_one_rank_bench.json
 FJ_BENCH_FORCE_DIST=1 FJ_OPTIONS=lab_hooks=17 timeout 600 python bench.py --workload c5 --steps 5 --warmup 2 --no-host-entry --no-cpu-baseline 2>/dev/null | tail -1 > $O/c5_one_rank_loopback_bench.json

@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r04}
 O=gpurun_out/$TAG; mkdir -p $O
-export FJ_OPTIONS=lab_hooks=16 FJ_BENCH_FORCE_DIST=1
+export FJ_OPTIONS=lab_hooks=16 FJ_DIST_RESERVE_CUS=32 FJ_DIST_STRATEGY=shuffle FJ_BENCH_FORCE_DIST=1
 for w in c5_bloom c5; do for pf in 0 1 auto; do
   FJ_DIST_PREFILTER=$pf timeout 600 python bench.py --workload $w --steps 8 --warmup 2 --no-host-entry --no-cpu-baseline 2>$O/pf_${w}_$pf.err | tail -1 > $O/pf_${w}_$pf.json
   python - $O/pf_${w}_$pf.json $w $pf <<'PY'
