@@ -441,7 +441,11 @@ def main() -> None:
             res = api.join_device(algo, bloom, materialize, bk, bv, pk, return_arrays=False)
         else:
             t = {}
-            res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t, transport=transport, force_exchange=force_dist)
+            # a materialising step writes its pairs inside the timed region (return_arrays: the pairs this rank keeps; dropped at once)
+            res = distributed_join(bk, bv, pk, materialize=bool(materialize), bloom=bool(bloom), engine=engine, timings=t, transport=transport, force_exchange=force_dist,
+                                   return_arrays=bool(materialize))
+            if materialize:
+                res = (res[0], res[1])
             if t.get("prefilter_sampled_survivors") is not None:       # (warm-up steps included: "auto" samples once per shape, then remembers)
                 dsampled.update(survivors=t["prefilter_sampled_survivors"], below=t.get("prefilter_below"))
             if record:

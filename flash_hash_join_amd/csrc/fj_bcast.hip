@@ -226,7 +226,10 @@ __global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
     const u32 tid = threadIdx.x;
     const u32 item_lo = a.toff[a.part_lo], item_hi = a.toff[a.part_hi];
     u32 cur_part = 0xFFFFFFFFu;
-    for (u32 it = item_lo + blockIdx.x; it < item_hi; it += gridDim.x) {
+    // a workgroup takes a RUN of consecutive items: the items of one partition (few ranks: several per partition) share one table build
+    const u32 nit = item_hi - item_lo;
+    const u32 my_lo = item_lo + (u32)((u64)nit * blockIdx.x / gridDim.x), my_hi = item_lo + (u32)((u64)nit * (blockIdx.x + 1u) / gridDim.x);
+    for (u32 it = my_lo; it < my_hi; ++it) {
         const uint4 d = a.items[it];                               // {probe list pos, probe chunks, partition, -}
         const u32 part = d.z;
         if (tid < 4) sh[tid] = tid == 1 || tid == 2 ? sh[tid] : 0u;
@@ -235,21 +238,43 @@ __global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
             if (tid == 1 || tid == 2) sh[tid] = 0;
             __syncthreads();
             const u32 top = a.bits ? part << (32u - a.bits) : 0u;
-            for (u32 s = 0; s < a.nsrc; ++s) {
-                const u32* offs = reinterpret_cast<const u32*>(a.base + a.offs_off[s]);
+            // every source's run is loaded by its own waves (16 / nsrc rounded up to a power of two: the source, its bounds and its
+            // planes are wave-uniform - scalar loads, no per-key search), four keys per lane in flight
+            const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+            u32 wps = DM_NT / 64u;                                     // waves per source
+            while (wps > 1u && (DM_NT / 64u) / wps < a.nsrc) wps >>= 1;
+            const u32 src = wave / wps;
+            if (src < a.nsrc) {
+                const u32* offs = reinterpret_cast<const u32*>(a.base + a.offs_off[src]);
                 const u32 b = offs[part], e = offs[part + 1];
-                const u32* lo = reinterpret_cast<const u32*>(a.base + a.lo_off[s]);
-                for (u32 k = b + tid; k < e; k += DM_NT) {
-                    const u32 m = a.mid_bytes == 2 ? (u32)reinterpret_cast<const u16*>(a.base + a.mid_off[s])[k] : reinterpret_cast<const u32*>(a.base + a.mid_off[s])[k];
-                    const u64 key = ((u64)(top | m) << 32) | lo[k];
-                    u32 bk = FJ_HW2(key) & (DM_NBK - 1u), slot = 0xFFFFFFFFu;
-                    for (u32 step = 0; step < DM_MAXWALK; ++step) {
-                        const u32 o = atomicAdd(&fill[bk], 1u);
-                        if (o < DM_BS) { slot = bk * DM_BS + o; break; }
-                        bk = (bk + 1u) & (DM_NBK - 1u);
+                const u32* lo = reinterpret_cast<const u32*>(a.base + a.lo_off[src]);
+                const unsigned char* midp = a.base + a.mid_off[src];
+                const u64* vp = reinterpret_cast<const u64*>(a.base + a.val_off[src]);
+                const u32 stride = wps * 64u;
+                for (u32 k0 = b + (wave % wps) * 64u + lane; k0 - lane < e; k0 += 4u * stride) {      // (k0 - lane: wave-uniform trip count)
+                    u32 lw[4], mw[4]; u64 vw[4]; bool ok[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u32 k = k0 + (u32)j * stride;
+                        ok[j] = k < e;
+                        const u32 kk = ok[j] ? k : b;                  // (b: readable whenever the run is not empty; an empty run never gets here)
+                        lw[j] = lo[kk];
+                        mw[j] = a.mid_bytes == 2 ? (u32)reinterpret_cast<const u16*>(midp)[kk] : reinterpret_cast<const u32*>(midp)[kk];
+                        if (EMIT) vw[j] = vp[kk];
                     }
-                    if (slot == 0xFFFFFFFFu) sh[1] = 1;
-                    else { tkeys[slot] = key; if (EMIT) tvals[slot] = reinterpret_cast<const u64*>(a.base + a.val_off[s])[k]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!ok[j]) continue;
+                        const u64 key = ((u64)(top | mw[j]) << 32) | lw[j];
+                        u32 bk = FJ_HW2(key) & (DM_NBK - 1u), slot = 0xFFFFFFFFu;
+                        for (u32 step = 0; step < DM_MAXWALK; ++step) {
+                            const u32 o = atomicAdd(&fill[bk], 1u);
+                            if (o < DM_BS) { slot = bk * DM_BS + o; break; }
+                            bk = (bk + 1u) & (DM_NBK - 1u);
+                        }
+                        if (slot == 0xFFFFFFFFu) sh[1] = 1;
+                        else { tkeys[slot] = key; if (EMIT) tvals[slot] = vw[j]; }
+                    }
                 }
             }
             __syncthreads();
@@ -276,23 +301,39 @@ __global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
         const bool bad = sh[1] != 0;
         u32 my_hits = 0;
         if (!bad) {
-            for (u32 idx = tid; idx < d.y * FJ_CHUNK; idx += DM_NT) {
-                const u32 e = a.probe.list[d.x + (idx >> FJ_CHUNK_LOG)], k = idx & (FJ_CHUNK - 1u);
-                if (k >= FJ_LIST_CNT(e)) continue;
-                const u64 key = a.probe.keys[(u64)FJ_LIST_ID(e) * FJ_CHUNK + k];
-                u32 bk = FJ_HW2(key) & (DM_NBK - 1u), hit = 0xFFFFFFFFu;
-                for (u32 step = 0; step < DM_MAXWALK && hit == 0xFFFFFFFFu; ++step) {
-                    const u32 f = fill[bk], n = f < DM_BS ? f : DM_BS;
-                    for (u32 j = 0; j < n; ++j) if (tkeys[bk * DM_BS + j] == key) { hit = bk * DM_BS + j; break; }
-                    if (f <= DM_BS) break;                         // nobody was sent on from this bucket
-                    bk = (bk + 1u) & (DM_NBK - 1u);
+            // the item's probe keys, eight per lane in flight (list entries first, then the keys they point at)
+            for (u32 idx0 = tid; idx0 - tid < d.y * FJ_CHUNK; idx0 += 8u * DM_NT) {
+                u32 le[8]; u64 pk[8]; bool ok[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const u32 idx = idx0 + (u32)j * DM_NT;
+                    ok[j] = idx < d.y * FJ_CHUNK;
+                    le[j] = a.probe.list[d.x + (ok[j] ? (idx >> FJ_CHUNK_LOG) : 0u)];
                 }
-                if (hit != 0xFFFFFFFFu) {
-                    ++my_hits;
-                    if (EMIT) {
-                        const u32 w = atomicAdd(&sh[3], 1u);
-                        const u64 o = a.out_off[it] + w;
-                        a.out_keys[o] = fj_key_unmix(key); a.out_vals[o] = tvals[hit];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const u32 k = (idx0 + (u32)j * DM_NT) & (FJ_CHUNK - 1u);
+                    ok[j] = ok[j] && k < FJ_LIST_CNT(le[j]);
+                    pk[j] = a.probe.keys[(u64)FJ_LIST_ID(le[j]) * FJ_CHUNK + (ok[j] ? k : 0u)];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (!ok[j]) continue;
+                    const u64 key = pk[j];
+                    u32 bk = FJ_HW2(key) & (DM_NBK - 1u), hit = 0xFFFFFFFFu;
+                    for (u32 step = 0; step < DM_MAXWALK && hit == 0xFFFFFFFFu; ++step) {
+                        const u32 f = fill[bk], n = f < DM_BS ? f : DM_BS;
+                        for (u32 t = 0; t < n; ++t) if (tkeys[bk * DM_BS + t] == key) { hit = bk * DM_BS + t; break; }
+                        if (f <= DM_BS) break;                         // nobody was sent on from this bucket
+                        bk = (bk + 1u) & (DM_NBK - 1u);
+                    }
+                    if (hit != 0xFFFFFFFFu) {
+                        ++my_hits;
+                        if (EMIT) {
+                            const u32 w = atomicAdd(&sh[3], 1u);
+                            const u64 o = a.out_off[it] + w;
+                            a.out_keys[o] = fj_key_unmix(key); a.out_vals[o] = tvals[hit];
+                        }
                     }
                 }
             }
@@ -487,7 +528,7 @@ int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* regio
         if (dense_mat_args(c, d_base, nsrc, region_off, nkeys, &a)) return 1;
         a.part_lo = part_lo; a.part_hi = part_hi;
         HIPCHK(fj_set_max_lds_once(reinterpret_cast<const void*>(fj_dense_mat_join<false>), dense_mat_lds(false)));
-        hipLaunchKernelGGL(fj_dense_mat_join<false>, dim3(cus), dim3(DM_NT), dense_mat_lds(false), (hipStream_t)stream, a);
+        hipLaunchKernelGGL(fj_dense_mat_join<false>, dim3(2 * cus), dim3(DM_NT), dense_mat_lds(false), (hipStream_t)stream, a);      // (72 KiB of LDS: two workgroups per CU, one builds while the other probes)
         HIPCHK(hipGetLastError());
         bc.mat_base = d_base; bc.mat_nsrc = nsrc;
         for (int i = 0; i < nsrc; ++i) { bc.mat_off[i] = region_off[i]; bc.mat_nk[i] = nkeys[i]; }

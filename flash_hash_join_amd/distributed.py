@@ -239,22 +239,26 @@ def set_link_rate(bytes_per_s: float, measured: bool = True) -> None:
 def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] = None, nb_total: Optional[int] = None, np_global: Optional[int] = None,
                materialize: bool = False) -> dict:
     """The C++ driver's cost model for a step of `world` ranks holding at most nb x np_ rows each (fj_dist_model): modelled seconds in
-    either form and the pick.  materialize: the broadcast's regions carry the values too (14 bytes per build row instead of 6) and its
-    join is the plain kernel (csrc/fj_bcast.hip: ~2x the counting kernel's time), the shuffle ships 16 bytes per build row; the pairs
-    are written in either form."""
+    either form and the pick.  materialize: the same arithmetic with the materialising kernels' constants, measured on one MI355X as
+    one rank of 1 / 2 / 8 (profiles/r06_bcast_mat_one_rank.txt, tools/bcast_one_gpu.py ... 1): the regions carry the values (14 bytes
+    per build row, 16 under 16-bit plans), the pack takes 22.9 ps per build row, the plain join 11.7 ps per build key of all ranks +
+    7.4 ps per local probe key, writing the pairs (behind the step: nothing overlaps it) 6.1 ps + 8.1 ps; the shuffle ships 15 bytes
+    per build row and its owner writes the pairs of what it received (~4 ms per 1.25B probe rows at 50 % hits)."""
     from . import _lib
     nb_total = nb_total if nb_total is not None else nb * world
     np_global = np_global if np_global is not None else np_ * world
+    rate = float(link_bytes_per_s or _LINK_BYTES_PER_S)
     ts, tb = ctypes.c_double(0), ctypes.c_double(0)
-    region = 0
-    if materialize:
-        bits = max(5, (max(1, -(-nb_total // 4096)) - 1).bit_length()) if nb_total > 4096 else 5
-        region = int(nb * (14 if bits >= 16 else 16) + 4 * ((1 << bits) + 1) + 64)
-    f = _lib.load().fj_dist_model(world, nb, np_, nb_total, np_global, region, float(link_bytes_per_s or _LINK_BYTES_PER_S), ctypes.byref(ts), ctypes.byref(tb))
+    f = _lib.load().fj_dist_model(world, nb, np_, nb_total, np_global, 0, rate, ctypes.byref(ts), ctypes.byref(tb))
     t_s, t_b = ts.value, tb.value
     if materialize:
-        t_b += 1.0 * (nb_total * 3.2e-12 + np_ * 2.45e-12)                    # the plain join kernel in the counting kernel's place
-        t_s += (16.0 - 7.02) * nb_total / (world * world) / float(link_bytes_per_s or _LINK_BYTES_PER_S) if world > 1 else 0.0     # build rows travel with their values
+        bits = max(5, (max(1, -(-nb_total // 4096)) - 1).bit_length()) if nb_total > 4096 else 5
+        region = nb * (14 if bits >= 16 else 16) + 4 * ((1 << bits) + 1) + 64
+        pack, passes = nb * 22.9e-12, np_ * (6.34e-12 + 0.27e-12 * max(0, min(bits, 18) - 16))
+        count, emit = nb_total * 11.7e-12 + np_ * 7.4e-12, nb_total * 6.1e-12 + np_ * 8.1e-12
+        wire = region / rate if world > 1 else 0.0
+        t_b = max(wire + pack + count / 4.0, pack + passes + count) + emit
+        t_s += ((15.0 - 7.02) * nb_total / (world * world) / rate if world > 1 else 0.0) + np_ * 3.2e-12
         f = FORM_BROADCAST if t_b < t_s else FORM_SHUFFLE
     return {"shuffle": t_s, "broadcast": t_b, "pick": "broadcast" if f == FORM_BROADCAST else "shuffle"}
 

@@ -1386,6 +1386,51 @@ def test_config5_build_broadcast_every_rank_at_full_size_on_one_gpu(fj):
     assert total == expected, (total, expected)
 
 
+def test_config5_materialising_build_broadcast_every_rank_at_full_size_on_one_gpu(fj):
+    """The same full-size emulation for the MATERIALISING join (_hash_join_radix_materialize, hash_join.cpp:315-381, across 8 GPUs
+    in the build-broadcast form): the regions carry the build values (14 bytes per row), every rank counts its 1.25B probe rows
+    against the 8 regions (fj_dense_mat_join) and writes its ~625M pairs beside them (fj_emit_pairs).  Per rank: the count is the
+    generator's closed form, every pair obeys the generator's key -> value rule with a value of the global build side, and the
+    pairs' keys sum to the sum of the probe keys that are build keys (computed from the rule, independently of any join)."""
+    import torch
+    from flash_hash_join_amd import datagen
+    from flash_hash_join_amd.lab import LabEngine as HipEngine
+    world, nb_rank, np_rank, pieces = 8, 125_000_000, 1_250_000_000, 4
+    nb_total = nb_rank * world
+    eng = HipEngine("cuda:0")
+    rb = eng.bcast_region_bytes(nb_total, nb_rank, True)
+    assert 14.0 < rb / nb_rank < 14.02
+    base = torch.empty(rb * world, dtype=torch.uint8, device="cuda:0")
+    offs = [r * rb for r in range(world)]
+    empty = torch.empty(16, dtype=torch.int64, device="cuda:0")[:0]
+    for r in range(world):
+        bk, bv = datagen.build_device(nb_rank, "cuda:0", first=r * nb_rank)
+        eng.bcast_pack(bk, nb_total, base[offs[r]: offs[r] + rb], pieces, vals=bv)
+        assert eng.bcast_pack_bounds(pieces)[-1] == nb_rank
+        eng.bcast_probe(empty, nb_total); eng.bcast_finish()
+        del bk, bv
+    M = -7046029254386353131                               # build row i: key (i + 1) * M, value i (fj_generate_build)
+    Minv = pow(M % 2**64, -1, 2**64)
+    Minv = Minv - 2**64 if Minv >= 2**63 else Minv
+    for r in range(world):
+        bk, bv = datagen.build_device(nb_rank, "cuda:0", first=r * nb_rank)
+        pk, e = datagen.probe_device(np_rank, nb_total, "cuda:0", seed=1, hit_bp=5000, first=r * np_rank)
+        eng.bcast_pack(bk, nb_total, base[offs[r]: offs[r] + rb], pieces, vals=bv)
+        eng.bcast_probe(pk, nb_total)
+        for q in range(pieces):
+            eng.bcast_join(base, offs, [nb_rank] * world, 262144 * q // pieces, 262144 * (q + 1) // pieces)
+        n = eng.bcast_finish()
+        assert n == e, (r, n, e)
+        k, v = eng.emit_pairs(n)
+        assert k.numel() == n and int(v.min()) >= 0 and int(v.max()) < nb_total
+        assert bool(torch.all((v + 1) * M == k))
+        w = pk * Minv - 1
+        hit = (w >= 0) & (w < nb_total)
+        assert int(hit.sum()) == n and int((pk * hit).sum()) == int(k.sum()) and int((w * hit).sum()) == int(v.sum())
+        del bk, bv, pk, k, v, w, hit
+        torch.cuda.empty_cache()
+
+
 def test_config5_chunk_form_with_the_precheck_every_owner_at_full_size_on_one_gpu(fj):
     """The same full-size emulation (1B x 10B rows, the 8-rank plan: 9 + 9 bits, 262144 final partitions) with the sender-side
     precheck of the chunk form: every owner appends the 8 build shares and exports its 32768 partitions' Bloom filters
