@@ -19,9 +19,10 @@
 //     the table starts out filled with FJ_EMPTY_KEY (all ones), a key of the LAST partition - no probe key of any other partition
 //     can equal it; before the last partition goes in, the table is filled once more, with a key of the FIRST partition.  So
 //     every 64-bit value is a legal key on both sides and no value is handled out of band;
-//   * an item is two phases and two barriers: P (probe item k; zero the fill counts; requests and prefetches as before) | barrier
-//     | I (insert item k+1: its keys have been in registers for an iteration) | barrier.  Round 5 overlapped its claims with the
-//     probe and then paid a clear phase, a store phase and three barriers;
+//   * an item is two barriers: the returning atomic adds of item k+1's keys are ISSUED (on the fill counts of the other parity - two
+//     16-bit counts per 32-bit word - its keys have been in registers for an iteration), item k is probed, the counts of the parity
+//     after next are zeroed, the adds are RESOLVED (a key that found its bucket full walks on) | barrier | item k+1's keys are
+//     stored | barrier.  Round 5 paid a clear phase, a store phase and three barriers;
 //   * every wave owns whole 256-key chunks (4 keys per lane and chunk, two 16-B loads), so no lane looks up padding;
 //   * nothing in the loop waits for a dependent global load: item descriptors are fetched by one thread five items ahead and
 //     parked in LDS, chunk-list entries three items ahead, build keys two, probe keys one (no scalar loads in the loop: they
@@ -368,7 +369,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             hits += (u32)__popcll(__ballot(f & ok));
         }
         // the walk (1.5 % of the buckets are full at load 0.23: a lane or two of most chunks): a lane's walking keys one after the other -
-        // only the COUNT of the hits matters, so nothing is handed back per key
+        // only the COUNT of the hits matters, so nothing is handed back per key.  (Round 6 also asked the bucket's fill count first - only
+        // a count past BS sent a key on, 0.3 % of the buckets - with the counts zeroed behind barrier A instead of under the probe:
+        // dense join 4.95 -> 5.05 ms, c4's join 0.51 -> 0.56: the walks were not what the time goes into.)
         if (__ballot(cm != 0)) {
             do {
                 const u32 low = cm & (0u - cm);
@@ -466,8 +469,14 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     unsigned long long* tacc = reinterpret_cast<unsigned long long*>(meta + 4 * W_STRIDE);    // (the launch adds 72 bytes of LDS)
     if (tid == 0) { for (int i = 0; i < 8; ++i) tacc[i] = 0; tacc[8] = __builtin_amdgcn_s_memrealtime(); }
 #define W_STAMP(i) do { if (a.dbg && tid == 0) { const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tacc[i] += tn_ - tacc[8]; tacc[8] = tn_; } } while (0)
+    // ... and per WAVE (lane 0 of each): [0] top of the iteration -> probe done, [1] -> arrival at barrier A, [2] barrier A left -> arrival at barrier B
+    unsigned long long* wacc = tacc + 9;
+    if (tid < 64) wacc[tid] = 0;
+    unsigned long long tw_ = __builtin_amdgcn_s_memrealtime();
+#define W_WSTAMP(i, restart) do { if (a.dbg) { const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); if (!(restart) && lane == 0) wacc[wave * 4 + (i)] += tn_ - tw_; tw_ = tn_; } } while (0)
 #else
 #define W_STAMP(i) do { } while (0)
+#define W_WSTAMP(i, restart) do { } while (0)
 #endif
     for (u32 k = 0; k < nmine; ++k) {
         // at entry: the table holds item k (flags of parity k & 1); ka/kb = first probe chunks of item k; bkA = first build batch of
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             const u32 nbn = ns1 < W_META_P ? ns1 : W_META_P;
             load_chunks2(sl_k1, nbn, ka, na, kb, nbk);
         }
-        W_STAMP(1);
+        W_STAMP(1); W_WSTAMP(0, false);
         if (!sameA) {
             claim_resolve(fill_n, bkA, bokA, amA, parn, old, nslots);
             if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
@@ -522,9 +531,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         park(sl_k3, mp, mb, mb2);
         if (tid == 0) { store_boff(k + 4, bo4); store_items(k + 5, it5); }
         if (lane == 0 && wave_hits) atomicAdd(&hdr->cnt, wave_hits);
-        W_STAMP(2);
+        W_STAMP(2); W_WSTAMP(1, false);
         __syncthreads();                                         // A: every wave is done with the table in place; item k+1's slots are settled
-        W_STAMP(3);
+        W_STAMP(3); W_WSTAMP(3, true);
         // ---- 4. I: item k's result (one lane of the LAST wave: it holds the fewest probe chunks); item k+1 goes in: plain stores ----
         if (tid == WNT - 64) {
             const u32 cnt = skip ? 0u : hdr->cnt;
@@ -538,9 +547,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             if (k + 1 < nmine && is_last_part(part1)) { fill_table(W_POISON2); __syncthreads(); }     // (uniform; once per launch at most)
             store_keys(bkA, nslots, amA);
         }
-        W_STAMP(4);
+        W_STAMP(4); W_WSTAMP(2, false);
         __syncthreads();                                         // B
-        W_STAMP(5);
+        W_STAMP(5); W_WSTAMP(3, true);
         // ---- 5. rotate ----
         if constexpr (DENSE) assemble(rawB, topB, bkA);          // (the loads were issued at the top of the iteration: they are in)
         else {
@@ -553,12 +562,18 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     }
 #ifdef FJ_LAB
     if (a.dbg && tid == 0 && blockIdx.x < 4096) { for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 8 + i] = tacc[i]; }
+    __syncthreads();
+    if (a.dbg && tid < 64 && blockIdx.x < 256) a.dbg[2048 * 8 + blockIdx.x * 64 + tid] = wacc[tid];
 #endif
 }
 
 }  // namespace
 
-u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + NBK * 4 + 4 * W_STRIDE * 4 + 80); }     // (NBK * 4: two parities of NBK 16-bit counts)
+#ifdef FJ_LAB
+u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + NBK * 4 + 4 * W_STRIDE * 4 + 80 + 512); }     // (+ the stage stamps' accumulators)
+#else
+u32 fj_wide_lds_bytes() { return (u32)(sizeof(WHdr) + WS * 8 + NBK * 4 + 4 * W_STRIDE * 4 + 80); }
+#endif     // (NBK * 4: two parities of NBK 16-bit counts)
 
 // counting join over the final chunk sets with the 16384-slot table: a.items / a.nitems_dev / a.part_count / a.total / a.err as
 // for fj_launch_lds_join.  dense: the build side comes from w (build-broadcast wire format).

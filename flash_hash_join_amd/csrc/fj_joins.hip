@@ -326,6 +326,16 @@ int radix_join_tail(fj_ctx* c, int materialize, FjLdsJoinArgs& ja, const Plan& p
             const double per = (double)std::min<u32>(grid, 4096) * ((double)nit / grid);
             fprintf(stderr, "[FJ_WIDE_STAMPS] us per item (thread 0): rotate+requests %.3f  claim_issue+zero %.3f  barB %.3f  probe %.3f  resolve+park %.3f  barA %.3f  stores %.3f\n",
                     acc[0] / per, acc[5] / per, acc[6] / per, acc[1] / per, acc[2] / per, acc[3] / per, acc[4] / per);
+            // per wave: top of the iteration -> probe done -> arrival at barrier A; barrier A left -> arrival at barrier B
+            for (int ph = 0; ph < 3; ++ph) {
+                fprintf(stderr, "[FJ_WIDE_STAMPS] wave 0..15, %s:", ph == 0 ? "requests + claims issued + probe" : ph == 1 ? "claims resolved + park (to barrier A)" : "stores (barrier A to B)");
+                for (int w = 0; w < 16; ++w) {
+                    double sacc = 0;
+                    for (u32 g = 0; g < grid && g < 256; ++g) sacc += (double)h[2048 * 8 + g * 64 + w * 4 + ph] * 0.01;
+                    fprintf(stderr, " %.2f", sacc / ((double)std::min<u32>(grid, 256) * ((double)nit / grid)));
+                }
+                fprintf(stderr, "\n");
+            }
         }
     } else
     HIPCHK(fj_launch_lds_join(ja, false, s, &c->d_sc->next_item, options().persistent_min_items));

@@ -236,7 +236,7 @@ void join_item_geometry(u64 nparts, size_t np, u64 chunk_bound, u32* tc, u64* ma
 // table build costs a third of the cuckoo kernel's (one atomic add and one store per key, nothing to clear), its lookups somewhat
 // more (a whole 32-byte bucket per key).  Measured on one box, join kernel ms, cuckoo / wide: 800M x 1B 4.62 / 3.96, 400M x 1B
 // 2.80 / 2.57, config 4 behind its filter (100M x ~120M survivors) 0.60 / 0.51 - and 200M x 1B 1.81 / 2.29, 100M x 1B 1.48 / 2.06,
-// 125M x 1.25B 1.84 / 2.75: the switch is at ~3 probe rows per build row (gpurun_out/r6_wide_ab_g.txt, profiles/r06_wide_by_shape.txt).
+// 125M x 1.25B 1.84 / 2.75: the switch is at ~3 probe rows per build row (profiles/r06_wide_by_shape.txt).
 // np_eff: the probe rows that reach the join (behind a filter: an estimate).  Decided before the probe side's passes: the final
 // level's bookkeeping cuts the items to 32 chunks.
 bool wide_join_planned(bool materialize, size_t nb, size_t np_eff, int bits) {
