@@ -683,8 +683,8 @@ void fj_dist_comm_destroy(fj_dist_comm* dc) {
 // either form = max(bytes per link / link rate, kernel seconds per rank) + what cannot overlap.  Kernel seconds per row measured on
 // one MI355X at config 5's per-rank sizes (round 6: profiles/r06_bcast_one_rank_2_4_8.txt; shuffle: r04_c5_one_rank_kernel_stats.csv):
 // broadcast - pack 1.41 ms per 125M build rows; two probe-side passes 7.92 / 8.33 / 8.60 ms per 1.25B rows under the 16- / 17- / 18-bit
-// plans of 2 / 4 / 8 ranks; dense join (the bucketed table) 2.2 ps per build key of ALL ranks + 2.2 ps per local probe key = 3.3 / 3.85 /
-// 4.95 ms modelled, 3.32 / 4.26 / 4.96 measured at 2 / 4 / 8 ranks (round 5's table: 3.85 / 4.8 / 6.2), all of it kernels of this rank
+// plans of 2 / 4 / 8 ranks; dense join (the bucketed table) 2.0 ps per build key of ALL ranks + 2.2 ps per local probe key = 3.25 / 3.75 /
+// 4.75 ms modelled, 3.25 / 4.05 / 4.77 measured at 2 / 4 / 8 ranks (round 5's table: 3.85 / 4.8 / 6.2), all of it kernels of this rank
 // (the wire overlaps everything behind the pack); shuffle - 13.4 ms of kernels per 1.375B rows of both relations + ~2.5 ms of head and
 // tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: computed from nb_max and the plan).
 int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
@@ -693,7 +693,7 @@ int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_tota
     const int bits = fjh::make_plan((size_t)nb_total, 64).bits;
     if (region_max == 0) region_max = nb_max * (bits >= 16 ? 6u : 8u) + 4ull * ((1ull << bits) + 1) + 64;      // (fj_bcast_region_bytes: offset table + the two planes)
     const double pack = (double)nb_max * 11.3e-12, passes = (double)np_max * (6.34e-12 + 0.27e-12 * (bits > 16 ? std::min(bits, 18) - 16 : 0)),
-                 join = (double)nb_total * 2.2e-12 + (double)np_max * 2.2e-12;
+                 join = (double)nb_total * 2.0e-12 + (double)np_max * 2.2e-12;
     const double wire_b = N > 1 ? (double)region_max / rate : 0.0;
     const double t_b = std::max(wire_b + pack + join / 4.0, pack + passes + join);        // (the last of 4 partition ranges is joined after the wire is done)
     const double rows = (double)nb_max + (double)np_max;

@@ -38,6 +38,9 @@
 // are marked FJ_ITEM_RETRY exactly as fj_count_join_persistent does; the host's retry / re-partition ladder is unchanged.
 #include "fj_internal.h"
 #include <type_traits>
+#ifndef FJ_WIDE_ABLATE      // (timing-only variants, tools/mk_wide_variant.sh <name> -DFJ_WIDE_ABLATE=<1: no lookups | 2: no claims, no stores | 4: no stores, no barrier B | 8: stragglers dropped | sums>; counts wrong on purpose)
+#define FJ_WIDE_ABLATE 0
+#endif
 
 namespace {
 
@@ -245,8 +248,11 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
                 if ((bok >> j) & 1u) old[j] = fill_add(f, w_bucket(bk[j]));
         }
     };
-    auto claim_resolve = [&](u32* f, const u64 (&bk)[8], u32 bok, u32 am, u32 par, const u32 (&old)[8], u32 (&sl)[8]) {
-        u32 pend = 0;
+    // claim_mid (in front of the lookups, the first adds' answers are in): slots of the keys whose bucket had room; a lane's FIRST
+    // straggler asks the next bucket at once - that round trip too runs under the lookups.  pend: the lane's keys without a slot;
+    // b2 / o2: the bucket its first straggler asked and the answer
+    auto claim_mid = [&](u32* f, const u64 (&bk)[8], u32 bok, u32 am, const u32 (&old)[8], u32 (&sl)[8], u32& pend, u32& b2, u32& o2) {
+        pend = 0; b2 = 0; o2 = BS;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -260,11 +266,31 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
             }
         }
         if (__ballot(pend != 0)) {
-            // stragglers (0.35 % of the keys at load 0.23): a lane's pending keys one after the other, each walking bucket by bucket
+            const u32 low = pend & (0u - pend);
+            u32 b = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b |= w_bucket(bk[t]) & (0u - ((low >> t) & 1u));
+            b2 = (b + 1u) & (NBK - 1u);
+            if (pend) o2 = fill_add(f, b2);
+        }
+    };
+    // claim_resolve (behind the lookups): the first stragglers' answers; whoever is still without a slot (a second straggler of a lane, a
+    // straggler whose next bucket was full too: one key in tens of thousands) walks bucket by bucket, a lane's keys one after the other
+    auto claim_resolve = [&](u32* f, const u64 (&bk)[8], u32 par, u32 (&sl)[8], u32 pend, u32 b2, u32 o2) {
+        if (__ballot(pend != 0)) {
+            if (pend != 0 && o2 < BS) {
+                const u32 low = pend & (0u - pend), got = (b2 << BSLOG) + o2;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sl[t] = ((low >> t) & 1u) ? got : sl[t];
+                pend &= pend - 1u;
+            }
+        }
+        if (__ballot(pend != 0)) {
             u32 failed = 0;
             do {
                 // the lane's first pending key, picked with bit masks (a chain of selects on the key index becomes an indexed array in
-                // scratch memory: eight stores per item whether or not anything is pending)
+                // scratch memory: eight stores per item whether or not anything is pending).  A key whose second bucket was full starts
+                // over from its home: the count of that second bucket goes up once more, which changes nothing (it is full)
                 const u32 low = pend & (0u - pend);                // its bit alone
                 u32 b = 0;
 #pragma unroll
@@ -300,7 +326,13 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         for (u32 i = tid; i < WS / 2; i += WNT) reinterpret_cast<ulonglong2*>(tkeys)[i] = e2;
     };
     auto zero_fill_counts = [&](u32 par) {                         // one parity: NBK / 2 words
-        for (u32 i = tid; i < NBK / 8; i += WNT) reinterpret_cast<uint4*>(fill + par * (NBK / 2))[i] = make_uint4(0, 0, 0, 0);
+        // (a zero made on the spot: the compiler hoists a constant zero vector out of the item loop and, in the grouped dense kernels,
+        // SPILLS it - the reload's s_waitcnt vmcnt(0) then waits for every prefetch in flight, once per item)
+        // (... and the store's address hangs on that zero too: hoisted, it was spilled as well)
+        u32 z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        static_assert(NBK / 8 <= WNT, "one 16-byte store per thread");
+        if (tid < NBK / 8) reinterpret_cast<uint4*>(fill + par * (NBK / 2))[tid + z] = make_uint4(z, z, z, z);
     };
     // the partition whose keys' partition bits are all ones - the last one - must not find FJ_EMPTY_KEY (what the table starts out
     // with: all ones) in the table: a probe key could equal it, and every untouched bucket would read as full.  Uniform over the
@@ -445,9 +477,10 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         const uint4 ud[2] = {unit_desc(sl_k, 0), unit_desc(sl_k, 1)};
         load_build(sl_k, ring(0, 2), 0, nbc0 < W_META_B ? nbc0 : W_META_B, tot0, ud, bkA, rawB, bokA, amA);
         if constexpr (DENSE) assemble(rawB, top_of(ring(0, 2)), bkA);
-        u32 old[8], sl[8];
+        u32 old[8], sl[8], pend, b2, o2;
         claim_issue(fill, bkA, bokA, amA, old);
-        claim_resolve(fill, bkA, bokA, amA, 0, old, sl);
+        claim_mid(fill, bkA, bokA, amA, old, sl, pend, b2, o2);
+        claim_resolve(fill, bkA, 0, sl, pend, b2, o2);
         store_keys(bkA, sl, amA);
         if (is_big(nbc0, tot0)) hdr->full[0] = 1;
     }
@@ -483,6 +516,11 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         // item k+1 (tot1 units if DENSE); ring slots sl_k, sl_k1, sl_k2 hold the entries of items k, k+1, k+2; descriptors complete
         // up to k+3, the item-table part of k+4 is in the ring
         const u32 par = k & 1u, parn = par ^ 1u;
+        // ---- 0. slots for item k+1 are requested on its parity's fill counts (no lookup reads them; the table is not touched): the
+        // answers come back under the requests below ----
+        u32* fill_n = fill + parn * (NBK / 2);
+        u32 old[8], nslots[8], pend = 0, sb2 = 0, so2 = BS;
+        if (!sameA && !(FJ_WIDE_ABLATE & 2)) claim_issue(fill_n, bkA, bokA, amA, old);
         // ---- 1. requests: descriptor parts (one thread), entries of k+3, build keys of k+2 ----
         uint4 it5 = make_uint4(0, 0, 0, 0); uint2 bo4 = make_uint2(0, 0);
         // everything the first phases read from LDS in ONE batch - descriptor of item k+3, the flags of the table in place, (DENSE) the
@@ -506,25 +544,29 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         if (!sameB) { load_build(sl_k2, part2, 0, nbc2 < W_META_B ? nbc2 : W_META_B, tot2, ud2, bkB, rawB, bokB, amB); topB = DENSE ? top_of(part2) : 0u; }
         else { bokB = 0; amB = 0; }
         W_STAMP(0);
-        // ---- 2. P: slots for item k+1 are requested on its parity's fill counts (no lookup reads them; the table is not touched); item
-        // k is probed; then its successor's first probe chunks are requested into the same registers; the requests' answers are
-        // taken, stragglers placed; the fill counts of item k's parity are cleared for item k+2 ----
-        u32* fill_n = fill + parn * (NBK / 2);
-        u32 old[8], nslots[8];
-        if (!sameA) claim_issue(fill_n, bkA, bokA, amA, old);
+        // ---- 2. P: the claims' answers are taken, a lane's first straggler asks its next bucket (that round trip runs under the
+        // lookups); item k is probed; then its successor's first probe chunks are requested into the same registers; the stragglers
+        // are placed; the fill counts of item k's parity are cleared for item k+2 ----
+        if (FJ_WIDE_ABLATE & 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nslots[j] = W_NOSLOT;
+            if (((u32)(bkA[0] ^ bkA[1] ^ bkA[2] ^ bkA[3] ^ bkA[4] ^ bkA[5] ^ bkA[6] ^ bkA[7]) & 0xFFFFFu) == 0x12345u && bokA) nslots[0] = tid;      // (the loads stay)
+        } else if (!sameA) claim_mid(fill_n, bkA, bokA, amA, old, nslots, pend, sb2, so2);
         zero_fill_counts(par);
         const bool full = __builtin_amdgcn_readfirstlane(par ? flg.w : flg.z) != 0 || ns0 > 2 * W_WAVES;      // (an item longer than 32 probe chunks - a host-side bug - goes to the retry ladder)
         u32 wave_hits = 0;
         const bool skip = full || ns0 == 0;
-        if (!skip && na) wave_hits += probe4(ka, na);
-        if (!skip && nbk) wave_hits += probe4(kb, nbk);
+        if (!(FJ_WIDE_ABLATE & 1)) {
+            if (!skip && na) wave_hits += probe4(ka, na);
+            if (!skip && nbk) wave_hits += probe4(kb, nbk);
+        } else wave_hits += (u32)(ka[0] ^ ka[1] ^ ka[2] ^ ka[3] ^ kb[0] ^ kb[1] ^ kb[2] ^ kb[3]) & 1u;      // (the loads stay)
         {
             const u32 nbn = ns1 < W_META_P ? ns1 : W_META_P;
             load_chunks2(sl_k1, nbn, ka, na, kb, nbk);
         }
         W_STAMP(1); W_WSTAMP(0, false);
-        if (!sameA) {
-            claim_resolve(fill_n, bkA, bokA, amA, parn, old, nslots);
+        if (!sameA && !(FJ_WIDE_ABLATE & 2)) {
+            if (!(FJ_WIDE_ABLATE & 8)) claim_resolve(fill_n, bkA, parn, nslots, pend, sb2, so2);
             if (is_big(nbc1, tot1) && tid == 0) hdr->full[parn] = 1;
         }
         // ---- 3. park what was requested ----
@@ -545,17 +587,19 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         }
         if (!sameA) {
             if (k + 1 < nmine && is_last_part(part1)) { fill_table(W_POISON2); __syncthreads(); }     // (uniform; once per launch at most)
-            store_keys(bkA, nslots, amA);
+            if (!(FJ_WIDE_ABLATE & 4)) store_keys(bkA, nslots, amA);
         }
-        W_STAMP(4); W_WSTAMP(2, false);
-        __syncthreads();                                         // B
-        W_STAMP(5); W_WSTAMP(3, true);
-        // ---- 5. rotate ----
-        if constexpr (DENSE) assemble(rawB, topB, bkA);          // (the loads were issued at the top of the iteration: they are in)
+        // the next batch of build keys moves up while the stores drain and the other waves arrive (its loads were issued at the top of
+        // the iteration: they are in)
+        if constexpr (DENSE) assemble(rawB, topB, bkA);
         else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bkA[j] = bkB[j];
         }
+        W_STAMP(4); W_WSTAMP(2, false);
+        if (!(FJ_WIDE_ABLATE & 4)) __syncthreads();              // B
+        W_STAMP(5); W_WSTAMP(3, true);
+        // ---- 5. rotate ----
         bokA = bokB; amA = amB; tot1 = tot2; sameA = sameB;
         ns0 = ns1; ns1 = ns2; ns2 = ns3; nbc1 = nbc2; nbc2 = nbc3; part1 = part2; part2 = part3;
         u32* t = sl_k; sl_k = sl_k1; sl_k1 = sl_k2; sl_k2 = sl_k3; sl_k3 = t;
