@@ -121,9 +121,9 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     // (DENSE: the LAST wave - it holds the fewest probe chunks of an item - looks after the build side's entries: lane s of it keeps
     //  source s's plane offsets in registers and loads that source's (run begin, run end) for the item: mb, mb2)
     const bool bwave = DENSE && wave == W_WAVES - 1;
-    u32 my_lo16 = 0, my_mid16 = 0; const u32* my_offs = nullptr;
+    u32 my_lo16 = 0, my_mid16 = 0;                                 // (the source's offset table is found through LDS per item: kept in a register across the loop, its pointer - or its offset - was spilled in the 4-byte-plane kernels, and a scratch reload waits for every load in flight)
     auto dense_lane_setup = [&]() {                                // after hdr->*_off are visible
-        if (bwave && lane < w.nsrc) { my_lo16 = (u32)(hdr->lo_off[lane] >> 4); my_mid16 = (u32)(hdr->mid_off[lane] >> 4); my_offs = reinterpret_cast<const u32*>(w.base + hdr->offs_off[lane]); }
+        if (bwave && lane < w.nsrc) { my_lo16 = (u32)(hdr->lo_off[lane] >> 4); my_mid16 = (u32)(hdr->mid_off[lane] >> 4); }
     };
     // (ppos, part, b0: item q's descriptor fields 0, 2, 4 - the caller has them in scalar registers)
     auto request = [&](u32 q, u32 ns, u32 nbc, u32 ppos, u32 part, u32 b0, u32& mp, u32& mb, u32& mb2) {
@@ -131,7 +131,12 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
         const u32 np0 = ns < W_META_P ? ns : W_META_P;
         if (tid < np0) mp = a.probe.list[ppos + tid];
         if (DENSE) {
-            if (bwave && q < nmine && lane < w.nsrc) { mb = my_offs[part]; mb2 = my_offs[part + 1]; }
+            if (bwave && q < nmine && lane < w.nsrc) {
+                u32 z;                                         // (an opaque zero in the index: nothing of this address can be hoisted out of the item loop)
+                asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                const u32* my_offs = reinterpret_cast<const u32*>(w.base + hdr->offs_off[lane + z]);
+                mb = my_offs[part]; mb2 = my_offs[part + 1];
+            }
         } else {
             const u32 nb0 = nbc < W_META_B ? nbc : W_META_B;
             if (tid < nb0) mb = a.build.list[b0 + tid];
