@@ -968,7 +968,17 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
     u32* s_next = bm0 + 2 * JB_META;                         // [2] item ids handed out by the global counter
     u32* bits = s_next + 4;                                  // slot bitmap of the two-phase build
     u64* ovf = reinterpret_cast<u64*>(bits + S / 32);        // its overflow list
-    const u32 tid = threadIdx.x, lane = tid & 63;
+    // tid is NOT const: behind an item's probe rounds it is made afresh from the wave number (a scalar) and the lane id (fresh_tid).
+    // With 1024 threads the kernel lives at the 128-register cap; the compiler kept the thread id and nine addresses derived from it
+    // alive across the rounds by SPILLING them, and their reloads behind the loop came with s_waitcnt vmcnt(0): once per item every
+    // wave waited for all its loads and pair stores in flight.  Recomputed (3 instructions), nothing needs to survive the loop.
+    u32 tid = threadIdx.x;
+    const u32 lane = tid & 63, wave_s = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    auto fresh_tid = [&]() -> u32 {
+        u32 t;                                               // (the lane id too inside the asm: computed outside, it was hoisted and spilled)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %1, 6, %0" : "=&v"(t) : "s"(wave_s));
+        return t;
+    };
     const u32 nitems = *a.nitems_dev;
     constexpr u32 CPL = NT / (FJ_CHUNK / 2), CPR = 4 * CPL, BKPT = 4096 / NT;
     static_assert(JP_META <= NT && JB_META <= NT, "one staged list entry per thread");
@@ -1011,7 +1021,11 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
         }
     };
     auto reset_table = [&]() {
-        for (u32 i = tid; i < S; i += NT) { tkeys[i] = FJ_EMPTY_KEY; if (DEDUP) tvals[i] = ~0ull; }
+        u32 m1;                                              // all ones, made on the spot (the hoisted 64-bit constant was spilled as well)
+        asm volatile("v_mov_b32 %0, -1" : "=v"(m1));
+        const u64 empty = ((u64)m1 << 32) | m1;
+        static_assert(FJ_EMPTY_KEY == ~0ull, "the empty marker is all ones");
+        for (u32 i = tid; i < S; i += NT) { tkeys[i] = empty; if (DEDUP) tvals[i] = ~0ull; }
         if (DEDUP && tid < CK_STASH) hdr->stash_val[tid] = ~0ull;
         if (tid < S / 32) bits[tid] = 0;
         if (tid == 0) {
@@ -1338,6 +1352,7 @@ __global__ __launch_bounds__(NT, 4) void fj_emit_join_persistent(FjLdsJoinArgs a
                 }
             }
             }
+        tid = fresh_tid();                                    // (see the declaration of tid)
         if (!parked) park();                                  // skipped probe loop
         __syncthreads();                                      // every wave is done with the table; the parked entries are visible
         if (SINGLE && tid == 0 && d.item < nitems && !(lv && full)) a.part_count[d.item] = lv ? icnt : 0u;
