@@ -350,7 +350,7 @@ def main() -> None:
         spk, sexp = datagen.probe_device(np_s, nb_s * world, device, seed=3, hit_bp=5000, first=rank * np_s)
         e = torch.tensor([sexp], dtype=torch.int64, device=device)
         dist.all_reduce(e)
-        pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
+        pieces = int(os.environ.get("FJ_DIST_PIECES", "0")) or 4       # (0 / unset: the driver decides - 4, or 8 for a wire-bound broadcast step: smaller messages)
         msg = int(1.3 * np_gpu / max(1, pieces) / world) + 4096          # int64 per peer and piece in the chunk form
 
         def error_line(err, sc):

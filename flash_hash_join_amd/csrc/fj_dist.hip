@@ -687,15 +687,34 @@ void fj_dist_comm_destroy(fj_dist_comm* dc) {
 // 4.75 ms modelled, 3.25 / 4.05 / 4.77 measured at 2 / 4 / 8 ranks (round 5's table: 3.85 / 4.8 / 6.2), all of it kernels of this rank
 // (the wire overlaps everything behind the pack); shuffle - 13.4 ms of kernels per 1.375B rows of both relations + ~2.5 ms of head and
 // tail outside the overlap.  region_max: the largest fj_bcast_region_bytes of any rank (0: computed from nb_max and the plan).
+// the broadcast form's terms (seconds): bytes on one link, this rank's pack, probe-side passes, dense join
+static void bcast_terms(uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t region_max, double rate, int nranks, double* wire, double* pack, double* passes, double* join) {
+    const int bits = fjh::make_plan((size_t)nb_total, 64).bits;
+    if (region_max == 0) region_max = nb_max * (bits >= 16 ? 6u : 8u) + 4ull * ((1ull << bits) + 1) + 64;      // (fj_bcast_region_bytes: offset table + the two planes)
+    *pack = (double)nb_max * 11.3e-12;
+    *passes = (double)np_max * (6.34e-12 + 0.27e-12 * (bits > 16 ? std::min(bits, 18) - 16 : 0));
+    *join = (double)nb_total * 2.0e-12 + (double)np_max * 2.2e-12;
+    *wire = nranks > 1 ? (double)region_max / rate : 0.0;
+}
+// ... in p pieces: the last of p partition ranges is joined after the wire is done; a range join beyond the fourth costs ~20 us of
+// ramp and tail (measured as one rank of 8: join 4.76 / 4.84 / 4.92 ms in 4 / 8 / 16 ranges)
+static double bcast_time(double wire, double pack, double passes, double join, int p) {
+    return std::max(wire + pack + join / p, pack + passes + join + 20e-6 * (p > 4 ? p - 4 : 0));
+}
+// pieces = 0 ("the driver decides"): 8 where the wire bounds the broadcast step (the tail behind the last piece is an eighth of the
+// join instead of a quarter), else 4; the shuffle: 4 (the measured default)
+static int auto_pieces(bool bcast, int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t region_max, double rate) {
+    if (!bcast || nranks < 2) return 4;
+    double wire, pack, passes, join;
+    bcast_terms(nb_max, np_max, nb_total, region_max, rate, nranks, &wire, &pack, &passes, &join);
+    return bcast_time(wire, pack, passes, join, 8) < bcast_time(wire, pack, passes, join, 4) ? 8 : 4;
+}
 int fj_dist_model(int nranks, uint64_t nb_max, uint64_t np_max, uint64_t nb_total, uint64_t np_global, uint64_t region_max, double link_bytes_per_s,
                   double* t_shuffle, double* t_broadcast) {
     const double rate = link_bytes_per_s > 0 ? link_bytes_per_s : 55e9, N = nranks < 1 ? 1 : nranks;
-    const int bits = fjh::make_plan((size_t)nb_total, 64).bits;
-    if (region_max == 0) region_max = nb_max * (bits >= 16 ? 6u : 8u) + 4ull * ((1ull << bits) + 1) + 64;      // (fj_bcast_region_bytes: offset table + the two planes)
-    const double pack = (double)nb_max * 11.3e-12, passes = (double)np_max * (6.34e-12 + 0.27e-12 * (bits > 16 ? std::min(bits, 18) - 16 : 0)),
-                 join = (double)nb_total * 2.0e-12 + (double)np_max * 2.2e-12;
-    const double wire_b = N > 1 ? (double)region_max / rate : 0.0;
-    const double t_b = std::max(wire_b + pack + join / 4.0, pack + passes + join);        // (the last of 4 partition ranges is joined after the wire is done)
+    double wire_b, pack, passes, join;
+    bcast_terms(nb_max, np_max, nb_total, region_max, rate, nranks, &wire_b, &pack, &passes, &join);
+    const double t_b = std::min(bcast_time(wire_b, pack, passes, join, 4), bcast_time(wire_b, pack, passes, join, 8));      // (the piece count fj_dist_join takes by itself)
     const double rows = (double)nb_max + (double)np_max;
     const double wire_s = N > 1 ? 7.02 * ((double)np_global + (double)nb_total) / (N * N) / rate : 0.0;
     const double t_s = std::max(wire_s, rows * 9.75e-12) + 2.5e-3 * rows / 1.375e9;
@@ -726,7 +745,7 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
 
     if (materialize && (!dc->hip || (nb && !d_build_vals) || ((uintptr_t)d_build_vals & 15))) return derr("fj_dist_join: a materialising join needs the HIP engine and 16-byte aligned build values");
     const bool mat = materialize != 0;
-    if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: pieces must be 1..%d", MAX_PIECES);
+    if (pieces < 0 || pieces > MAX_PIECES) return derr("fj_dist_join_count: pieces must be 0 (the driver decides) or 1..%d", MAX_PIECES);
     if ((nb && !d_build_keys) || (np && !d_probe_keys) || (((uintptr_t)d_build_keys | (uintptr_t)d_probe_keys) & 15)) return derr("fj_dist_join_count: null or misaligned input");
     Net& net = *dc->net; Engine& eng = *dc->eng;
     const int N = net.nranks, me = net.rank;
@@ -770,7 +789,9 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
     const unsigned reserve_n = reserve_for_step(dc, net.shares_the_gpu() && (N > 1 || (fj_get_option("lab_hooks") & FJ_HOOK_RESERVE_ALWAYS)), tot_with, tot_without, &reserve_how);
     prefilter_below = (double)m[2] * 1e-9;
     pieces = (int)(m[3] >> 8);
-    if (pieces < 1 || pieces > MAX_PIECES) return derr("fj_dist_join_count: rank 0 asks for %d pieces (1..%d)", pieces, MAX_PIECES);
+    if (pieces < 0 || pieces > MAX_PIECES) return derr("fj_dist_join_count: rank 0 asks for %d pieces (0..%d)", pieces, MAX_PIECES);
+    const bool pieces_auto = pieces == 0;                     // (decided below, from what every rank knows: the same number everywhere)
+    if (pieces_auto) pieces = 4;
     const int form_req = (int)(m[3] & 0xFF);
     const double link_rate = m[4] > 0 ? (double)m[4] : 55e9;
     const bool want_pf = prefilter_below > 0;
@@ -785,6 +806,7 @@ int fj_dist_join(fj_dist_comm* dc, const uint64_t* d_build_keys, const uint64_t*
             bcast = fj_dist_model(N, nb_max, np_max, nb_total, np_global, region_max, link_rate, nullptr, nullptr) == FJ_DIST_FORM_BROADCAST;
         if (form_req == FJ_DIST_FORM_BROADCAST && !can)
             return derr("fj_dist_join_count: the build-broadcast form needs an engine that has it, <= %u ranks and a total build side with a partitioned plan (%llu rows)", FJ_WIDE_MAXSRC, nb_total);
+        if (bcast && pieces_auto && !mat) pieces = auto_pieces(true, N, nb_max, np_max, nb_total, region_max, link_rate);
         if (bcast) return dist_join_bcast(dc, d_build_keys, mat ? d_build_vals : nullptr, mat, nb, d_probe_keys, np, pieces, nb_of, nb_total, out_global_count, out_local_count, timings, reserve_n, reserve_how, tot_with, tot_without);
     }
     size_t CB = 0;

@@ -764,7 +764,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
             timings.update(split_s=0.0, exchange_s=0.0, join_s=time.perf_counter() - t0)
         return res
 
-    pieces = int(os.environ.get("FJ_DIST_PIECES", "4"))
+    pieces = int(os.environ.get("FJ_DIST_PIECES", "0"))         # 0: the driver decides (4; 8 where the wire bounds a broadcast step - fj_dist_join)
     no_fallback = bool(os.environ.get("FJ_DIST_NO_FALLBACK"))
     standin = hasattr(engine, "dist_engine_ops")
     # relation sizes of every rank, rank 0's link rate (every rank models with it: hosts that called set_link_rate with per-rank
@@ -808,7 +808,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
     for i, rung in enumerate(rungs):
         try:
             if rung == "broadcast":
-                res = _driver_join(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, build_values=build_values if materialize else None,
+                res = _driver_join(dist, group, engine, build_keys, probe_keys, max(0, pieces), tt, transport, build_values=build_values if materialize else None,
                                    return_arrays=return_arrays, form=FORM_BROADCAST)
             elif rung == "shuffle":
                 mode = "off" if (standin and not getattr(engine, "chunk_precheck", False)) else _chunk_prefilter_mode(bloom, world, prefilter)
@@ -816,7 +816,7 @@ def distributed_join(build_keys, build_values, probe_keys, *, materialize: bool 
                 res = None
                 for attempt in ((below, mode), (0.0, "off")) if below > 0 else ((0.0, mode),):     # (a failed step with the precheck is retried without it)
                     try:
-                        res = _driver_join(dist, group, engine, build_keys, probe_keys, max(1, pieces), tt, transport, build_values=build_values if materialize else None,
+                        res = _driver_join(dist, group, engine, build_keys, probe_keys, max(0, pieces), tt, transport, build_values=build_values if materialize else None,
                                            return_arrays=return_arrays, prefilter_below=attempt[0], prefilter_mode=attempt[1], form=FORM_SHUFFLE)
                         _precheck_remember(pf_key, tt, decision)
                         break

@@ -217,7 +217,9 @@ int fj_bcast_plan(size_t nb_total, int* bits, uint32_t* nparts, int* mid_bytes);
  *   reserve, its third without, both times the probe-side passes are timed (HIP events, an exchange in flight), the ranks add their
  *   times up in the next step's first all-gather, and every later step uses the faster setting (fj_dist_timings.reserve_*).
  *   FJ_DIST_RESERVE_CUS=n pins the number instead.
- *   fj_dist_join_count          - collective.  pieces: rounds of the probe exchange (4 is the measured default).  A build side
+ *   fj_dist_join_count          - collective.  pieces: rounds of the probe exchange / partition ranges of a broadcast step; 0 = the
+ *                                 driver decides (4, the measured default; 8 for a broadcast step that its model finds wire-bound:
+ *                                 the tail behind the last piece is an eighth of the join), rank 0's value counts.  A build side
  *                                 of less than ~2M rows in all is refused (one-pass plan: join it on one GPU).
  *   fj_dist_join                - the same step, optionally materialising (materialize != 0: the build rows travel with their
  *                                 values, 16 bytes per build row on the wire): *out_local_count = pairs this rank owns; the

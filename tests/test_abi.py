@@ -262,7 +262,7 @@ def test_multi_gpu_strategy_model():
             m = D.form_model(world, 125_000_000, 1_250_000_000, rate)
             assert m["pick"] == "broadcast" and m["broadcast"] < 0.021 and m["shuffle"] > 0.021, (world, rate, m)
     m = D.form_model(8, 125_000_000, 1_250_000_000, 55e9)
-    assert 0.0155 < m["broadcast"] < 0.0170 and 0.023 < m["shuffle"] < 0.026, m           # wire-bound at ~16.3 ms (kernels: 15.0) against a wire-bound ~24.4 ms
+    assert 0.0155 < m["broadcast"] < 0.0159 and 0.023 < m["shuffle"] < 0.026, m           # wire-bound at ~15.7 ms in the 8 pieces the driver then takes (16.3 in 4; kernels: 14.8) against a wire-bound ~24.4 ms
     assert 0.0145 < D.form_model(8, 125_000_000, 1_250_000_000, 70e9)["broadcast"] < 0.0153      # kernel-bound from ~62 GB/s up: pack 1.4 + passes 8.6 + join 4.95 ms
     # materialising joins: the regions carry the values (14 bytes per build row) and the join is the plain kernel - the broadcast
     # still wins where one or three links would carry the shuffle, the shuffle at 8 ranks
