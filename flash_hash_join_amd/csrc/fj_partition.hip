@@ -802,18 +802,58 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
 // consecutive ids, bins their (position, entry) pairs by bucket in LDS (counting sort: LDS atomics, one scan) and writes the
 // bins out in order: a wave's 64 stores then fall into a few 16-64-byte pieces instead of 64 sectors.  Positions and entries are
 // exactly those of fj_level_lists<0>.
+//
+// Round 6: the level's SCAN rides along (fj_level_scan's job: chunk counts -> list offsets boff and the consumer's tile offsets
+// toff, counts cleared) - one launch per level instead of two.  Every workgroup scans the <= 512 counts itself (2 KiB from L2) into
+// LDS and works from there; workgroup 0 also writes boff / toff out for the level's consumers; the counts may be cleared once
+// everybody has read them: each workgroup ticks a counter behind the counts (bchunks[nb]: zero at rest like the counts) when it
+// has, and the one that ticks last clears counts and counter.
 __global__ __launch_bounds__(1024) void fj_level_lists_binned(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
-                               u32 cap, const u32* __restrict__ boff, const u32* __restrict__ seg_off, u32 fan_mask,
+                               u32 cap, u32* __restrict__ boff_g, const u32* __restrict__ seg_off, u32 fan_mask,
                                u32 max_segs, u32* __restrict__ list,
-                               u32 nb, u32 tc, const u32* __restrict__ toff, uint4* __restrict__ tiles, u32 max_tiles,
-                               u32* __restrict__ zero_tail) {
+                               u32 nb, u32 tc, u32* __restrict__ toff_g, uint4* __restrict__ tiles, u32 max_tiles,
+                               u32* __restrict__ zero_tail, u32* __restrict__ bchunks) {
     constexpr u32 NT = 1024, BLK = 4096, NBMAX = 512;
     __shared__ u32 hist[NBMAX + 1];
     __shared__ u32 wsum[NBMAX / 64];
     __shared__ uint2 ent[BLK];
+    __shared__ u32 boff[NBMAX + 1], toff[NBMAX + 1];
+    __shared__ u64 wtot[NBMAX / 64];
+    __shared__ u32 s_last;
     u32 n = *nalloc; if (n > cap) n = cap;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 stride = gridDim.x * NT, gtid = blockIdx.x * NT + tid;
+    {   // ---- the scan (chunks in the low word, tiles in the high word of one 64-bit scan, as fj_level_scan does it) ----
+        const float rtc = tc ? 1.0f / (float)tc : 0.f;
+        auto tiles_of = [&](u32 c) -> u32 {          // ceil(c / tc) without an integer division (c < 2^24: exact after one correction)
+            if (!tc) return 0u;
+            u32 q = (u32)((float)c * rtc);
+            while (q * tc < c) ++q;
+            while (q && (q - 1) * tc >= c) --q;
+            return q;
+        };
+        u64 mine = 0, v = 0;
+        if (tid < NBMAX) {
+            const u32 c = tid < nb ? bchunks[tid] : 0u;
+            mine = (u64)c | ((u64)tiles_of(c) << 32);
+            v = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u64 y = __shfl_up(v, d, 64); if ((int)lane >= d) v += y; }
+            if (lane == 63) wtot[wave] = v;
+        }
+        __syncthreads();                               // this workgroup has read every count
+        if (tid == 0) { __threadfence(); s_last = atomicAdd(&bchunks[nb], 1u) == gridDim.x - 1 ? 1u : 0u; }
+        if (tid < NBMAX) {
+            u64 woff = 0;
+            for (u32 w = 0; w < wave; ++w) woff += wtot[w];
+            const u64 ex = woff + v - mine;
+            if (tid < nb) { boff[tid] = (u32)ex; toff[tid] = (u32)(ex >> 32); }
+            if (tid == nb - 1) { boff[nb] = (u32)(ex + mine); toff[nb] = (u32)((ex + mine) >> 32); }
+        }
+        __syncthreads();
+        if (s_last) { if (tid < nb) bchunks[tid] = 0; if (tid == 0) bchunks[nb] = 0; }       // every workgroup has read them: cleared for the next join
+        if (blockIdx.x == 0 && tid <= nb) { boff_g[tid] = boff[tid]; if (tc) toff_g[tid] = toff[tid]; }
+    }
     if (tc) {
         u32 total = toff[nb];
         if (total > max_tiles) total = max_tiles;
@@ -1020,18 +1060,18 @@ hipError_t fj_launch_partition(const FjPartArgs& a, bool vals, int line_log, u32
 // (no atomics) + the consumer's tile table.  tc == 0: no consumer tile table.
 hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles, u32 max_tiles, u32* zero_tail, hipStream_t s) {
     if (cs.nb & 3u) return hipErrorInvalidValue;           // fj_level_scan works in 16-B pieces
-    // many buckets: one workgroup per 4096 counts, and the chunk-list launch clears the counts (fj_level_scan_wide)
-    const bool wide = cs.nb >= 8192u && cs.nb <= (1u << 19) && !(cs.run_log == 0 && cs.nb <= 512);
-    if (wide) hipLaunchKernelGGL(fj_level_scan_wide, dim3((cs.nb + 4095u) / 4096u), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
-    else hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
     static_assert(FJ_RUN_LOG == 1 || FJ_RUN_LOG == 2, "fj_level_lists reads a run's directory words with one 8-B or 16-B load");
     if (cs.run_log != 0 && cs.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
-    if (cs.run_log == 0 && cs.nb <= 512 && cs.cap >= 4096) {       // few buckets, single ids: bin the list entries by bucket before storing them
+    if (cs.run_log == 0 && cs.nb <= 512 && cs.cap >= 4096) {       // few buckets, single ids: ONE launch - scan, binned list entries, tile table
         const u32 blocks = (cs.cap + 4095u) / 4096u;
         hipLaunchKernelGGL(fj_level_lists_binned, dim3(blocks < 4096u ? blocks : 4096u), dim3(1024), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff,
-                           cs.seg_off, cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail);
+                           cs.seg_off, cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail, cs.bchunks);
         return hipGetLastError();
     }
+    // many buckets: one workgroup per 4096 counts, and the chunk-list launch clears the counts (fj_level_scan_wide)
+    const bool wide = cs.nb >= 8192u && cs.nb <= (1u << 19);
+    if (wide) hipLaunchKernelGGL(fj_level_scan_wide, dim3((cs.nb + 4095u) / 4096u), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
+    else hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
     auto kern = cs.run_log ? fj_level_lists<FJ_RUN_LOG> : fj_level_lists<0>;
     hipLaunchKernelGGL(kern, dim3(2048), dim3(256), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff, cs.seg_off,
                        cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail, wide ? cs.bchunks : (u32*)nullptr);

@@ -175,7 +175,7 @@ int pass_prepare(fj_ctx* c, PassIter& it, u32 appends, hipStream_t s) {
     if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
     if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
     if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
-    if (get_zeroed_buf(c, base + W_BCHUNKS, nb_out * 4, &p, s)) return 1; cs.bchunks = (u32*)p;
+    if (get_zeroed_buf(c, base + W_BCHUNKS, nb_out * 4 + 16, &p, s)) return 1; cs.bchunks = (u32*)p;      // (+ the completion counter of fj_level_lists_binned behind the counts)
     if (get_buf(c, base + W_BOFF, (nb_out + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
     if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * F * 4, &p)) return 1; cs.seg_off = (u32*)p;
     cs.alloc = it.alloc_word ? it.alloc_word : &c->d_sc->alloc[it.side * 4 + i];
@@ -304,7 +304,7 @@ int bloom_stage(fj_ctx* c, PassIter& it, hipStream_t s) {
     if (get_buf(c, base + W_DIR, cap64 * 4, &p)) return 1; cs.dir = (u32*)p;
     if (get_buf(c, base + W_REL, cap64 * 8, &p)) return 1; cs.rel = (u64*)p;
     if (get_buf(c, base + W_LIST, cap64 * 4, &p)) return 1; cs.list = (u32*)p;
-    if (get_zeroed_buf(c, base + W_BCHUNKS, (size_t)cs.nb * 4, &p, s)) return 1; cs.bchunks = (u32*)p;
+    if (get_zeroed_buf(c, base + W_BCHUNKS, (size_t)cs.nb * 4 + 16, &p, s)) return 1; cs.bchunks = (u32*)p;
     if (get_buf(c, base + W_BOFF, ((size_t)cs.nb + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
     if (get_buf(c, base + W_SEGOFF, (size_t)cs.max_segs * 4, &p)) return 1; cs.seg_off = (u32*)p;
     cs.alloc = &c->d_sc->alloc[it.side * 4 + 3];

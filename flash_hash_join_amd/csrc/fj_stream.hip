@@ -482,7 +482,7 @@ int stream_append_chunks(fj_ctx* c, int side, const void* d_chunks, const u64* d
     if (get_buf(c, W_RX_REL, (size_t)n * 8, &p)) return 1; cs.rel = (u64*)p;
     if (get_buf(c, W_RX_LIST, (size_t)n * 4, &p)) return 1; cs.list = (u32*)p;
     if (get_buf(c, W_RX_SEGOFF, (size_t)nblocks * fan * 4, &p)) return 1; cs.seg_off = (u32*)p;
-    if (get_zeroed_buf(c, W_RX_BCH, (size_t)fan * 4, &p, s)) return 1; cs.bchunks = (u32*)p;
+    if (get_zeroed_buf(c, W_RX_BCH, (size_t)fan * 4 + 16, &p, s)) return 1; cs.bchunks = (u32*)p;
     if (get_buf(c, W_RX_BOFF, ((size_t)st.nbk_pad + 1) * 4, &p)) return 1; cs.boff = (u32*)p;
     if (get_buf(c, W_RX_TOFF, ((size_t)st.nbk_pad + 1) * 4, &p)) return 1; u32* toff = (u32*)p;
     if (get_buf(c, W_RX_TILES, (size_t)max_tiles * sizeof(uint4), &p)) return 1; uint4* tiles = (uint4*)p;
