@@ -191,6 +191,23 @@ int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits
     parts.erase(std::unique(parts.begin(), parts.end()), parts.end());
     const u32 m = (u32)parts.size();
     if (m == 0 || m > 64) return 0;
+    // A partition's probe side may be cut into MANY items (items of <= 32 chunks for the bucketed kernel; slices of a probe side
+    // swollen by a hot key), and the tagged kernel's verdict is per item: under millions of copies of one build key its racing
+    // inserts overflow a group in one item and not in the next.  The partitions below are joined again WHOLE, so whatever their
+    // other items have already counted comes off the total (and those items count as flagged: an emitting pass must not write
+    // their pairs twice).  Found by tools/r6_wide_fuzz.py: 5 distinct build keys x 2.3M copies counted one key's probe rows twice.
+    u64 already = 0;
+    {
+        u32 nlive = nitems;
+        HIPCHK(hipMemcpy(&nlive, ja.nitems_dev, 4, hipMemcpyDeviceToHost));
+        if (nlive > nitems) nlive = nitems;
+        for (u32 i = 0; i < nlive; ++i) {
+            if (pc[i] == FJ_ITEM_TOOBIG || pc[i] == FJ_ITEM_RETRY || !std::binary_search(parts.begin(), parts.end(), items[i].z)) continue;
+            already += pc[i];
+            flagged.push_back(i);
+            HIPCHK(hipMemsetAsync(&ja.part_count[i], 0, 4, s));
+        }
+    }
     // chunk-list ranges of those partitions on both sides
     std::vector<u32> bo(2 * m), po(2 * m);
     for (u32 j = 0; j < m; ++j) {
@@ -209,7 +226,11 @@ int skew_join(fj_ctx* c, const FjLdsJoinArgs& ja, const Plan& plan, int top_bits
     if (get_buf(c, W_SK_NT, 16, &p)) return 1;
     u32* d_nt = (u32*)p;
     PassIter bit2, pit2;
-    const u64 count_main = c->h_sc->total;                                       // what every other partition found
+    const u64 count_main = c->h_sc->total - already;                             // what every other partition found
+    if (already) {
+        HIPCHK(hipMemcpyAsync(&c->d_sc->total, &count_main, 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));                                         // (count_main lives on this stack frame)
+    }
     const bool had_dups = (c->h_sc->err & FJ_STAT_DUPS) != 0;
     HIPCHK(hipMemsetAsync(&c->d_sc->err, 0, 4, s));                              // the main join's status bits have been acted on
     if (skew_side(c, bit2, 0, materialize != 0, ja.build, bo, bchunks, S, top_bits - plan.bits, plan.npass, W_SK_TILES_B, d_nt, s)) return 1;

@@ -207,6 +207,31 @@ def test_adaptive_threshold_both_sides(fj, oracle):
         assert fj.adaptive_join_count_bloom(bk, bv, pk)[0] == exp
 
 
+@pytest.mark.gpu
+def test_millions_of_copies_of_a_few_build_keys_are_counted_once(fj):
+    """Three distinct build keys, two million copies each, in a shape that takes the bucketed join (fewer than 3 probe rows per build
+    row): their partitions are far beyond any LDS table, the probe side of each is cut into hundreds of items, and the retry ladder
+    - tagged table per item, then the partition re-partitioned and joined whole (skew_join) - must not count an item twice.  Round 6's
+    fuzz (tools/r6_wide_fuzz.py) found it doing so: the tagged kernel's verdict on a partition differs from item to item under
+    racing duplicate inserts, and skew_join added the whole partition on top of what its other items had counted (15.9M instead of
+    12M matches, differently on every run).  hash_join.cpp:125 (duplicates dropped at insert), :153-182 (one match per probe row)."""
+    import torch
+    dev = "cuda:0"
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    nb, npk, d = 6_000_000, 12_000_000, 3
+    bk = torch.randint(-2**62, 2**62, (nb,), device=dev, dtype=torch.int64, generator=g)[:d].repeat(nb // d).contiguous()
+    bv = torch.arange(bk.numel(), device=dev, dtype=torch.int64)
+    pk = bk[torch.randint(0, bk.numel(), (npk,), device=dev, generator=g)].contiguous()
+    try:
+        for mode in (2, 1, 0):                                  # the plan's choice (the bucketed kernel), the bucketed kernel forced, the cuckoo kernel
+            fj.set_option("join_wide", mode)
+            for rep in range(3):
+                n = fj.join_device(1, 0, 0, bk, bv, pk, return_arrays=False)[0]
+                assert n == npk, (mode, rep, n, fj.last_timings())
+    finally:
+        fj.set_option("join_wide", 2)
+
+
 def test_lds_overflow_falls_back_to_global_table(fj, oracle):
     """Every build key lands in ONE radix partition (> LDS table capacity): the radix path must detect it; the join
     re-partitions that partition alone by more radix bits (counting and materialising joins) - exact either way."""
