@@ -199,15 +199,18 @@ __global__ __launch_bounds__(DP_NT) void fj_dense_copy_vals(const u64* __restric
     }
 }
 
-// ---- the join of a MATERIALISING build-broadcast step (insert_local + probe_vectorized of one radix partition with the build rows'
-// values, hash_join.cpp:112-128, :153-182, inside _hash_join_radix_materialize, :315-381).  The counting step's kernel
-// (fj_count_join_wide<DENSE>) is a deep software pipeline without room for values; this one is the plain form: one 1024-thread
-// workgroup per CU walks its items; per item the partition's runs of all sources go into an 8192-slot bucketed table (2048 buckets of
-// 4 slots: keys 64 KiB + values 64 KiB of LDS; one returning atomic add on the bucket's fill count per key, a full bucket sends the
-// key to the next one), then the item's probe chunks are looked up.  EMIT = false: counts per item (part_count) and reports
-// duplicate build keys (FJ_STAT_DUPS: a materialising join must emit the FIRST occurrence's value, which only the owner-scatter
-// form can tell) and partitions beyond the table (FJ_STAT_RETRY); EMIT = true: writes the pairs (probe key un-mixed, build value)
-// at out_off[item].  Not a fast path (~2x the counting kernel's time): the pairs' 16 bytes each are what a materialising join costs.
+// ---- the pair writer of a MATERIALISING build-broadcast step (insert_local + probe_vectorized of one radix partition with the build
+// rows' values, hash_join.cpp:112-128, :153-182, inside _hash_join_radix_materialize, :315-381).  The step is COUNTED by the counting
+// step's kernel (fj_count_join_wide<DENSE>: a probe row counts once however many copies of its key the build side holds - the
+// reference's rule, duplicates dropped at insert, :125 - and its per-item counts are what the pairs' offsets are scanned from); that
+// kernel is a deep software pipeline without room for values, so the pairs are written by this plain one behind fj_emit_pairs: one
+// 1024-thread workgroup per CU walks a run of items; per partition the runs of all sources go into an 8192-slot bucketed table
+// (2048 buckets of 4 slots: keys 64 KiB + values 64 KiB of LDS; one returning atomic add on the bucket's fill count per key, a full
+// bucket sends the key to the next one), then the item's probe chunks are looked up and every hit writes (probe key un-mixed, build
+// value) at out_off[item] + a cursor.  A duplicated build key occupies several slots and a probe row takes the first it meets: ONE
+// pair per matching probe row, carrying the value of one of the copies - across GPUs there is no "first" occurrence to prefer.
+// The counting launch refuses partitions of more than 24 load units (FjWideArgs::max_units: ~6000 keys), so that what it accepts
+// fits this table; should a partition overflow it all the same, the launch says so (FJ_STAT_RETRY) and fj_emit_pairs fails.
 constexpr u32 DM_NT = 1024, DM_SLOTS = 8192, DM_BS = 4, DM_NBK = DM_SLOTS / DM_BS, DM_MAXWALK = 256;
 struct DenseMatArgs {
     FjChunkSet probe; const uint4* items; const u32* toff; u32 part_lo, part_hi;
@@ -216,12 +219,12 @@ struct DenseMatArgs {
     u32* part_count; unsigned long long* total; u32* err;
     const u64* out_off; u64* out_keys; u64* out_vals;
 };
-template <bool EMIT>
 __global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
+    constexpr bool EMIT = true;
     extern __shared__ __attribute__((aligned(16))) unsigned char dm_smem[];
     u64* tkeys = reinterpret_cast<u64*>(dm_smem);
     u64* tvals = tkeys + DM_SLOTS;
-    u32* fill = reinterpret_cast<u32*>(tvals + (EMIT ? DM_SLOTS : 0));
+    u32* fill = reinterpret_cast<u32*>(tvals + DM_SLOTS);
     u32* sh = fill + DM_NBK;                                       // [0] hits of the item, [1] table overflow, [2] duplicates, [3] pairs written
     const u32 tid = threadIdx.x;
     const u32 item_lo = a.toff[a.part_lo], item_hi = a.toff[a.part_hi];
@@ -278,23 +281,6 @@ __global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
                 }
             }
             __syncthreads();
-            if (!EMIT) {
-                // duplicate build keys: a key that meets its own value in an EARLIER slot of its bucket chain.  Every thread checks the slots it can reach
-                for (u32 slot = tid; slot < DM_SLOTS; slot += DM_NT) {
-                    const u32 bk = slot / DM_BS, pos = slot % DM_BS;
-                    if (pos >= (fill[bk] < DM_BS ? fill[bk] : DM_BS)) continue;
-                    const u64 key = tkeys[slot];
-                    u32 hb = FJ_HW2(key) & (DM_NBK - 1u);
-                    bool dup = false;
-                    for (u32 step = 0; step < DM_MAXWALK && !dup; ++step) {          // from the key's home bucket up to its own slot
-                        const u32 n = hb == bk ? pos : (fill[hb] < DM_BS ? fill[hb] : DM_BS);
-                        for (u32 j = 0; j < n; ++j) dup |= tkeys[hb * DM_BS + j] == key;
-                        if (hb == bk) break;
-                        hb = (hb + 1u) & (DM_NBK - 1u);
-                    }
-                    if (dup) sh[2] = 1;
-                }
-            }
             cur_part = part;
             __syncthreads();
         } else __syncthreads();
@@ -338,17 +324,8 @@ __global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
                 }
             }
         }
-        if (!EMIT) {
-            const u32 wsum = fj_wave_sum(my_hits);
-            if ((tid & 63) == 0 && wsum) atomicAdd(&sh[0], wsum);
-            __syncthreads();
-            if (tid == 0) {
-                a.part_count[it] = bad ? 0u : sh[0];
-                if (bad) atomicOr(a.err, FJ_STAT_RETRY);
-                else if (sh[0]) atomicAdd(a.total, (unsigned long long)sh[0]);
-                if (sh[2]) atomicOr(a.err, FJ_STAT_DUPS);
-            }
-        }
+        (void)my_hits;
+        if (bad && tid == 0) atomicOr(a.err, FJ_STAT_RETRY);       // (the counting launch accepted a partition this table cannot hold: reported, fj_emit_pairs fails)
         __syncthreads();
     }
 }
@@ -508,7 +485,7 @@ static int dense_mat_args(fj_ctx* c, const void* d_base, int nsrc, const uint64_
     a->part_count = bc.ja.part_count; a->total = &c->d_sc->total; a->err = &c->d_sc->err;
     return 0;
 }
-static u32 dense_mat_lds(bool emit) { return DM_SLOTS * 8 * (emit ? 2 : 1) + DM_NBK * 4 + 16; }
+static u32 dense_mat_lds() { return DM_SLOTS * 8 * 2 + DM_NBK * 4 + 16; }
 
 int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* region_off, const uint64_t* nkeys, uint32_t part_lo, uint32_t part_hi, void* stream) {
     if (!c) return set_err("fj_bcast_join: null context");
@@ -521,28 +498,20 @@ int fj_bcast_join(fj_ctx* c, const void* d_base, int nsrc, const uint64_t* regio
     if (bc.np == 0 || part_lo == part_hi) return 0;
     FJ_ENTER(c);
     const u32 cus = c->reserve_cus < c->num_cus ? c->num_cus - c->reserve_cus : 1u;
-    if (bc.with_vals) {
-        // a materialising step: the plain kernel with duplicate detection counts per item; the pairs are written by fj_emit_pairs behind
-        // the step (the regions and the probe partitions stay where they are until then)
-        DenseMatArgs a;
-        if (dense_mat_args(c, d_base, nsrc, region_off, nkeys, &a)) return 1;
-        a.part_lo = part_lo; a.part_hi = part_hi;
-        HIPCHK(fj_set_max_lds_once(reinterpret_cast<const void*>(fj_dense_mat_join<false>), dense_mat_lds(false)));
-        hipLaunchKernelGGL(fj_dense_mat_join<false>, dim3(2 * cus), dim3(DM_NT), dense_mat_lds(false), (hipStream_t)stream, a);      // (72 KiB of LDS: two workgroups per CU, one builds while the other probes)
-        HIPCHK(hipGetLastError());
+    if (bc.with_vals) {      // a materialising step is counted like a counting one; fj_emit_pairs needs to find the regions again (they stay where they are)
         bc.mat_base = d_base; bc.mat_nsrc = nsrc;
         for (int i = 0; i < nsrc; ++i) { bc.mat_off[i] = region_off[i]; bc.mat_nk[i] = nkeys[i]; }
-        return 0;
     }
     FjWideArgs w{};
     w.toff = bc.pit.toff; w.part_lo = part_lo; w.part_hi = part_hi;
     w.base = (const unsigned char*)d_base; w.nsrc = (u32)nsrc; w.bits = L0.bits; w.mid_bytes = L0.mid_bytes; w.pmask = fj_wide_pmask((int)L0.bits, 64);
+    w.max_units = bc.with_vals ? 24u : 0u;                   // (what is counted for a materialising step must fit the pair writer's 8192-slot table)
     // few ranks = few, fat partitions: > ~28 probe chunks each means two or three items per partition (items hold <= 32 probe chunks),
     // dealt in runs of 8 so that a partition's items find their table built (2 and 4 ranks of config 5: 3 and 2 items per partition)
     w.group_log = bc.np / L0.nparts > 7000 ? 3u : 0u;
     for (int i = 0; i < nsrc; ++i) {
         Layout L;
-        if (layout_of(bc.nb_total, (size_t)nkeys[i], &L)) return 1;
+        if (layout_of(bc.nb_total, (size_t)nkeys[i], &L, bc.with_vals)) return 1;
         if (region_off[i] & 15) return set_err("fj_bcast_join: region offsets must be multiples of 16");
         w.offs_off[i] = region_off[i]; w.lo_off[i] = region_off[i] + L.lo_off; w.mid_off[i] = region_off[i] + L.mid_off;
     }
@@ -570,10 +539,12 @@ int fj_bcast_emit(fj_ctx* c, uint64_t* d_out_keys, uint64_t* d_out_vals, size_t 
     if (layout_of(bc.nb_total, 0, &L0)) return 1;
     a.part_lo = 0; a.part_hi = L0.nparts;
     a.out_off = (const u64*)p; a.out_keys = d_out_keys; a.out_vals = d_out_vals;
-    HIPCHK(fj_set_max_lds_once(reinterpret_cast<const void*>(fj_dense_mat_join<true>), dense_mat_lds(true)));
-    hipLaunchKernelGGL(fj_dense_mat_join<true>, dim3(c->num_cus), dim3(DM_NT), dense_mat_lds(true), s, a);
+    HIPCHK(hipMemsetAsync(&c->d_sc->err, 0, 4, s));
+    HIPCHK(fj_set_max_lds_once(reinterpret_cast<const void*>(fj_dense_mat_join), dense_mat_lds()));
+    hipLaunchKernelGGL(fj_dense_mat_join, dim3(c->num_cus), dim3(DM_NT), dense_mat_lds(), s, a);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
+    if (read_scalars(c, s)) return 1;
+    if (c->h_sc->err & FJ_STAT_RETRY) return set_err("internal error: a partition the counting kernel accepted does not fit the pair writer's table (fj_bcast_emit)");
     return 0;
 }
 
@@ -588,13 +559,12 @@ int fj_bcast_finish(fj_ctx* c, void* stream, uint64_t* out_count, fj_timings* ti
     const u32 err = c->h_sc->err;
     const int npass = bc.plan.npass, bits = bc.plan.bits, evc = bc.evc;
     const bool mat = bc.with_vals;
-    if (!mat || (err & (FJ_ERR_POOL | FJ_STAT_RETRY | FJ_ERR_LDS_FULL | FJ_STAT_DUPS))) bc = BcastState();
+    if (!mat || (err & (FJ_ERR_POOL | FJ_STAT_RETRY | FJ_ERR_LDS_FULL))) bc = BcastState();
     else { bc.packed = bc.probed = false; bc.mat_ready = true; bc.mat_count = c->h_sc->total; bc.mat_items = bc.pit.items_cap; }      // (the emit reads the regions and the probe partitions where they lie)
     if (err & FJ_ERR_POOL) return set_err("internal error: chunk pool exhausted during a partition pass");
     end_plan(c);
     // a final partition beyond the LDS table (> ~8000 build keys in all: build-side skew): the caller takes another form
     if (err & (FJ_STAT_RETRY | FJ_ERR_LDS_FULL)) return set_err("build broadcast: a final partition does not fit the LDS table (skewed build keys)");
-    if (mat && (err & FJ_STAT_DUPS)) return set_err("build broadcast: duplicate build keys in a materialising join (the first occurrence's value is what counts: the owner-scatter form serves them)");
     if (out_count) *out_count = c->h_sc->total;
     fj_timings t; memset(&t, 0, sizeof t);
     t.path = 0; t.passes = npass; t.radix_bits = bits; t.partitions = 1ull << bits; t.sampled_hit_bp = -1;

@@ -189,6 +189,7 @@ struct FjWideArgs {
     // low words u32[n_s] and the low (32 - bits) bits of their high words as u16[n_s] (mid_bytes == 2) or u32[n_s]; partition p supplies the top `bits` bits
     const unsigned char* base; u32 nsrc, bits, mid_bytes;
     u32 group_log;                               // items are dealt to the workgroups in runs of 2^group_log consecutive ones (0: one by one); > 0 where partitions are cut into several items: a run's items of one partition share one table build
+    u32 max_units;                               // DENSE: a partition of more 256-slot load units than this is marked for the retry ladder (0: the kernel's own limit, 32 = 8192 key slots)
     u32 pmask;                                   // the bits of a mixed key's HIGH word that name its final partition (all radix digits come from hash word 1): what tells a
                                                  // table entry of the partition in place from one that an earlier partition left behind (fj_wide_pmask)
     u64 offs_off[FJ_WIDE_MAXSRC], lo_off[FJ_WIDE_MAXSRC], mid_off[FJ_WIDE_MAXSRC];

@@ -445,7 +445,8 @@ __global__ __launch_bounds__(WNT) void fj_count_join_wide(FjLdsJoinArgs a, FjWid
     // host's retry ladder like any partition the table cannot hold (no rarely-taken loads inside the loop: they would make every
     // wait on the loads in flight conservative)
     // (DENSE: `total` = the partition's 256-slot units over all sources, dense_total)
-    auto is_big = [&](u32 nbc, u32 total) -> bool { return DENSE ? total > 2 * W_WAVES : nbc > 2 * W_WAVES; };
+    const u32 max_units = DENSE && w.max_units && w.max_units < 2 * W_WAVES ? w.max_units : 2 * W_WAVES;
+    auto is_big = [&](u32 nbc, u32 total) -> bool { return DENSE ? total > max_units : nbc > 2 * W_WAVES; };
 
     // ---- prologue (synchronous): descriptors 0..4, entries of items 0..2, item 0 built, probe keys of item 0, build keys of item 1
     if (DENSE && tid < w.nsrc) { hdr->lo_off[tid] = w.lo_off[tid]; hdr->mid_off[tid] = w.mid_off[tid]; hdr->offs_off[tid] = w.offs_off[tid]; }

@@ -17,10 +17,13 @@ over the ranks of a group takes the first of three FORMS that applies and succee
    Both forms run inside ONE C++ driver, csrc/fj_dist.hip (fj_dist_join): over RCCL under the nccl backend, over three callbacks
    into torch.distributed otherwise (_CallbackTransport: gloo, a transport object), with a stand-in for the rank's own work in the
    CPU test-suite.  A step that fails on one rank fails on every rank (the driver agrees on it), so all ranks move down together.
-3. OWNER SCATTER (the plain last resort, driven from here: small build sides, duplicate build keys in a materialising join, and
-   any step the forms above failed on): every rank splits its rows by owner GPU = (top 16 hash bits * world) >> 16
+3. OWNER SCATTER (the plain last resort, driven from here: small build sides and any step the forms above failed on): every rank splits its rows by owner GPU = (top 16 hash bits * world) >> 16
    (fj_owner_split), ONE all-to-all per relation moves each segment to its owner (torch.distributed all_to_all_single), each rank
    joins what it owns with the single-GPU radix join (hash_top_bits = 48), one all-reduce adds the counts.  No precheck of its own.
+
+A build key that occurs more than once - on one rank or on several - yields ONE pair per matching probe row in every form, with the
+value of one of its copies (a single GPU emits the first occurrence's, hash_join.cpp:125; across GPUs there is no global row order
+to define a first one).
 
 FJ_DIST_STRATEGY = auto (default) | broadcast | shuffle | scatter pins the first rung; a rung that failed for a join shape is
 remembered and skipped for the next 32 steps of that shape (_FORM_MEMO).  `engine` abstracts the per-rank primitives so that the
@@ -241,9 +244,10 @@ def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] 
     """The C++ driver's cost model for a step of `world` ranks holding at most nb x np_ rows each (fj_dist_model): modelled seconds in
     either form and the pick.  materialize: the same arithmetic with the materialising kernels' constants, measured on one MI355X as
     one rank of 1 / 2 / 8 (profiles/r06_bcast_mat_one_rank.txt, tools/bcast_one_gpu.py ... 1): the regions carry the values (14 bytes
-    per build row, 16 under 16-bit plans), the pack takes 22.9 ps per build row, the plain join 11.7 ps per build key of all ranks +
-    7.4 ps per local probe key, writing the pairs (behind the step: nothing overlaps it) 6.1 ps + 8.1 ps; the shuffle ships 15 bytes
-    per build row and its owner writes the pairs of what it received (~4 ms per 1.25B probe rows at 50 % hits)."""
+    per build row, 16 under 16-bit plans), the pack takes 22.9 ps per build row, the step is counted by the counting step's kernel
+    (2.0 ps per build key of all ranks + 2.2 ps per local probe key), writing the pairs (behind the step: nothing overlaps it) costs
+    6.1 ps + 8.1 ps; the shuffle ships 15 bytes per build row and its owner writes the pairs of what it received (~4 ms per 1.25B
+    probe rows at 50 % hits)."""
     from . import _lib
     nb_total = nb_total if nb_total is not None else nb * world
     np_global = np_global if np_global is not None else np_ * world
@@ -255,7 +259,7 @@ def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] 
         bits = max(5, (max(1, -(-nb_total // 4096)) - 1).bit_length()) if nb_total > 4096 else 5
         region = nb * (14 if bits >= 16 else 16) + 4 * ((1 << bits) + 1) + 64
         pack, passes = nb * 22.9e-12, np_ * (6.34e-12 + 0.27e-12 * max(0, min(bits, 18) - 16))
-        count, emit = nb_total * 11.7e-12 + np_ * 7.4e-12, nb_total * 6.1e-12 + np_ * 8.1e-12
+        count, emit = nb_total * 2.0e-12 + np_ * 2.2e-12, nb_total * 6.1e-12 + np_ * 8.1e-12
         wire = region / rate if world > 1 else 0.0
         t_b = max(wire + pack + count / 4.0, pack + passes + count) + emit
         t_s += ((15.0 - 7.02) * nb_total / (world * world) / rate if world > 1 else 0.0) + np_ * 3.2e-12

@@ -304,7 +304,8 @@ typedef struct fj_dist_engine_ops {   /* a stand-in for the rank's own work (the
  *   FJ_DIST_FORM_BROADCAST - the build broadcast (csrc/fj_bcast.hip): the probe rows stay, every rank's build rows travel to every
  *                            peer, 6 bytes per key; up to 16 ranks.  Materialising joins too (round 6): the values travel as a
  *                            fourth part (14 bytes per build row) and the pairs stay with the rank that holds the PROBE row
- *                            (fj_emit_pairs after the step); duplicate build keys are refused (the shuffle forms serve them);
+ *                            (fj_emit_pairs after the step).  In every form a build key that occurs more than once yields ONE pair
+ *                            per matching probe row, with the value of one of its copies;
  *   FJ_DIST_FORM_AUTO      - (default) whichever a per-link / per-rank cost model puts ahead for the step's sizes: bytes per link
  *                            over link_bytes_per_s (<= 0: 55e9) against the kernel time per rank measured on one MI355X
  *                            (profiles/r05_scale_model.txt).  Probe-heavy joins (BASELINE configs[4]: 10 probe rows per build row)

@@ -102,10 +102,10 @@ int fj_part_filter_sample(fj_ctx* ctx, const uint64_t* d_raw_keys, size_t n, siz
  *                            the caller takes another form (fj_dist_join does).
  * MATERIALISING joins (_hash_join_radix_materialize, hash_join.cpp:315-381, across GPUs; round 6): fj_bcast_pack with with_vals = 1
  * writes the build values as a fourth part of the region (u64[n]: 14 bytes per build row; fj_bcast_region_bytes / _piece_span with
- * with_vals = 1 / part 3); fj_bcast_join then counts with a plain kernel that also reports duplicate build keys (an error of
- * fj_bcast_finish: the first occurrence's value is what counts, which only the owner-scatter form can tell); fj_bcast_finish leaves
- * the regions and the probe partitions in place and fj_emit_pairs (fj_bcast_emit) writes this rank's pairs - (probe key, build value)
- * of its OWN probe rows: in this form the pairs stay with the probe rows.
+ * with_vals = 1 / part 3); fj_bcast_join counts with the counting step's kernel (a probe row counts once however many copies of its
+ * key the build side holds; partitions of more than ~6000 keys are refused: they must fit the pair writer's table); fj_bcast_finish
+ * leaves the regions and the probe partitions in place and fj_emit_pairs (fj_bcast_emit) writes this rank's pairs - (probe key, value
+ * of one copy of the build key) of its OWN probe rows: in this form the pairs stay with the probe rows.
  */
 size_t fj_bcast_region_bytes(size_t nb_total, size_t nkeys, int with_vals);
 int fj_bcast_piece_span(size_t nb_total, size_t nkeys, size_t k_lo, size_t k_hi, int part, size_t* offset, size_t* bytes);

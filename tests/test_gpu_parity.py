@@ -821,6 +821,11 @@ def test_distributed_protocol_on_one_rank_over_rccl(fj, monkeypatch):
         t = {}
         n, sec = dj(dk, dv, pk, timings=t)
         assert n == exp and t["strategy"] == "broadcast" and "broadcast_form_error" not in t, t
+        # ... materialising too: one pair per matching probe row, whatever the number of copies (round 6: the step is counted by the same kernel)
+        tm = {}
+        n, sec, k, v = dj(dk, dv, pk, materialize=True, return_arrays=True, timings=tm)
+        assert n == exp == k.numel() and tm["strategy"] == "broadcast" and "broadcast_form_error" not in tm and bool(torch.all((v + 1) * M == k)), tm
+        del k, v
         # ... and one key repeated 20000 times: its final partition does not fit the LDS table (that form has no per-partition
         # recovery) - the step fails on every rank alike and moves down the ladder to the shuffle, whose skew ladder takes it
         hot = bk[12345:12346].repeat(20000)
@@ -1272,10 +1277,10 @@ def test_build_broadcast_form_matches_the_oracle(fj, oracle, world, nb_total, np
                                                               (3, 400_000, 9_000_001, 4096), (4, 40_000, 90_000, 256)])
 def test_build_broadcast_form_materialising_matches_the_oracle(fj, oracle, world, nb_total, np_total, target):
     """The MATERIALISING build-broadcast step (_hash_join_radix_materialize, hash_join.cpp:315-381, across GPUs; csrc/fj_bcast.hip:
-    the values travel as a fourth part of every region, fj_dense_mat_join counts with duplicate detection, fj_emit_pairs writes every
-    rank's pairs - (probe key, build value) of its OWN probe rows), all ranks played by this GPU: the ranks' pair sets together are
-    the NumPy oracle's pair list, digest for digest; ragged blocks, repeated probe keys, both plane widths, 1 and several pieces.
-    Duplicate build keys across ranks are refused loudly (the first occurrence's value is what counts: the shuffle forms serve them)."""
+    the values travel as a fourth part of every region, the step is counted by the counting step's kernel, fj_emit_pairs writes every
+    rank's pairs - (probe key, build value) of its OWN probe rows - with fj_dense_mat_join), all ranks played by this GPU: the ranks'
+    pair sets together are the NumPy oracle's pair list, digest for digest; ragged blocks, repeated probe keys, both plane widths, 1
+    and several pieces.  A build key that two ranks hold yields one pair per matching probe row, with one of the copies' values."""
     import torch
     from flash_hash_join_amd.lab import LabEngine
     fj.set_option("plan_target_keys", target)
@@ -1317,7 +1322,8 @@ def test_build_broadcast_form_materialising_matches_the_oracle(fj, oracle, world
                 ks.append(k.cpu().numpy().view(np.uint64)); vs.append(v.cpu().numpy().view(np.uint64)); total += n
             assert total == exp
             assert _digest(oracle, np.concatenate(ks), np.concatenate(vs)) == _digest(oracle, ek, ev)
-        # the same key on two ranks: refused
+        # the same key on two ranks: served - ONE pair per matching probe row, carrying the value of one of the copies (across GPUs there
+        # is no first occurrence to prefer; hash_join.cpp:125 drops duplicates at insert, so a probe row never yields two pairs)
         dup_b = [torch.cat([bks[-1], bks[1][:3] if world > 1 and sizes[1] >= 3 else bks[-1][:3]])] if sizes[-1] else None
         if dup_b is not None and world > 1 and sizes[1] >= 3:
             bks2, bvs2 = bks[:-1] + dup_b, bvs[:-1] + [torch.cat([bvs[-1], bvs[1][:3]])]
@@ -1334,8 +1340,15 @@ def test_build_broadcast_form_materialising_matches_the_oracle(fj, oracle, world
                 eng.bcast_pack(bks2[0], nbt2, base[offs[0]: offs[0] + rbs[0]], 1, vals=bvs2[0])
                 eng.bcast_probe(probe_all, nbt2)
                 eng.bcast_join(base, offs, sizes2, 0, eng.bcast_plan(nbt2)[1])
-                with pytest.raises(RuntimeError, match="duplicate build keys in a materialising join"):
-                    eng.bcast_finish()
+                n = eng.bcast_finish()
+                bk_all, bv_all = torch.cat(bks2), torch.cat(bvs2)
+                assert n == int(torch.isin(probe_all, bk_all).sum())
+                k, v = eng.emit_pairs(n)
+                assert bool(torch.equal(torch.sort(k)[0], torch.sort(probe_all[torch.isin(probe_all, bk_all)])[0]))
+                M = -7046029254386353131
+                assert bool(torch.isin(k * M + v, bk_all * M + bv_all).all())            # every value belongs to a copy of its key
+                d3 = torch.isin(k, bks[1][:3])                                           # the duplicated keys were probed (probe_all ends with them)
+                assert int(d3.sum()) >= 3
     finally:
         fj.set_option("plan_target_keys", 4096)
 
