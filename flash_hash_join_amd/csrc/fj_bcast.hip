@@ -220,113 +220,209 @@ struct DenseMatArgs {
     const u64* out_off; u64* out_keys; u64* out_vals;
 };
 __global__ __launch_bounds__(DM_NT) void fj_dense_mat_join(DenseMatArgs a) {
-    constexpr bool EMIT = true;
     extern __shared__ __attribute__((aligned(16))) unsigned char dm_smem[];
     u64* tkeys = reinterpret_cast<u64*>(dm_smem);
     u64* tvals = tkeys + DM_SLOTS;
     u32* fill = reinterpret_cast<u32*>(tvals + DM_SLOTS);
-    u32* sh = fill + DM_NBK;                                       // [0] hits of the item, [1] table overflow, [2] duplicates, [3] pairs written
-    const u32 tid = threadIdx.x;
+    u32* sh = fill + DM_NBK;                                       // [1] table overflow (kept while the partition stays), [3] pairs written by the item
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 item_lo = a.toff[a.part_lo], item_hi = a.toff[a.part_hi];
-    u32 cur_part = 0xFFFFFFFFu;
     // a workgroup takes a RUN of consecutive items: the items of one partition (few ranks: several per partition) share one table build
     const u32 nit = item_hi - item_lo;
     const u32 my_lo = item_lo + (u32)((u64)nit * blockIdx.x / gridDim.x), my_hi = item_lo + (u32)((u64)nit * (blockIdx.x + 1u) / gridDim.x);
-    for (u32 it = my_lo; it < my_hi; ++it) {
-        const uint4 d = a.items[it];                               // {probe list pos, probe chunks, partition, -}
-        const u32 part = d.z;
-        if (tid < 4) sh[tid] = tid == 1 || tid == 2 ? sh[tid] : 0u;
-        if (part != cur_part) {                                    // (items of one partition that follow each other in a workgroup share the table)
-            for (u32 i = tid; i < DM_NBK; i += DM_NT) fill[i] = 0;
-            if (tid == 1 || tid == 2) sh[tid] = 0;
-            __syncthreads();
-            const u32 top = a.bits ? part << (32u - a.bits) : 0u;
-            // every source's run is loaded by its own waves (16 / nsrc rounded up to a power of two: the source, its bounds and its
-            // planes are wave-uniform - scalar loads, no per-key search), four keys per lane in flight
-            const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-            u32 wps = DM_NT / 64u;                                     // waves per source
-            while (wps > 1u && (DM_NT / 64u) / wps < a.nsrc) wps >>= 1;
-            const u32 src = wave / wps;
-            if (src < a.nsrc) {
-                const u32* offs = reinterpret_cast<const u32*>(a.base + a.offs_off[src]);
-                const u32 b = offs[part], e = offs[part + 1];
-                const u32* lo = reinterpret_cast<const u32*>(a.base + a.lo_off[src]);
-                const unsigned char* midp = a.base + a.mid_off[src];
-                const u64* vp = reinterpret_cast<const u64*>(a.base + a.val_off[src]);
-                const u32 stride = wps * 64u;
-                for (u32 k0 = b + (wave % wps) * 64u + lane; k0 - lane < e; k0 += 4u * stride) {      // (k0 - lane: wave-uniform trip count)
-                    u32 lw[4], mw[4]; u64 vw[4]; bool ok[4];
+    if (my_lo >= my_hi) return;
+    // every source's run is loaded by its own waves (16 / nsrc rounded up to a power of two: the source, its bounds and its planes are
+    // wave-uniform - scalar loads, no per-key search), four keys per lane and round
+    u32 wps = DM_NT / 64u;                                         // waves per source
+    while (wps > 1u && (DM_NT / 64u) / wps < a.nsrc) wps >>= 1;
+    const u32 src = wave / wps, stride = wps * 64u, wofs = (wave % wps) * 64u + lane;
+    const bool has_src = src < a.nsrc;
+    const u32* offs = reinterpret_cast<const u32*>(a.base + a.offs_off[has_src ? src : 0]);
+    const u32* lo = reinterpret_cast<const u32*>(a.base + a.lo_off[has_src ? src : 0]);
+    const unsigned char* midp = a.base + a.mid_off[has_src ? src : 0];
+    const u64* vp = reinterpret_cast<const u64*>(a.base + a.val_off[has_src ? src : 0]);
+
+    // The item loop is a software pipeline over three levels of dependent loads (one 1024-thread workgroup per CU - the table and the
+    // value array take 136 KiB - so nothing else hides them): item descriptors two items ahead; the next item's run bounds and probe
+    // list entries requested before this item's table is built; the next item's first round of build rows and its probe keys requested
+    // between this item's build and its lookups.  (Plain form, everything loaded where it was needed: 16.3 ms as one rank of 8.)
+    auto desc = [&](u32 it) -> uint4 { return it < my_hi ? a.items[it] : make_uint4(0, 0, 0xFFFFFFFFu, 0); };   // {probe list pos, probe chunks, partition, -}
+    auto bounds = [&](u32 part, u32& b, u32& e) { b = 0; e = 0; if (has_src && part != 0xFFFFFFFFu) { b = offs[part]; e = offs[part + 1]; } };
+    auto build_loads = [&](u32 k0, u32 b, u32 e, u32 (&lw)[4], u32 (&mw)[4], u64 (&vw)[4], u32& okm) {
+        okm = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const u32 k = k0 + (u32)j * stride;
-                        ok[j] = k < e;
-                        const u32 kk = ok[j] ? k : b;                  // (b: readable whenever the run is not empty; an empty run never gets here)
-                        lw[j] = lo[kk];
-                        mw[j] = a.mid_bytes == 2 ? (u32)reinterpret_cast<const u16*>(midp)[kk] : reinterpret_cast<const u32*>(midp)[kk];
-                        if (EMIT) vw[j] = vp[kk];
-                    }
+        for (int j = 0; j < 4; ++j) {
+            const u32 k = k0 + (u32)j * stride;
+            const bool ok = k < e;
+            const u32 kk = ok ? k : (b < e ? b : 0u);                // (a readable key of the run; an empty run reads key 0 of the plane - the region is never empty: it has its offset table)
+            lw[j] = lo[kk];
+            mw[j] = a.mid_bytes == 2 ? (u32)reinterpret_cast<const u16*>(midp)[kk] : reinterpret_cast<const u32*>(midp)[kk];
+            vw[j] = vp[kk];
+            okm |= (ok ? 1u : 0u) << j;
+        }
+    };
+    auto insert4 = [&](u32 top, const u32 (&lw)[4], const u32 (&mw)[4], const u64 (&vw)[4], u32 okm) {
+        u64 key[4]; u32 bk[4], o[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (!ok[j]) continue;
-                        const u64 key = ((u64)(top | mw[j]) << 32) | lw[j];
-                        u32 bk = FJ_HW2(key) & (DM_NBK - 1u), slot = 0xFFFFFFFFu;
-                        for (u32 step = 0; step < DM_MAXWALK; ++step) {
-                            const u32 o = atomicAdd(&fill[bk], 1u);
-                            if (o < DM_BS) { slot = bk * DM_BS + o; break; }
-                            bk = (bk + 1u) & (DM_NBK - 1u);
-                        }
-                        if (slot == 0xFFFFFFFFu) sh[1] = 1;
-                        else { tkeys[slot] = key; if (EMIT) tvals[slot] = vw[j]; }
-                    }
+        for (int j = 0; j < 4; ++j) {                              // the four returning adds in flight together
+            key[j] = ((u64)(top | mw[j]) << 32) | lw[j];
+            bk[j] = FJ_HW2(key[j]) & (DM_NBK - 1u);
+            o[j] = ((okm >> j) & 1u) ? atomicAdd(&fill[bk[j]], 1u) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!((okm >> j) & 1u)) continue;
+            u32 slot = o[j] < DM_BS ? bk[j] * DM_BS + o[j] : 0xFFFFFFFFu;
+            if (slot == 0xFFFFFFFFu) {                             // the home bucket was full: on to the next ones
+                u32 b2 = bk[j];
+                for (u32 step = 1; step < DM_MAXWALK; ++step) {
+                    b2 = (b2 + 1u) & (DM_NBK - 1u);
+                    const u32 o2 = atomicAdd(&fill[b2], 1u);
+                    if (o2 < DM_BS) { slot = b2 * DM_BS + o2; break; }
                 }
             }
-            __syncthreads();
-            cur_part = part;
-            __syncthreads();
-        } else __syncthreads();
-        const bool bad = sh[1] != 0;
-        u32 my_hits = 0;
-        if (!bad) {
-            // the item's probe keys, eight per lane in flight (list entries first, then the keys they point at)
-            for (u32 idx0 = tid; idx0 - tid < d.y * FJ_CHUNK; idx0 += 8u * DM_NT) {
-                u32 le[8]; u64 pk[8]; bool ok[8];
+            if (slot == 0xFFFFFFFFu) sh[1] = 1;
+            else { tkeys[slot] = key[j]; tvals[slot] = vw[j]; }
+        }
+    };
+    auto list_loads = [&](const uint4& d, u32 idx0, u32 (&le)[8]) {    // the list entries of the lane's eight key slots idx0 + j * 1024
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const u32 idx = idx0 + (u32)j * DM_NT;
-                    ok[j] = idx < d.y * FJ_CHUNK;
-                    le[j] = a.probe.list[d.x + (ok[j] ? (idx >> FJ_CHUNK_LOG) : 0u)];
-                }
+        for (int j = 0; j < 8; ++j) {
+            const u32 idx = idx0 + (u32)j * DM_NT;
+            le[j] = (d.y && d.z != 0xFFFFFFFFu) ? a.probe.list[d.x + (idx < d.y * FJ_CHUNK ? (idx >> FJ_CHUNK_LOG) : 0u)] : 0u;
+        }
+    };
+    auto key_loads = [&](const uint4& d, u32 idx0, const u32 (&le)[8], u64 (&pk)[8], u32& okm) {
+        okm = 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const u32 k = (idx0 + (u32)j * DM_NT) & (FJ_CHUNK - 1u);
-                    ok[j] = ok[j] && k < FJ_LIST_CNT(le[j]);
-                    pk[j] = a.probe.keys[(u64)FJ_LIST_ID(le[j]) * FJ_CHUNK + (ok[j] ? k : 0u)];
-                }
+        for (int j = 0; j < 8; ++j) {
+            const u32 idx = idx0 + (u32)j * DM_NT, k = idx & (FJ_CHUNK - 1u);
+            const bool ok = d.z != 0xFFFFFFFFu && idx < d.y * FJ_CHUNK && k < FJ_LIST_CNT(le[j]);
+            pk[j] = a.probe.keys[(u64)FJ_LIST_ID(le[j]) * FJ_CHUNK + (ok ? k : 0u)];       // (chunk 0 stands in where there is no item)
+            okm |= (ok ? 1u : 0u) << j;
+        }
+    };
+    // the lookups of a lane's eight probe keys, four at a time: the home bucket whole (two 16-byte reads) and its fill count, all reads
+    // of the four in flight, then the compares; only a key that is not in an OVERFLOWED home bucket walks on (rare).  (First form: per
+    // key a loop over the bucket's slots with an early exit - nested divergent loops of dependent LDS reads: 9.7 of the kernel's 16.4
+    // ms as one rank of 8, by ablation.)  obase: the item's first output position - read once per item (behind every pair store the
+    // compiler would have to read out_off[it] again: the output arrays might alias it)
+    auto probe8 = [&](u64 obase, const u64 (&pk)[8], u32 okm) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (!ok[j]) continue;
-                    const u64 key = pk[j];
-                    u32 bk = FJ_HW2(key) & (DM_NBK - 1u), hit = 0xFFFFFFFFu;
-                    for (u32 step = 0; step < DM_MAXWALK && hit == 0xFFFFFFFFu; ++step) {
-                        const u32 f = fill[bk], n = f < DM_BS ? f : DM_BS;
-                        for (u32 t = 0; t < n; ++t) if (tkeys[bk * DM_BS + t] == key) { hit = bk * DM_BS + t; break; }
-                        if (f <= DM_BS) break;                         // nobody was sent on from this bucket
-                        bk = (bk + 1u) & (DM_NBK - 1u);
-                    }
-                    if (hit != 0xFFFFFFFFu) {
-                        ++my_hits;
-                        if (EMIT) {
-                            const u32 w = atomicAdd(&sh[3], 1u);
-                            const u64 o = a.out_off[it] + w;
-                            a.out_keys[o] = fj_key_unmix(key); a.out_vals[o] = tvals[hit];
+        for (int h0 = 0; h0 < 8; h0 += 4) {
+            uint4 q0[4], q1[4]; u32 fc[4], bkt[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bkt[i] = FJ_HW2(pk[h0 + i]) & (DM_NBK - 1u);
+                const uint4* bp = reinterpret_cast<const uint4*>(tkeys + bkt[i] * DM_BS);
+                q0[i] = bp[0]; q1[i] = bp[1];
+                fc[i] = fill[bkt[i]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u64 key = pk[h0 + i];
+                const bool ok = (okm >> (h0 + i)) & 1u;
+                const u32 n = fc[i] < DM_BS ? fc[i] : DM_BS;
+                const u64 e0 = ((u64)q0[i].y << 32) | q0[i].x, e1 = ((u64)q0[i].w << 32) | q0[i].z, e2 = ((u64)q1[i].y << 32) | q1[i].x, e3 = ((u64)q1[i].w << 32) | q1[i].z;
+                const bool m0 = (e0 == key) & (n > 0u), m1 = (e1 == key) & (n > 1u), m2 = (e2 == key) & (n > 2u), m3 = (e3 == key) & (n > 3u);
+                u32 hit = m0 ? 0u : m1 ? 1u : m2 ? 2u : m3 ? 3u : 0xFFFFFFFFu;
+                if (hit != 0xFFFFFFFFu) hit += bkt[i] * DM_BS;
+                if (!ok) hit = 0xFFFFFFFFu;
+                bool walk = ok & (hit == 0xFFFFFFFFu) & (fc[i] > DM_BS);      // somebody was sent on from this bucket
+                if (__ballot(walk)) {
+                    u32 bk = bkt[i];
+                    for (u32 step = 1; step < DM_MAXWALK && __ballot(walk); ++step) {
+                        if (walk) {
+                            bk = (bk + 1u) & (DM_NBK - 1u);
+                            const u32 f = fill[bk], nn = f < DM_BS ? f : DM_BS;
+                            for (u32 t = 0; t < nn; ++t) if (tkeys[bk * DM_BS + t] == key) { hit = bk * DM_BS + t; break; }
+                            walk = hit == 0xFFFFFFFFu && f > DM_BS;
                         }
+                    }
+                }
+                // the item's cursor is bumped once per wave and key slot; the lanes rank themselves inside the ballot
+                const bool h = hit != 0xFFFFFFFFu;
+                const u64 m = __ballot(h);
+                if (m) {
+                    u32 wb = 0;
+                    if (lane == (u32)__builtin_ctzll(m)) wb = atomicAdd(&sh[3], (u32)__popcll(m));
+                    wb = (u32)__builtin_amdgcn_readlane((int)wb, __builtin_ctzll(m));
+#ifndef FJ_DM_ABLATE      // (timing-only variants: 1 no pair stores | 2 no lookups | 4 no inserts)
+#define FJ_DM_ABLATE 0
+#endif
+                    if (h && !(FJ_DM_ABLATE & 1)) {
+                        const u64 o = obase + wb + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                        a.out_keys[o] = fj_key_unmix(key); a.out_vals[o] = tvals[hit];
                     }
                 }
             }
         }
-        (void)my_hits;
+    };
+
+    // ---- prologue: item my_lo's loads, level by level ----
+    uint4 d = desc(my_lo), dn = desc(my_lo + 1);
+    u32 b = 0, e = 0;
+    bounds(d.z, b, e);
+    u32 le[8];
+    list_loads(d, tid, le);
+    u32 lw[4], mw[4], bokm = 0; u64 vw[4];
+    build_loads(b + wofs, b, e, lw, mw, vw, bokm);
+    u64 pk[8]; u32 pokm = 0;
+    key_loads(d, tid, le, pk, pokm);
+    u32 cur_part = 0xFFFFFFFFu;
+    if (tid < 4) sh[tid] = 0;
+
+    for (u32 it = my_lo; it < my_hi; ++it) {
+        const u32 part = d.z;
+        const bool newpart = part != cur_part;
+        // level 1 of the next item: its descriptor is here; bounds of its partition (if another one), its probe list entries; the
+        // descriptor after it
+        const uint4 dnn = desc(it + 2);
+        u32 nb_ = 0, ne_ = 0, len[8];
+        if (dn.z != part) bounds(dn.z, nb_, ne_);
+        list_loads(dn, tid, len);
+        if (tid == 3) sh[3] = 0;
+        if (newpart) {
+            for (u32 i = tid; i < DM_NBK; i += DM_NT) fill[i] = 0;
+            if (tid == 1) sh[1] = 0;
+        }
+        __syncthreads();
+        if (newpart) {                                             // (items of one partition that follow each other in a workgroup share the table)
+            const u32 top = a.bits ? part << (32u - a.bits) : 0u;
+            if (!(FJ_DM_ABLATE & 4)) insert4(top, lw, mw, vw, bokm);
+            for (u32 k0 = b + wofs + 4u * stride; k0 - lane < e && has_src; k0 += 4u * stride) {      // (runs of more than 4 keys per lane: skew; loaded on the spot)
+                build_loads(k0, b, e, lw, mw, vw, bokm);
+                insert4(top, lw, mw, vw, bokm);
+            }
+            cur_part = part;
+        }
+        __syncthreads();
+        // level 2 of the next item: the first round of its partition's build rows (if another partition), its probe keys
+        u64 pkn[8]; u32 pokn = 0;
+        if (dn.z != part) build_loads(nb_ + wofs, nb_, ne_, lw, mw, vw, bokm);
+        key_loads(dn, tid, len, pkn, pokn);
+        // ---- this item's lookups and pairs ----
+        const bool bad = sh[1] != 0;
+        const u64 obase = a.out_off[it];
+        if (!bad && !(FJ_DM_ABLATE & 2)) {
+            probe8(obase, pk, pokm);
+            for (u32 idx0 = tid + 8u * DM_NT; idx0 - tid < d.y * FJ_CHUNK; idx0 += 8u * DM_NT) {     // (items of more than 32 chunks: none from fj_bcast_probe; loaded on the spot)
+                u32 le2[8]; u64 pk2[8]; u32 ok2;
+                list_loads(d, idx0, le2);
+                key_loads(d, idx0, le2, pk2, ok2);
+                probe8(obase, pk2, ok2);
+            }
+        }
         if (bad && tid == 0) atomicOr(a.err, FJ_STAT_RETRY);       // (the counting launch accepted a partition this table cannot hold: reported, fj_emit_pairs fails)
         __syncthreads();
+        // ---- rotate ----
+        if (dn.z != part) { b = nb_; e = ne_; }
+        d = dn; dn = dnn;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pk[j] = pkn[j];
+        pokm = pokn;
     }
 }
 

@@ -246,7 +246,7 @@ def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] 
     one rank of 1 / 2 / 8 (profiles/r06_bcast_mat_one_rank.txt, tools/bcast_one_gpu.py ... 1): the regions carry the values (14 bytes
     per build row, 16 under 16-bit plans), the pack takes 22.9 ps per build row, the step is counted by the counting step's kernel
     (2.0 ps per build key of all ranks + 2.2 ps per local probe key), writing the pairs (behind the step: nothing overlaps it) costs
-    6.1 ps + 8.1 ps; the shuffle ships 15 bytes per build row and its owner writes the pairs of what it received (~4 ms per 1.25B
+    5.5 ps + 7.45 ps; the shuffle ships 15 bytes per build row and its owner writes the pairs of what it received (~4 ms per 1.25B
     probe rows at 50 % hits)."""
     from . import _lib
     nb_total = nb_total if nb_total is not None else nb * world
@@ -259,7 +259,7 @@ def form_model(world: int, nb: int, np_: int, link_bytes_per_s: Optional[float] 
         bits = max(5, (max(1, -(-nb_total // 4096)) - 1).bit_length()) if nb_total > 4096 else 5
         region = nb * (14 if bits >= 16 else 16) + 4 * ((1 << bits) + 1) + 64
         pack, passes = nb * 22.9e-12, np_ * (6.34e-12 + 0.27e-12 * max(0, min(bits, 18) - 16))
-        count, emit = nb_total * 2.0e-12 + np_ * 2.2e-12, nb_total * 6.1e-12 + np_ * 8.1e-12
+        count, emit = nb_total * 2.0e-12 + np_ * 2.2e-12, nb_total * 5.5e-12 + np_ * 7.45e-12
         wire = region / rate if world > 1 else 0.0
         t_b = max(wire + pack + count / 4.0, pack + passes + count) + emit
         t_s += ((15.0 - 7.02) * nb_total / (world * world) / rate if world > 1 else 0.0) + np_ * 3.2e-12
