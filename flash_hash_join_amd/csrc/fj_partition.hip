@@ -807,7 +807,9 @@ __global__ __launch_bounds__(256) void fj_level_lists(const u32* __restrict__ di
 // toff, counts cleared) - one launch per level instead of two.  Every workgroup scans the <= 512 counts itself (2 KiB from L2) into
 // LDS and works from there; workgroup 0 also writes boff / toff out for the level's consumers; the counts may be cleared once
 // everybody has read them: each workgroup ticks a counter behind the counts (bchunks[nb]: zero at rest like the counts) when it
-// has, and the one that ticks last clears counts and counter.
+// has, and the one that ticks last clears counts and counter.  FUSED = false: the offsets come from fj_level_scan (levels of more than
+// 512 workgroups - a 1B-row level has 1200 - where 1200 little scans cost more than the launch they save: 80 us against 8 + 35).
+template <bool FUSED>
 __global__ __launch_bounds__(1024) void fj_level_lists_binned(const u32* __restrict__ dir, const u64* __restrict__ rel, const u32* __restrict__ nalloc,
                                u32 cap, u32* __restrict__ boff_g, const u32* __restrict__ seg_off, u32 fan_mask,
                                u32 max_segs, u32* __restrict__ list,
@@ -817,13 +819,15 @@ __global__ __launch_bounds__(1024) void fj_level_lists_binned(const u32* __restr
     __shared__ u32 hist[NBMAX + 1];
     __shared__ u32 wsum[NBMAX / 64];
     __shared__ uint2 ent[BLK];
-    __shared__ u32 boff[NBMAX + 1], toff[NBMAX + 1];
+    __shared__ u32 boff_s[FUSED ? NBMAX + 1 : 1], toff_s[FUSED ? NBMAX + 1 : 1];
     __shared__ u64 wtot[NBMAX / 64];
     __shared__ u32 s_last;
+    const u32* boff = FUSED ? boff_s : boff_g;
+    const u32* toff = FUSED ? toff_s : toff_g;
     u32 n = *nalloc; if (n > cap) n = cap;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 stride = gridDim.x * NT, gtid = blockIdx.x * NT + tid;
-    {   // ---- the scan (chunks in the low word, tiles in the high word of one 64-bit scan, as fj_level_scan does it) ----
+    if constexpr (FUSED) {   // ---- the scan (chunks in the low word, tiles in the high word of one 64-bit scan, as fj_level_scan does it) ----
         const float rtc = tc ? 1.0f / (float)tc : 0.f;
         auto tiles_of = [&](u32 c) -> u32 {          // ceil(c / tc) without an integer division (c < 2^24: exact after one correction)
             if (!tc) return 0u;
@@ -847,12 +851,12 @@ __global__ __launch_bounds__(1024) void fj_level_lists_binned(const u32* __restr
             u64 woff = 0;
             for (u32 w = 0; w < wave; ++w) woff += wtot[w];
             const u64 ex = woff + v - mine;
-            if (tid < nb) { boff[tid] = (u32)ex; toff[tid] = (u32)(ex >> 32); }
-            if (tid == nb - 1) { boff[nb] = (u32)(ex + mine); toff[nb] = (u32)((ex + mine) >> 32); }
+            if (tid < nb) { boff_s[tid] = (u32)ex; toff_s[tid] = (u32)(ex >> 32); }
+            if (tid == nb - 1) { boff_s[nb] = (u32)(ex + mine); toff_s[nb] = (u32)((ex + mine) >> 32); }
         }
         __syncthreads();
         if (s_last) { if (tid < nb) bchunks[tid] = 0; if (tid == 0) bchunks[nb] = 0; }       // every workgroup has read them: cleared for the next join
-        if (blockIdx.x == 0 && tid <= nb) { boff_g[tid] = boff[tid]; if (tc) toff_g[tid] = toff[tid]; }
+        if (blockIdx.x == 0 && tid <= nb) { boff_g[tid] = boff_s[tid]; if (tc) toff_g[tid] = toff_s[tid]; }
     }
     if (tc) {
         u32 total = toff[nb];
@@ -1062,10 +1066,16 @@ hipError_t fj_launch_group(const FjChunkSet& cs, u32 tc, u32* toff, uint4* tiles
     if (cs.nb & 3u) return hipErrorInvalidValue;           // fj_level_scan works in 16-B pieces
     static_assert(FJ_RUN_LOG == 1 || FJ_RUN_LOG == 2, "fj_level_lists reads a run's directory words with one 8-B or 16-B load");
     if (cs.run_log != 0 && cs.run_log != FJ_RUN_LOG) return hipErrorInvalidValue;
-    if (cs.run_log == 0 && cs.nb <= 512 && cs.cap >= 4096) {       // few buckets, single ids: ONE launch - scan, binned list entries, tile table
+    if (cs.run_log == 0 && cs.nb <= 512 && cs.cap >= 4096) {       // few buckets, single ids: binned list entries + tile table - and, up to 512 workgroups, the scan in the same launch
         const u32 blocks = (cs.cap + 4095u) / 4096u;
-        hipLaunchKernelGGL(fj_level_lists_binned, dim3(blocks < 4096u ? blocks : 4096u), dim3(1024), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff,
-                           cs.seg_off, cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail, cs.bchunks);
+        if (blocks <= 512u) {
+            hipLaunchKernelGGL(fj_level_lists_binned<true>, dim3(blocks), dim3(1024), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff,
+                               cs.seg_off, cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail, cs.bchunks);
+        } else {
+            hipLaunchKernelGGL(fj_level_scan, dim3(1), dim3(1024), 0, s, cs.bchunks, cs.boff, cs.nb, tc, toff);
+            hipLaunchKernelGGL(fj_level_lists_binned<false>, dim3(blocks < 4096u ? blocks : 4096u), dim3(1024), 0, s, cs.dir, cs.rel, cs.alloc, cs.cap, cs.boff,
+                               cs.seg_off, cs.fan_mask, cs.max_segs, cs.list, cs.nb, tc, toff, tiles, max_tiles, zero_tail, cs.bchunks);
+        }
         return hipGetLastError();
     }
     // many buckets: one workgroup per 4096 counts, and the chunk-list launch clears the counts (fj_level_scan_wide)
