@@ -98,6 +98,19 @@ __device__ __forceinline__ bool lds_insert(u64* __restrict__ tkeys, u64* __restr
             return true;
         }
         if (step == 0) { g = galt; continue; }
+        // Both candidate groups are full.  Before the key walks on: is a copy of it in there by now?  Hundreds of copies of ONE key
+        // inserted in the same instant all miss each other's tags at the top (a claim's tag is written a few instructions after its
+        // add), fill both groups with copies and would then walk the table until it counts as full - a build side of 756 rows, all
+        // the same key, failed every materialising join that way (tools/r6_api_fuzz.py).  The copies that took the groups' slots
+        // have their tags in place by the time a loser gets here (two LDS round trips later), and a loser that still sees none
+        // looks again at every step of its walk.
+        {
+            u32 n1 = tag_matches(ttags[g1], pat), n2 = tag_matches(ttags[g2], pat);
+            while (n1) { const u32 c = g1 * FJ_LDS_GROUP + ((u32)__builtin_ctz(n1) >> 3);
+                         if (tkeys[c] == key) { if (MAT && dedup) atomicMin((unsigned long long*)&tvals[c], (unsigned long long)val); return false; } n1 &= n1 - 1; }
+            while (n2) { const u32 c = g2 * FJ_LDS_GROUP + ((u32)__builtin_ctz(n2) >> 3);
+                         if (tkeys[c] == key) { if (MAT && dedup) atomicMin((unsigned long long*)&tvals[c], (unsigned long long)val); return false; } n2 &= n2 - 1; }
+        }
         if (step == 1) { hdr->ovf = 1; g = g1; }           // both candidate groups full: walk from g1
         // (somebody else already walked the whole table in vain: an oversized partition - do not repeat the 2048-step walk per key)
         if ((step & 31u) == 31u && *reinterpret_cast<volatile u32*>(&hdr->full)) return false;

@@ -208,6 +208,32 @@ def test_adaptive_threshold_both_sides(fj, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("copies", [756, 3900])
+def test_a_small_build_side_of_one_repeated_key_joins(fj, copies):
+    """A build side below the partitioning threshold (no pass: one LDS table for the whole join) that is ONE key repeated: hundreds of
+    copies inserted in the same instant miss each other's tags, and the tagged table of the materialising pass used to fill both
+    candidate groups with copies and then walk until it counted as full - every materialising function raised "could not place every
+    partition in LDS" (found by tools/r6_api_fuzz.py).  All twelve functions: counts exact, one pair per probe row, the FIRST
+    occurrence's value (hash_join.cpp:125)."""
+    import torch
+    dev = "cuda:0"
+    key = 123456789012345
+    bk = torch.full((copies,), key, device=dev, dtype=torch.int64)
+    bv = torch.arange(copies, device=dev, dtype=torch.int64) + 17
+    pk = torch.cat([bk[:1].repeat(1793), torch.arange(5, device=dev, dtype=torch.int64)]).contiguous()
+    for name in ("adaptive_join_count", "adaptive_join_count_bloom", "hash_join_count_radix", "hash_join_count", "hash_join_count_radix_bloom", "hash_join_count_bloom"):
+        assert getattr(fj, name)(bk, bv, pk)[0] == 1793, name
+    for name in ("adaptive_join", "adaptive_join_bloom", "hash_join_radix", "hash_join", "hash_join_radix_bloom", "hash_join_bloom"):
+        for single in (1, 0):
+            fj.set_option("mat_single_pass", single)
+            try:
+                n, _, k, v = getattr(fj, name)(bk, bv, pk, return_arrays=True)
+            finally:
+                fj.set_option("mat_single_pass", 1)
+            assert n == 1793 == k.numel() and bool((k == key).all()) and bool((v == 17).all()), (name, single, n)
+
+
+@pytest.mark.gpu
 def test_millions_of_copies_of_a_few_build_keys_are_counted_once(fj):
     """Three distinct build keys, two million copies each, in a shape that takes the bucketed join (fewer than 3 probe rows per build
     row): their partitions are far beyond any LDS table, the probe side of each is cut into hundreds of items, and the retry ladder
