@@ -12,12 +12,18 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fj.initialize()
 dev = "cuda:0"
+from flash_hash_join_amd import _lib
+_EMPTY_RAW = int(_lib.load().fj_key_unmix64(2**64 - 1))                # the raw key whose mixed form is the tables' empty marker
+_EMPTY_RAW = _EMPTY_RAW - 2**64 if _EMPTY_RAW >= 2**63 else _EMPTY_RAW
+SPECIAL = [0, -1, 1, -2**63, 2**63 - 1, _EMPTY_RAW]
+EDGES = [1, 2, 255, 256, 257, 3949, 3950, 3951, 4095, 4096, 4097, 8191, 8192, 8193, 999_999, 1_000_000, 1_000_001]
 COUNT = ["adaptive_join_count", "adaptive_join_count_bloom", "hash_join_count_radix", "hash_join_count", "hash_join_count_radix_bloom", "hash_join_count_bloom"]
 MAT = ["adaptive_join", "adaptive_join_bloom", "hash_join_radix", "hash_join", "hash_join_radix_bloom", "hash_join_bloom"]
 OPTS = {"join_wide": [0, 1, 2], "mat_single_pass": [0, 1], "scalar_hbm_table": [0, 0, 0, 1], "persistent_min_items": [0, 8192, 1 << 30], "plan_target_keys": [4096, 4096, 1024, 256]}
 t0 = time.time()
 for c in range(cases):
     nb = int(10 ** rng.uniform(float(sys.argv[3]) if len(sys.argv) > 3 else 3.0, float(sys.argv[4]) if len(sys.argv) > 4 else 7.5))
+    if rng.random() < 0.2: nb = rng.choice(EDGES)                # sizes at the plans' and the dispatch's thresholds
     npk = max(1, int(nb * 10 ** rng.uniform(-1, 1.3)))
     if nb * 8 + npk * 24 > 2e10: npk = int((2e10 - nb * 8) / 24)
     kind = rng.choice(["random", "sequential", "dups", "fewdistinct", "highword"])
@@ -30,6 +36,9 @@ for c in range(cases):
         bk = bk[torch.randperm(bk.numel(), device=dev, generator=g)].contiguous()
     if kind == "fewdistinct":
         d = rng.choice([1, 5, 1000]); bk = bk[:d].repeat(nb // d + 1)[:nb].contiguous()
+    if rng.random() < 0.3:                                     # special key values on the build side (the probe side draws from it)
+        sp = torch.tensor(rng.sample(SPECIAL, rng.randrange(1, len(SPECIAL) + 1)), device=dev, dtype=torch.int64)
+        bk = bk.clone(); bk[torch.randint(0, bk.numel(), (sp.numel(),), device=dev, generator=g)] = sp
     nb = int(bk.numel())
     bv = torch.randint(-2**62, 2**62, (nb,), device=dev, dtype=torch.int64, generator=g)
     hit = rng.choice([0.0, 0.05, 0.5, 1.0])
@@ -37,6 +46,9 @@ for c in range(cases):
     miss = torch.randint(-2**62, 2**62, (npk,), device=dev, dtype=torch.int64, generator=g)
     pk = torch.where(torch.rand(npk, device=dev, generator=g) < hit, bk[idx], miss).contiguous()
     if rng.random() < 0.2: pk = pk[: max(1, npk // 50)].repeat(50)[:npk].contiguous()        # repeated probe keys
+    if rng.random() < 0.3:                                     # ... and special values among the probe keys whether or not the build side has them
+        sp = torch.tensor(SPECIAL, device=dev, dtype=torch.int64)
+        pk = pk.clone(); pk[torch.randint(0, pk.numel(), (sp.numel(),), device=dev, generator=g)] = sp
     npk = int(pk.numel())
     hitmask = torch.isin(pk, bk)
     exp = int(hitmask.sum())
