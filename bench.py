@@ -590,7 +590,8 @@ def main() -> None:
                        "chunk_form_error": dlast.get("chunk_form_error"), "broadcast_form_error": dlast.get("broadcast_form_error"),
                        "strategy_timed": dlast.get("strategy"), "form_model": form_pick,
                        # what the passes left to the transport's kernels in the last timed step, and the measurements behind that choice
-                       "cu_reserve": dlast.get("cu_reserve")})
+                       "cu_reserve": dlast.get("cu_reserve"),
+                       "pieces": dlast.get("pieces")})            # (FJ_DIST_PIECES unset: the driver's own choice - 4, or 8 for a wire-bound broadcast step)
 
     out = {
         "metric": "probe throughput (billion probes/sec), int64 keys, whole join (build + probe phases) per step",
