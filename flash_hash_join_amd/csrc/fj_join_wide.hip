@@ -45,7 +45,10 @@
 namespace {
 
 constexpr int WNT = 1024;
-constexpr u32 WSLOG = 14, WS = 1u << WSLOG;
+#ifndef FJ_WIDE_WSLOG      // (13: an 8192-slot table - what a double-buffered pair of tables would have to live with; experiment)
+#define FJ_WIDE_WSLOG 14
+#endif
+constexpr u32 WSLOG = FJ_WIDE_WSLOG, WS = 1u << WSLOG;
 #ifndef FJ_WIDE_BS
 #define FJ_WIDE_BS 4
 #endif
