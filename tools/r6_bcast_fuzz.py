@@ -41,6 +41,7 @@ for c in range(cases):
     exp = int(hitmask.sum())
     os.environ["FJ_DIST_PIECES"] = str(rng.choice([0, 1, 4, 7]))
     os.environ["FJ_DIST_NATIVE"] = rng.choice(["1", "1", "0"])
+    api.set_option("lab_hooks", rng.choice([0, 0, 1]))           # 1: the rank's own share travels through ncclSend / ncclRecv too (the path every peer's share takes at N > 1)
     mat = rng.random() < 0.4 and exp < 80_000_000
     D._FORM_MEMO.clear()
     t = {}
