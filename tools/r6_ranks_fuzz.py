@@ -3,7 +3,7 @@ tensors staged through the host; everything else is the production path - HipEng
 the ladder).  Random relation sizes, ragged and EMPTY blocks, duplicate build keys within and across ranks, every starting rung,
 counting and materialising.  Every rank checks the global count against torch.isin over the whole relations and - materialising -
 that the ranks' pairs together are the matching probe rows, each once, with a value of their key's.
-usage: python tools/r6_ranks_fuzz.py [world=2] [cases=12] [seed=1]"""
+usage: python tools/r6_ranks_fuzz.py [world=2] [cases=12] [seed=1] [log10 of the smallest build side=5] [of the largest=7]"""
 import os, random, socket, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 from two_ranks_one_gpu import HostStagedDist
 
 
-def worker(rank, world, port, cases, seed, q):
+def worker(rank, world, port, cases, seed, q, lo=5.0, hi=7.0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -25,7 +25,7 @@ def worker(rank, world, port, cases, seed, q):
         M = -7046029254386353131
         forms = {}
         for c in range(cases):
-            nb = int(10 ** rng.uniform(5.0, 7.0))
+            nb = int(10 ** rng.uniform(lo, hi))
             npk = int(nb * 10 ** rng.uniform(-0.5, 0.9))
             kind = rng.choice(["random", "random", "sequential", "dups", "fewdistinct"])
             g = torch.Generator(device=dev); g.manual_seed(rng.randrange(1 << 30))      # (same data on every rank; each keeps its block)
@@ -83,7 +83,8 @@ if __name__ == "__main__":
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn"); q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, world, port, cases, seed, q)) for r in range(world)]
+    lo = float(sys.argv[4]) if len(sys.argv) > 4 else 5.0; hi = float(sys.argv[5]) if len(sys.argv) > 5 else 7.0
+    ps = [ctx.Process(target=worker, args=(r, world, port, cases, seed, q, lo, hi)) for r in range(world)]
     for p in ps: p.start()
     for p in ps: p.join(timeout=1500)
     codes = [p.exitcode for p in ps]
