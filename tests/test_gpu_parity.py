@@ -2210,3 +2210,22 @@ def test_duplicate_build_keys_first_occurrence_wins(fj, oracle, nb, dom, npk, sc
     n, _, k, v = fj.hash_join(bk, bv, pk, return_arrays=True)               # scalar path: some occurrence of the right key
     assert n == exp and np.array_equal(np.sort(k), ref[0])
     assert np.array_equal(bk[(v - np.uint64(10**12)).astype(np.int64)], k)
+
+
+@pytest.mark.parametrize("tool,args,expect", [
+    ("r6_wide_fuzz.py", ["30", "101"], "OK: 30 cases"),                    # shapes of the bucketed join, duplicates up to millions of copies
+    ("r6_api_fuzz.py", ["150", "102", "2", "6.8"], "OK: 150 cases"),       # the twelve functions + inner_join_count, random options, special keys, edge sizes
+    ("r6_host_fuzz.py", ["60", "103"], "OK: 60 cases"),                    # the NumPy entry: int64 / uint64, strided, N-D, empty
+    ("r6_bcast_fuzz.py", ["40", "104"], "OK: 40 joins"),                   # the multi-GPU ladder from the broadcast rung on one rank over RCCL
+    ("r6_threads_fuzz.py", ["4", "20", "105"], "OK: 4 threads"),           # several Python threads on one context
+    ("r6_ranks_fuzz.py", ["2", "6", "106"], "OK: 2 ranks on one GPU"),     # two ranks sharing this GPU over gloo: ragged / empty blocks, duplicates across ranks
+])
+def test_random_inputs(fj, tool, args, expect):
+    """Round 6's random-input tools (EXPERIMENTS.md "Fuzzing": they found the double-counted re-partitioned partition and the
+    one-repeated-key failure of the tagged table), a short fixed-seed run of each: every count against torch.isin / numpy.isin, every
+    pair against the first-occurrence rule on one GPU (hash_join.cpp:125) and the some-copy rule across GPUs."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=900, cwd=os.path.join(ROOT, "tools"))
+    assert out.returncode == 0 and expect in out.stdout, out.stdout[-1500:] + out.stderr[-2500:]
